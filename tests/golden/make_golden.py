@@ -1,0 +1,185 @@
+"""Generate golden vectors by running the REFERENCE itself on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py enerf
+    python tests/golden/make_golden.py boost_enerf
+
+Each invocation imports the reference with the stand-ins of
+reference_loader.py, seeds default-initialised weights, perturbs them so that
+no term is trivially zero (biases, batch-norm statistics, sharper depth
+logits), runs the reference on the synthetic batch of
+boostmvsnerfs_amd/synthetic.py and stores inputs, weights, the outputs of every
+hot-path function (captured by wrapping the reference's own functions) and the
+final output dict in tests/golden/<name>.npz.  The fixtures are data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from reference_loader import load_reference  # noqa: E402
+
+TINY_H, TINY_W = 64, 96
+TINY_PLANES = [16, 8]
+
+
+def perturb_(net, seed=1):
+    """Deterministic, non-degenerate weights (same recipe for every fixture)."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, m in net.named_modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)) or type(m).__name__ == "InPlaceABN":
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+                m.weight.copy_(0.75 + 0.5 * torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+            elif isinstance(m, (nn.Linear, nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d)):
+                if m.bias is not None:
+                    m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                if "depth_conv" in name:
+                    m.weight.mul_(40.0)    # peaky, spatially varying depth distributions
+    return net
+
+
+class Recorder:
+    def __init__(self):
+        self.data = {}
+        self.count = {}
+
+    def _store(self, name, value):
+        i = self.count.get(name, 0)
+        self.count[name] = i + 1
+        key = f"{name}#{i}"
+        if torch.is_tensor(value):
+            self.data[key] = value.detach().clone().numpy()
+        elif isinstance(value, (tuple, list)):
+            for j, v in enumerate(value):
+                if torch.is_tensor(v):
+                    self.data[f"{key}.{j}"] = v.detach().clone().numpy()
+        elif isinstance(value, dict):
+            for j, v in value.items():
+                if torch.is_tensor(v):
+                    self.data[f"{key}.{j}"] = v.detach().clone().numpy()
+
+    def wrap(self, module, fname):
+        orig = getattr(module, fname)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            self._store(fname, out)
+            return out
+
+        setattr(module, fname, wrapped)
+
+    def hook(self, mod, name):
+        def fwd_hook(m, inp, out):
+            self._store(name, out)
+        mod.register_forward_hook(fwd_hook)
+
+
+UTIL_FUNCS = ["get_proj_mats", "get_depth_values", "homo_warp", "build_feature_volume", "depth_regression",
+              "build_rays", "sample_along_depth", "get_vox_feat", "get_img_feat", "raw2outputs",
+              "mask_viewport", "raw2outputs_blend", "unpreprocess"]
+
+
+def save(name, inputs, sd, rec, out, extra=None):
+    blob = {}
+    for k, v in inputs.items():
+        if torch.is_tensor(v) and not (k.startswith("all_") and k[4:] in inputs and v.shape == inputs[k[4:]].shape):
+            blob["in/" + k] = v.numpy()
+    if sd is not None:
+        for k, v in sd.items():
+            blob["sd/" + k] = v.numpy()
+    for k, v in rec.data.items():
+        if k.startswith("homo_warp#") and k.split("#")[1].split(".")[0] not in ("1", "4"):
+            continue                                   # keep one warped view per level
+        blob["cap/" + k] = v
+    for k, v in out.items():
+        blob["out/" + k] = v.detach().numpy()
+    for k, v in (extra or {}).items():
+        blob["extra/" + k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
+
+
+def gen_enerf():
+    from boostmvsnerfs_amd.synthetic import make_batch
+    cfg = load_reference("configs/exps/evaluate/enerf/free_eval.yaml")
+    from lib.networks.enerf import network, utils
+    cfg.enerf.cas_config.volume_planes = list(TINY_PLANES)
+    cfg.enerf.cas_config.render_if = [True, True]          # both levels: covers eval (level 1) and fine-tune
+    torch.manual_seed(0)
+    net = perturb_(network.Network().eval())
+    rec = Recorder()
+    for f in UTIL_FUNCS:
+        rec.wrap(utils, f)
+    for i in range(2):
+        rec.hook(getattr(net, f"cost_reg_{i}"), f"cost_reg_{i}")
+        rec.hook(getattr(net, f"nerf_{i}"), f"nerf_{i}")
+    rec.hook(net.feature_net, "feature_net")
+    batch = make_batch(TINY_H, TINY_W, n_views=3, seed=0)
+    inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        out = net(batch)
+    save("enerf_tiny", inputs, net.state_dict(), rec, out,
+         extra={"volume_planes": TINY_PLANES, "render_if": [1, 1], "hw": [TINY_H, TINY_W]})
+
+
+def gen_boost_enerf():
+    import json
+    from boostmvsnerfs_amd.synthetic import make_batch
+    cfg = load_reference("configs/exps/evaluate/enerf_ours/free_eval.yaml")
+    from lib.networks.boost_enerf import network
+    from lib.networks.enerf import utils
+    cc = cfg.enerf.cas_config
+    cc.volume_planes = list(TINY_PLANES)
+    cc.k_best = 3
+    n_views = 5                                             # C(5,3) = 10 triplets
+    os.makedirs(cfg.result_dir, exist_ok=True)
+    torch.manual_seed(0)
+    net = perturb_(network.Network(preprocess=True).eval())
+    batch = make_batch(TINY_H, TINY_W, n_views=n_views, seed=0)
+    inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    # --- view selection (a17), eval config renders level 1 only
+    rec_sel = Recorder()
+    orig_calc = net.calc_mask
+
+    def calc_mask(ids, b):
+        m = orig_calc(ids, b)
+        rec_sel._store("calc_mask", m)
+        return m
+
+    net.calc_mask = calc_mask
+    with torch.no_grad():
+        sel = net.forward_view_selection(batch)
+    print("view selection:", sel)
+    with open(os.path.join(cfg.result_dir, "view_selection.json"), "w") as f:
+        json.dump(sel, f)
+    # --- fused forward (a15, a16)
+    torch.manual_seed(0)
+    net2 = perturb_(network.Network().eval())
+    rec = Recorder()
+    for f in ("mask_viewport", "raw2outputs_blend"):
+        rec.wrap(utils, f)
+    batch2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    with torch.no_grad():
+        out = net2(batch2)
+    rec.data.update({"sel/" + k: v for k, v in rec_sel.data.items()})
+    key = list(sel.keys())[0]
+    # weights are identical to enerf_tiny.npz (same seed + perturbation): not stored again
+    save("boost_enerf_tiny", inputs, None, rec, out,
+         extra={"volume_planes": TINY_PLANES, "k_best": sel[key], "n_views": n_views, "hw": [TINY_H, TINY_W]})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "enerf"
+    {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf}[which]()

@@ -1,0 +1,108 @@
+"""Pin the CPU oracle (oracle/enerf.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import torch
+
+from conftest import assert_close, tiny_cfg
+from oracle import enerf as O
+
+
+def test_proj_mats(enerf_fx):
+    b = enerf_fx.batch()
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    for lvl in range(2):
+        P = O.proj_mats(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"], c.im_feat_scale[lvl], c.volume_scale[lvl])
+        assert_close(P, enerf_fx.t(f"cap/get_proj_mats#{lvl}"), rtol=1e-4, atol_scale=1e-5, name=f"proj{lvl}")
+
+
+def test_depth_hypotheses(enerf_fx):
+    b = enerf_fx.batch()
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    dv0, nf0 = O.depth_hypotheses_uniform(b["near_far"], c.volume_planes[0], 8, 12, True)
+    assert_close(dv0, enerf_fx.t("cap/get_depth_values#0.0"), rtol=1e-6, atol_scale=0, name="dv0")
+    assert_close(nf0, enerf_fx.t("cap/get_depth_values#0.1"), rtol=1e-6, atol_scale=0, name="nf0")
+    depth, std = enerf_fx.t("cap/depth_regression#0.0"), enerf_fx.t("cap/depth_regression#0.1")
+    dv1, nf1 = O.depth_hypotheses_cascade(depth, std, nf0, 4.0, c.volume_planes[1], True, False)
+    assert_close(dv1, enerf_fx.t("cap/get_depth_values#1.0"), rtol=1e-5, atol_scale=0, name="dv1")
+    assert_close(nf1, enerf_fx.t("cap/get_depth_values#1.1"), rtol=1e-5, atol_scale=0, name="nf1")
+
+
+def test_warp_and_variance(enerf_fx):
+    b = enerf_fx.batch()
+    f2, f1, f0 = (enerf_fx.t(f"cap/feature_net#0.{i}") for i in range(3))
+    feats = {0: f2[None], 1: f1[None]}
+    for lvl in range(2):
+        P = enerf_fx.t(f"cap/get_proj_mats#{lvl}")
+        dv = enerf_fx.t(f"cap/get_depth_values#{lvl}.0")
+        w, g = O.homo_warp(feats[lvl][:, 1], P[:, 1], dv)
+        call = 1 + 3 * lvl
+        assert_close(g, enerf_fx.t(f"cap/homo_warp#{call}.1"), rtol=1e-5, atol_scale=1e-5, name=f"grid{lvl}")
+        assert_close(w, enerf_fx.t(f"cap/homo_warp#{call}.0"), name=f"warp{lvl}")
+        var = O.variance_volume(feats[lvl], P, dv)
+        assert_close(var, enerf_fx.t(f"cap/build_feature_volume#{lvl}.0"), name=f"var{lvl}")
+
+
+def test_feature_net_and_cost_reg(enerf_fx):
+    sd = enerf_fx.group("sd")
+    b = enerf_fx.batch()
+    f2, f1, f0 = O.feature_net(sd, b["src_inps"][0])
+    for i, f in enumerate((f2, f1, f0)):
+        assert_close(f, enerf_fx.t(f"cap/feature_net#0.{i}"), rtol=1e-4, atol_scale=1e-5, name=f"feat{i}")
+    for lvl in range(2):
+        feat, prob = O.cost_reg(sd, f"cost_reg_{lvl}.", enerf_fx.t(f"cap/build_feature_volume#{lvl}.0"), deep=lvl > 0)
+        assert_close(feat, enerf_fx.t(f"cap/cost_reg_{lvl}#0.0"), rtol=1e-4, atol_scale=1e-5, name=f"fvol{lvl}")
+        assert_close(prob, enerf_fx.t(f"cap/cost_reg_{lvl}#0.1"), rtol=1e-4, atol_scale=1e-5, name=f"prob{lvl}")
+
+
+def test_depth_regress(enerf_fx):
+    for lvl, inv in ((0, True), (1, False)):
+        d, s = O.depth_regress(enerf_fx.t(f"cap/cost_reg_{lvl}#0.1"), enerf_fx.t(f"cap/get_depth_values#{lvl}.0"), inv)
+        assert_close(d, enerf_fx.t(f"cap/depth_regression#{lvl}.0"), rtol=1e-5, atol_scale=0, name=f"depth{lvl}")
+        assert_close(s, enerf_fx.t(f"cap/depth_regression#{lvl}.1"), rtol=1e-4, atol_scale=1e-6, name=f"std{lvl}")
+
+
+def test_rays_samples(enerf_fx):
+    b = enerf_fx.batch()
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    for lvl, inv in ((0, True), (1, False)):
+        rays = O.rays_with_bounds(b[f"rays_{lvl}"], enerf_fx.t(f"cap/depth_regression#{lvl}.0"),
+                                  enerf_fx.t(f"cap/depth_regression#{lvl}.1"), enerf_fx.t(f"cap/get_depth_values#{lvl}.1"),
+                                  c.render_scale[lvl] / c.volume_scale[lvl], inv)
+        assert_close(rays, enerf_fx.t(f"cap/build_rays#{lvl}"), rtol=1e-5, atol_scale=1e-6, name=f"rays{lvl}")
+        xyz, uvd, z = O.sample_points(rays, c.num_samples[lvl], inv)
+        assert_close(xyz, enerf_fx.t(f"cap/sample_along_depth#{lvl}.0"), rtol=1e-5, atol_scale=1e-6, name="xyz")
+        assert_close(uvd, enerf_fx.t(f"cap/sample_along_depth#{lvl}.1"), rtol=1e-4, atol_scale=1e-5, name="uvd")
+        assert_close(z, enerf_fx.t(f"cap/sample_along_depth#{lvl}.2"), rtol=1e-5, atol_scale=1e-6, name="z")
+
+
+def test_lookups_mlp_composite(enerf_fx):
+    sd = enerf_fx.group("sd")
+    b = enerf_fx.batch()
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    feats = {0: enerf_fx.t("cap/feature_net#0.0")[None], 2: enerf_fx.t("cap/feature_net#0.2")[None]}
+    for lvl in range(2):
+        rs = c.render_scale[lvl]
+        rgbs = O.unpreprocess(b["src_inps"], rs)
+        assert_close(rgbs, enerf_fx.t(f"cap/unpreprocess#{lvl}"), rtol=1e-5, atol_scale=1e-6, name="unpre")
+        uvd = enerf_fx.t(f"cap/sample_along_depth#{lvl}.1")
+        Hr, Wr = int(H * rs), int(W * rs)
+        uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3)
+        vox = O.vox_lookup(uvd01, enerf_fx.t(f"cap/cost_reg_{lvl}#0.0"))
+        assert_close(vox, enerf_fx.t(f"cap/get_vox_feat#{lvl}"), name=f"vox{lvl}")
+        img = torch.cat([feats[c.render_im_feat_level[lvl]], rgbs], 2)
+        feat = O.img_lookup(enerf_fx.t(f"cap/sample_along_depth#{lvl}.0"), img, b["src_exts"], b["src_ixts"], b["tar_ext"], rs)
+        assert_close(feat, enerf_fx.t(f"cap/get_img_feat#{lvl}"), name=f"imgfeat{lvl}")
+        raw = O.nerf_mlp(sd, f"nerf_{lvl}.", vox, feat)
+        assert_close(raw, enerf_fx.t(f"cap/nerf_{lvl}#0"), name=f"mlp{lvl}")
+        out = O.composite(raw.reshape(1, -1, c.num_samples[lvl], 4), enerf_fx.t(f"cap/sample_along_depth#{lvl}.2"))
+        for k in ("rgb", "depth", "weights"):
+            assert_close(out[k], enerf_fx.t(f"cap/raw2outputs#{lvl}.{k}"), name=f"{k}{lvl}")
+
+
+def test_enerf_forward_end_to_end(enerf_fx):
+    sd = enerf_fx.group("sd")
+    out = O.enerf_forward(sd, enerf_fx.batch(), tiny_cfg(enerf_fx))
+    want = enerf_fx.group("out")
+    assert set(out) == set(want)
+    for k in want:
+        assert_close(out[k], want[k], name=k)
