@@ -1,0 +1,112 @@
+"""ctypes binding of libbmv.so (include/bmv.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, an
+exception is raised.  The product path never routes through torch ops or the
+CPU oracle for the functions this library implements.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbmv.so")
+
+_lib = None
+
+c_f = C.c_void_p   # device pointers travel as void*
+c_i = C.c_int
+c_l = C.c_long
+c_fl = C.c_float
+
+
+class NerfParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "view_fc_w", "view_fc_b", "global_fc_w", "global_fc_b", "agg_w_w", "agg_w_b", "fc_w", "fc_b",
+        "lr0_w", "lr0_b", "sigma_w", "sigma_b", "color0_w", "color0_b", "color2_w", "color2_b")]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("rays", "depth", "std", "near_far", "volume", "im_feat", "rgb_src",
+                                           "src_exts", "src_ixts", "tar_ext", "blob")]
+                + [(n, C.c_int) for n in ("B", "N", "S", "feat_ch", "Ns", "depth_inv", "hv", "wv", "Dv", "Hr", "Wr")]
+                + [("render_scale", C.c_float)]
+                + [(n, C.c_int) for n in ("rgb_affine", "white_bkgd", "mode", "ray_begin", "ray_end")]
+                + [(n, C.c_void_p) for n in ("out0", "out1", "out2")])
+
+
+# name -> argtypes (all return int unless noted); mirrors include/bmv.h one to one
+SIGNATURES = {
+    "bmv_proj_mats": [c_f, c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_f, c_f],
+    "bmv_depth_values_uniform": [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f],
+    "bmv_depth_regress_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_build_rays": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_sample_along_depth": [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_unpreprocess": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_vox_feat": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_img_feat": [c_f, c_f, c_f, c_f, c_f, c_fl, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_nerf_blob_size": [c_i],
+    "bmv_nerf_pack_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],
+    "bmv_nerf_mlp_fwd": [c_f, c_f, c_f, c_i, c_l, c_f, c_f],
+    "bmv_composite_fwd": [c_f, c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_mask_viewport": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_i, c_f, c_f],
+    "bmv_blend_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_render_rays_fwd": [C.POINTER(RenderArgs), c_f],
+    "bmv_version": [],
+}
+
+
+def load():
+    """Load libbmv.so once; raises ImportError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if os.environ.get("BMV_AUTOBUILD", "0") == "1":
+            from . import build
+            build.build(verbose=False)
+        else:
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP kernels first "
+                "(python -m boostmvsnerfs_amd.build, or __graft_entry__.build()). "
+                "There is no CPU / torch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so is stale: loud by design
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.bmv_last_error.argtypes = []
+    lib.bmv_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bmv_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libbmv {what} failed (code {rc}): {msg}")
+
+
+def dptr(t, name="tensor"):
+    """Device pointer of a contiguous fp32 CUDA tensor (validated)."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the BoostMVSNeRFs hot path runs on the GPU only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,129 @@
+// Shared device helpers for the BoostMVSNeRFs hot-path kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bmv.h"
+
+namespace bmv {
+
+void set_error(const char* fmt, ...);
+
+#define BMV_REQUIRE(cond, ...)                  \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::bmv::set_error(__VA_ARGS__);            \
+      return BMV_ERR_INVALID;                   \
+    }                                           \
+  } while (0)
+
+#define BMV_LAUNCH_END(name)                                                        \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      ::bmv::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return BMV_ERR_LAUNCH;                                                        \
+    }                                                                               \
+    return BMV_OK;                                                                  \
+  } while (0)
+
+static inline hipStream_t as_stream(bmv_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// Bilinear taps with torch.grid_sample(align_corners=True) semantics.
+// Offsets are in elements of one channel plane (y * W + x); taps that fall
+// outside get weight 0 and offset 0 so loads stay in bounds.
+// ---------------------------------------------------------------------------
+struct Taps2 {
+  int o00, o01, o10, o11;
+  float w00, w01, w10, w11;
+};
+
+// grid -> pixel:  ix = ((g + 1) / 2) * (W - 1)        (aten grid_sampler_unnormalize)
+__device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * 0.5f) * (float)(size - 1); }
+
+// padding_mode='zeros'.  Finite but huge coordinates (the reference divides by
+// clamp_min(z, 1e-6)) and NaN give all-zero weights; the float->int conversion
+// only happens for coordinates known to be in range.
+__device__ __forceinline__ Taps2 taps_zeros(float ix, float iy, int W, int H) {
+  Taps2 t;
+  float fx = floorf(ix), fy = floorf(iy);
+  bool ok = (fx >= -1.f) && (fx <= (float)(W - 1)) && (fy >= -1.f) && (fy <= (float)(H - 1));
+  if (!ok) {
+    t.o00 = t.o01 = t.o10 = t.o11 = 0;
+    t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+    return t;
+  }
+  int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  float ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy;  // (ix_se - ix), (iy_se - iy)
+  float ax = ix - fx, ay = iy - fy;
+  bool vx0 = x0 >= 0, vx1 = x1 <= W - 1, vy0 = y0 >= 0, vy1 = y1 <= H - 1;
+  t.w00 = (vx0 && vy0) ? ex * ey : 0.f;
+  t.w01 = (vx1 && vy0) ? ax * ey : 0.f;
+  t.w10 = (vx0 && vy1) ? ex * ay : 0.f;
+  t.w11 = (vx1 && vy1) ? ax * ay : 0.f;
+  int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : W - 1, cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : H - 1;
+  t.o00 = cy0 * W + cx0;
+  t.o01 = cy0 * W + cx1;
+  t.o10 = cy1 * W + cx0;
+  t.o11 = cy1 * W + cx1;
+  return t;
+}
+
+// padding_mode='border': coordinates are clipped to [0, size-1] first.
+__device__ __forceinline__ Taps2 taps_border(float ix, float iy, int W, int H) {
+  ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+  if (!(ix == ix)) ix = 0.f;
+  if (!(iy == iy)) iy = 0.f;
+  float fx = floorf(ix), fy = floorf(iy);
+  int x0 = (int)fx, y0 = (int)fy;
+  int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  bool vx1 = (x0 + 1) <= W - 1, vy1 = (y0 + 1) <= H - 1;
+  float ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy;
+  float ax = ix - fx, ay = iy - fy;
+  Taps2 t;
+  t.w00 = ex * ey;
+  t.w01 = vx1 ? ax * ey : 0.f;
+  t.w10 = vy1 ? ex * ay : 0.f;
+  t.w11 = (vx1 && vy1) ? ax * ay : 0.f;
+  t.o00 = y0 * W + x0;
+  t.o01 = y0 * W + x1;
+  t.o10 = y1 * W + x0;
+  t.o11 = y1 * W + x1;
+  return t;
+}
+
+__device__ __forceinline__ float tap_fetch(const float* __restrict__ p, const Taps2& t) {
+  // same accumulation order as aten's grid_sampler_2d: nw, ne, sw, se
+  float v = p[t.o00] * t.w00;
+  v += p[t.o01] * t.w01;
+  v += p[t.o10] * t.w10;
+  v += p[t.o11] * t.w11;
+  return v;
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) source coordinate of one axis
+// (aten area_pixel_compute_scale / compute_source_index_and_lambda).
+struct Lerp1 {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp1 upsample_axis(int dst, int in_size, int out_size) {
+  Lerp1 r;
+  float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  float src = scale * (float)dst;
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
+  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+__device__ __forceinline__ float upsample_fetch(const float* __restrict__ p, int W, const Lerp1& ly, const Lerp1& lx) {
+  return ly.l0 * (lx.l0 * p[ly.i0 * W + lx.i0] + lx.l1 * p[ly.i0 * W + lx.i1]) +
+         ly.l1 * (lx.l0 * p[ly.i1 * W + lx.i0] + lx.l1 * p[ly.i1 * W + lx.i1]);
+}
+
+}  // namespace bmv

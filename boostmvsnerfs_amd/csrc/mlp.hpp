@@ -1,0 +1,334 @@
+// ENeRF's tiny MLP (a11: Agg + NeRF, lib/networks/enerf/nerf.py:29-43, 74-89) on
+// the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Orientation.  Every layer is computed transposed, OUT^T[n, sample] = W[n, k] IN^T[k, sample],
+// with the weights as the MFMA A operand and the activations as B, so that the
+// SAMPLE index lives on the lane (lane & 31) and the neurons live in the 16
+// accumulator registers: lane (s, h = lane >> 5) register r holds neuron
+// n16(r, h) = (r & 3) + 8 (r >> 2) + 4 h of sample s.  A 32x32x2 step consumes
+// k = 2 inputs, one from each lane half, so the accumulator registers of one
+// layer are directly the B operands of the next (k-step r takes register r from
+// both halves = inputs n16(r,0), n16(r,1)); the weights are pre-permuted to that
+// k order once (pack kernel below).  No activation ever crosses lanes or LDS
+// between layers; only the 1-wide heads (agg weight, sigma, colour logit) need a
+// single cross-half add.
+//
+// Algebra.  global_fc and color.0 are split into a part shared by the S=3 views
+// (computed once, then used as the C-in of each view's chain) and a per-view part:
+//   global_fc([f_i, var, mean]) = Wg[:, :F] f_i + (Wg[:, F:2F] var + Wg[:, 2F:] mean + b)
+//   color.0([x, v, in_i])       = Wc[:, 88:] in_i + (Wc[:, :88] [x, v] + b)
+// 205 MFMAs per 32 samples for feat_ch = 8 (26.2 kFLOP/sample instead of 50.9).
+#pragma once
+#include "bmv_common.hpp"
+
+namespace bmv {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__host__ __device__ constexpr int n16(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int FEAT_CH>
+struct MlpLayout {
+  static constexpr int FC = FEAT_CH + 3;       // image feature + rgb channels per view
+  static constexpr int KFC = (FC + 1) / 2;     // k-steps covering them (2 per step)
+  static constexpr int KF = KFC + 2;           // + 4 direction components
+  static constexpr int IN = FC + 4;            // per-view input width of the reference
+  // MFMA A tables: [step][tile][64 lanes]
+  static constexpr int A_GSH = 0;                          // global_fc, var|mean part: 2*KFC steps
+  static constexpr int A_GV = A_GSH + 2 * KFC * 64;        // global_fc, per-view part:  KFC steps
+  static constexpr int A_FC = A_GV + KFC * 64;             // agg.fc: 16 steps
+  static constexpr int A_L0 = A_FC + 16 * 64;              // lr0: 12 steps x 2 tiles
+  static constexpr int A_CSH = A_L0 + 12 * 2 * 64;         // color.0 shared part: 44 steps x 2 tiles
+  static constexpr int A_CV = A_CSH + 44 * 2 * 64;         // color.0 per-view part: KF steps x 2 tiles
+  // VALU tables: [idx][2 halves]
+  static constexpr int V_VF = A_CV + KF * 2 * 64;          // view_fc: [KFC][4 w + bias]
+  static constexpr int V_BG = V_VF + KFC * 5 * 2;          // global_fc bias [16]
+  static constexpr int V_WA = V_BG + 32;                   // agg_w_fc weight [16]
+  static constexpr int V_BFC = V_WA + 32;                  // agg.fc bias [16]
+  static constexpr int V_B0 = V_BFC + 32;                  // lr0 bias [2*16]
+  static constexpr int V_WS = V_B0 + 64;                   // sigma weight [2*16]
+  static constexpr int V_BC = V_WS + 64;                   // color.0 bias [2*16]
+  static constexpr int V_WC2 = V_BC + 64;                  // color.2 weight [2*16]
+  static constexpr int V_SC = V_WC2 + 64;                  // scalars: agg_w bias, sigma bias, color.2 bias
+  static constexpr int TOTAL = (V_SC + 4 + 3) / 4 * 4;
+};
+
+// --------------------------------------------------------------------------
+// Weight packing: one thread per blob element, reading the reference's
+// parameter tensors (row-major (out, in) weights) directly.
+// --------------------------------------------------------------------------
+template <int FEAT_CH>
+__global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
+  using L = MlpLayout<FEAT_CH>;
+  constexpr int FC = L::FC, KFC = L::KFC;
+  constexpr int CW = 88 + FC + 4;  // color.0 input width
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L::TOTAL) return;
+  float v = 0.f;
+  if (idx < L::V_VF) {
+    int lane = idx & 63, e = idx >> 6;  // all A tables are 64-aligned
+    int i = lane & 31, h = lane >> 5;
+    if (idx < L::A_GV) {
+      int t = e - L::A_GSH / 64;
+      int which = t / KFC, c = 2 * (t % KFC) + h;
+      if (c < FC) v = p.global_fc_w[i * 3 * FC + FC * (1 + which) + c];
+    } else if (idx < L::A_FC) {
+      int t = e - L::A_GV / 64, c = 2 * t + h;
+      if (c < FC) v = p.global_fc_w[i * 3 * FC + c];
+    } else if (idx < L::A_L0) {
+      int t = e - L::A_FC / 64;
+      if (i < 16) v = p.fc_w[i * 32 + n16(t, h)];
+    } else if (idx < L::A_CSH) {
+      int q = e - L::A_L0 / 64, t = q >> 1, n = 32 * (q & 1) + i;
+      int k = t < 4 ? 2 * t + h : 8 + n16(t - 4, h);
+      v = p.lr0_w[n * 24 + k];
+    } else if (idx < L::A_CV) {
+      int q = e - L::A_CSH / 64, t = q >> 1, n = 32 * (q & 1) + i;
+      int k;
+      if (t < 32)
+        k = 32 * (t >> 4) + n16(t & 15, h);
+      else if (t < 36)
+        k = 64 + 2 * (t - 32) + h;
+      else
+        k = 72 + n16(t - 36, h);
+      v = p.color0_w[n * CW + k];
+    } else {
+      int q = e - L::A_CV / 64, t = q >> 1, n = 32 * (q & 1) + i;
+      if (t < KFC) {
+        int c = 2 * t + h;
+        if (c < FC) v = p.color0_w[n * CW + 88 + c];
+      } else {
+        v = p.color0_w[n * CW + 88 + FC + 2 * (t - KFC) + h];
+      }
+    }
+  } else {
+    int rel, h;
+    if (idx < L::V_BG) {
+      rel = idx - L::V_VF, h = rel & 1, rel >>= 1;
+      int j = rel / 5, q = rel % 5, c = 2 * j + h;
+      if (c < FC) v = q < 4 ? p.view_fc_w[c * 4 + q] : p.view_fc_b[c];
+    } else if (idx < L::V_WA) {
+      rel = idx - L::V_BG, h = rel & 1, rel >>= 1;
+      v = p.global_fc_b[n16(rel, h)];
+    } else if (idx < L::V_BFC) {
+      rel = idx - L::V_WA, h = rel & 1, rel >>= 1;
+      v = p.agg_w_w[n16(rel, h)];
+    } else if (idx < L::V_B0) {
+      rel = idx - L::V_BFC, h = rel & 1, rel >>= 1;
+      int n = n16(rel, h);
+      if (n < 16) v = p.fc_b[n];
+    } else if (idx < L::V_WS) {
+      rel = idx - L::V_B0, h = rel & 1, rel >>= 1;
+      v = p.lr0_b[32 * (rel >> 4) + n16(rel & 15, h)];
+    } else if (idx < L::V_BC) {
+      rel = idx - L::V_WS, h = rel & 1, rel >>= 1;
+      v = p.sigma_w[32 * (rel >> 4) + n16(rel & 15, h)];
+    } else if (idx < L::V_WC2) {
+      rel = idx - L::V_BC, h = rel & 1, rel >>= 1;
+      v = p.color0_b[32 * (rel >> 4) + n16(rel & 15, h)];
+    } else if (idx < L::V_SC) {
+      rel = idx - L::V_WC2, h = rel & 1, rel >>= 1;
+      v = p.color2_w[32 * (rel >> 4) + n16(rel & 15, h)];
+    } else {
+      rel = idx - L::V_SC;
+      v = rel == 0 ? p.agg_w_b[0] : rel == 1 ? p.sigma_b[0] : rel == 2 ? p.color2_b[0] : 0.f;
+    }
+  }
+  blob[idx] = v;
+}
+
+#define BMV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// The weight reads are LDS loads with compile-time offsets; left alone, the
+// scheduler hoists dozens of them ahead of the MFMA chain they feed and spills.
+// A scheduling fence every few k-steps keeps the live set to one chunk.
+#define BMV_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BMV_FENCE_EVERY(t, n) \
+  do {                         \
+    if (((t) % (n)) == (n)-1) BMV_FENCE(); \
+  } while (0)
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// --------------------------------------------------------------------------
+// Per-lane inputs (lane = (sample s, half h)):
+//   fin[i][j]  j <  KFC : channel 2j+h of view i's [feature, rgb] vector (0 beyond FC)
+//              j >= KFC : direction component 2(j-KFC)+h
+//   dir[i][q]  all four direction components of view i
+//   vox[j]     feature-volume channel 2j+h
+// W: the packed blob in LDS.  out = [r, g, b, sigma], identical in both halves.
+// --------------------------------------------------------------------------
+template <int FEAT_CH>
+__device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lane,
+                                            const float (&fin)[3][MlpLayout<FEAT_CH>::KF], const float (&dir)[3][4],
+                                            const float (&vox)[4], float (&out)[4]) {
+  using L = MlpLayout<FEAT_CH>;
+  constexpr int KFC = L::KFC, KF = L::KF;
+  const int h = lane >> 5;
+  const float* __restrict__ Wa = W + lane;
+  const float* __restrict__ Wv = W + h;
+
+  // Agg.view_fc + residual (nerf.py:77-79): f_i = in_i[:F] + relu(W_v dir_i + b).  f is
+  // cheap, so it is recomputed where the per-view chain needs it instead of kept live.
+  auto fval = [&](int i, int j) -> float {
+    float pre = Wv[L::V_VF + (j * 5 + 4) * 2] + Wv[L::V_VF + (j * 5 + 0) * 2] * dir[i][0] +
+                Wv[L::V_VF + (j * 5 + 1) * 2] * dir[i][1] + Wv[L::V_VF + (j * 5 + 2) * 2] * dir[i][2] +
+                Wv[L::V_VF + (j * 5 + 3) * 2] * dir[i][3];
+    return fin[i][j] + fmaxf(pre, 0.f);
+  };
+  // unbiased variance and mean over the 3 views (nerf.py:83-84)
+  float var[KFC], mean[KFC];
+#pragma unroll
+  for (int j = 0; j < KFC; ++j) {
+    float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
+    float m = (f0 + f1 + f2) / 3.f;
+    float d0 = f0 - m, d1 = f1 - m, d2 = f2 - m;
+    mean[j] = m;
+    var[j] = (d0 * d0 + d1 * d1 + d2 * d2) * 0.5f;
+    BMV_FENCE_EVERY(j, 6);
+  }
+  BMV_FENCE();
+  // global_fc (nerf.py:86-87)
+  f32x16 gsh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
+#pragma unroll
+  for (int t = 0; t < KFC; ++t) {
+    gsh = BMV_MFMA(Wa[L::A_GSH + t * 64], var[t], gsh);
+    BMV_FENCE_EVERY(t, 6);
+  }
+  BMV_FENCE();
+#pragma unroll
+  for (int t = 0; t < KFC; ++t) {
+    gsh = BMV_MFMA(Wa[L::A_GSH + (KFC + t) * 64], mean[t], gsh);
+    BMV_FENCE_EVERY(t, 6);
+  }
+  BMV_FENCE();
+  f32x16 g[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g[i] = gsh;
+#pragma unroll
+    for (int t = 0; t < KFC; ++t) {
+      g[i] = BMV_MFMA(Wa[L::A_GV + t * 64], fval(i, t), g[i]);
+      BMV_FENCE_EVERY(t, 6);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[i][r] = fmaxf(g[i][r], 0.f);
+    BMV_FENCE();
+  }
+  // agg_w_fc + softmax over views + weighted sum (nerf.py:88-89)
+  float aw[3];
+  const float ba = W[L::V_SC + 0], bs = W[L::V_SC + 1], bc2 = W[L::V_SC + 2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += Wv[L::V_WA + r * 2] * g[i][r];
+    aw[i] = fmaxf(xhalf_sum(s) + ba, 0.f);
+  }
+  {
+    float m = fmaxf(aw[0], fmaxf(aw[1], aw[2]));
+    float e0 = __expf(aw[0] - m), e1 = __expf(aw[1] - m), e2 = __expf(aw[2] - m);
+    float inv = 1.f / (e0 + e1 + e2);
+    aw[0] = e0 * inv, aw[1] = e1 * inv, aw[2] = e2 * inv;
+  }
+  // agg.fc (nerf.py:90): 32 -> 16
+  f32x16 q;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = Wv[L::V_BFC + r * 2];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float im = aw[0] * g[0][t] + aw[1] * g[1][t] + aw[2] * g[2][t];
+    q = BMV_MFMA(Wa[L::A_FC + t * 64], im, q);
+    BMV_FENCE_EVERY(t, 8);
+  }
+  BMV_FENCE();
+  float im16[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) im16[r] = fmaxf(q[r], 0.f);
+  // lr0 (nerf.py:34-35): [vox(8), im(16)] -> 64
+  f32x16 x[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[tl][r] = Wv[L::V_B0 + (tl * 16 + r) * 2];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) {
+    float b = t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) x[tl] = BMV_MFMA(Wa[L::A_L0 + (t * 2 + tl) * 64], b, x[tl]);
+    BMV_FENCE_EVERY(t, 4);
+  }
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[tl][r] = fmaxf(x[tl][r], 0.f);
+  // sigma head (nerf.py:38)
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Wv[L::V_WS + (tl * 16 + r) * 2] * x[tl][r];
+    float pre = xhalf_sum(s) + bs;
+    out[3] = pre > 20.f ? pre : log1pf(__expf(pre));
+  }
+  // color.0 shared part: [x(64), vox(8), im(16)]
+  f32x16 csh[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) csh[tl][r] = Wv[L::V_BC + (tl * 16 + r) * 2];
+#pragma unroll
+  for (int t = 0; t < 44; ++t) {
+    float b;
+    if (t < 32)
+      b = x[t < 32 ? (t >> 4) : 0][t & 15];
+    else if (t < 36)
+      b = vox[t >= 32 && t < 36 ? t - 32 : 0];
+    else
+      b = im16[t >= 36 ? t - 36 : 0];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) csh[tl] = BMV_MFMA(Wa[L::A_CSH + (t * 2 + tl) * 64], b, csh[tl]);
+    BMV_FENCE_EVERY(t, 4);
+  }
+  BMV_FENCE();
+  // per-view part + color.2 + softmax over views (nerf.py:39-42)
+  float cl[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f32x16 hc[2] = {csh[0], csh[1]};
+#pragma unroll
+    for (int t = 0; t < KF; ++t) {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) hc[tl] = BMV_MFMA(Wa[L::A_CV + (t * 2 + tl) * 64], fin[i][t], hc[tl]);
+      BMV_FENCE_EVERY(t, 4);
+    }
+    BMV_FENCE();
+    float s = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Wv[L::V_WC2 + (tl * 16 + r) * 2] * fmaxf(hc[tl][r], 0.f);
+    cl[i] = fmaxf(xhalf_sum(s) + bc2, 0.f);
+    BMV_FENCE();
+  }
+  {
+    float m = fmaxf(cl[0], fmaxf(cl[1], cl[2]));
+    float e0 = __expf(cl[0] - m), e1 = __expf(cl[1] - m), e2 = __expf(cl[2] - m);
+    float inv = 1.f / (e0 + e1 + e2);
+    cl[0] = e0 * inv, cl[1] = e1 * inv, cl[2] = e2 * inv;
+  }
+  // blend the sampled source colours: channels FEAT_CH + {0,1,2} sit at
+  // (half 0, slot J), (half 1, slot J), (half 0, slot J+1) with J = FEAT_CH / 2
+  constexpr int J = FEAT_CH / 2;
+  static_assert(FEAT_CH % 2 == 0, "feat_ch must be even");
+  float pa = cl[0] * fin[0][J] + cl[1] * fin[1][J] + cl[2] * fin[2][J];
+  float pb = cl[0] * fin[0][J + 1] + cl[1] * fin[1][J + 1] + cl[2] * fin[2][J + 1];
+  float oa = __shfl_xor(pa, 32, 64), ob = __shfl_xor(pb, 32, 64);
+  out[0] = h == 0 ? pa : oa;
+  out[1] = h == 0 ? oa : pa;
+  out[2] = h == 0 ? pb : ob;
+}
+
+}  // namespace bmv

@@ -1,0 +1,286 @@
+// Fused renderer: rays -> per-ray bounds -> samples -> volume / image lookups ->
+// MFMA MLP -> alpha compositing, one kernel (a6-a12, a14).
+// Reference: lib/networks/enerf/network.py:24-43 (render_rays),
+//            lib/networks/boost_enerf/network.py:123-149 (MLP-only variant + masks).
+//
+// Work decomposition: a wave owns tiles of 32 samples (= 32/Ns consecutive rays);
+// lane = (sample s = lane & 31, half h = lane >> 5).  Both halves compute the
+// sample's geometry; the gathers are split between them by channel parity, which
+// is exactly the k-slot order the MLP wants (mlp.hpp).  The MLP weights sit in
+// LDS once per workgroup (4 waves) and the workgroup walks tiles grid-stride.
+#include "mlp.hpp"
+#include "render_geom.hpp"
+
+namespace bmv {
+
+struct RenderCams {
+  Cam cam[3];
+  float tar_c[4];
+};
+
+template <int FEAT_CH>
+__global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
+                                                           const float* __restrict__ img,
+                                                           const float* __restrict__ blob, long npts,
+                                                           float* __restrict__ out) {
+  using L = MlpLayout<FEAT_CH>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(blob)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 31, h = lane >> 5;
+  long ntiles = (npts + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    long pt = tile * 32 + s;
+    bool valid = pt < npts;
+    long p = valid ? pt : npts - 1;
+    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vox[j] = vox_feat[p * 8 + 2 * j + h];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float* q = img + (p * 3 + i) * L::IN;
+#pragma unroll
+      for (int j = 0; j < L::KFC; ++j) fin[i][j] = (2 * j + h < L::FC) ? q[2 * j + h] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) fin[i][L::KFC + k] = q[L::FC + 2 * k + h];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dir[i][k] = q[L::FC + k];
+    }
+    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    if (valid && h == 0) {
+      float4 o = {res[0], res[1], res[2], res[3]};
+      reinterpret_cast<float4*>(out)[pt] = o;
+    }
+  }
+}
+
+template <int FEAT_CH, int NS, bool INV>
+__global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) {
+  using L = MlpLayout<FEAT_CH>;
+  static_assert(32 % NS == 0, "samples per ray must divide 32");
+  constexpr int RAYS_PER_TILE = 32 / NS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  RenderCams* rc = reinterpret_cast<RenderCams*>(lds + L::TOTAL);
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
+  if (threadIdx.x < 3)
+    load_cam(a.src_exts + ((size_t)b * 3 + threadIdx.x) * 16, a.src_ixts + ((size_t)b * 3 + threadIdx.x) * 9,
+             a.render_scale, rc->cam[threadIdx.x]);
+  if (threadIdx.x == 3) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 31, h = lane >> 5;
+  const int k = s % NS;  // sample index along the ray
+  const size_t hwv = (size_t)a.hv * a.wv;
+  const size_t plane = (size_t)a.Hr * a.Wr;
+  const float* depth = a.depth + b * hwv;
+  const float* std_ = a.std + b * hwv;
+  const float* nf = a.near_far + b * 2 * hwv;
+  const float* vol = a.volume + (size_t)b * 8 * a.Dv * hwv;
+  const float inv_w = (float)(a.Wr - 1), inv_h = (float)(a.Hr - 1);
+
+  const int nrays = a.ray_end - a.ray_begin;
+  const int ntiles = (nrays + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    int ray = a.ray_begin + tile * RAYS_PER_TILE + s / NS;
+    bool valid = ray < a.ray_end;
+    int rr = valid ? ray : a.ray_end - 1;
+    const float* r = a.rays + ((size_t)b * a.N + rr) * 8;
+    float o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
+    float px = r[6], py = r[7];
+    float rn, rf, vn, vf;
+    ray_bounds(depth, std_, nf, a.hv, a.wv, a.Hr, a.Wr, (int)px, (int)py, INV, rn, rf, vn, vf);
+    float z, xyz[3], dn;
+    sample_point(o, d, rn, rf, vn, vf, k, NS, INV, z, xyz, dn);
+
+    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    {  // a9: trilinear lookup, this half's 4 channels
+      Taps3 t3 = taps3_zeros(px / inv_w, py / inv_h, dn, a.wv, a.hv, a.Dv);
+      size_t cs = (size_t)a.Dv * hwv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch(vol + (size_t)(2 * j + h) * cs, t3);
+    }
+    BMV_FENCE();
+    float vis = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
+      const Cam& cam = rc->cam[i];
+      Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
+      const float* fp = a.im_feat + ((size_t)b * 3 + i) * FEAT_CH * plane;
+      const float* cp = a.rgb_src + ((size_t)b * 3 + i) * 3 * plane;
+#pragma unroll
+      for (int j = 0; j < L::KFC; ++j) {
+        int c = 2 * j + h;  // channel of [feature, rgb]
+        float v = 0.f;
+        if (2 * j + 1 < FEAT_CH) {  // both halves read a feature channel
+          v = tap_fetch(fp + (size_t)c * plane, t2);
+        } else if (2 * j >= FEAT_CH) {  // colour channels (the last slot of half 1 is padding)
+          int cc = c - FEAT_CH;
+          if (cc < 3) {
+            v = tap_fetch(cp + (size_t)cc * plane, t2);
+            if (a.rgb_affine) v = v * 0.5f + 0.5f;
+          }
+        }
+        fin[i][j] = v;
+        BMV_FENCE_EVERY(j, 6);
+      }
+      dir_feature(xyz, rc->tar_c, cam.c, dir[i]);
+      fin[i][L::KFC] = h ? dir[i][1] : dir[i][0];
+      fin[i][L::KFC + 1] = h ? dir[i][3] : dir[i][2];
+      if (a.mode == 1) vis += visible(cam, xyz, inv_w, inv_h);
+      BMV_FENCE();
+    }
+
+    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+
+    if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
+      if (valid && h == 0) {
+        size_t pt = ((size_t)b * a.N + ray) * NS + k;
+        float4 o4 = {res[0], res[1], res[2], res[3]};
+        reinterpret_cast<float4*>(a.out0)[pt] = o4;
+        a.out1[pt] = z;
+        a.out2[pt] = vis / 3.f;
+      }
+      continue;
+    }
+    // a12: composite the NS samples of a ray; they sit on NS consecutive lanes.
+    float alpha = 1.f - __expf(-res[3]);
+    float om = 1.f - alpha + 1e-10f;
+    float T = 1.f;  // exclusive product of om over samples before k
+#pragma unroll
+    for (int j = 1; j < NS; ++j) {
+      float prev = __shfl_up(om, j, NS);
+      if (k >= j) T *= prev;
+    }
+    float w = alpha * T;
+    float c0 = w * res[0], c1 = w * res[1], c2 = w * res[2];
+    float wmax = w;
+#pragma unroll
+    for (int m = 1; m < NS; m <<= 1) {
+      c0 += __shfl_xor(c0, m, NS);
+      c1 += __shfl_xor(c1, m, NS);
+      c2 += __shfl_xor(c2, m, NS);
+      wmax = fmaxf(wmax, __shfl_xor(wmax, m, NS));
+    }
+    float e = __expf(w - wmax), den = e;
+#pragma unroll
+    for (int m = 1; m < NS; m <<= 1) den += __shfl_xor(den, m, NS);
+    float sm = e / den;
+    float dz = sm * z, acc = sm;
+#pragma unroll
+    for (int m = 1; m < NS; m <<= 1) {
+      dz += __shfl_xor(dz, m, NS);
+      acc += __shfl_xor(acc, m, NS);
+    }
+    if (a.white_bkgd) c0 += 1.f - acc, c1 += 1.f - acc, c2 += 1.f - acc;
+    if (valid && h == 0) {
+      size_t ro = (size_t)b * a.N + ray;
+      a.out2[ro * NS + k] = sm;
+      if (k == 0) {
+        a.out0[ro * 3] = c0, a.out0[ro * 3 + 1] = c1, a.out0[ro * 3 + 2] = c2;
+        a.out1[ro] = dz;
+      }
+    }
+  }
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? 0 : -1;
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+extern "C" {
+
+int bmv_nerf_blob_size(int feat_ch) {
+  if (feat_ch == 8) return MlpLayout<8>::TOTAL;
+  if (feat_ch == 32) return MlpLayout<32>::TOTAL;
+  set_error("bmv_nerf_blob_size: feat_ch=%d unsupported (8 or 32)", feat_ch);
+  return BMV_ERR_UNSUPPORTED;
+}
+
+int bmv_nerf_pack_weights(const bmv_nerf_params* p, int feat_ch, float* blob, bmv_stream_t stream) {
+  BMV_REQUIRE(p && blob, "bmv_nerf_pack_weights: null pointer");
+  const float* const* pp = reinterpret_cast<const float* const*>(p);
+  for (int i = 0; i < 16; ++i) BMV_REQUIRE(pp[i], "bmv_nerf_pack_weights: parameter %d is null", i);
+  if (feat_ch == 8)
+    hipLaunchKernelGGL(nerf_pack_kernel<8>, dim3(cdiv(MlpLayout<8>::TOTAL, 256)), dim3(256), 0, as_stream(stream), *p,
+                       blob);
+  else if (feat_ch == 32)
+    hipLaunchKernelGGL(nerf_pack_kernel<32>, dim3(cdiv(MlpLayout<32>::TOTAL, 256)), dim3(256), 0, as_stream(stream),
+                       *p, blob);
+  else {
+    set_error("bmv_nerf_pack_weights: feat_ch=%d unsupported (8 or 32)", feat_ch);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  BMV_LAUNCH_END("bmv_nerf_pack_weights");
+}
+
+int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob, int feat_ch, long npts, float* out,
+                     bmv_stream_t stream) {
+  BMV_REQUIRE(vox_feat && img && blob && out, "bmv_nerf_mlp_fwd: null pointer");
+  BMV_REQUIRE(npts >= 0, "bmv_nerf_mlp_fwd: npts=%ld", npts);
+  if (npts == 0) return BMV_OK;
+  long ntiles = (npts + 31) / 32;
+  unsigned grid = (unsigned)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
+  if (feat_ch == 8) {
+    size_t lds = MlpLayout<8>::TOTAL * 4;
+    BMV_REQUIRE(set_lds(nerf_mlp_kernel<8>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(nerf_mlp_kernel<8>, dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts,
+                       out);
+  } else if (feat_ch == 32) {
+    size_t lds = MlpLayout<32>::TOTAL * 4;
+    BMV_REQUIRE(set_lds(nerf_mlp_kernel<32>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(nerf_mlp_kernel<32>, dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts,
+                       out);
+  } else {
+    set_error("bmv_nerf_mlp_fwd: feat_ch=%d unsupported (8 or 32)", feat_ch);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
+}
+
+int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
+  BMV_REQUIRE(a, "bmv_render_rays_fwd: null args");
+  BMV_REQUIRE(a->rays && a->depth && a->std && a->near_far && a->volume && a->im_feat && a->rgb_src && a->src_exts &&
+                  a->src_ixts && a->tar_ext && a->blob && a->out0 && a->out1 && a->out2,
+              "bmv_render_rays_fwd: null pointer");
+  BMV_REQUIRE(a->S == 3, "bmv_render_rays_fwd: S=%d, the MLP is built for 3 source views", a->S);
+  BMV_REQUIRE(a->B > 0 && a->N > 0 && a->hv > 0 && a->wv > 0 && a->Dv > 0 && a->Hr > 1 && a->Wr > 1,
+              "bmv_render_rays_fwd: bad shape");
+  BMV_REQUIRE(a->ray_begin >= 0 && a->ray_end <= a->N && a->ray_begin <= a->ray_end,
+              "bmv_render_rays_fwd: ray range [%d,%d) outside [0,%d)", a->ray_begin, a->ray_end, a->N);
+  BMV_REQUIRE(a->mode == 0 || a->mode == 1, "bmv_render_rays_fwd: mode=%d", a->mode);
+  if (a->ray_begin == a->ray_end) return BMV_OK;
+  int nrays = a->ray_end - a->ray_begin;
+#define RENDER_CASE(FC, NSV, INVV)                                                                                  \
+  if (a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                                            \
+    size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
+    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");   \
+    int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
+    unsigned grid = (unsigned)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);                                  \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
+    BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
+  }
+  RENDER_CASE(8, 2, false)
+  RENDER_CASE(32, 8, true)
+  RENDER_CASE(8, 1, false)
+  RENDER_CASE(8, 4, false)
+  RENDER_CASE(8, 8, false)
+  RENDER_CASE(32, 2, true)
+  RENDER_CASE(32, 4, true)
+#undef RENDER_CASE
+  set_error("bmv_render_rays_fwd: no kernel for feat_ch=%d Ns=%d depth_inv=%d", a->feat_ch, a->Ns, a->depth_inv);
+  return BMV_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

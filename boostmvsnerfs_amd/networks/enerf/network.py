@@ -1,0 +1,143 @@
+"""ENeRF on the MI355X hot-path kernels.
+
+Same module boundary as the reference's lib/networks/enerf/network.py:11-113:
+`Network()` is an nn.Module with sub-modules feature_net, cost_reg_{i}, nerf_{i}
+(identical state-dict keys), `forward(batch)` returns
+{rgb,depth,weights,depth_mvs,std}_level{i} for every level with render_if[i].
+
+Inside, a cascade level is five launches instead of the reference's ~150 torch
+ops: projection matrices -> depth hypotheses -> fused plane-sweep variance ->
+[3-D regulariser, torch/MIOpen] -> depth regression -> ONE fused kernel from
+rays to composited pixels (per-ray bounds, samples, volume + image lookups,
+MFMA MLP, alpha compositing).  No warped volume, sample tensor or per-view
+feature tensor is ever materialised.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...config import cfg
+from .cnn import CostRegNet, FeatureNet, MinCostRegNet
+from .nerf import NeRF
+
+
+class LevelState:
+    """What one cascade level hands to the next (and to the renderer)."""
+    __slots__ = ("depth", "std", "near_far", "feature_volume", "depth_values")
+
+    def __init__(self):
+        self.depth = self.std = self.near_far = self.feature_volume = self.depth_values = None
+
+
+class Network(nn.Module):
+    def __init__(self):
+        super().__init__()
+        cc = cfg.enerf.cas_config
+        self.feature_net = FeatureNet()
+        for i in range(cc.num):
+            width = int(32 * 2 ** (-i))
+            setattr(self, f"cost_reg_{i}", MinCostRegNet(width) if i == 0 else CostRegNet(width))
+            setattr(self, f"nerf_{i}", NeRF(feat_ch=cc.nerf_model_feat_ch[i] + 3))
+        # optional intra-frame ray sharding (boostmvsnerfs_amd/sharding.py): render rays [begin, end) only
+        self.ray_range = None
+        self.sweep_algo = 0
+
+    # ------------------------------------------------------------------ 2-D features
+    def forward_feat(self, x):
+        """(B,V,3,H,W) -> {'level_0': 32ch @ 1/4, 'level_1': 16ch @ 1/2, 'level_2': 8ch @ 1}
+        (lib/networks/enerf/network.py:58-67)."""
+        B, V, C, H, W = x.shape
+        coarse, mid, fine = self.feature_net(x.reshape(B * V, C, H, W))
+        return {"level_0": coarse.reshape(B, V, -1, H // 4, W // 4),
+                "level_1": mid.reshape(B, V, -1, H // 2, W // 2),
+                "level_2": fine.reshape(B, V, -1, H, W)}
+
+    # ------------------------------------------------------------------ cost volume of one level
+    def level_front(self, i, feats_i, views, batch, prev):
+        """Plane sweep + regulariser + depth regression (network.py:81-90).
+        `views` = (src_inps, src_exts, src_ixts) of the S views of this cost volume."""
+        cc = cfg.enerf.cas_config
+        src_inps, src_exts, src_ixts = views
+        H, W = src_inps.shape[-2:]
+        h, w = int(H * cc.volume_scale[i]), int(W * cc.volume_scale[i])
+        D = cc.volume_planes[i]
+        st = LevelState()
+        if prev is None or prev.depth is None:
+            st.depth_values, st.near_far = ops.depth_values_uniform(batch["near_far"], D, h, w, cc.depth_inv[i])
+        else:
+            if not cc.depth_inv[i - 1] or cc.depth_inv[i]:
+                raise NotImplementedError("cascade levels must go disparity -> depth")
+            st.depth_values, st.near_far = ops.depth_values_cascade(prev.depth, prev.std, prev.near_far, h, w, D)
+        proj = ops.proj_mats(src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"], cc.im_feat_scale[i],
+                             cc.volume_scale[i])
+        variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
+        st.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
+        st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
+        return st
+
+    # ------------------------------------------------------------------ fused renderer of one level
+    def render_level(self, i, st, im_feat, views, batch, mode=0):
+        """rays -> pixels (mode 0) or raw MLP outputs + depths + visibility (mode 1)
+        (network.py:24-55, boost_enerf/network.py:123-161)."""
+        cc = cfg.enerf.cas_config
+        src_inps, src_exts, src_ixts = views
+        H, W = src_inps.shape[-2:]
+        rs = cc.render_scale[i]
+        Hr, Wr = int(H * rs), int(W * rs)
+        if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
+            raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
+        if rs == 1.0:
+            rgb_src, affine = src_inps, True
+        else:
+            rgb_src, affine = ops.unpreprocess(src_inps, Hr, Wr), False
+        nerf = getattr(self, f"nerf_{i}")
+        rays = batch[f"rays_{i}"]
+        N = rays.shape[1]
+        begin, end = self.ray_range if self.ray_range is not None else (0, N)
+        chunk = int(cfg.enerf.chunk_size)
+        # one launch per chunk keeps the reference's memory bound; with fused kernels a whole frame is one chunk
+        outs = None
+        for c0 in range(begin, end, chunk):
+            o = ops.render_rays(rays, st.depth, st.std, st.near_far, st.feature_volume, im_feat, rgb_src, src_exts,
+                                src_ixts, batch["tar_ext"], nerf.packed_weights(), feat_ch=nerf.feat_ch - 3,
+                                Ns=cc.num_samples[i], depth_inv=cc.depth_inv[i], Hr=Hr, Wr=Wr, render_scale=rs,
+                                rgb_affine=affine, white_bkgd=cfg.enerf.white_bkgd, mode=mode,
+                                ray_range=(c0, min(c0 + chunk, end)))
+            if outs is None:
+                outs = o
+            else:  # later chunks wrote into fresh buffers: merge their slice
+                for dst, src in zip(outs, o):
+                    dst[:, c0:min(c0 + chunk, end)] = src[:, c0:min(c0 + chunk, end)]
+        if (begin, end) != (0, N):
+            outs = tuple(t[:, begin:end] for t in outs)
+        return outs
+
+    # reference method names kept callable (network.py:24-55)
+    def render_rays(self, rays, **kw):
+        raise NotImplementedError("use render_level(): sampling, lookups, MLP and compositing are one fused kernel")
+
+    batchify_rays = render_rays
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("training (backward kernels) is not part of this build yet; "
+                                      "call under torch.no_grad() / eval()")
+        cc = cfg.enerf.cas_config
+        views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
+        feats = self.forward_feat(batch["src_inps"])
+        ret = {}
+        st = None
+        for i in range(cc.num):
+            st = self.level_front(i, feats[f"level_{i}"], views, batch, st)
+            if not cc.render_if[i]:
+                continue
+            rgb, depth, weights = self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)
+            ret_i = {"rgb": rgb, "depth": depth, "weights": weights,
+                     "depth_mvs": torch.reciprocal(st.depth) if cc.depth_inv[i] else st.depth, "std": st.std}
+            if os.environ.get("BMV_CHECK_NAN") == "1" and bool(rgb.isnan().any()):
+                raise FloatingPointError(f"NaN in rgb_level{i}")   # reference: ipdb trap, network.py:110-111
+            ret.update({f"{k}_level{i}": v for k, v in ret_i.items()})
+        return ret

@@ -1,0 +1,244 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of
+include/bmv.h).  Inputs must be CUDA fp32 tensors; outputs are allocated with
+torch (device memory + stream plumbing only) and filled by the HIP kernels.
+Everything runs on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import dptr, stream
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):
+    B, S = src_exts.shape[:2]
+    out = torch.empty(B, S, 3, 4, device=src_exts.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_proj_mats(dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
+                                 dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"),
+                                 float(src_scale), float(tar_scale), B, S, dptr(out), stream()), "proj_mats")
+    return out
+
+
+def depth_values_uniform(near_far, D, h, w, depth_inv):
+    B = near_far.shape[0]
+    dv = torch.empty(B, D, h, w, device=near_far.device, dtype=torch.float32)
+    nf = torch.empty(B, 2, h, w, device=near_far.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_depth_values_uniform(dptr(_c(near_far), "near_far"), B, D, h, w, int(bool(depth_inv)),
+                                            dptr(dv), dptr(nf), stream()), "depth_values_uniform")
+    return dv, nf
+
+
+def depth_values_cascade(depth, std, near_far, h, w, D):
+    B, h0, w0 = depth.shape
+    dv = torch.empty(B, D, h, w, device=depth.device, dtype=torch.float32)
+    nf = torch.empty(B, 2, h, w, device=depth.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_depth_values_cascade(dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                            dptr(_c(near_far), "near_far"), B, h0, w0, h, w, D, dptr(dv), dptr(nf),
+                                            stream()), "depth_values_cascade")
+    return dv, nf
+
+
+def homo_warp(src_feat, proj, depth_values, want_grid=True):
+    B, C_, Hs, Ws = src_feat.shape
+    _, D, h, w = depth_values.shape
+    warped = torch.empty(B, C_, D, h, w, device=src_feat.device, dtype=torch.float32)
+    grid = torch.empty(B, D, h, w, 2, device=src_feat.device, dtype=torch.float32) if want_grid else None
+    lib = _lib.load()
+    _lib.check(lib.bmv_homo_warp_fwd(dptr(_c(src_feat), "src_feat"), dptr(_c(proj), "proj"),
+                                     dptr(_c(depth_values), "depth_values"), B, C_, Hs, Ws, D, h, w, dptr(warped),
+                                     dptr(grid), stream()), "homo_warp")
+    return warped, grid
+
+
+def sweep_variance(feats, proj, depth_values, algo=0, out=None):
+    B, S, C_, Hs, Ws = feats.shape
+    _, D, h, w = depth_values.shape
+    if out is None:
+        out = torch.empty(B, C_, D, h, w, device=feats.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_sweep_variance_fwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
+                                          dptr(_c(depth_values), "depth_values"), B, S, C_, Hs, Ws, D, h, w,
+                                          dptr(out), int(algo), stream()), "sweep_variance")
+    return out
+
+
+def depth_regress(depth_prob, depth_values, depth_inv):
+    B, D, h, w = depth_values.shape
+    depth = torch.empty(B, h, w, device=depth_values.device, dtype=torch.float32)
+    std = torch.empty_like(depth)
+    lib = _lib.load()
+    _lib.check(lib.bmv_depth_regress_fwd(dptr(_c(depth_prob), "depth_prob"), dptr(_c(depth_values), "depth_values"),
+                                         B, D, h, w, int(bool(depth_inv)), dptr(depth), dptr(std), stream()),
+               "depth_regress")
+    return depth, std
+
+
+def build_rays(rays, depth, std, near_far, Hr, Wr, depth_inv):
+    B, N = rays.shape[:2]
+    hv, wv = depth.shape[-2:]
+    out = torch.empty(B, N, 12, device=rays.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_build_rays(dptr(_c(rays), "rays"), dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                  dptr(_c(near_far), "near_far"), B, N, hv, wv, Hr, Wr, int(bool(depth_inv)),
+                                  dptr(out), stream()), "build_rays")
+    return out
+
+
+def sample_along_depth(rays, Ns, depth_inv):
+    B, N = rays.shape[:2]
+    xyz = torch.empty(B, N, Ns, 3, device=rays.device, dtype=torch.float32)
+    uvd = torch.empty(B, N, Ns, 3, device=rays.device, dtype=torch.float32)
+    z = torch.empty(B, N, Ns, device=rays.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_sample_along_depth(dptr(_c(rays), "rays"), B, N, Ns, int(bool(depth_inv)), dptr(xyz),
+                                          dptr(uvd), dptr(z), stream()), "sample_along_depth")
+    return xyz, uvd, z
+
+
+def unpreprocess(src, Ho, Wo):
+    """src (B,S,3,H,W) in [-1,1] -> (B,S,3,Ho,Wo)."""
+    B, S, C_, H, W = src.shape
+    out = torch.empty(B, S, C_, Ho, Wo, device=src.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_unpreprocess(dptr(_c(src), "src"), B * S, C_, H, W, Ho, Wo, dptr(out), stream()),
+               "unpreprocess")
+    return out
+
+
+def vox_feat(uvd01, volume):
+    B, P = uvd01.shape[:2]
+    _, C_, D, h, w = volume.shape
+    out = torch.empty(B, P, C_, device=volume.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_vox_feat(dptr(_c(uvd01), "uvd"), dptr(_c(volume), "volume"), B, P, C_, D, h, w, dptr(out),
+                                stream()), "vox_feat")
+    return out
+
+
+def img_feat(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale):
+    B, S, C_, H, W = img_feat_rgb.shape
+    pts = _c(xyz).reshape(B, -1, 3)
+    P = pts.shape[1]
+    out = torch.empty(B, P, S, C_ + 4, device=xyz.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_img_feat(dptr(pts, "xyz"), dptr(_c(img_feat_rgb), "img_feat_rgb"),
+                                dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
+                                dptr(_c(tar_ext), "tar_ext"), float(render_scale), B, P, S, C_, H, W, dptr(out),
+                                stream()), "img_feat")
+    return out
+
+
+NERF_PARAM_ORDER = ("agg.view_fc.0", "agg.global_fc.0", "agg.agg_w_fc.0", "agg.fc.0", "lr0.0", "sigma.0",
+                    "color.0", "color.2")
+
+
+def nerf_pack_weights(tensors, feat_ch, out=None):
+    """tensors: 16 CUDA tensors (weight, bias of the 8 Linear layers in NERF_PARAM_ORDER)."""
+    lib = _lib.load()
+    n = lib.bmv_nerf_blob_size(int(feat_ch))
+    if n < 0:
+        _lib.check(n, "nerf_blob_size")
+    if out is None:
+        out = torch.empty(n, device=tensors[0].device, dtype=torch.float32)
+    held = [_c(t.detach()) for t in tensors]
+    params = _lib.NerfParams(*[dptr(t, f"nerf param {i}") for i, t in enumerate(held)])
+    _lib.check(lib.bmv_nerf_pack_weights(C.byref(params), int(feat_ch), dptr(out), stream()), "nerf_pack_weights")
+    return out
+
+
+def nerf_mlp(vox_feat_t, img_feat_rgb_dir, blob, feat_ch):
+    lead = vox_feat_t.shape[:-1]
+    npts = vox_feat_t.numel() // 8
+    if img_feat_rgb_dir.shape[-2] != 3:
+        raise ValueError("the MLP kernel is built for 3 source views per cost volume")
+    out = torch.empty(*lead, 4, device=vox_feat_t.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_nerf_mlp_fwd(dptr(_c(vox_feat_t), "vox_feat"), dptr(_c(img_feat_rgb_dir), "img_feat_rgb_dir"),
+                                    dptr(blob, "blob"), int(feat_ch), npts, dptr(out), stream()), "nerf_mlp")
+    return out
+
+
+def composite(raw, z_vals, white_bkgd=False):
+    lead = raw.shape[:-2]
+    Ns = raw.shape[-2]
+    nrays = raw.numel() // (Ns * 4)
+    rgb = torch.empty(*lead, 3, device=raw.device, dtype=torch.float32)
+    depth = torch.empty(*lead, device=raw.device, dtype=torch.float32)
+    weights = torch.empty(*lead, Ns, device=raw.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_composite_fwd(dptr(_c(raw), "raw"), dptr(_c(z_vals), "z_vals"), nrays, Ns,
+                                     int(bool(white_bkgd)), dptr(rgb), dptr(depth), dptr(weights), stream()),
+               "composite")
+    return rgb, depth, weights
+
+
+def mask_viewport(xyz, src_exts, src_ixts, inv_w, inv_h):
+    B = xyz.shape[0]
+    pts = _c(xyz).reshape(B, -1, 3)
+    P = pts.shape[1]
+    V = src_exts.shape[1]
+    mask = torch.empty(B, P, device=xyz.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_mask_viewport(dptr(pts, "xyz"), dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
+                                     float(inv_w), float(inv_h), B, P, V, dptr(mask), stream()), "mask_viewport")
+    return mask
+
+
+def blend(raws, masks, z_vals, normalise):
+    B, K, N, Ns = raws.shape[:4]
+    rgb = torch.empty(B, N, 3, device=raws.device, dtype=torch.float32)
+    depth = torch.empty(B, N, device=raws.device, dtype=torch.float32)
+    weights = torch.empty(B, N, Ns, device=raws.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_blend_fwd(dptr(_c(raws), "raws"), dptr(_c(masks).reshape(B, K, N, Ns), "masks"),
+                                 dptr(_c(z_vals), "z_vals"), B, K, N, Ns, int(bool(normalise)), dptr(rgb),
+                                 dptr(depth), dptr(weights), stream()), "blend")
+    return rgb, depth, weights
+
+
+def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext, blob, *, feat_ch,
+                Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None):
+    """Fused a6..a12 (+a14).  mode 0 -> (rgb, depth, weights); mode 1 -> (raw, z_vals, mask).
+    ray_range=(begin, end) renders only those rays; the outputs keep the full (B,N,...) shape and
+    only that slice is written."""
+    B, N = rays.shape[:2]
+    S = src_exts.shape[1]
+    _, _, Dv, hv, wv = volume.shape
+    dev = rays.device
+    if mode == 0:
+        o0 = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        o1 = torch.empty(B, N, device=dev, dtype=torch.float32)
+        o2 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)
+    else:
+        o0 = torch.empty(B, N, Ns, 4, device=dev, dtype=torch.float32)
+        o1 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)
+        o2 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)
+    if tuple(im_feat.shape[-2:]) != (Hr, Wr) or tuple(rgb_src.shape[-2:]) != (Hr, Wr):
+        raise ValueError(f"im_feat {tuple(im_feat.shape)} / rgb_src {tuple(rgb_src.shape)} must be at the render "
+                         f"resolution ({Hr},{Wr})")
+    begin, end = ray_range if ray_range is not None else (0, N)
+    held = [_c(t) for t in (rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext)]
+    a = _lib.RenderArgs()
+    for name, t in zip(("rays", "depth", "std", "near_far", "volume", "im_feat", "rgb_src", "src_exts", "src_ixts",
+                        "tar_ext"), held):
+        setattr(a, name, dptr(t, name))
+    a.blob = dptr(blob, "blob")
+    a.B, a.N, a.S, a.feat_ch, a.Ns, a.depth_inv = B, N, S, int(feat_ch), int(Ns), int(bool(depth_inv))
+    a.hv, a.wv, a.Dv, a.Hr, a.Wr = hv, wv, Dv, int(Hr), int(Wr)
+    a.render_scale = float(render_scale)
+    a.rgb_affine, a.white_bkgd, a.mode = int(bool(rgb_affine)), int(bool(white_bkgd)), int(mode)
+    a.ray_begin, a.ray_end = int(begin), int(end)
+    a.out0, a.out1, a.out2 = dptr(o0), dptr(o1), dptr(o2)
+    lib = _lib.load()
+    _lib.check(lib.bmv_render_rays_fwd(C.byref(a), stream()), "render_rays")
+    return o0, o1, o2

@@ -1,0 +1,166 @@
+/* libbmv -- MI355X (gfx950) kernels for the BoostMVSNeRFs rendering hot path.
+ *
+ * C ABI: plain device pointers (fp32, contiguous, row-major, shapes as written),
+ * ints for sizes, an opaque HIP stream.  No allocation, no synchronisation and
+ * no ownership transfer inside any entry point; every call only enqueues
+ * kernels on `stream` (graph-capturable).  Return value: BMV_OK or a negative
+ * error code; bmv_last_error() gives the message (thread-local).
+ *
+ * The reference has no FFI: its hot path is Python calling stock torch ops.
+ * Each entry point therefore names the reference *function* it replaces
+ * (file:line relative to the reference checkout); the Python binding a
+ * maintainer would add is in INTEGRATION.md and boostmvsnerfs_amd/_lib.py.
+ *
+ * Conventions: B batch, S source views of one cost volume (3), C channels,
+ * D depth planes, (h, w) volume resolution, (Hs, Ws) source-feature resolution,
+ * N rays, Ns samples per ray, P = N*Ns points, K fused cost volumes.
+ */
+#ifndef BMV_H_
+#define BMV_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bmv_stream_t; /* hipStream_t */
+
+enum { BMV_OK = 0, BMV_ERR_INVALID = -1, BMV_ERR_LAUNCH = -2, BMV_ERR_UNSUPPORTED = -3 };
+
+int bmv_version(void);
+const char* bmv_last_error(void);
+
+/* ---- a1  get_proj_mats                    lib/networks/enerf/utils.py:35-55
+ * proj[b,s] = (K_s' E_s[:3]) inverse([K_t' E_t[:3]; 0 0 0 1]), K' rows 0-1 scaled.
+ * src_exts (B,S,4,4), src_ixts (B,S,3,3), tar_ext (B,4,4), tar_ixt (B,3,3) -> proj (B,S,3,4) */
+int bmv_proj_mats(const float* src_exts, const float* src_ixts, const float* tar_ext, const float* tar_ixt,
+                  float src_scale, float tar_scale, int B, int S, float* proj, bmv_stream_t stream);
+
+/* ---- a2  get_depth_values                 lib/networks/enerf/utils.py:98-153
+ * level 0 (:103-111): D planes between near_far[b,0..1], uniform in disparity if depth_inv.
+ * near_far (B,2) -> depth_values (B,D,h,w), near_far_out (B,2,h,w) (= 1/clamp(.,1e-6) if depth_inv) */
+int bmv_depth_values_uniform(const float* near_far, int B, int D, int h, int w, int depth_inv,
+                             float* depth_values, float* near_far_out, bmv_stream_t stream);
+/* cascade level (:112-153, prev level in disparity, this level in depth): bilinear
+ * (align_corners) upsample of depth/std (B,h0,w0) and near_far (B,2,h0,w0) to (h,w);
+ * [depth+std, depth-std] clamped to near_far, inverted, D planes uniform in depth. */
+int bmv_depth_values_cascade(const float* depth, const float* std, const float* near_far, int B, int h0, int w0,
+                             int h, int w, int D, float* depth_values, float* near_far_out, bmv_stream_t stream);
+
+/* ---- a3  homo_warp                        lib/networks/enerf/utils.py:57-95
+ * src_feat (B,C,Hs,Ws), proj (B,3,4), depth_values (B,D,h,w) -> warped (B,C,D,h,w),
+ * grid (B,D,h,w,2) (may be NULL).  Bilinear, zeros padding, align_corners=True. */
+int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* depth_values, int B, int C, int Hs,
+                      int Ws, int D, int h, int w, float* warped, float* grid, bmv_stream_t stream);
+
+/* ---- a3+a4 build_feature_volume           lib/networks/enerf/utils.py:324-351
+ * Fused plane sweep: feats (B,S,C,Hs,Ws), proj (B,S,3,4), depth_values (B,D,h,w)
+ * -> variance (B,C,D,h,w) = sum_s(x^2)/S - (sum_s(x)/S)^2, never materialising the
+ * S warped volumes.  `algo`: 0 = auto, 1 = direct gather, 2 = LDS-tiled. */
+int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
+                           int Hs, int Ws, int D, int h, int w, float* variance, int algo, bmv_stream_t stream);
+
+/* ---- a5  depth_regression                 lib/networks/enerf/utils.py:722-731
+ * depth_prob, depth_values (B,D,h,w) -> depth, std (B,h,w); softmax over D,
+ * values inverted (1/clamp_min(v,1e-6)) first when depth_inv. */
+int bmv_depth_regress_fwd(const float* depth_prob, const float* depth_values, int B, int D, int h, int w,
+                          int depth_inv, float* depth, float* std, bmv_stream_t stream);
+
+/* ---- a6  build_rays                       lib/networks/enerf/utils.py:392-422
+ * rays (B,N,8) [o,d,x,y]; depth,std (B,hv,wv), near_far (B,2,hv,wv) upsampled
+ * (bilinear, align_corners) to (Hr,Wr) -> rays_out (B,N,12). */
+int bmv_build_rays(const float* rays, const float* depth, const float* std, const float* near_far, int B, int N,
+                   int hv, int wv, int Hr, int Wr, int depth_inv, float* rays_out, bmv_stream_t stream);
+
+/* ---- a7  sample_along_depth               lib/networks/enerf/utils.py:424-443
+ * rays (B,N,12) -> world_xyz (B,N,Ns,3), uvd (B,N,Ns,3) [x,y,dnorm], z_vals (B,N,Ns) */
+int bmv_sample_along_depth(const float* rays, int B, int N, int Ns, int depth_inv, float* world_xyz, float* uvd,
+                           float* z_vals, bmv_stream_t stream);
+
+/* ---- a8  unpreprocess                     lib/networks/enerf/utils.py:669-676
+ * src (n,3,H,W) in [-1,1] -> out (n,3,Ho,Wo) = bilinear(align_corners)(0.5*src+0.5) */
+int bmv_unpreprocess(const float* src, int n, int C, int H, int W, int Ho, int Wo, float* out, bmv_stream_t stream);
+
+/* ---- a9  get_vox_feat                     lib/networks/enerf/utils.py:458-460
+ * uvd01 (B,P,3) in [0,1]^3, volume (B,C,D,h,w) -> out (B,P,C); trilinear, zeros. */
+int bmv_vox_feat(const float* uvd01, const float* volume, int B, int P, int C, int D, int h, int w, float* out,
+                 bmv_stream_t stream);
+
+/* ---- a10 get_img_feat                     lib/networks/enerf/utils.py:753-786
+ * xyz (B,P,3); img_feat_rgb (B,S,C,H,W) -> out (B,P,S,C+4) (bilinear border +
+ * direction feature).  src_ixts rows 0-1 are scaled by render_scale in the kernel. */
+int bmv_img_feat(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                 const float* tar_ext, float render_scale, int B, int P, int S, int C, int H, int W, float* out,
+                 bmv_stream_t stream);
+
+/* ---- a11 NeRF.forward / Agg.forward       lib/networks/enerf/nerf.py:29-43, 74-89
+ * Parameter pointers in the reference's state-dict order (weight (out,in), bias). */
+typedef struct {
+  const float *view_fc_w, *view_fc_b;     /* agg.view_fc.0    (F,4)        F = feat_ch+3 */
+  const float *global_fc_w, *global_fc_b; /* agg.global_fc.0  (32,3F)                    */
+  const float *agg_w_w, *agg_w_b;         /* agg.agg_w_fc.0   (1,32)                     */
+  const float *fc_w, *fc_b;               /* agg.fc.0         (16,32)                    */
+  const float *lr0_w, *lr0_b;             /* lr0.0            (64,24)                    */
+  const float *sigma_w, *sigma_b;         /* sigma.0          (1,64)                     */
+  const float *color0_w, *color0_b;       /* color.0          (64,88+F+4)                */
+  const float *color2_w, *color2_b;       /* color.2          (1,64)                     */
+} bmv_nerf_params;
+
+/* floats needed for the packed (MFMA-ordered) weight blob of a given feat_ch (8 or 32) */
+int bmv_nerf_blob_size(int feat_ch);
+int bmv_nerf_pack_weights(const bmv_nerf_params* params, int feat_ch, float* blob, bmv_stream_t stream);
+/* vox_feat (B*P,8), img_feat_rgb_dir (B*P,3,F+4) -> out (B*P,4) = [rgb, sigma]; S must be 3 */
+int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* blob, int feat_ch, long npts,
+                     float* out, bmv_stream_t stream);
+
+/* ---- a12 raw2outputs                      lib/networks/enerf/utils.py:605-637
+ * raw (B*N,Ns,4), z_vals (B*N,Ns) -> rgb (B*N,3), depth (B*N), weights (B*N,Ns) (softmaxed) */
+int bmv_composite_fwd(const float* raw, const float* z_vals, long nrays, int Ns, int white_bkgd, float* rgb,
+                      float* depth, float* weights, bmv_stream_t stream);
+
+/* ---- a14 get_ndc_coords / mask_viewport   lib/networks/enerf/utils.py:490-520
+ * xyz (B,P,3), src_exts (B,V,4,4), src_ixts (B,V,3,3), inv_scale (W-1,H-1) -> mask (B,P) */
+int bmv_mask_viewport(const float* xyz, const float* src_exts, const float* src_ixts, float inv_w, float inv_h,
+                      int B, int P, int V, float* mask, bmv_stream_t stream);
+
+/* ---- a16 raw2outputs_blend + mask normalisation
+ *          lib/networks/enerf/utils.py:639-667, lib/networks/boost_enerf/network.py:163-170
+ * raws (B,K,N,Ns,4), masks (B,K,N,Ns) (raw visibility fractions if normalise!=0),
+ * z_vals (B,K,N,Ns) -> rgb (B,N,3), depth (B,N), weights (B,N,Ns) */
+int bmv_blend_fwd(const float* raws, const float* masks, const float* z_vals, int B, int K, int N, int Ns,
+                  int normalise, float* rgb, float* depth, float* weights, bmv_stream_t stream);
+
+/* ---- fused a6..a12 (+a14): Network.render_rays
+ *          lib/networks/enerf/network.py:24-43, lib/networks/boost_enerf/network.py:123-149
+ * One kernel from rays to composited pixels: per-ray bounds, samples, trilinear
+ * volume lookup, per-view image lookup + direction feature, MFMA MLP, composite.
+ * mode 0: rgb (B,N,3), depth (B,N), weights (B,N,Ns)
+ * mode 1: raw (B,N,Ns,4), z_vals (B,N,Ns), mask (B,N,Ns)   (boost path, no composite) */
+typedef struct {
+  const float* rays;      /* (B,N,8)                                   */
+  const float* depth;     /* (B,hv,wv) regressed depth (or disparity)  */
+  const float* std;       /* (B,hv,wv)                                 */
+  const float* near_far;  /* (B,2,hv,wv) volume bounds                 */
+  const float* volume;    /* (B,8,Dv,hv,wv) regularised feature volume */
+  const float* im_feat;   /* (B,S,feat_ch,Hr,Wr)                       */
+  const float* rgb_src;   /* (B,S,3,Hr,Wr); raw src_inps if rgb_affine */
+  const float* src_exts;  /* (B,S,4,4)                                 */
+  const float* src_ixts;  /* (B,S,3,3) full-resolution intrinsics      */
+  const float* tar_ext;   /* (B,4,4)                                   */
+  const float* blob;      /* packed MLP weights                        */
+  int B, N, S, feat_ch, Ns, depth_inv;
+  int hv, wv, Dv, Hr, Wr;
+  float render_scale;
+  int rgb_affine;         /* 1: rgb = 0.5*sample + 0.5 (render_scale == 1) */
+  int white_bkgd;
+  int mode;
+  int ray_begin, ray_end; /* render rays [ray_begin, ray_end) of every batch item */
+  float* out0;            /* rgb  | raw    */
+  float* out1;            /* depth| z_vals */
+  float* out2;            /* weights | mask */
+} bmv_render_args;
+int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMV_H_ */

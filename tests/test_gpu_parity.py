@@ -1,0 +1,205 @@
+"""GPU parity: every HIP entry point (through the C ABI / ctypes) against the
+golden vectors generated from the reference, function by function, then the
+whole network.  Tolerance: 1e-3 relative (BASELINE.json north_star) with an
+absolute floor of 1e-3 * rms(reference tensor) -- see conftest.assert_close."""
+import pytest
+import torch
+
+from conftest import assert_close, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no fallback path exists)")
+    from boostmvsnerfs_amd import ops as o
+    return o
+
+
+def g(fx, key):
+    return fx.t(key, DEV)
+
+
+def test_proj_mats(ops, enerf_fx):
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    for lvl in range(2):
+        P = ops.proj_mats(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"], c.im_feat_scale[lvl], c.volume_scale[lvl])
+        assert_close(P, enerf_fx.t(f"cap/get_proj_mats#{lvl}"), rtol=1e-4, atol_scale=1e-5, name=f"proj{lvl}")
+
+
+def test_depth_values(ops, enerf_fx):
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    dv0, nf0 = ops.depth_values_uniform(b["near_far"], c.volume_planes[0], 8, 12, True)
+    assert_close(dv0, enerf_fx.t("cap/get_depth_values#0.0"), rtol=1e-5, atol_scale=0, name="dv0")
+    assert_close(nf0, enerf_fx.t("cap/get_depth_values#0.1"), rtol=1e-5, atol_scale=0, name="nf0")
+    dv1, nf1 = ops.depth_values_cascade(g(enerf_fx, "cap/depth_regression#0.0"), g(enerf_fx, "cap/depth_regression#0.1"),
+                                        g(enerf_fx, "cap/get_depth_values#0.1"), 32, 48, c.volume_planes[1])
+    assert_close(dv1, enerf_fx.t("cap/get_depth_values#1.0"), rtol=1e-5, atol_scale=0, name="dv1")
+    assert_close(nf1, enerf_fx.t("cap/get_depth_values#1.1"), rtol=1e-5, atol_scale=0, name="nf1")
+
+
+@pytest.mark.parametrize("algo", [1, 0])
+def test_warp_and_sweep(ops, enerf_fx, algo):
+    feats = {0: g(enerf_fx, "cap/feature_net#0.0")[None], 1: g(enerf_fx, "cap/feature_net#0.1")[None]}
+    for lvl in range(2):
+        P = g(enerf_fx, f"cap/get_proj_mats#{lvl}")
+        dv = g(enerf_fx, f"cap/get_depth_values#{lvl}.0")
+        w, grid = ops.homo_warp(feats[lvl][:, 1].contiguous(), P[:, 1].contiguous(), dv)
+        call = 1 + 3 * lvl
+        assert_close(grid, enerf_fx.t(f"cap/homo_warp#{call}.1"), rtol=1e-5, atol_scale=1e-5, name=f"grid{lvl}")
+        assert_close(w, enerf_fx.t(f"cap/homo_warp#{call}.0"), name=f"warp{lvl}")
+        var = ops.sweep_variance(feats[lvl], P, dv, algo=algo)
+        assert_close(var, enerf_fx.t(f"cap/build_feature_volume#{lvl}.0"), name=f"var{lvl}")
+
+
+def test_depth_regress(ops, enerf_fx):
+    for lvl, inv in ((0, True), (1, False)):
+        d, s = ops.depth_regress(g(enerf_fx, f"cap/cost_reg_{lvl}#0.1"), g(enerf_fx, f"cap/get_depth_values#{lvl}.0"), inv)
+        assert_close(d, enerf_fx.t(f"cap/depth_regression#{lvl}.0"), rtol=1e-5, atol_scale=0, name=f"depth{lvl}")
+        assert_close(s, enerf_fx.t(f"cap/depth_regression#{lvl}.1"), rtol=1e-4, atol_scale=1e-5, name=f"std{lvl}")
+
+
+def test_rays_and_samples(ops, enerf_fx):
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    for lvl, inv in ((0, True), (1, False)):
+        rs = c.render_scale[lvl]
+        rays = ops.build_rays(b[f"rays_{lvl}"], g(enerf_fx, f"cap/depth_regression#{lvl}.0"),
+                              g(enerf_fx, f"cap/depth_regression#{lvl}.1"), g(enerf_fx, f"cap/get_depth_values#{lvl}.1"),
+                              int(H * rs), int(W * rs), inv)
+        assert_close(rays, enerf_fx.t(f"cap/build_rays#{lvl}"), rtol=1e-5, atol_scale=1e-6, name=f"rays{lvl}")
+        xyz, uvd, z = ops.sample_along_depth(g(enerf_fx, f"cap/build_rays#{lvl}"), c.num_samples[lvl], inv)
+        assert_close(xyz, enerf_fx.t(f"cap/sample_along_depth#{lvl}.0"), rtol=1e-5, atol_scale=1e-6, name="xyz")
+        assert_close(uvd, enerf_fx.t(f"cap/sample_along_depth#{lvl}.1"), rtol=1e-4, atol_scale=1e-5, name="uvd")
+        assert_close(z, enerf_fx.t(f"cap/sample_along_depth#{lvl}.2"), rtol=1e-5, atol_scale=1e-6, name="z")
+
+
+def test_lookups(ops, enerf_fx):
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    feats = {0: g(enerf_fx, "cap/feature_net#0.0")[None], 2: g(enerf_fx, "cap/feature_net#0.2")[None]}
+    for lvl in range(2):
+        rs = c.render_scale[lvl]
+        Hr, Wr = int(H * rs), int(W * rs)
+        rgbs = ops.unpreprocess(b["src_inps"], Hr, Wr)
+        assert_close(rgbs, enerf_fx.t(f"cap/unpreprocess#{lvl}"), rtol=1e-5, atol_scale=1e-6, name="unpre")
+        uvd = g(enerf_fx, f"cap/sample_along_depth#{lvl}.1")
+        uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3).contiguous()
+        vox = ops.vox_feat(uvd01, g(enerf_fx, f"cap/cost_reg_{lvl}#0.0"))
+        assert_close(vox, enerf_fx.t(f"cap/get_vox_feat#{lvl}"), name=f"vox{lvl}")
+        img = torch.cat([feats[c.render_im_feat_level[lvl]], g(enerf_fx, f"cap/unpreprocess#{lvl}")], 2).contiguous()
+        feat = ops.img_feat(g(enerf_fx, f"cap/sample_along_depth#{lvl}.0"), img, b["src_exts"], b["src_ixts"], b["tar_ext"], rs)
+        assert_close(feat, enerf_fx.t(f"cap/get_img_feat#{lvl}"), name=f"imgfeat{lvl}")
+
+
+def _pack(ops, sd, prefix, feat_ch):
+    tensors = []
+    for name in ops.NERF_PARAM_ORDER:
+        tensors += [sd[f"{prefix}{name}.weight"].contiguous(), sd[f"{prefix}{name}.bias"].contiguous()]
+    return ops.nerf_pack_weights(tensors, feat_ch)
+
+
+def test_mlp_and_composite(ops, enerf_fx):
+    sd = enerf_fx.group("sd", DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    for lvl, feat_ch in ((1, 8), (0, 32)):
+        blob = _pack(ops, sd, f"nerf_{lvl}.", feat_ch)
+        raw = ops.nerf_mlp(g(enerf_fx, f"cap/get_vox_feat#{lvl}"), g(enerf_fx, f"cap/get_img_feat#{lvl}"), blob, feat_ch)
+        assert_close(raw, enerf_fx.t(f"cap/nerf_{lvl}#0"), name=f"mlp{lvl}")
+        Ns = c.num_samples[lvl]
+        rgb, depth, weights = ops.composite(g(enerf_fx, f"cap/nerf_{lvl}#0").reshape(1, -1, Ns, 4),
+                                            g(enerf_fx, f"cap/sample_along_depth#{lvl}.2"))
+        assert_close(rgb, enerf_fx.t(f"cap/raw2outputs#{lvl}.rgb"), name="rgb")
+        assert_close(depth, enerf_fx.t(f"cap/raw2outputs#{lvl}.depth"), name="depth")
+        assert_close(weights, enerf_fx.t(f"cap/raw2outputs#{lvl}.weights"), name="weights")
+
+
+def test_fused_render(ops, enerf_fx):
+    sd = enerf_fx.group("sd", DEV)
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    feats = {0: g(enerf_fx, "cap/feature_net#0.0")[None], 2: g(enerf_fx, "cap/feature_net#0.2")[None]}
+    for lvl, feat_ch, inv in ((1, 8, False), (0, 32, True)):
+        rs = c.render_scale[lvl]
+        Hr, Wr = int(H * rs), int(W * rs)
+        blob = _pack(ops, sd, f"nerf_{lvl}.", feat_ch)
+        rgb_src = b["src_inps"] if rs == 1.0 else ops.unpreprocess(b["src_inps"], Hr, Wr)
+        common = dict(feat_ch=feat_ch, Ns=c.num_samples[lvl], depth_inv=inv, Hr=Hr, Wr=Wr, render_scale=rs,
+                      rgb_affine=(rs == 1.0))
+        args = (b[f"rays_{lvl}"], g(enerf_fx, f"cap/depth_regression#{lvl}.0"), g(enerf_fx, f"cap/depth_regression#{lvl}.1"),
+                g(enerf_fx, f"cap/get_depth_values#{lvl}.1"), g(enerf_fx, f"cap/cost_reg_{lvl}#0.0"),
+                feats[c.render_im_feat_level[lvl]], rgb_src, b["src_exts"], b["src_ixts"], b["tar_ext"], blob)
+        rgb, depth, weights = ops.render_rays(*args, mode=0, **common)
+        assert_close(rgb, enerf_fx.t(f"cap/raw2outputs#{lvl}.rgb"), name=f"rgb{lvl}")
+        assert_close(depth, enerf_fx.t(f"cap/raw2outputs#{lvl}.depth"), name=f"depth{lvl}")
+        assert_close(weights, enerf_fx.t(f"cap/raw2outputs#{lvl}.weights"), name=f"weights{lvl}")
+        raw, z, mask = ops.render_rays(*args, mode=1, **common)
+        assert_close(raw.reshape(1, -1, 4), enerf_fx.t(f"cap/nerf_{lvl}#0"), name=f"raw{lvl}")
+        assert_close(z, enerf_fx.t(f"cap/sample_along_depth#{lvl}.2"), rtol=1e-5, atol_scale=1e-6, name=f"z{lvl}")
+        # ragged range: only rays [5, 77) are written
+        N = b[f"rays_{lvl}"].shape[1]
+        part = ops.render_rays(*args, mode=0, ray_range=(5, min(77, N)), **common)[0]
+        assert_close(part[:, 5:min(77, N)], enerf_fx.t(f"cap/raw2outputs#{lvl}.rgb")[:, 5:min(77, N)], name="ragged")
+
+
+def _network(fx, preset="enerf_eval"):
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    set_cfg(tiny_cfg(fx, preset))
+    net = Network()
+    net.load_state_dict(fx.group("sd"), strict=True)
+    return net.to(DEV).eval()
+
+
+def test_network_forward_matches_reference(ops, enerf_fx):
+    net = _network(enerf_fx)
+    with torch.no_grad():
+        out = net(enerf_fx.batch(DEV))
+    want = enerf_fx.group("out")
+    assert set(out) == set(want)
+    for k in want:
+        assert_close(out[k], want[k], name=k)
+    mse = float(((out["rgb_level1"].cpu() - want["rgb_level1"]) ** 2).mean())
+    assert mse < 1e-8, f"PSNR delta too large (mse between renders {mse:.3e})"
+
+
+def test_network_ray_sharding(ops, enerf_fx):
+    net = _network(enerf_fx)
+    from boostmvsnerfs_amd.config import get_cfg
+    get_cfg().enerf.cas_config.render_if = [False, True]     # eval config: only level 1 is rendered
+    b = enerf_fx.batch(DEV)
+    with torch.no_grad():
+        full = net(b)["rgb_level1"]
+        N = b["rays_1"].shape[1]
+        net.ray_range = (N // 2, N)
+        half = net(b)["rgb_level1"]
+    assert half.shape[1] == N - N // 2
+    assert torch.equal(half, full[:, N // 2:])
+
+
+def test_errors_are_loud(ops):
+    x = torch.zeros(1, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.depth_values_uniform(x, 4, 2, 2, True)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.nerf_pack_weights([torch.zeros(4, device=DEV)] * 16, 5)
+
+
+def test_sweep_extreme_coordinates(ops):
+    """Planes at ~0 depth send the warp to 1e6+ pixels: must give exact zeros, no NaN/overflow."""
+    torch.manual_seed(0)
+    feats = torch.randn(1, 3, 8, 16, 20, device=DEV)
+    proj = torch.eye(4, device=DEV)[:3][None, None].repeat(1, 3, 1, 1).contiguous()
+    proj[..., 3] = torch.tensor([5.0, -3.0, -0.5], device=DEV)   # z < 0 -> clamp 1e-6
+    dv = torch.full((1, 4, 8, 10), 1e-9, device=DEV)
+    var = ops.sweep_variance(feats, proj, dv, algo=1)
+    assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
