@@ -1,0 +1,37 @@
+"""Optional per-kernel timing with HIP events on the stream the kernels run on
+(torch's current stream).  Off by default; bench.py switches it on so the
+roofline numbers come from the timed region itself."""
+import contextlib
+
+import torch
+
+enabled = False
+_records = {}
+
+
+def reset():
+    _records.clear()
+
+
+@contextlib.contextmanager
+def region(name):
+    if not enabled:
+        yield
+        return
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    try:
+        yield
+    finally:
+        e.record()
+        _records.setdefault(name, []).append((s, e))
+
+
+def summary():
+    """name -> (launches, mean ms, min ms); call after a device synchronize."""
+    out = {}
+    for name, evs in _records.items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        out[name] = (len(ms), sum(ms) / len(ms), min(ms))
+    return out

@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ktimer
 from ._lib import dptr, stream
 
 
@@ -66,9 +66,11 @@ def sweep_variance(feats, proj, depth_values, algo=0, out=None):
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=feats.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.bmv_sweep_variance_fwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
-                                          dptr(_c(depth_values), "depth_values"), B, S, C_, Hs, Ws, D, h, w,
-                                          dptr(out), int(algo), stream()), "sweep_variance")
+    args = (dptr(_c(feats), "feats"), dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"), B, S, C_, Hs,
+            Ws, D, h, w, dptr(out), int(algo), stream())
+    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]"):
+        rc = lib.bmv_sweep_variance_fwd(*args)
+    _lib.check(rc, "sweep_variance")
     return out
 
 
@@ -240,5 +242,7 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     a.ray_begin, a.ray_end = int(begin), int(end)
     a.out0, a.out1, a.out2 = dptr(o0), dptr(o1), dptr(o2)
     lib = _lib.load()
-    _lib.check(lib.bmv_render_rays_fwd(C.byref(a), stream()), "render_rays")
+    with ktimer.region(f"render_rays[feat={feat_ch},Ns={Ns},mode={mode}]"):
+        rc = lib.bmv_render_rays_fwd(C.byref(a), stream())
+    _lib.check(rc, "render_rays")
     return o0, o1, o2

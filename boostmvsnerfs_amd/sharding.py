@@ -1,0 +1,72 @@
+"""Multi-GPU sharding of the render path (one process per GPU, torch.distributed;
+backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+Two ways the path shards, neither needs a collective
+inside the kernels:
+  * views: every rank renders a different target frame; the only exchange is
+    an all-gather of the finished (rgb, depth) tiles (N*4 floats per rank).
+  * rays:  one frame, contiguous row-major ray ranges per rank (the front end --
+    features, sweep, regulariser -- is replicated: no halo logic, no traffic),
+    then the same all-gather reassembles the frame.
+Tiles are packed (rgb, depth) into one buffer so a step issues ONE collective;
+at 512x640 it moves 5.2 MB per rank, latency-bound on xGMI.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def ray_slice(n_rays, world, rank):
+    """Contiguous, near-equal split of [0, n_rays): rank r gets [begin, end)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    base, rem = divmod(n_rays, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def all_slices(n_rays, world):
+    return [ray_slice(n_rays, world, r) for r in range(world)]
+
+
+class TileGather:
+    """Reusable buffers + one all_gather per step."""
+
+    def __init__(self, world, n_rays=None, device="cpu", group=None):
+        self.world = world
+        self.group = group
+        self.device = device
+        self._send = None
+        self._recv = None
+
+    def _buffers(self, rows, device):
+        if self._send is None or self._send.shape[0] != rows:
+            self._send = torch.empty(rows, 4, device=device, dtype=torch.float32)
+            self._recv = torch.empty(self.world * rows, 4, device=device, dtype=torch.float32)
+        return self._send, self._recv
+
+    def all_gather_frames(self, rgb, depth):
+        """views sharding: rgb (1,N,3), depth (1,N) of this rank's frame ->
+        (world, N, 4) tensor [r, g, b, depth] of every rank's frame."""
+        n = rgb.shape[-2]
+        send, recv = self._buffers(n, rgb.device)
+        send[:, :3] = rgb.reshape(n, 3)
+        send[:, 3] = depth.reshape(n)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv.view(self.world, n, 4)
+
+    def all_gather_ray_tiles(self, rgb, depth, n_rays):
+        """rays sharding: this rank's tile (1,n_r,3)/(1,n_r) -> full frame (n_rays, 4).
+        Tiles differ by at most one ray; they are padded to the largest for a single collective."""
+        slices = all_slices(n_rays, self.world)
+        rows = max(e - b for b, e in slices)
+        n = rgb.shape[-2]
+        send, recv = self._buffers(rows, rgb.device)
+        send[:n, :3] = rgb.reshape(n, 3)
+        send[:n, 3] = depth.reshape(n)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        parts = recv.view(self.world, rows, 4)
+        if all(e - b == rows for b, e in slices):
+            return parts.reshape(n_rays, 4)
+        return torch.cat([parts[r, : e - b] for r, (b, e) in enumerate(slices)], 0)
