@@ -166,6 +166,9 @@ def main():
                 n, mean_ms, min_ms = ks[name]
                 kernels[f"sweep_level{lvl}"] = {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3,
                                                 "algorithmic_bytes": nbytes, "GB/s": nbytes / (mean_ms * 1e-3) / 1e9}
+        for name, (n, mean_ms, min_ms) in ks.items():
+            if not name.startswith("sweep_variance"):
+                kernels[name] = {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3}
         rname = f"render_rays[feat=8,Ns={cc.num_samples[1]},mode=0]"
         mfma = None
         if rname in ks:

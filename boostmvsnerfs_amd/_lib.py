@@ -43,7 +43,8 @@ SIGNATURES = {
     "bmv_depth_values_uniform": [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
-    "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f],
+    "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],
+    "bmv_nchw_to_nhwc": [c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_depth_regress_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_build_rays": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_sample_along_depth": [c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],

@@ -50,16 +50,14 @@ __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) *
 __device__ __forceinline__ Taps2 taps_zeros(float ix, float iy, int W, int H) {
   Taps2 t;
   float fx = floorf(ix), fy = floorf(iy);
-  bool ok = (fx >= -1.f) && (fx <= (float)(W - 1)) && (fy >= -1.f) && (fy <= (float)(H - 1));
-  if (!ok) {
-    t.o00 = t.o01 = t.o10 = t.o11 = 0;
-    t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
-    return t;
-  }
-  int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  // branch-free: clamp to [-2, size] before the int conversion (fmaxf/fminf also map NaN
+  // there), so anything outside comes out with both taps invalid and weight exactly 0
+  int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H);
+  int x1 = x0 + 1, y1 = y0 + 1;
   float ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy;  // (ix_se - ix), (iy_se - iy)
   float ax = ix - fx, ay = iy - fy;
-  bool vx0 = x0 >= 0, vx1 = x1 <= W - 1, vy0 = y0 >= 0, vy1 = y1 <= H - 1;
+  bool vx0 = (x0 >= 0) & (x0 <= W - 1), vx1 = (x1 >= 0) & (x1 <= W - 1);
+  bool vy0 = (y0 >= 0) & (y0 <= H - 1), vy1 = (y1 >= 0) & (y1 <= H - 1);
   t.w00 = (vx0 && vy0) ? ex * ey : 0.f;
   t.w01 = (vx1 && vy0) ? ax * ey : 0.f;
   t.w10 = (vx0 && vy1) ? ex * ay : 0.f;

@@ -218,31 +218,64 @@ __global__ void __launch_bounds__(256) sweep_direct_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------
-// a5: one thread per pixel, three passes over D (max, partition sum + mean, variance)
+// a5: one thread per pixel.  DT > 0: the D logits and hypotheses are loaded once
+// (all loads independent and in flight together) and the softmax / mean / variance
+// passes run out of registers; DT == 0: generic three-pass fallback for any D.
 // ---------------------------------------------------------------------------
-__global__ void depth_regress_kernel(const float* __restrict__ prob, const float* __restrict__ dv, int D, int hw,
-                                     int depth_inv, float* __restrict__ depth, float* __restrict__ std_) {
+template <int DT>
+__global__ void __launch_bounds__(64) depth_regress_kernel(const float* __restrict__ prob,
+                                                            const float* __restrict__ dv, int D, int hw,
+                                                            int depth_inv, float* __restrict__ depth,
+                                                            float* __restrict__ std_) {
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
   const float* p = prob + (size_t)b * D * hw + i;
   const float* v = dv + (size_t)b * D * hw + i;
-  float mx = -INFINITY;
-  for (int d = 0; d < D; ++d) mx = fmaxf(mx, p[(size_t)d * hw]);
-  float den = 0.f;
-  for (int d = 0; d < D; ++d) den += expf(p[(size_t)d * hw] - mx);
-  float mean = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float val = v[(size_t)d * hw];
-    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
-    mean += (expf(p[(size_t)d * hw] - mx) / den) * val;
-  }
-  float var = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float val = v[(size_t)d * hw];
-    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
-    float df = val - mean;
-    var += (expf(p[(size_t)d * hw] - mx) / den) * (df * df);
+  float mean = 0.f, var = 0.f;
+  if constexpr (DT > 0) {
+    float e[DT], val[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      e[d] = p[(size_t)d * hw];
+      val[d] = v[(size_t)d * hw];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) mx = fmaxf(mx, e[d]);
+    float den = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      e[d] = expf(e[d] - mx);
+      den += e[d];
+      if (depth_inv) val[d] = 1.f / fmaxf(val[d], 1e-6f);
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      e[d] = e[d] / den;
+      mean += e[d] * val[d];
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      float df = val[d] - mean;
+      var += e[d] * (df * df);
+    }
+  } else {
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, p[(size_t)d * hw]);
+    float den = 0.f;
+    for (int d = 0; d < D; ++d) den += expf(p[(size_t)d * hw] - mx);
+    for (int d = 0; d < D; ++d) {
+      float val = v[(size_t)d * hw];
+      if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+      mean += (expf(p[(size_t)d * hw] - mx) / den) * val;
+    }
+    for (int d = 0; d < D; ++d) {
+      float val = v[(size_t)d * hw];
+      if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+      float df = val - mean;
+      var += (expf(p[(size_t)d * hw] - mx) / den) * (df * df);
+    }
   }
   depth[(size_t)b * hw + i] = mean;
   std_[(size_t)b * hw + i] = sqrtf(fmaxf(var, 1e-10f));
@@ -294,19 +327,23 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
   BMV_LAUNCH_END("bmv_homo_warp_fwd");
 }
 
-int bmv_sweep_tiled_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                           int D, int h, int w, float* out, hipStream_t stream);
+int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
+                          int D, int h, int w, float* out, hipStream_t stream);
 
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
-                           int Hs, int Ws, int D, int h, int w, float* variance, int algo, bmv_stream_t stream) {
+                           int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
+                           bmv_stream_t stream) {
   BMV_REQUIRE(feats && proj && depth_values && variance, "bmv_sweep_variance_fwd: null pointer");
   BMV_REQUIRE(B > 0 && S > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_fwd: bad shape");
-  BMV_REQUIRE(algo >= 0 && algo <= 2, "bmv_sweep_variance_fwd: algo=%d", algo);
+  BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
+  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0), "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d",
+              algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
-  if (algo == 0 || algo == 2) {
-    int rc = bmv_sweep_tiled_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, as_stream(stream));
-    if (rc != BMV_ERR_UNSUPPORTED || algo == 2) return rc;
+  if (feat_layout == 1) {
+    int rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, as_stream(stream));
+    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
+    return rc;
   }
   dim3 block(256);
 #define LAUNCH(CB)                                                                                              \
@@ -328,8 +365,17 @@ int bmv_depth_regress_fwd(const float* depth_prob, const float* depth_values, in
                           int depth_inv, float* depth, float* std_, bmv_stream_t stream) {
   BMV_REQUIRE(depth_prob && depth_values && depth && std_, "bmv_depth_regress_fwd: null pointer");
   BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bmv_depth_regress_fwd: bad shape");
-  hipLaunchKernelGGL(depth_regress_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, as_stream(stream), depth_prob,
-                     depth_values, D, h * w, depth_inv, depth, std_);
+#define DR(DT)                                                                                                 \
+  hipLaunchKernelGGL(depth_regress_kernel<DT>, dim3(cdiv(h * w, 64), B), dim3(64), 0, as_stream(stream), depth_prob, \
+                     depth_values, D, h * w, depth_inv, depth, std_)
+  switch (D) {
+    case 8: DR(8); break;
+    case 16: DR(16); break;
+    case 32: DR(32); break;
+    case 64: DR(64); break;
+    default: DR(0); break;
+  }
+#undef DR
   BMV_LAUNCH_END("bmv_depth_regress_fwd");
 }
 

@@ -60,14 +60,37 @@ def homo_warp(src_feat, proj, depth_values, want_grid=True):
     return warped, grid
 
 
-def sweep_variance(feats, proj, depth_values, algo=0, out=None):
-    B, S, C_, Hs, Ws = feats.shape
+def nchw_to_nhwc(x):
+    """(..., C, H, W) -> (..., H, W, C) contiguous, C % 4 == 0 (HIP transpose kernel)."""
+    C_, H, W = x.shape[-3:]
+    n = x.numel() // (C_ * H * W)
+    out = torch.empty(*x.shape[:-3], H, W, C_, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"nchw_to_nhwc[C={C_},{H}x{W}]"):
+        rc = lib.bmv_nchw_to_nhwc(dptr(_c(x), "x"), n, C_, H, W, dptr(out), stream())
+    _lib.check(rc, "nchw_to_nhwc")
+    return out
+
+
+def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
+    """feats: (B,S,C,Hs,Ws) in the reference layout, or channel-last (B,S,Hs,Ws,C) when
+    channels_last=True.  With channels_last=None (default) a reference-layout input with C in
+    {16, 32} is first put into the channel-last layout (one transpose kernel) and the fast
+    channel-last sweep runs; algo=1 forces the reference-layout direct-gather kernel."""
+    if channels_last:
+        B, S, Hs, Ws, C_ = feats.shape
+    else:
+        B, S, C_, Hs, Ws = feats.shape
     _, D, h, w = depth_values.shape
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=feats.device, dtype=torch.float32)
+    layout = 1 if channels_last else 0
+    if channels_last is None and algo == 0 and C_ in (16, 32):
+        feats = nchw_to_nhwc(feats)
+        layout = 1
     lib = _lib.load()
     args = (dptr(_c(feats), "feats"), dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"), B, S, C_, Hs,
-            Ws, D, h, w, dptr(out), int(algo), stream())
+            Ws, D, h, w, dptr(out), layout, int(algo), stream())
     with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]"):
         rc = lib.bmv_sweep_variance_fwd(*args)
     _lib.check(rc, "sweep_variance")

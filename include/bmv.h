@@ -53,11 +53,16 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
                       int Ws, int D, int h, int w, float* warped, float* grid, bmv_stream_t stream);
 
 /* ---- a3+a4 build_feature_volume           lib/networks/enerf/utils.py:324-351
- * Fused plane sweep: feats (B,S,C,Hs,Ws), proj (B,S,3,4), depth_values (B,D,h,w)
+ * Fused plane sweep: feats, proj (B,S,3,4), depth_values (B,D,h,w)
  * -> variance (B,C,D,h,w) = sum_s(x^2)/S - (sum_s(x)/S)^2, never materialising the
- * S warped volumes.  `algo`: 0 = auto, 1 = direct gather, 2 = LDS-tiled. */
+ * S warped volumes.  feat_layout: 0 = feats is (B,S,C,Hs,Ws) as the reference holds it,
+ * 1 = channel-last (B,S,Hs,Ws,C) (bmv_nchw_to_nhwc converts).  algo: 0 = best kernel for
+ * the layout, 1 = reference-layout direct gather (needs feat_layout 0). */
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
-                           int Hs, int Ws, int D, int h, int w, float* variance, int algo, bmv_stream_t stream);
+                           int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
+                           bmv_stream_t stream);
+/* (n,C,H,W) -> (n,H,W,C), C % 4 == 0: puts the 2-D features into the sweep's channel-last layout */
+int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, bmv_stream_t stream);
 
 /* ---- a5  depth_regression                 lib/networks/enerf/utils.py:722-731
  * depth_prob, depth_values (B,D,h,w) -> depth, std (B,h,w); softmax over D,
