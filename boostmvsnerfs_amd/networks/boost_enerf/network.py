@@ -1,0 +1,188 @@
+"""BoostMVSNeRFs on the ENeRF backbone: K cost volumes (view triplets chosen by
+a 3-D visibility criterion) are rendered per sample and fused by
+visibility-weighted alpha compositing.
+
+Boundary of lib/networks/boost_enerf/network.py:10-237: `Network(preprocess)`,
+`forward(batch)` (needs `<cfg.result_dir>/view_selection.json`),
+`forward_view_selection(batch)` -> {f"{scene}_{tar_view}": [triplet ids]}.
+
+Kernel plan per rendered level: for each of the K volumes one fused render launch
+in MLP-only mode (raw [rgb, sigma], sample depths and the viewport visibility
+fraction come out of the same kernel), then ONE blend kernel that normalises the
+masks over K, fuses alphas/colours and composites -- the (B,K,N,Ns,*) stacks are
+written once and read once.  View selection needs sample positions only, so the
+MLP evaluation the reference performs and discards (network.py:53-59) is skipped.
+"""
+import itertools
+import json
+import os
+
+import torch
+
+from ... import ops
+from ...config import cfg
+from ..enerf import network as enerf_network
+
+
+def view_triplets(n_views, per_volume=3):
+    """torch.combinations(arange(N), 3) order (lexicographic)."""
+    return list(itertools.combinations(range(n_views), per_volume))
+
+
+def greedy_cover(masks, k):
+    """search_k_best_views (network.py:71-95): masks (T,H,W) on any device -> list of <= k ids.
+    Greedy set cover on the visibility maps: repeatedly take the triplet that adds most
+    not-yet-covered visibility; stop early when nothing adds any."""
+    T, H, W = masks.shape
+    remaining = torch.ones_like(masks[0])
+    chosen = []
+    for _ in range(k):
+        gains = ((masks * remaining).sum((1, 2)) / (H * W)).tolist()
+        best, best_id = 0.0, None
+        for i, g in enumerate(gains):
+            if i in chosen:
+                continue
+            if g > best:
+                best, best_id = g, i
+        if best_id is None:
+            break
+        remaining = remaining * (1 - masks[best_id])
+        chosen.append(best_id)
+    return chosen or [0]
+
+
+class Network(enerf_network.Network):
+    def __init__(self, preprocess=False):
+        super().__init__()
+        self.view_selection_outputs = None
+        self.capture = None
+        if not preprocess:
+            path = os.path.join(cfg.result_dir, "view_selection.json")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found: run the view-selection preprocess first "
+                                        "(forward_view_selection, run.py:39-85)")
+            with open(path, "r") as f:
+                self.view_selection_outputs = json.load(f)
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _pick(batch, ids):
+        """ids: (B,S) long tensor of view indices -> the S views of every batch item."""
+        bi = torch.arange(ids.shape[0], device=ids.device)[:, None]
+        return (batch["all_src_inps"][bi, ids], batch["all_src_exts"][bi, ids], batch["all_src_ixts"][bi, ids])
+
+    # ------------------------------------------------------------------ view selection (a17)
+    def calc_mask(self, src_views_id, batch, feats=None):
+        """2-D visibility map of one triplet for every rendered level (network.py:22-69)."""
+        cc = cfg.enerf.cas_config
+        B = batch["all_src_inps"].shape[0]
+        ids = torch.as_tensor(src_views_id, device=batch["all_src_inps"].device).view(1, -1).expand(B, -1)
+        views = self._pick(batch, ids)
+        if feats is None:
+            feats = self.forward_feat(views[0])
+            pick = lambda f: f
+        else:
+            bi = torch.arange(B, device=ids.device)[:, None]
+            pick = lambda f: f[bi, ids]
+        H, W = views[0].shape[-2:]
+        out, st = {}, None
+        for i in range(cc.num):
+            st = self.level_front(i, pick(feats[f"level_{i}"]), views, batch, st)
+            if not cc.render_if[i]:
+                continue
+            rs = cc.render_scale[i]
+            Hr, Wr = int(H * rs), int(W * rs)
+            Ns = cc.num_samples[i]
+            rays = ops.build_rays(batch[f"rays_{i}"], st.depth, st.std, st.near_far, Hr, Wr, cc.depth_inv[i])
+            xyz, _, z = ops.sample_along_depth(rays, Ns, cc.depth_inv[i])
+            vis = ops.mask_viewport(xyz, views[1], views[2], Wr - 1, Hr - 1).view(B, -1, Ns) / Ns
+            # the reference composites the mask as if it were [rgb, sigma] and keeps the mean colour
+            rgb, _, _ = ops.composite(vis[..., None].expand(-1, -1, -1, 4).contiguous(), z, cfg.enerf.white_bkgd)
+            out[f"mask_level{i}"] = rgb.mean(-1).view(B, Hr, Wr)
+        return out
+
+    def search_k_best_views(self, masks, k, level):
+        T = len(masks)
+        stack = torch.stack([masks[f"mask_level{level}_view{i}"] for i in range(T)])
+        return greedy_cover(stack.reshape(T, *stack.shape[-2:]), k)
+
+    def forward_view_selection(self, batch):
+        cc = cfg.enerf.cas_config
+        N = batch["all_src_inps"].shape[1]
+        with torch.no_grad():
+            feats = self.forward_feat(batch["all_src_inps"])      # once for all N views, not per triplet
+            all_masks = {}
+            for t, ids in enumerate(view_triplets(N, 3)):
+                m = self.calc_mask(ids, batch, feats)
+                all_masks.update({f"{k}_view{t}": v for k, v in m.items()})
+        result = {}
+        for i in range(cc.num):
+            if not cc.render_if[i]:
+                continue
+            level_masks = {k: v for k, v in all_masks.items() if k.startswith(f"mask_level{i}")}
+            sel = [int(s) for s in self.search_k_best_views(level_masks, cc.k_best, i)]
+            for scene, view in zip(batch["meta"]["scene"], batch["meta"]["tar_view"]):
+                result[f"{scene}_{view}"] = sel
+        return result
+
+    # ------------------------------------------------------------------ fused forward (a15, a16)
+    def merge_mlp_outputs(self, raws, masks, z_vals):
+        """(B,K,N,Ns,4), (B,K,N,Ns), (B,K,N,Ns) -> fused rgb/depth/weights (network.py:163-170 +
+        utils.py:639-667); mask normalisation over K happens inside the kernel."""
+        if cfg.enerf.white_bkgd:
+            raise NotImplementedError          # as the reference (utils.py:660-661)
+        rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=True)
+        return {"rgb": rgb, "depth": depth, "weights": weights}
+
+    def forward(self, batch):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("training (backward kernels) is not part of this build yet")
+        if self.view_selection_outputs is None:
+            raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
+        cc = cfg.enerf.cas_config
+        dev = batch["all_src_inps"].device
+        B, N = batch["all_src_inps"].shape[:2]
+        trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)
+        k_best = torch.tensor([self.view_selection_outputs[f"{s}_{v}"]
+                               for s, v in zip(batch["meta"]["scene"], batch["meta"]["tar_view"])], device=dev)
+        K = int(cc.k_best)
+        if k_best.shape[1] < K:
+            raise ValueError(f"view_selection.json holds {k_best.shape[1]} volumes per target, cfg k_best={K}")
+        sel = trip[k_best[:, :K]]                                   # (B,K,3)
+        feats = self.forward_feat(batch["all_src_inps"])            # all N views once
+        bi = torch.arange(B, device=dev)[:, None]
+        states = [None] * K
+        ret = {}
+        for i in range(cc.num):
+            raws, zs, ms = [], [], []
+            stacks = None
+            if cc.render_if[i] and B == 1:      # K render launches write straight into the stacked buffers
+                n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
+                stacks = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
+                          torch.empty(1, K, n_i, ns_i, device=dev))
+            for k in range(K):
+                ids = sel[:, k]
+                views = self._pick(batch, ids)
+                states[k] = self.level_front(i, feats[f"level_{i}"][bi, ids], views, batch, states[k])
+                if not cc.render_if[i]:
+                    continue
+                im_feat = feats[f"level_{cc.render_im_feat_level[i]}"][bi, ids]
+                if stacks is not None and self.ray_range is None:
+                    self.render_level(i, states[k], im_feat, views, batch, mode=1, outs=tuple(t[:, k] for t in stacks))
+                else:
+                    raw, z, m = self.render_level(i, states[k], im_feat, views, batch, mode=1)
+                    raws.append(raw), zs.append(z), ms.append(m)
+            if not cc.render_if[i]:
+                continue
+            if raws:
+                stacks = (torch.stack(raws, 1), torch.stack(zs, 1), torch.stack(ms, 1))
+            if self.capture is not None:     # tests: per-volume raw outputs / depths / visibility masks
+                self.capture[f"level{i}"] = stacks
+            out = self.merge_mlp_outputs(stacks[0], stacks[2], stacks[1])
+            st0 = states[0]                                         # depth_mvs / std come from volume 0 only
+            out["depth_mvs"] = torch.reciprocal(st0.depth) if cc.depth_inv[i] else st0.depth
+            out["std"] = st0.std
+            ret.update({f"{k_}_level{i}": v for k_, v in out.items()})
+        # the reference leaves the last triplet in batch['src_*'] (network.py:196-198)
+        batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
+        return ret

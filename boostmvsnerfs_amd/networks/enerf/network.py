@@ -78,7 +78,7 @@ class Network(nn.Module):
         return st
 
     # ------------------------------------------------------------------ fused renderer of one level
-    def render_level(self, i, st, im_feat, views, batch, mode=0):
+    def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None):
         """rays -> pixels (mode 0) or raw MLP outputs + depths + visibility (mode 1)
         (network.py:24-55, boost_enerf/network.py:123-161)."""
         cc = cfg.enerf.cas_config
@@ -98,18 +98,13 @@ class Network(nn.Module):
         begin, end = self.ray_range if self.ray_range is not None else (0, N)
         chunk = int(cfg.enerf.chunk_size)
         # one launch per chunk keeps the reference's memory bound; with fused kernels a whole frame is one chunk
-        outs = None
         for c0 in range(begin, end, chunk):
             o = ops.render_rays(rays, st.depth, st.std, st.near_far, st.feature_volume, im_feat, rgb_src, src_exts,
                                 src_ixts, batch["tar_ext"], nerf.packed_weights(), feat_ch=nerf.feat_ch - 3,
                                 Ns=cc.num_samples[i], depth_inv=cc.depth_inv[i], Hr=Hr, Wr=Wr, render_scale=rs,
                                 rgb_affine=affine, white_bkgd=cfg.enerf.white_bkgd, mode=mode,
-                                ray_range=(c0, min(c0 + chunk, end)))
-            if outs is None:
-                outs = o
-            else:  # later chunks wrote into fresh buffers: merge their slice
-                for dst, src in zip(outs, o):
-                    dst[:, c0:min(c0 + chunk, end)] = src[:, c0:min(c0 + chunk, end)]
+                                ray_range=(c0, min(c0 + chunk, end)), outs=outs)
+            outs = o      # every chunk writes its own ray slice of the same buffers
         if (begin, end) != (0, N):
             outs = tuple(t[:, begin:end] for t in outs)
         return outs

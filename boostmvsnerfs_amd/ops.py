@@ -232,7 +232,7 @@ def blend(raws, masks, z_vals, normalise):
 
 
 def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext, blob, *, feat_ch,
-                Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None):
+                Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None, outs=None):
     """Fused a6..a12 (+a14).  mode 0 -> (rgb, depth, weights); mode 1 -> (raw, z_vals, mask).
     ray_range=(begin, end) renders only those rays; the outputs keep the full (B,N,...) shape and
     only that slice is written."""
@@ -240,7 +240,13 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     S = src_exts.shape[1]
     _, _, Dv, hv, wv = volume.shape
     dev = rays.device
-    if mode == 0:
+    if outs is not None:
+        o0, o1, o2 = outs
+        want = ((B, N, 3), (B, N), (B, N, Ns)) if mode == 0 else ((B, N, Ns, 4), (B, N, Ns), (B, N, Ns))
+        for t, shp in zip(outs, want):
+            if tuple(t.shape) != shp:
+                raise ValueError(f"render_rays: output buffer {tuple(t.shape)} != {shp}")
+    elif mode == 0:
         o0 = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
         o1 = torch.empty(B, N, device=dev, dtype=torch.float32)
         o2 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)

@@ -1,0 +1,71 @@
+"""Host-side boundary (CPU): the drop-in shims load through the reference's path-based
+factory, expose the reference's module tree / state-dict keys, and cfg presets carry the
+values of the reference yaml chains."""
+import os
+
+import pytest
+import torch
+
+from conftest import REPO, load_fixture, tiny_cfg
+from boostmvsnerfs_amd.config import make_cfg, set_cfg
+
+
+def test_presets_match_reference_yaml_values():
+    c = make_cfg("enerf_eval").enerf.cas_config
+    assert c.volume_planes == [64, 8] and c.num_samples == [8, 2] and c.render_if == [False, True]
+    assert c.depth_inv == [True, False] and c.volume_scale == [0.125, 0.5] and c.render_im_feat_level == [0, 2]
+    b = make_cfg("enerf_ours_eval")
+    assert b.enerf.cas_config.k_best == 4 and b.enerf.cost_volume_input_views == 3 and b.require_view_selection
+    assert b.network_module == "lib.networks.boost_enerf.network"
+    o = make_cfg("enerf_eval", opts=["enerf.cas_config.volume_planes", "[32, 8]", "other_opts", "x", "1"])
+    assert o.enerf.cas_config.volume_planes == [32, 8]
+
+
+def test_yaml_parent_chain(tmp_path):
+    (tmp_path / "base.yaml").write_text("enerf:\n  cas_config:\n    volume_planes: [48, 8]\nexp_name: base\n")
+    (tmp_path / "child.yaml").write_text(f"parent_cfg: {tmp_path / 'base.yaml'}\nexp_name: child\n"
+                                         "enerf:\n  cas_config:\n    render_if: [False, True]\n")
+    c = make_cfg(cfg_file=str(tmp_path / "child.yaml"))
+    assert c.exp_name == "child" and c.enerf.cas_config.volume_planes == [48, 8]
+    assert c.enerf.cas_config.render_if == [False, True] and c.enerf.cas_config.num_samples == [8, 2]
+
+
+def test_dropin_factory_and_state_dict_keys():
+    fx = load_fixture("enerf_tiny")
+    cfg = set_cfg(tiny_cfg(fx))
+    import importlib.util
+    path = os.path.join(REPO, "boostmvsnerfs_amd", "dropin", "lib", "networks", "make_network.py")
+    spec = importlib.util.spec_from_file_location("dropin_make_network", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg.network_path = os.path.join(REPO, "boostmvsnerfs_amd", "dropin", "lib", "networks", "enerf", "network.py")
+    net = mod.make_network(cfg)
+    ref_keys = [k for k in fx.group("sd")]
+    assert list(net.state_dict().keys()) == ref_keys          # same names, same order as the reference
+    net.load_state_dict(fx.group("sd"), strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 436012
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        with torch.no_grad():
+            net.eval()(fx.batch())                             # CPU tensors: refuses, never falls back
+
+
+def test_boost_needs_view_selection(tmp_path):
+    fx = load_fixture("boost_enerf_tiny")
+    c = tiny_cfg(fx, "enerf_ours_eval")
+    c.result_dir = str(tmp_path)
+    set_cfg(c)
+    from boostmvsnerfs_amd.networks.boost_enerf.network import Network, greedy_cover, view_triplets
+    with pytest.raises(FileNotFoundError):
+        Network()
+    assert Network(preprocess=True).view_selection_outputs is None
+    assert view_triplets(5)[:3] == [(0, 1, 2), (0, 1, 3), (0, 1, 4)] and len(view_triplets(6)) == 20
+    # greedy cover: ties keep the first, zero gain stops, empty -> [0]  (boost_enerf/network.py:71-95)
+    m = torch.zeros(3, 2, 2)
+    assert greedy_cover(m, 2) == [0]
+    m[1, 0, 0] = 1.0
+    m[2, 0, 0] = 1.0
+    assert greedy_cover(m, 3) == [1]
+    m[2, 1, 1] = 0.5
+    assert greedy_cover(m, 3) == [2]
+    m[0, 0, 1] = 0.7
+    assert greedy_cover(m, 3) == [2, 0]

