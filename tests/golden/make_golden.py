@@ -180,6 +180,90 @@ def gen_boost_enerf():
          extra={"volume_planes": TINY_PLANES, "k_best": sel[key], "n_views": n_views, "hw": [TINY_H, TINY_W]})
 
 
+class zero_filled_empty:
+    """build_volume_costvar_img reads uninitialised memory (torch.empty, mvsnerf/network.py:912);
+    pin it to zeros while the reference runs so the fixture is reproducible."""
+
+    def __enter__(self):
+        self._orig = torch.empty
+        torch.empty = lambda *a, **k: torch.zeros(*a, **k)
+
+    def __exit__(self, *exc):
+        torch.empty = self._orig
+
+
+MVS_NS = 8
+
+
+def _mvs_batch(n_views):
+    from boostmvsnerfs_amd.synthetic import make_batch
+    b = make_batch(TINY_H, TINY_W, n_views=n_views, render_scales=(1.0,), seed=0, depth_ranges=True)
+    # the reference marches from rays[...,6] to rays[...,7] (with the shipped loaders these hold the pixel
+    # x, y: SURVEY quirk 9); the fixture puts a real depth interval there so samples land inside the volume
+    b["rays_0"][..., 6] = 2.2
+    b["rays_0"][..., 7] = 7.5
+    b["rays_0"] = b["rays_0"][:, ::8].contiguous()      # any ray list is legal; keeps the fixture small
+    return b
+
+
+def gen_mvsnerf():
+    cfg = load_reference("configs/exps/evaluate/mvsnerf/free_eval.yaml")
+    from lib.networks.mvsnerf import network
+    from lib.networks.mvsnerf import utils as mutils, renderer as mrend
+    cfg.enerf.cas_config.num_samples = [MVS_NS]
+    torch.manual_seed(0)
+    net = perturb_(network.Network().eval())
+    rec = Recorder()
+    rec.wrap(network, "get_ndc_coordinate")
+    rec.wrap(network, "gen_dir_feature")
+    rec.wrap(network, "gen_pts_feats")
+    rec.hook(net.feature, "feature")
+    rec.hook(net.cost_reg_2, "cost_reg_2")
+    rec.hook(net.nerf, "nerf")
+    for name in ("build_volume_costvar_img", "get_proj_mats", "ray_marcher", "run_network_mvs"):
+        orig = getattr(net, name)
+        setattr(net, name, (lambda o, n: (lambda *a, **k: (lambda out: (rec._store(n, out), out)[1])(o(*a, **k))))(orig, name))
+    batch = _mvs_batch(3)
+    inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad(), zero_filled_empty():
+        out = net(batch)
+    save("mvsnerf_tiny", inputs, net.state_dict(), rec, out, extra={"num_samples": [MVS_NS], "hw": [TINY_H, TINY_W]})
+
+
+def gen_boost_mvsnerf():
+    import json
+    cfg = load_reference("configs/exps/evaluate/mvsnerf_ours/free_eval.yaml")
+    from lib.networks.boost_mvsnerf import network
+    from lib.networks.enerf import utils
+    cfg.enerf.cas_config.num_samples = [MVS_NS]
+    cfg.enerf.cas_config.k_best = 3
+    n_views = 5
+    os.makedirs(cfg.result_dir, exist_ok=True)
+    torch.manual_seed(0)
+    net = perturb_(network.Network(preprocess=True).eval())
+    batch = _mvs_batch(n_views)
+    inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    rec = Recorder()
+    orig_calc = net.calc_mask
+    net.calc_mask = lambda ids, b: (lambda m: (rec._store("sel/calc_mask", m), m)[1])(orig_calc(ids, b))
+    with torch.no_grad():
+        sel = net.forward_view_selection(batch)
+    print("view selection:", sel)
+    with open(os.path.join(cfg.result_dir, "view_selection.json"), "w") as f:
+        json.dump(sel, f)
+    torch.manual_seed(0)
+    net2 = perturb_(network.Network().eval())
+    for f in ("mask_viewport", "raw2outputs_blend"):
+        rec.wrap(network, f)          # star-imported into the module namespace
+    batch2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    with torch.no_grad(), zero_filled_empty():
+        out = net2(batch2)
+    key = list(sel.keys())[0]
+    save("boost_mvsnerf_tiny", inputs, None, rec, out,
+         extra={"num_samples": [MVS_NS], "k_best": sel[key], "n_views": n_views, "hw": [TINY_H, TINY_W]})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "enerf"
-    {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf}[which]()
+    {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf, "mvsnerf": gen_mvsnerf,
+     "boost_mvsnerf": gen_boost_mvsnerf}[which]()
