@@ -37,6 +37,18 @@ class RenderArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("out0", "out1", "out2")])
 
 
+class MvsMlpParams(C.Structure):
+    _fields_ = ([("pts_w", C.c_void_p * 6), ("pts_b", C.c_void_p * 6)]
+                + [(n, C.c_void_p) for n in ("bias_w", "bias_b", "views_w", "views_b", "feature_w", "feature_b",
+                                             "alpha_w", "alpha_b", "rgb_w", "rgb_b")])
+
+
+class MvsRenderArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("rays", "volume", "src_inps", "src_exts", "src_ixts", "near_far", "blob")]
+                + [(n, C.c_int) for n in ("N", "Ns", "S", "D", "hp", "wp", "H", "W", "pad", "ray_begin", "ray_end")]
+                + [(n, C.c_void_p) for n in ("raw", "z_vals", "mask", "inputs86")])
+
+
 # name -> argtypes (all return int unless noted); mirrors include/bmv.h one to one
 SIGNATURES = {
     "bmv_proj_mats": [c_f, c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_f, c_f],
@@ -58,6 +70,14 @@ SIGNATURES = {
     "bmv_mask_viewport": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_i, c_f, c_f],
     "bmv_blend_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
     "bmv_render_rays_fwd": [C.POINTER(RenderArgs), c_f],
+    "bmv_mvs_proj_mats": [c_f, c_f, c_i, c_i, c_f, c_f],
+    "bmv_resize_bilinear": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_mvs_sweep_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_mvs_mlp_blob_size": [],
+    "bmv_mvs_mlp_pack_weights": [C.POINTER(MvsMlpParams), c_f, c_f],
+    "bmv_mvs_mlp_fwd": [c_f, c_f, c_l, c_f, c_f],
+    "bmv_mvs_render_fwd": [C.POINTER(MvsRenderArgs), c_f],
+    "bmv_mvs_march_mask": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f],
     "bmv_version": [],
 }
 

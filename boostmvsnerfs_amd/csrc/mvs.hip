@@ -1,0 +1,662 @@
+// MVSNeRF backbone kernels (a18-a25): reference-view projection matrices, the padded
+// plane sweep with colour channels and in-frustum counting, and the fused
+// sample -> 6x128 MLP kernel.
+// Reference: lib/networks/mvsnerf/network.py:153-229, 887-1126; utils.py:112-146, 300-383,
+//            580-630; renderer.py:111-137.
+#include "mlp.hpp"          // f32x16, n16(), BMV_MFMA, fences, xhalf_sum
+#include "render_geom.hpp"
+
+namespace bmv {
+
+// ---------------------------------------------------------------------------
+// a18
+// ---------------------------------------------------------------------------
+__device__ inline void invert4x4(double m[4][8]) {  // Gauss-Jordan, partial pivoting, [A | I] -> [I | A^-1]
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    double best = fabs(m[col][col]);
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(m[r][col]) > best) best = fabs(m[r][col]), piv = r;
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) {
+        double t = m[col][c];
+        m[col][c] = m[piv][c];
+        m[piv][c] = t;
+      }
+    double inv = 1.0 / m[col][col];
+    for (int c = 0; c < 8; ++c) m[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      double f = m[r][col];
+      for (int c = 0; c < 8; ++c) m[r][c] -= f * m[col][c];
+    }
+  }
+}
+
+__device__ inline void scaled_proj(const float* K, const float* E, float P[4][4]) {
+  for (int r = 0; r < 3; ++r) {
+    float k[3];
+    for (int c = 0; c < 3; ++c) k[c] = r < 2 ? K[r * 3 + c] * 0.25f : K[r * 3 + c];
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
+      for (int j = 0; j < 3; ++j) a += k[j] * E[j * 4 + c];
+      P[r][c] = a;
+    }
+  }
+  P[3][0] = P[3][1] = P[3][2] = 0.f, P[3][3] = 1.f;
+}
+
+__global__ void mvs_proj_mats_kernel(const float* __restrict__ exts, const float* __restrict__ ixts, int B, int S,
+                                     float* __restrict__ proj) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * S) return;
+  int b = idx / S, i = idx - b * S;
+  float* out = proj + (size_t)idx * 12;
+  if (i == 0) {
+    for (int k = 0; k < 12; ++k) out[k] = (k == 0 || k == 5 || k == 10) ? 1.f : 0.f;
+    return;
+  }
+  float Pr[4][4], Pi[4][4];
+  scaled_proj(ixts + ((size_t)b * S) * 9, exts + ((size_t)b * S) * 16, Pr);
+  scaled_proj(ixts + (size_t)idx * 9, exts + (size_t)idx * 16, Pi);
+  double m[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) m[r][c] = (double)Pr[r][c], m[r][4 + c] = r == c ? 1.0 : 0.0;
+  invert4x4(m);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double a = 0.0;
+      for (int k = 0; k < 4; ++k) a += (double)Pi[r][k] * (double)(float)m[k][4 + c];
+      out[r * 4 + c] = (float)a;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// F.interpolate(mode='bilinear', align_corners=False), size given
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ Lerp1 half_pixel_axis(int dst, int in_size, int out_size) {
+  Lerp1 r;
+  float scale = (float)in_size / (float)out_size;
+  float src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
+  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ src, int H, int W, int h, int w,
+                                       float* __restrict__ dst) {
+  int plane = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * w) return;
+  int y = i / w, x = i - y * w;
+  Lerp1 ly = half_pixel_axis(y, H, h), lx = half_pixel_axis(x, W, w);
+  dst[(size_t)plane * h * w + i] = upsample_fetch(src + (size_t)plane * H * W, W, ly, lx);
+}
+
+// ---------------------------------------------------------------------------
+// a19 + a20: one thread per padded voxel, all channels in registers.
+// ---------------------------------------------------------------------------
+template <int C, int S>
+__global__ void __launch_bounds__(256) mvs_sweep_kernel(const float* __restrict__ imgs,
+                                                         const float* __restrict__ feats,
+                                                         const float* __restrict__ proj,
+                                                         const float* __restrict__ depth_values, int h, int w, int D,
+                                                         int pad, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
+  const size_t nvox = (size_t)D * hp * wp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  const int xp = (int)(i % wp), yp = (int)((i / wp) % hp), d = (int)(i / ((size_t)hp * wp));
+  const int x = xp - pad, y = yp - pad;
+  const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+  const size_t plane = (size_t)h * w;
+  const float depth = depth_values[b * D + d];
+  float* o = out + (size_t)b * (3 * S + C) * nvox + i;
+
+  float acc[C], acc2[C];
+  {  // reference view: un-warped, zero-padded (network.py:907-918)
+    const float* f0 = feats + ((size_t)b * S) * C * plane + (inside ? (size_t)y * w + x : 0);
+    const float* c0 = imgs + ((size_t)b * S) * 3 * plane + (inside ? (size_t)y * w + x : 0);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = inside ? f0[c * plane] : 0.f;
+      acc[c] = v, acc2[c] = v * v;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c * nvox] = inside ? c0[c * plane] : 0.f;
+  }
+  float count = 1.f;
+#pragma unroll
+  for (int s = 1; s < S; ++s) {
+    const float* P = proj + ((size_t)b * S + s) * 12;
+    float px = P[0] * x + P[1] * y + P[2] + P[3] / depth;
+    float py = P[4] * x + P[5] * y + P[6] + P[7] / depth;
+    float pz = P[8] * x + P[9] * y + P[10] + P[11] / depth;
+    float gx = (px / pz) / ((float)(w - 1) * 0.5f) - 1.f;  // no z clamp in this variant (utils.py:617)
+    float gy = (py / pz) / ((float)(h - 1) * 0.5f) - 1.f;
+    count += (gx > -1.f && gx < 1.f && gy > -1.f && gy < 1.f) ? 1.f : 0.f;
+    Taps2 t = taps_zeros(unnorm(gx, w), unnorm(gy, h), w, h);
+    const float* f = feats + ((size_t)b * S + s) * C * plane;
+    const float* cimg = imgs + ((size_t)b * S + s) * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[(3 * s + c) * nvox] = tap_fetch(cimg + c * plane, t);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = tap_fetch(f + c * plane, t);
+      acc[c] += v, acc2[c] += v * v;
+    }
+  }
+  const float inv = 1.f / count;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float m = acc[c] * inv;
+    o[(3 * S + c) * nvox] = acc2[c] * inv - m * m;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a25: Renderer_ours (6 x 128) on fp32 MFMA, same transposed orientation as mlp.hpp
+// (sample on the lane, neurons in accumulators, outputs of a layer are the B operands of
+// the next).  The 0.5 MB of weights does not fit LDS: the packed blob is a sequence of
+// CHUNKS (one per layer and pair of 32-neuron output tiles, [k-step][2 tiles][64 lanes]),
+// streamed through one LDS buffer by the whole workgroup; the 4 waves of a workgroup walk
+// the chunks in lockstep, each on its own 32-sample tile.
+// ---------------------------------------------------------------------------
+struct MvsMlp {
+  static constexpr int N_CHUNKS = 17;
+  // k-steps per chunk: bias x2, L0 x2, L1..L4 x2 each, L5 x2, feature x2, views x1
+  __host__ __device__ static constexpr int steps(int c) {
+    return c < 2 ? 10 : c < 4 ? 32 : c < 12 ? 64 : c < 14 ? 96 : c < 16 ? 64 : 66;
+  }
+  __host__ __device__ static constexpr int offset(int c) {
+    int o = 0;
+    for (int i = 0; i < c; ++i) o += steps(i) * 128;
+    return o;
+  }
+  static constexpr int CHUNK_MAX = 96 * 128;  // floats (48 KB)
+  static constexpr int A_TOTAL = 2 * 10 * 128 + 2 * 32 * 128 + 8 * 64 * 128 + 2 * 96 * 128 + 2 * 64 * 128 + 66 * 128;
+  // resident small tables, [idx][half] with idx = tile*16 + reg
+  static constexpr int S_BBIAS = 0;                   // pts_bias bias          [64]
+  static constexpr int S_BL = S_BBIAS + 128;          // pts_linears.{0..5} bias [6][64]
+  static constexpr int S_BF = S_BL + 6 * 128;         // feature_linear bias     [64]
+  static constexpr int S_BV = S_BF + 128;             // views_linears.0 bias    [32]
+  static constexpr int S_WA = S_BV + 64;              // alpha_linear weight     [64]
+  static constexpr int S_WRGB = S_WA + 128;           // rgb_linear weight       [3][32]
+  static constexpr int S_SC = S_WRGB + 3 * 64;        // alpha bias, rgb bias x3
+  static constexpr int S_TOTAL = S_SC + 4;
+  static constexpr int TOTAL = A_TOTAL + S_TOTAL;
+};
+static_assert(MvsMlp::offset(MvsMlp::N_CHUNKS) == MvsMlp::A_TOTAL, "chunk table");
+
+__device__ __forceinline__ int hid_index(int u, int h) { return 32 * (u >> 4) + n16(u & 15, h); }  // k-step u of a 128-wide input
+
+__global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ blob) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= MvsMlp::TOTAL) return;
+  float v = 0.f;
+  if (idx < MvsMlp::A_TOTAL) {
+    int c = 0, base = 0;
+    while (idx >= base + MvsMlp::steps(c) * 128) base += MvsMlp::steps(c) * 128, ++c;
+    int rel = idx - base;
+    int lane = rel & 63, tl = (rel >> 6) & 1, t = rel >> 7;
+    int i = lane & 31, h = lane >> 5;
+    if (c < 2) {                                    // pts_bias: 20 -> 128
+      int n = 64 * c + 32 * tl + i, k = 2 * t + h;
+      if (k < 20) v = p.bias_w[n * 20 + k];
+    } else if (c < 4) {                             // pts_linears.0: 63 -> 128
+      int n = 64 * (c - 2) + 32 * tl + i, k = 2 * t + h;
+      if (k < 63) v = p.pts_w[0][n * 63 + k];
+    } else if (c < 12) {                            // pts_linears.1-4: 128 -> 128
+      int l = 1 + (c - 4) / 2, n = 64 * ((c - 4) & 1) + 32 * tl + i;
+      v = p.pts_w[l][n * 128 + hid_index(t, h)];
+    } else if (c < 14) {                            // pts_linears.5: [pts 63 | h 128] -> 128
+      int n = 64 * (c - 12) + 32 * tl + i;
+      if (t < 32) {
+        int k = 2 * t + h;
+        if (k < 63) v = p.pts_w[5][n * 191 + k];
+      } else {
+        v = p.pts_w[5][n * 191 + 63 + hid_index(t - 32, h)];
+      }
+    } else if (c < 16) {                            // feature_linear: 128 -> 128
+      int n = 64 * (c - 14) + 32 * tl + i;
+      v = p.feature_w[n * 128 + hid_index(t, h)];
+    } else {                                        // views_linears.0: [feature 128 | dir 3] -> 64
+      int n = 32 * tl + i;
+      if (t < 64) {
+        v = p.views_w[n * 131 + hid_index(t, h)];
+      } else {
+        int k = 2 * (t - 64) + h;
+        if (k < 3) v = p.views_w[n * 131 + 128 + k];
+      }
+    }
+  } else {
+    int rel = idx - MvsMlp::A_TOTAL;
+    if (rel >= MvsMlp::S_SC) {
+      int k = rel - MvsMlp::S_SC;
+      v = k == 0 ? p.alpha_b[0] : p.rgb_b[k - 1];
+    } else {
+      int h = rel & 1, e = rel >> 1;
+      if (rel < MvsMlp::S_BL) {
+        v = p.bias_b[hid_index(e, h)];
+      } else if (rel < MvsMlp::S_BF) {
+        int q = e - MvsMlp::S_BL / 2;
+        v = p.pts_b[q / 64][hid_index(q % 64, h)];
+      } else if (rel < MvsMlp::S_BV) {
+        v = p.feature_b[hid_index(e - MvsMlp::S_BF / 2, h)];
+      } else if (rel < MvsMlp::S_WA) {
+        v = p.views_b[hid_index(e - MvsMlp::S_BV / 2, h)];
+      } else if (rel < MvsMlp::S_WRGB) {
+        v = p.alpha_w[hid_index(e - MvsMlp::S_WA / 2, h)];
+      } else {
+        int q = e - MvsMlp::S_WRGB / 2;
+        v = p.rgb_w[(q / 32) * 64 + hid_index(q % 32, h)];
+      }
+    }
+  }
+  blob[idx] = v;
+}
+
+// stage chunk c of the blob into the LDS buffer (whole workgroup, 256 threads)
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ blob, float* __restrict__ buf, int c) {
+  const float4* src = reinterpret_cast<const float4*>(blob + MvsMlp::offset(c));
+  float4* dst = reinterpret_cast<float4*>(buf);
+  const int n4 = MvsMlp::steps(c) * 32;
+  for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+}
+
+// acc{0,1} += W_chunk[:, steps T0..T0+NT) * B, B given by `bval(t)` for the chunk-local step t
+#define MVS_GEMM(buf, T0, NT, BEXPR, ACC0, ACC1)                                   \
+  _Pragma("unroll") for (int t_ = 0; t_ < (NT); ++t_) {                            \
+    const int t = t_;                                                              \
+    float b_ = (BEXPR);                                                            \
+    ACC0 = BMV_MFMA((buf)[((T0) + t_) * 128 + lane], b_, ACC0);                    \
+    ACC1 = BMV_MFMA((buf)[((T0) + t_) * 128 + 64 + lane], b_, ACC1);               \
+    BMV_FENCE_EVERY(t_, 4);                                                        \
+  }
+
+// e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
+// Must be called by all 4 waves of the workgroup together (chunk staging uses __syncthreads).
+__device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
+                                                float* __restrict__ buf, int lane, const float (&e)[32],
+                                                const float (&f)[10], const float (&dv)[2], float (&out)[4]) {
+  const int h = lane >> 5;
+  const float* __restrict__ Sv = small + h;
+  f32x16 bias[4], hcur[4], hnew[4];
+  int chunk = 0;
+  auto next_chunk = [&]() {
+    __syncthreads();  // everyone is done with the previous chunk
+    stage_chunk(blob, buf, chunk);
+    __syncthreads();
+    ++chunk;
+  };
+  // pts_bias (network.py:210): bias = W_b feat + b_b
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bias[2 * tp][r] = Sv[(MvsMlp::S_BBIAS / 2 + (2 * tp) * 16 + r) * 2];
+      bias[2 * tp + 1][r] = Sv[(MvsMlp::S_BBIAS / 2 + (2 * tp + 1) * 16 + r) * 2];
+    }
+    next_chunk();
+    MVS_GEMM(buf, 0, 10, f[t], bias[2 * tp], bias[2 * tp + 1]);
+  }
+  // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4
+#pragma unroll
+  for (int layer = 0; layer < 6; ++layer) {
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hnew[2 * tp][r] = Sv[(MvsMlp::S_BL / 2 + layer * 64 + (2 * tp) * 16 + r) * 2];
+        hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BL / 2 + layer * 64 + (2 * tp + 1) * 16 + r) * 2];
+      }
+      next_chunk();
+      if (layer == 0) {
+        MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
+      } else if (layer == 5) {
+        MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
+        MVS_GEMM(buf, 32, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+      } else {
+        MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hcur[tl][r] = fmaxf(hnew[tl][r] * bias[tl][r], 0.f);
+    BMV_FENCE();
+  }
+  // alpha head (network.py:220)
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Sv[(MvsMlp::S_WA / 2 + tl * 16 + r) * 2] * hcur[tl][r];
+    out[3] = fmaxf(xhalf_sum(s) + small[MvsMlp::S_SC], 0.f);
+  }
+  // feature_linear (network.py:221), no activation
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hnew[2 * tp][r] = Sv[(MvsMlp::S_BF / 2 + (2 * tp) * 16 + r) * 2];
+      hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BF / 2 + (2 * tp + 1) * 16 + r) * 2];
+    }
+    next_chunk();
+    MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+  }
+  // views_linears.0 (network.py:222-226): relu(W_v [feature, dir] + b_v), 131 -> 64
+  f32x16 hv[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hv[tl][r] = Sv[(MvsMlp::S_BV / 2 + tl * 16 + r) * 2];
+  next_chunk();
+  MVS_GEMM(buf, 0, 64, hnew[t >> 4][t & 15], hv[0], hv[1]);
+  MVS_GEMM(buf, 64, 2, dv[t], hv[0], hv[1]);
+  // rgb head (network.py:228): sigmoid(W_rgb relu(hv) + b)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Sv[(MvsMlp::S_WRGB / 2 + c * 32 + tl * 16 + r) * 2] * fmaxf(hv[tl][r], 0.f);
+    float pre = xhalf_sum(s) + small[MvsMlp::S_SC + 1 + c];
+    out[c] = 1.f / (1.f + __expf(-pre));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a21-a24: per-sample inputs of the MLP
+// ---------------------------------------------------------------------------
+struct MvsCams {
+  Cam cam[4];
+  float near_v, far_v;
+};
+
+// value j (0..62) of Embedder.embed(ndc): [x | sin(x 2^k) k=0..9 | cos(x 2^k)], component fastest
+__device__ __forceinline__ float embed_value(int j, const float (&ndc)[3], const float (&sn)[30],
+                                             const float (&cs)[30]) {
+  return j < 3 ? ndc[j < 3 ? j : 0] : j < 33 ? sn[j >= 3 && j < 33 ? j - 3 : 0] : j < 63 ? cs[j >= 33 && j < 63 ? j - 33 : 0] : 0.f;
+}
+
+template <int S>
+__device__ __forceinline__ void mvs_point_inputs(const bmv_mvs_render_args& a, const MvsCams& mc, int ray, int k,
+                                                 int h, float (&e)[32], float (&f)[10], float (&dv)[2], float& z,
+                                                 float& vis) {
+  const float* r = a.rays + (size_t)ray * 8;
+  const float o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
+  const float t = linspace01(k, a.Ns);
+  z = r[6] * (1.f - t) + r[7] * t;  // network.py:952
+  const float xyz[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};
+  const float inv_w = (float)(a.W - 1), inv_h = (float)(a.H - 1);
+  float ndc[3];
+  {  // a22: reference view (view 0), depth normalised by the sweep bounds, re-mapped into the padded volume
+    const Cam& c = mc.cam[0];
+    float cx = xyz[0] * c.E[0] + xyz[1] * c.E[1] + xyz[2] * c.E[2] + c.E[3];
+    float cy = xyz[0] * c.E[4] + xyz[1] * c.E[5] + xyz[2] * c.E[6] + c.E[7];
+    float cz = xyz[0] * c.E[8] + xyz[1] * c.E[9] + xyz[2] * c.E[10] + c.E[11];
+    float qx = cx * c.Kf[0] + cy * c.Kf[1] + cz * c.Kf[2];
+    float qy = cx * c.Kf[3] + cy * c.Kf[4] + cz * c.Kf[5];
+    float qz = cx * c.Kf[6] + cy * c.Kf[7] + cz * c.Kf[8];
+    float u = (qx / qz + 0.f) / inv_w, v = (qy / qz + 0.f) / inv_h;
+    float wf = (inv_w + 1.f) / 4.f, hf = (inv_h + 1.f) / 4.f;
+    float p2 = (float)(a.pad * 2);
+    ndc[1] = v * hf / (hf + p2) + (float)a.pad / (hf + p2);
+    ndc[0] = u * wf / (wf + p2) + (float)a.pad / (wf + p2);
+    ndc[2] = (qz - mc.near_v) / (mc.far_v - mc.near_v);
+  }
+  {  // a23: regularised volume, trilinear, zeros padding; this half's 4 channels
+    Taps3 t3 = taps3_zeros(ndc[0], ndc[1], ndc[2], a.wp, a.hp, a.D);
+    size_t cs = (size_t)a.D * a.hp * a.wp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = tap3_fetch(a.volume + (size_t)(2 * j + h) * cs, t3);
+  }
+  vis = 0.f;
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {  // build_color_volume: rgb (bilinear, border) + inside flag per view
+    const Cam& c = mc.cam[i];
+    float cx = xyz[0] * c.E[0] + xyz[1] * c.E[1] + xyz[2] * c.E[2] + c.E[3];
+    float cy = xyz[0] * c.E[4] + xyz[1] * c.E[5] + xyz[2] * c.E[6] + c.E[7];
+    float cz = xyz[0] * c.E[8] + xyz[1] * c.E[9] + xyz[2] * c.E[10] + c.E[11];
+    float qx = cx * c.Kf[0] + cy * c.Kf[1] + cz * c.Kf[2];
+    float qy = cx * c.Kf[3] + cy * c.Kf[4] + cz * c.Kf[5];
+    float qz = cx * c.Kf[6] + cy * c.Kf[7] + cz * c.Kf[8];
+    float gx = ((qx / qz + 0.f) / inv_w) * 2.f - 1.f, gy = ((qy / qz + 0.f) / inv_h) * 2.f - 1.f;
+    Taps2 t2 = taps_border(unnorm(gx, a.W), unnorm(gy, a.H), a.W, a.H);
+    const float* img = a.src_inps + (size_t)i * 3 * plane;
+    // feature slots 4+2i, 5+2i hold (r | g) and (b | inside) for (half 0 | half 1)
+    float c0 = tap_fetch(img + (size_t)h * plane, t2) * 0.5f + 0.5f;          // r or g
+    float c1 = tap_fetch(img + (size_t)2 * plane, t2) * 0.5f + 0.5f;          // b
+    float ins = (gx > -1.f && gx < 1.f && gy > -1.f && gy < 1.f) ? 1.f : 0.f;
+    f[4 + 2 * i] = c0;
+    f[5 + 2 * i] = h ? ins : c1;
+    if (a.mask) vis += visible(c, xyz, inv_w, inv_h);
+  }
+  {  // gen_dir_feature: unit ray direction in the reference camera frame
+    float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float dn[3] = {d[0] / n, d[1] / n, d[2] / n};
+    const Cam& c = mc.cam[0];
+    float a0 = dn[0] * c.E[0] + dn[1] * c.E[1] + dn[2] * c.E[2];
+    float a1 = dn[0] * c.E[4] + dn[1] * c.E[5] + dn[2] * c.E[6];
+    float a2 = dn[0] * c.E[8] + dn[1] * c.E[9] + dn[2] * c.E[10];
+    dv[0] = h ? a1 : a0;
+    dv[1] = h ? 0.f : a2;
+  }
+  {  // a24: positional encoding of the NDC point
+    float sn[30], cs[30];
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sincosf(ndc[c] * (float)(1 << q), &sn[q * 3 + c], &cs[q * 3 + c]);
+#pragma unroll
+    for (int tt = 0; tt < 32; ++tt) {
+      float v0 = embed_value(2 * tt, ndc, sn, cs), v1 = embed_value(2 * tt + 1, ndc, sn, cs);
+      e[tt] = h ? v1 : v0;
+    }
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 16 B)
+  float* buf = lds + ((MvsMlp::S_TOTAL + 3) / 4) * 4;   // one weight chunk
+  MvsCams* mc = reinterpret_cast<MvsCams*>(buf + MvsMlp::CHUNK_MAX);
+  if (a.blob)
+    for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = a.blob[MvsMlp::A_TOTAL + i];
+  if ((int)threadIdx.x < S) load_cam(a.src_exts + threadIdx.x * 16, a.src_ixts + threadIdx.x * 9, 1.f, mc->cam[threadIdx.x]);
+  if (threadIdx.x == 32) {
+    float n0 = a.near_far[0], n1 = a.near_far[1];
+    mc->near_v = fminf(n0, n1), mc->far_v = fmaxf(n0, n1);  // batch['near_far'].min() / .max()
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 31, h = lane >> 5;
+  const long npts = (long)(a.ray_end - a.ray_begin) * a.Ns;
+  const long ntiles = (npts + 31) / 32;
+  const long per_round = (long)gridDim.x * 4;
+  for (long round = 0; round * per_round < ntiles; ++round) {   // uniform trip count across the workgroup
+    long tile = round * per_round + (long)blockIdx.x * 4 + wave;
+    long pt = tile * 32 + s;
+    bool valid = pt < npts;
+    long pc = valid ? pt : npts - 1;
+    int ray = a.ray_begin + (int)(pc / a.Ns), k = (int)(pc % a.Ns);
+    float e[32], f[10], dv[2], z, vis, res[4];
+    mvs_point_inputs<S>(a, *mc, ray, k, h, e, f, dv, z, vis);
+    size_t gi = (size_t)ray * a.Ns + k;
+    if (a.inputs86 && valid) {  // test / API-parity hook: the reference's 86-wide MLP input row
+      float* row = a.inputs86 + gi * 86;
+#pragma unroll
+      for (int t = 0; t < 32; ++t)
+        if (2 * t + h < 63) row[2 * t + h] = e[t];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) row[63 + 2 * t + h] = f[t];
+      if (h == 0) row[83] = dv[0], row[85] = dv[1];
+      else row[84] = dv[0];
+    }
+    if (a.blob) {
+      mvs_mlp_forward(a.blob, small, buf, lane, e, f, dv, res);
+      if (valid && h == 0) {
+        float4 o4 = {res[0], res[1], res[2], res[3]};
+        reinterpret_cast<float4*>(a.raw)[gi] = o4;
+      }
+    }
+    if (valid && h == 0) {
+      if (a.z_vals) a.z_vals[gi] = z;
+      if (a.mask) a.mask[gi] = vis / (float)S;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict__ x, const float* __restrict__ blob,
+                                                          long npts, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* small = lds;
+  float* buf = lds + ((MvsMlp::S_TOTAL + 3) / 4) * 4;
+  for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = blob[MvsMlp::A_TOTAL + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 31, h = lane >> 5;
+  const long ntiles = (npts + 31) / 32;
+  const long per_round = (long)gridDim.x * 4;
+  for (long round = 0; round * per_round < ntiles; ++round) {
+    long pt = (round * per_round + (long)blockIdx.x * 4 + wave) * 32 + s;
+    bool valid = pt < npts;
+    const float* row = x + (valid ? pt : npts - 1) * 86;
+    float e[32], f[10], dv[2], res[4];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) e[t] = (2 * t + h < 63) ? row[2 * t + h] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) f[t] = row[63 + 2 * t + h];
+    dv[0] = row[83 + h];
+    dv[1] = h ? 0.f : row[85];
+    mvs_mlp_forward(blob, small, buf, lane, e, f, dv, res);
+    if (valid && h == 0) {
+      float4 o4 = {res[0], res[1], res[2], res[3]};
+      reinterpret_cast<float4*>(out)[pt] = o4;
+    }
+  }
+}
+
+// boost_mvsnerf calc_mask (boost_mvsnerf/network.py:23-45): march Ns samples, viewport visibility fraction
+__global__ void mvs_march_mask_kernel(const float* __restrict__ rays, const float* __restrict__ exts,
+                                      const float* __restrict__ ixts, long total, int Ns, int V, float inv_w,
+                                      float inv_h, float* __restrict__ zv, float* __restrict__ mask) {
+  extern __shared__ float smem[];
+  Cam* cams = reinterpret_cast<Cam*>(smem);
+  for (int v = threadIdx.x; v < V; v += blockDim.x) load_cam(exts + (size_t)v * 16, ixts + (size_t)v * 9, 1.f, cams[v]);
+  __syncthreads();
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long ray = i / Ns;
+  int k = (int)(i - ray * Ns);
+  const float* r = rays + ray * 8;
+  float t = linspace01(k, Ns);
+  float z = r[6] * (1.f - t) + r[7] * t;
+  float xyz[3] = {r[0] + r[3] * z, r[1] + r[4] * z, r[2] + r[5] * z};
+  float acc = 0.f;
+  for (int v = 0; v < V; ++v) acc += visible(cams[v], xyz, inv_w, inv_h);
+  zv[i] = z;
+  mask[i] = acc / (float)V;
+}
+
+static constexpr size_t kMvsLds = (((MvsMlp::S_TOTAL + 3) / 4) * 4 + MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
+
+}  // namespace bmv
+
+using namespace bmv;
+
+extern "C" {
+
+int bmv_mvs_proj_mats(const float* src_exts, const float* src_ixts, int B, int S, float* proj, bmv_stream_t stream) {
+  BMV_REQUIRE(src_exts && src_ixts && proj, "bmv_mvs_proj_mats: null pointer");
+  BMV_REQUIRE(B > 0 && S > 0, "bmv_mvs_proj_mats: bad shape");
+  hipLaunchKernelGGL(mvs_proj_mats_kernel, dim3(cdiv(B * S, 64)), dim3(64), 0, as_stream(stream), src_exts, src_ixts, B,
+                     S, proj);
+  BMV_LAUNCH_END("bmv_mvs_proj_mats");
+}
+
+int bmv_resize_bilinear(const float* src, int n, int C, int H, int W, int h, int w, float* dst, bmv_stream_t stream) {
+  BMV_REQUIRE(src && dst, "bmv_resize_bilinear: null pointer");
+  BMV_REQUIRE(n > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bmv_resize_bilinear: bad shape");
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(cdiv(h * w, 256), n * C), dim3(256), 0, as_stream(stream), src, H, W,
+                     h, w, dst);
+  BMV_LAUNCH_END("bmv_resize_bilinear");
+}
+
+int bmv_mvs_sweep_fwd(const float* imgs, const float* feats, const float* proj, const float* depth_values, int B,
+                      int S, int C, int h, int w, int D, int pad, float* volume, bmv_stream_t stream) {
+  BMV_REQUIRE(imgs && feats && proj && depth_values && volume, "bmv_mvs_sweep_fwd: null pointer");
+  BMV_REQUIRE(B > 0 && h > 1 && w > 1 && D > 0 && pad >= 0, "bmv_mvs_sweep_fwd: bad shape");
+  if (C != 32 || S != 3) {
+    set_error("bmv_mvs_sweep_fwd: built for C=32 feature channels and S=3 views (got C=%d S=%d)", C, S);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  size_t nvox = (size_t)D * (h + 2 * pad) * (w + 2 * pad);
+  hipLaunchKernelGGL((mvs_sweep_kernel<32, 3>), dim3(cdiv(nvox, 256), B), dim3(256), 0, as_stream(stream), imgs, feats,
+                     proj, depth_values, h, w, D, pad, volume);
+  BMV_LAUNCH_END("bmv_mvs_sweep_fwd");
+}
+
+int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* src_ixts, int N, int Ns, int V,
+                       float inv_w, float inv_h, float* z_vals, float* mask, bmv_stream_t stream) {
+  BMV_REQUIRE(rays && src_exts && src_ixts && z_vals && mask, "bmv_mvs_march_mask: null pointer");
+  BMV_REQUIRE(N >= 0 && Ns > 0 && V > 0 && V <= 64, "bmv_mvs_march_mask: bad shape");
+  long total = (long)N * Ns;
+  if (total == 0) return BMV_OK;
+  hipLaunchKernelGGL(mvs_march_mask_kernel, dim3(cdiv(total, 256)), dim3(256), sizeof(Cam) * V, as_stream(stream), rays,
+                     src_exts, src_ixts, total, Ns, V, inv_w, inv_h, z_vals, mask);
+  BMV_LAUNCH_END("bmv_mvs_march_mask");
+}
+
+int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL; }
+
+int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* p, float* blob, bmv_stream_t stream) {
+  BMV_REQUIRE(p && blob, "bmv_mvs_mlp_pack_weights: null pointer");
+  const float* const* pp = reinterpret_cast<const float* const*>(p);
+  for (int i = 0; i < 22; ++i) BMV_REQUIRE(pp[i], "bmv_mvs_mlp_pack_weights: parameter %d is null", i);
+  hipLaunchKernelGGL(mvs_mlp_pack_kernel, dim3(cdiv(MvsMlp::TOTAL, 256)), dim3(256), 0, as_stream(stream), *p, blob);
+  BMV_LAUNCH_END("bmv_mvs_mlp_pack_weights");
+}
+
+static int mvs_lds_ok(const void* k) {
+  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMvsLds) == hipSuccess;
+}
+
+int bmv_mvs_mlp_fwd(const float* x, const float* blob, long npts, float* out, bmv_stream_t stream) {
+  BMV_REQUIRE(x && blob && out, "bmv_mvs_mlp_fwd: null pointer");
+  BMV_REQUIRE(npts >= 0, "bmv_mvs_mlp_fwd: npts=%ld", npts);
+  if (npts == 0) return BMV_OK;
+  BMV_REQUIRE(mvs_lds_ok(reinterpret_cast<const void*>(mvs_mlp_kernel)), "bmv_mvs_mlp_fwd: cannot reserve LDS");
+  long ntiles = (npts + 31) / 32;
+  unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
+  hipLaunchKernelGGL(mvs_mlp_kernel, dim3(grid), dim3(256), kMvsLds, as_stream(stream), x, blob, npts, out);
+  BMV_LAUNCH_END("bmv_mvs_mlp_fwd");
+}
+
+int bmv_mvs_render_fwd(const bmv_mvs_render_args* a, bmv_stream_t stream) {
+  BMV_REQUIRE(a, "bmv_mvs_render_fwd: null args");
+  BMV_REQUIRE(a->rays && a->volume && a->src_inps && a->src_exts && a->src_ixts && a->near_far,
+              "bmv_mvs_render_fwd: null pointer");
+  BMV_REQUIRE(a->blob ? (a->raw != nullptr) : (a->inputs86 != nullptr),
+              "bmv_mvs_render_fwd: need raw output (with weights) or inputs86 (without)");
+  BMV_REQUIRE(a->S == 3, "bmv_mvs_render_fwd: S=%d, built for 3 source views per cost volume", a->S);
+  BMV_REQUIRE(a->N > 0 && a->Ns > 0 && a->D > 0 && a->hp > 0 && a->wp > 0 && a->H > 1 && a->W > 1,
+              "bmv_mvs_render_fwd: bad shape");
+  BMV_REQUIRE(a->ray_begin >= 0 && a->ray_end <= a->N && a->ray_begin <= a->ray_end, "bmv_mvs_render_fwd: ray range");
+  if (a->ray_begin == a->ray_end) return BMV_OK;
+  BMV_REQUIRE(mvs_lds_ok(reinterpret_cast<const void*>(mvs_render_kernel<3>)), "bmv_mvs_render_fwd: cannot reserve LDS");
+  long ntiles = ((long)(a->ray_end - a->ray_begin) * a->Ns + 31) / 32;
+  unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
+  hipLaunchKernelGGL(mvs_render_kernel<3>, dim3(grid), dim3(256), kMvsLds, as_stream(stream), *a);
+  BMV_LAUNCH_END("bmv_mvs_render_fwd");
+}
+
+}  // extern "C"

@@ -275,3 +275,115 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
         rc = lib.bmv_render_rays_fwd(C.byref(a), stream())
     _lib.check(rc, "render_rays")
     return o0, o1, o2
+
+
+# ======================================================================= MVSNeRF backbone
+def mvs_proj_mats(src_exts, src_ixts):
+    B, S = src_exts.shape[:2]
+    out = torch.empty(B, S, 3, 4, device=src_exts.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_mvs_proj_mats(dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"), B, S, dptr(out),
+                                     stream()), "mvs_proj_mats")
+    return out
+
+
+def resize_bilinear(x, h, w):
+    """F.interpolate(x, (h, w), mode='bilinear', align_corners=False) on (..., C, H, W)."""
+    C_, H, W = x.shape[-3:]
+    n = x.numel() // (C_ * H * W)
+    out = torch.empty(*x.shape[:-2], h, w, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_resize_bilinear(dptr(_c(x), "x"), n, C_, H, W, h, w, dptr(out), stream()), "resize_bilinear")
+    return out
+
+
+def mvs_sweep(imgs_small, feats, proj, depth_values, pad):
+    B, S, C_, h, w = feats.shape
+    D = depth_values.shape[1]
+    out = torch.empty(B, 3 * S + C_, D, h + 2 * pad, w + 2 * pad, device=feats.device, dtype=torch.float32)
+    lib = _lib.load()
+    args = (dptr(_c(imgs_small), "imgs"), dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
+            dptr(_c(depth_values), "depth_values"), B, S, C_, h, w, D, int(pad), dptr(out), stream())
+    with ktimer.region(f"mvs_sweep[C={C_},D={D},{h}x{w},pad={pad}]"):
+        rc = lib.bmv_mvs_sweep_fwd(*args)
+    _lib.check(rc, "mvs_sweep")
+    return out
+
+
+MVS_MLP_PARAM_ORDER = tuple([f"pts_linears.{i}" for i in range(6)]) + ("pts_bias", "views_linears.0", "feature_linear",
+                                                                        "alpha_linear", "rgb_linear")
+
+
+def mvs_mlp_pack_weights(weights, biases):
+    """weights / biases: dicts name -> tensor for the names in MVS_MLP_PARAM_ORDER."""
+    lib = _lib.load()
+    held = {k: (_c(weights[k].detach()), _c(biases[k].detach())) for k in MVS_MLP_PARAM_ORDER}
+    p = _lib.MvsMlpParams()
+    for i in range(6):
+        p.pts_w[i] = held[f"pts_linears.{i}"][0].data_ptr()
+        p.pts_b[i] = held[f"pts_linears.{i}"][1].data_ptr()
+    for field, name in (("bias", "pts_bias"), ("views", "views_linears.0"), ("feature", "feature_linear"),
+                        ("alpha", "alpha_linear"), ("rgb", "rgb_linear")):
+        setattr(p, field + "_w", dptr(held[name][0], name + ".weight"))
+        setattr(p, field + "_b", dptr(held[name][1], name + ".bias"))
+    for i in range(6):
+        dptr(held[f"pts_linears.{i}"][0], f"pts_linears.{i}.weight")   # validation only
+    dev = held["pts_bias"][0].device
+    blob = torch.empty(lib.bmv_mvs_mlp_blob_size(), device=dev, dtype=torch.float32)
+    _lib.check(lib.bmv_mvs_mlp_pack_weights(C.byref(p), dptr(blob), stream()), "mvs_mlp_pack_weights")
+    return blob
+
+
+def mvs_mlp(x, blob):
+    lead = x.shape[:-1]
+    if x.shape[-1] != 86:
+        raise ValueError("MVSNeRF MLP input is 63 + 20 + 3 = 86 wide")
+    npts = x.numel() // 86
+    out = torch.empty(*lead, 4, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region("mvs_mlp"):
+        rc = lib.bmv_mvs_mlp_fwd(dptr(_c(x), "x"), dptr(blob, "blob"), npts, dptr(out), stream())
+    _lib.check(rc, "mvs_mlp")
+    return out
+
+
+def mvs_render(rays, volume, src_inps, src_exts, src_ixts, near_far, blob, Ns, pad, want_mask=False,
+               want_inputs=False, ray_range=None, outs=None):
+    """rays (N,8); volume (8,D,hp,wp); src_inps (S,3,H,W); -> raw (N,Ns,4), z (N,Ns), mask (N,Ns)|None,
+    inputs86 (N,Ns,86)|None."""
+    N = rays.shape[0]
+    S, _, H, W = src_inps.shape
+    _, D, hp, wp = volume.shape
+    dev = rays.device
+    if outs is not None:
+        raw, z, mask = outs
+    else:
+        raw = torch.empty(N, Ns, 4, device=dev, dtype=torch.float32) if blob is not None else None
+        z = torch.empty(N, Ns, device=dev, dtype=torch.float32)
+        mask = torch.empty(N, Ns, device=dev, dtype=torch.float32) if want_mask else None
+    x86 = torch.empty(N, Ns, 86, device=dev, dtype=torch.float32) if want_inputs else None
+    held = [_c(t) for t in (rays, volume, src_inps, src_exts, src_ixts, near_far)]
+    a = _lib.MvsRenderArgs()
+    for name, t in zip(("rays", "volume", "src_inps", "src_exts", "src_ixts", "near_far"), held):
+        setattr(a, name, dptr(t, name))
+    a.blob = dptr(blob, "blob")
+    a.N, a.Ns, a.S, a.D, a.hp, a.wp, a.H, a.W, a.pad = N, int(Ns), S, D, hp, wp, H, W, int(pad)
+    a.ray_begin, a.ray_end = ray_range if ray_range is not None else (0, N)
+    a.raw, a.z_vals, a.mask, a.inputs86 = dptr(raw), dptr(z), dptr(mask), dptr(x86)
+    lib = _lib.load()
+    with ktimer.region(f"mvs_render[Ns={Ns}]"):
+        rc = lib.bmv_mvs_render_fwd(C.byref(a), stream())
+    _lib.check(rc, "mvs_render")
+    return raw, z, mask, x86
+
+
+def mvs_march_mask(rays, src_exts, src_ixts, Ns, inv_w, inv_h):
+    N = rays.shape[0]
+    V = src_exts.shape[0]
+    z = torch.empty(N, Ns, device=rays.device, dtype=torch.float32)
+    mask = torch.empty(N, Ns, device=rays.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_mvs_march_mask(dptr(_c(rays), "rays"), dptr(_c(src_exts), "src_exts"),
+                                      dptr(_c(src_ixts), "src_ixts"), N, int(Ns), V, float(inv_w), float(inv_h),
+                                      dptr(z), dptr(mask), stream()), "mvs_march_mask")
+    return z, mask

@@ -165,6 +165,72 @@ typedef struct {
 } bmv_render_args;
 int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
 
+/* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
+
+/* ---- a18 Network.get_proj_mats            lib/networks/mvsnerf/network.py:1070-1090
+ * View 0 of each triplet is the reference view: P_0 = I, P_i = (K_i/4 E_i) inverse(K_0/4 E_0).
+ * src_exts (B,S,4,4), src_ixts (B,S,3,3) -> proj (B,S,3,4) */
+int bmv_mvs_proj_mats(const float* src_exts, const float* src_ixts, int B, int S, float* proj, bmv_stream_t stream);
+
+/* ---- F.interpolate(bilinear, align_corners=False) used by a20 (network.py:913)
+ * src (n,C,H,W) -> dst (n,C,h,w) */
+int bmv_resize_bilinear(const float* src, int n, int C, int H, int W, int h, int w, float* dst, bmv_stream_t stream);
+
+/* ---- a19+a20 homo_warp(pad) + build_volume_costvar_img
+ *          lib/networks/mvsnerf/utils.py:580-630, network.py:887-942
+ * imgs (B,S,3,h,w) (source images already resized to the feature resolution), feats (B,S,C,h,w),
+ * proj (B,S,3,4), depth_values (B,D) -> volume (B, 3*S+C, D, h+2pad, w+2pad):
+ *   ch 0-2 reference rgb inside the un-padded window (0 in the border: the reference leaves it
+ *   uninitialised), ch 3.. warped source rgb, last C: sum(x^2)c - (sum(x)c)^2 over the zero-padded
+ *   reference + warped source features, c = 1 / (1 + number of source views whose grid is inside). */
+int bmv_mvs_sweep_fwd(const float* imgs, const float* feats, const float* proj, const float* depth_values, int B,
+                      int S, int C, int h, int w, int D, int pad, float* volume, bmv_stream_t stream);
+
+/* ---- a25 Renderer_ours parameters          lib/networks/mvsnerf/network.py:153-229
+ * D=6, W=128, input_ch=63, input_ch_feat=20, input_ch_views=3 (network.py:803-805) */
+typedef struct {
+  const float *pts_w[6], *pts_b[6];     /* pts_linears.{0..5}: (128,63) (128,128)x4 (128,191) */
+  const float *bias_w, *bias_b;         /* pts_bias        (128,20)  */
+  const float *views_w, *views_b;       /* views_linears.0 (64,131)  */
+  const float *feature_w, *feature_b;   /* feature_linear  (128,128) */
+  const float *alpha_w, *alpha_b;       /* alpha_linear    (1,128)   */
+  const float *rgb_w, *rgb_b;           /* rgb_linear      (3,64)    */
+} bmv_mvs_mlp_params;
+int bmv_mvs_mlp_blob_size(void);
+int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* params, float* blob, bmv_stream_t stream);
+/* x (npts, 86) = [embed(ndc) 63 | volume+colour feature 20 | view direction 3] -> out (npts,4) = [sigmoid rgb, relu alpha] */
+int bmv_mvs_mlp_fwd(const float* x, const float* blob, long npts, float* out, bmv_stream_t stream);
+
+/* ---- a21..a25 fused: ray_marcher, get_ndc_coordinate, gen_dir_feature, gen_pts_feats, Embedder, MLP
+ *          lib/networks/mvsnerf/network.py:945-1042, utils.py:112-146,300-383, renderer.py:111-137
+ * rays (N,8): near/far are columns 6 and 7 verbatim.  volume (8,D,hp,wp) = regularised cost volume of the
+ * reference view's padded frustum.  src_inps (S,3,H,W) raw images in [-1,1].  near_far: the two
+ * plane-sweep bounds (device scalars, as the reference keeps them in batch['near_far']).
+ * Outputs: raw (N,Ns,4), z_vals (N,Ns), mask (N,Ns) (viewport visibility fraction; NULL to skip),
+ * inputs86 (N,Ns,86) (the MLP input, NULL to skip; test / API-parity hook). */
+typedef struct {
+  const float* rays;      /* (N,8)            */
+  const float* volume;    /* (8,D,hp,wp)      */
+  const float* src_inps;  /* (S,3,H,W)        */
+  const float* src_exts;  /* (S,4,4)          */
+  const float* src_ixts;  /* (S,3,3)          */
+  const float* near_far;  /* (2,)             */
+  const float* blob;      /* packed MLP weights (may be NULL when only inputs86 is wanted) */
+  int N, Ns, S, D, hp, wp, H, W, pad;
+  int ray_begin, ray_end;
+  float* raw;
+  float* z_vals;
+  float* mask;
+  float* inputs86;
+} bmv_mvs_render_args;
+int bmv_mvs_render_fwd(const bmv_mvs_render_args* args, bmv_stream_t stream);
+
+/* ---- boost_mvsnerf calc_mask               lib/networks/boost_mvsnerf/network.py:23-45
+ * rays (N,8) marched with Ns samples between columns 6 and 7; src_exts (V,4,4), src_ixts (V,3,3)
+ * -> z_vals (N,Ns), mask (N,Ns) = fraction of the V views whose viewport holds the sample */
+int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* src_ixts, int N, int Ns, int V,
+                       float inv_w, float inv_h, float* z_vals, float* mask, bmv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,130 @@
+"""GPU parity of the MVSNeRF / boost_mvsnerf kernels (a18-a26) against golden vectors
+produced by the reference."""
+import json
+
+import pytest
+import torch
+
+from conftest import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return load_fixture("mvsnerf_tiny")
+
+
+@pytest.fixture(scope="module")
+def bfx():
+    return load_fixture("boost_mvsnerf_tiny")
+
+
+def chunks(f, name, dim=0):
+    keys = sorted((k for k in f.raw if k.startswith(f"cap/{name}#")), key=lambda k: int(k.split("#")[1].split(".")[0]))
+    return torch.cat([f.t(k) for k in keys], dim)
+
+
+def _cfg(f, preset, tmp_path=None):
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    c = make_cfg(preset)
+    c.enerf.cas_config.num_samples = [int(x) for x in f.raw["extra/num_samples"]]
+    if "extra/k_best" in f.raw:
+        c.enerf.cas_config.k_best = len(f.raw["extra/k_best"])
+    if tmp_path is not None:
+        c.result_dir = str(tmp_path)
+    return set_cfg(c)
+
+
+def test_proj_resize_sweep(fx):
+    from boostmvsnerfs_amd import ops
+    from oracle import mvsnerf as M
+    b = fx.batch(DEV)
+    P = ops.mvs_proj_mats(b["all_src_exts"], b["all_src_ixts"])
+    assert_close(P, fx.t("cap/get_proj_mats#0"), rtol=1e-4, atol_scale=1e-5, name="proj")
+    small = ops.resize_bilinear(b["all_src_inps"], 16, 24)
+    want_small = torch.nn.functional.interpolate(b["all_src_inps"][0].cpu(), (16, 24), mode="bilinear", align_corners=False)
+    assert_close(small[0], want_small, rtol=1e-5, atol_scale=1e-6, name="resize")
+    dv, _, _ = M.depth_planes(b["depth_ranges"].cpu(), 8)
+    vol = ops.mvs_sweep(small, fx.t("cap/feature#0", DEV), fx.t("cap/get_proj_mats#0", DEV), dv[None].to(DEV), 24)
+    assert_close(vol, fx.t("cap/build_volume_costvar_img#0"), name="cost volume")
+
+
+def _blob(fx):
+    from boostmvsnerfs_amd import ops
+    sd = fx.group("sd", DEV)
+    w = {k: sd[f"nerf.nerf.{k}.weight"] for k in ops.MVS_MLP_PARAM_ORDER}
+    bb = {k: sd[f"nerf.nerf.{k}.bias"] for k in ops.MVS_MLP_PARAM_ORDER}
+    return ops.mvs_mlp_pack_weights(w, bb)
+
+
+def test_mlp(fx):
+    from boostmvsnerfs_amd import ops
+    x = chunks(fx, "run_network_mvs").to(DEV)
+    raw = ops.mvs_mlp(x, _blob(fx))
+    assert_close(raw, chunks(fx, "nerf"), name="6x128 mlp")
+    # ragged point count (not a multiple of the 128-sample workgroup round)
+    raw2 = ops.mvs_mlp(x.reshape(-1, 86)[:1001].contiguous(), _blob(fx))
+    assert_close(raw2, chunks(fx, "nerf").reshape(-1, 4)[:1001], name="ragged")
+
+
+def test_fused_sampler_and_mlp(fx):
+    from boostmvsnerfs_amd import ops
+    from oracle import mvsnerf as M
+    b = fx.batch(DEV)
+    volume = fx.t("cap/cost_reg_2#0", DEV)[0]
+    _, near, far = M.depth_planes(b["depth_ranges"].cpu(), 8)
+    nf = torch.stack([near, far]).to(DEV)
+    raw, z, mask, x86 = ops.mvs_render(b["rays_0"][0], volume, b["all_src_inps"][0], b["all_src_exts"][0],
+                                       b["all_src_ixts"][0], nf, _blob(fx), Ns=8, pad=24, want_mask=True, want_inputs=True)
+    want_x = chunks(fx, "run_network_mvs")
+    assert_close(x86[..., 63:], want_x[..., 63:], name="features + view direction")
+    assert_close(x86[..., :3], want_x[..., :3], rtol=1e-4, atol_scale=1e-5, name="ndc")
+    assert_close(x86[..., :63], want_x[..., :63], rtol=1e-3, atol_scale=3e-3, name="embedding")   # sin/cos(512 x)
+    assert_close(z[None], fx.t("cap/ray_marcher#0.1"), rtol=1e-5, atol_scale=1e-6, name="z")
+    assert_close(raw, chunks(fx, "nerf"), name="raw", max_outlier_frac=1e-3)
+    assert float(mask.min()) >= 0 and float(mask.max()) <= 1
+
+
+def _net(fx, cls, **kw):
+    net = cls(**kw)
+    net.load_state_dict(fx.group("sd"), strict=True)
+    return net.to(DEV).eval()
+
+
+def test_mvsnerf_network(fx):
+    _cfg(fx, "mvsnerf_eval")
+    from boostmvsnerfs_amd.networks.mvsnerf.network import Network
+    net = _net(fx, Network)
+    assert list(net.state_dict().keys()) == list(fx.group("sd").keys())
+    b = fx.batch(DEV)
+    with torch.no_grad():
+        out = net(b)
+    want = fx.group("out")
+    assert set(out) == set(want)
+    for k in want:
+        assert_close(out[k], want[k], name=k)
+    assert b["near_far"].shape == (2,) and b["src_inps"].shape[1] == 3      # reference side effects on the batch
+
+
+def test_boost_mvsnerf_network(fx, bfx, tmp_path):
+    _cfg(bfx, "mvsnerf_ours_eval", tmp_path)
+    from boostmvsnerfs_amd.networks.boost_mvsnerf.network import Network
+    pre = _net(fx, Network, preprocess=True)
+    b = bfx.batch(DEV)
+    sel = pre.forward_view_selection(b)
+    want_sel = {"synthetic_0": [int(k) for k in bfx.raw["extra/k_best"]]}
+    assert sel == want_sel
+    with torch.no_grad():
+        m = pre.calc_mask((0, 1, 2), b)["mask_level0"]
+    assert_close(m, bfx.t("cap/sel/calc_mask#0.mask_level0"), rtol=1e-4, atol_scale=1e-5, name="vis0", max_outlier_frac=2e-3)
+    with open(tmp_path / "view_selection.json", "w") as f:
+        json.dump(want_sel, f)
+    net = _net(fx, Network)
+    net.capture = {}
+    with torch.no_grad():
+        out = net(bfx.batch(DEV))
+    want = bfx.group("out")
+    for k in want:
+        assert_close(out[k], want[k], name=k, max_outlier_frac=3e-3)   # discontinuous viewport masks, see conftest
