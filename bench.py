@@ -19,11 +19,16 @@ One JSON line on rank 0, with `roofline` (plane-sweep kernel, HIP-event timed in
 the timed region, algorithmic bytes of SURVEY.md section 8d) and `cpu_baseline`
 (the CPU oracle -- the port of the reference's PyTorch-CPU path -- on this
 host's cores, one frame of the same workload).
+
+Other workloads (`--workload`) time the remaining BASELINE configs; they are not
+the headline line and print the same JSON shape without `cpu_baseline` unless
+`--cpu-baseline` is given.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import torch
@@ -35,10 +40,16 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
 
+HEADLINE = "enerf_512x640_3src_64planes"
 WORKLOADS = {
-    # name: (preset, H, W, volume_planes, n_views)
-    "enerf_512x640_3src_64planes": ("enerf_eval", 512, 640, [64, 8], 3),      # BASELINE configs[1] (metric config)
-    "enerf_256x320_3src_32planes": ("enerf_eval", 256, 320, [32, 8], 3),      # BASELINE configs[0]
+    # name: dict(net, preset, H, W, planes | samples, views, k_best)
+    HEADLINE: dict(net="enerf", preset="enerf_eval", H=512, W=640, planes=[64, 8], views=3),          # configs[1]
+    "enerf_256x320_3src_32planes": dict(net="enerf", preset="enerf_eval", H=256, W=320, planes=[32, 8], views=3),
+    "enerf_ours_480x736_6src_k4": dict(net="boost_enerf", preset="enerf_ours_eval", H=480, W=736, planes=[64, 8],
+                                       views=6, k_best=4),                                           # configs[2]
+    "mvsnerf_224x352_32planes": dict(net="mvsnerf", preset="mvsnerf_eval", H=224, W=352, samples=32, views=3),
+    "mvsnerf_ours_224x352_128planes_k4": dict(net="boost_mvsnerf", preset="mvsnerf_ours_eval", H=224, W=352,
+                                              samples=128, views=6, k_best=4),                       # configs[3]
 }
 
 
@@ -52,18 +63,75 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="enerf_512x640_3src_64planes", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default="views", choices=["views", "rays"])
     ap.add_argument("--sweep-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, state_dict, batch_cpu, H, W):
-    """The oracle (CPU port of the reference path) on this host's cores: one full frame."""
-    from oracle import enerf as O   # checker / baseline only
+def build(args, rank, dev):
+    """Network, resident batch and bookkeeping for the chosen workload."""
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
     from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    wl = WORKLOADS[args.workload]
+    cfg = make_cfg(wl["preset"])
+    cc = cfg.enerf.cas_config
+    if "planes" in wl:
+        cc.volume_planes = list(wl["planes"])
+    if "samples" in wl:
+        cc.num_samples = [wl["samples"]]
+    if "k_best" in wl:
+        cc.k_best = wl["k_best"]
+    cfg.result_dir = tempfile.mkdtemp(prefix="bmv_bench_")
+    set_cfg(cfg)
+    H, W = wl["H"], wl["W"]
+    mvs = wl["net"] in ("mvsnerf", "boost_mvsnerf")
+    tar_offset = (0.05 * rank, 0.0, 0.0) if args.shard == "views" else (0.0, 0.0, 0.0)
+    batch_cpu = make_batch(H, W, n_views=wl["views"], seed=0, tar_offset=tar_offset, depth_ranges=mvs,
+                           render_scales=(1.0,) if mvs else (0.25, 1.0))
+    if mvs:   # a real depth interval in the near/far columns (the shipped loaders put pixel x, y there: quirk 9)
+        batch_cpu["rays_0"][..., 6], batch_cpu["rays_0"][..., 7] = 2.2, 7.5
+    torch.manual_seed(0)
+    if wl["net"] == "enerf":
+        from boostmvsnerfs_amd.networks.enerf.network import Network
+        net = Network()
+    elif wl["net"] == "mvsnerf":
+        from boostmvsnerfs_amd.networks.mvsnerf.network import Network
+        net = Network()
+    else:
+        if wl["net"] == "boost_enerf":
+            from boostmvsnerfs_amd.networks.boost_enerf.network import Network
+        else:
+            from boostmvsnerfs_amd.networks.boost_mvsnerf.network import Network
+        pre = Network(preprocess=True).eval().to(dev)           # offline view selection (untimed, run.py:39-85)
+        with torch.no_grad():
+            sel = pre.forward_view_selection(clone_batch(batch_cpu, dev))
+        key = next(iter(sel))
+        if len(sel[key]) < cc.k_best:                            # degenerate synthetic geometry: pad the cover
+            sel[key] = (sel[key] + [i for i in range(20) if i not in sel[key]])[: cc.k_best]
+        with open(os.path.join(cfg.result_dir, "view_selection.json"), "w") as f:
+            json.dump(sel, f)
+        torch.manual_seed(0)
+        net = Network()
+    net = net.eval()
+    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    if hasattr(net, "sweep_algo"):
+        net.sweep_algo = args.sweep_algo
+    level = 0 if mvs else 1
+    return cfg, wl, net, sd_cpu, batch_cpu, clone_batch(batch_cpu, dev), level
+
+
+def cpu_baseline(args, cfg, wl, state_dict, batch_cpu):
+    """The oracle (CPU port of the reference path) on this host's cores: one full frame."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    H, W = wl["H"], wl["W"]
+    if wl["net"] != "enerf":
+        return None     # bounded-sample baselines for the K-volume / MVSNeRF workloads: see DESIGN.md
+    from oracle import enerf as O   # checker / baseline only
     with torch.no_grad():
         O.enerf_forward(state_dict, make_batch(64, 96), cfg)              # page-in / thread-pool warm-up
         t0 = time.perf_counter()
@@ -92,26 +160,12 @@ def main():
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
 
     from boostmvsnerfs_amd import ktimer, sharding
-    from boostmvsnerfs_amd.config import make_cfg, set_cfg
-    from boostmvsnerfs_amd.networks.enerf.network import Network
-    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
 
-    preset, H, W, planes, n_views = WORKLOADS[args.workload]
-    cfg = make_cfg(preset)
-    cfg.enerf.cas_config.volume_planes = list(planes)
-    set_cfg(cfg)
+    cfg, wl, net, sd_cpu, batch_cpu, batch, level = build(args, rank, dev)
     cc = cfg.enerf.cas_config
-
-    torch.manual_seed(0)
-    net = Network().eval()
-    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
-    net = net.to(dev)
-    net.sweep_algo = args.sweep_algo
-    # views sharding: rank r renders its own target (camera shifted along x), same sources
-    tar_offset = (0.05 * rank, 0.0, 0.0) if args.shard == "views" else (0.0, 0.0, 0.0)
-    batch_cpu = make_batch(H, W, n_views=n_views, seed=0, tar_offset=tar_offset)
-    batch = clone_batch(batch_cpu, dev)
+    H, W = wl["H"], wl["W"]
     N = H * W
+    rgb_key, depth_key = f"rgb_level{level}", f"depth_level{level}"
     if args.shard == "rays" and world > 1:
         net.ray_range = sharding.ray_slice(N, world, rank)
     gather = sharding.TileGather(world, N if args.shard == "views" else None, dev) if world > 1 else None
@@ -121,8 +175,8 @@ def main():
             out = net(batch)
         if gather is not None:
             if args.shard == "views":
-                return gather.all_gather_frames(out["rgb_level1"], out["depth_level1"])
-            return gather.all_gather_ray_tiles(out["rgb_level1"], out["depth_level1"], N)
+                return gather.all_gather_frames(out[rgb_key], out[depth_key])
+            return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
         return out
 
     for _ in range(args.warmup):
@@ -150,63 +204,77 @@ def main():
     if rank == 0:
         frames = args.steps * (world if args.shard == "views" else 1)
         value = frames * N / dt / 1e6
-        # ---- roofline of the plane-sweep kernel (level 1 launch: the larger one)
         ks = ktimer.summary()
-        h1, w1 = int(H * cc.volume_scale[1]), int(W * cc.volume_scale[1])
-        h0, w0 = int(H * cc.volume_scale[0]), int(W * cc.volume_scale[0])
-        lv = {
-            0: (f"sweep_variance[C=32,D={planes[0]},{h0}x{w0}]",
-                sweep_bytes(3, 32, int(H * cc.im_feat_scale[0]), int(W * cc.im_feat_scale[0]), planes[0], h0, w0)),
-            1: (f"sweep_variance[C=16,D={planes[1]},{h1}x{w1}]",
-                sweep_bytes(3, 16, int(H * cc.im_feat_scale[1]), int(W * cc.im_feat_scale[1]), planes[1], h1, w1)),
-        }
-        kernels = {}
-        for lvl, (name, nbytes) in lv.items():
-            if name in ks:
-                n, mean_ms, min_ms = ks[name]
-                kernels[f"sweep_level{lvl}"] = {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3,
-                                                "algorithmic_bytes": nbytes, "GB/s": nbytes / (mean_ms * 1e-3) / 1e9}
-        for name, (n, mean_ms, min_ms) in ks.items():
-            if not name.startswith("sweep_variance"):
-                kernels[name] = {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3}
-        rname = f"render_rays[feat=8,Ns={cc.num_samples[1]},mode=0]"
-        mfma = None
-        if rname in ks:
-            n, mean_ms, min_ms = ks[rname]
-            rays_launch = N // world if (args.shard == "rays" and world > 1) else N
-            flops = 50.9e3 * rays_launch * cc.num_samples[1]          # SURVEY.md 8(d) algorithmic FLOPs of a11
-            mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "launches": n,
-                    "avg_us": mean_ms * 1e3, "achieved": flops / (mean_ms * 1e-3) / 1e12,
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": flops / (mean_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
-        roofline = None
-        if "sweep_level1" in kernels:
-            k = kernels["sweep_level1"]
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "sweep_pmc.json")   # rocprofv3 --pmc pass, see profiles/README.md
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(args.workload, {}).get("sweep_level1_hbm_bytes")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": "sweep_variance level 1 (a3+a4 fused plane sweep)",
-                        "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["GB/s"] / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes": k["algorithmic_bytes"], "avg_us": k["avg_us"],
-                        "launches": k["launches"]}
+        kernels = {name: {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3}
+                   for name, (n, mean_ms, min_ms) in ks.items()}
+        roofline = mfma = None
+        if wl["net"] in ("enerf", "boost_enerf"):
+            planes = cc.volume_planes
+            # ---- roofline of the plane-sweep kernel (level 1 launch: the larger one)
+            for lvl, C in ((0, 32), (1, 16)):
+                h, w = int(H * cc.volume_scale[lvl]), int(W * cc.volume_scale[lvl])
+                name = f"sweep_variance[C={C},D={planes[lvl]},{h}x{w}]"
+                if name in kernels:
+                    nb = sweep_bytes(3, C, int(H * cc.im_feat_scale[lvl]), int(W * cc.im_feat_scale[lvl]), planes[lvl], h, w)
+                    kernels[name].update({"algorithmic_bytes": nb, "GB/s": nb / kernels[name]["avg_us"] / 1e3})
+                    if lvl == 1:
+                        k = kernels[name]
+                        traffic = None
+                        pmc = os.path.join(REPO, "profiles", "sweep_pmc.json")   # rocprofv3 --pmc passes (profiles/README.md)
+                        if os.path.exists(pmc):
+                            try:
+                                traffic = json.load(open(pmc)).get(args.workload, {}).get("sweep_level1_hbm_bytes")
+                            except Exception:
+                                traffic = None
+                        roofline = {"bound": "hbm", "kernel": "sweep_variance level 1 (a3+a4 fused plane sweep)",
+                                    "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": k["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": nb,
+                                    "avg_us": k["avg_us"], "launches": k["launches"]}
+            rname = next((n for n in kernels if n.startswith("render_rays[feat=8")), None)
+            if rname:
+                rays_launch = N // world if (args.shard == "rays" and world > 1) else N
+                flops = 50.9e3 * rays_launch * cc.num_samples[1]      # SURVEY.md 8(d) algorithmic FLOPs of a11
+                tf = flops / kernels[rname]["avg_us"] / 1e6
+                mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "achieved": tf,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                        "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
+        else:
+            Ns = cc.num_samples[0]
+            rname = f"mvs_render[Ns={Ns}]"
+            if rname in kernels:
+                flops = 251e3 * N * Ns                                 # a25, per launch (one volume)
+                tf = flops / kernels[rname]["avg_us"] / 1e6
+                mfma = {"bound": "mfma", "kernel": "mvs_render (a21-a25 fused, 6x128 fp32 MFMA MLP)", "achieved": tf,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                        "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
+            sname = next((n for n in kernels if n.startswith("mvs_sweep[")), None)
+            if sname:
+                h, w = H // 4, W // 4
+                nb = 4 * (3 * 32 * h * w + 2 * 3 * h * w + 41 * Ns * (h + 48) * (w + 48))
+                gbs = nb / kernels[sname]["avg_us"] / 1e3
+                roofline = {"bound": "hbm", "kernel": "mvs_sweep (a19+a20 padded sweep)", "achieved": gbs,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes": nb, "avg_us": kernels[sname]["avg_us"],
+                            "launches": kernels[sname]["launches"]}
+        headline = args.workload == HEADLINE
         line = {
-            "metric": "rendered Mray/s per GPU (512x640, 3 src views, 64 planes)" if "512x640" in args.workload
-            else "rendered Mray/s per GPU", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
+            "metric": "rendered Mray/s per GPU (512x640, 3 src views, 64 planes)" if headline
+            else f"rendered Mray/s per GPU ({args.workload})",
+            "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.shard == "views" else "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": args.workload, "network": "enerf", "H": H, "W": W,
-                                            "src_views": n_views, "volume_planes": planes,
-                                            "num_samples": list(cc.num_samples), "render_if": list(cc.render_if),
-                                            "shard": args.shard if world > 1 else "none",
-                                            "weights": "random init (seed 0)"},
+            "data": "synthetic",
+            "config": {"workload": args.workload, "network": wl["net"], "H": H, "W": W, "src_views": wl["views"],
+                       "volume_planes": list(cc.volume_planes) if "planes" in wl else None,
+                       "num_samples": list(cc.num_samples), "render_if": list(cc.render_if),
+                       "k_best": wl.get("k_best"), "shard": args.shard if world > 1 else "none",
+                       "weights": "random init (seed 0)"},
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, batch_cpu, H, W)
+        if world == 1 and not args.no_cpu_baseline and (headline or args.cpu_baseline):
+            cb = cpu_baseline(args, cfg, wl, sd_cpu, batch_cpu)
+            if cb is not None:
+                line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
