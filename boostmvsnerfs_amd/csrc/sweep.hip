@@ -329,6 +329,8 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
 
 int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                           int D, int h, int w, float* out, hipStream_t stream);
+int bmv_sweep_lds_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
+                         int D, int h, int w, float* out, int shape, hipStream_t stream);
 
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
@@ -337,11 +339,25 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
   BMV_REQUIRE(B > 0 && S > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_fwd: bad shape");
   BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
-  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0), "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d",
-              algo, feat_layout);
+  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) || ((algo == 2 || algo == 3) && feat_layout == 1),
+              "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d", algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
   if (feat_layout == 1) {
-    int rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, as_stream(stream));
+    int rc = BMV_ERR_UNSUPPORTED;
+    // Measured on MI355X (scripts/bench_sweep.py, config 2 level 1): gather 29 us, LDS-staged 37-52 us.
+    // The staged kernel is kept selectable (algo 3) but is not the default.
+    if (algo == 3) {  // LDS-staged windows: tile shape by source / volume scale
+      float scale = (float)Ws / (float)w;
+      int shape = scale <= 1.25f ? 0 : scale <= 2.5f ? 1 : -1;
+      if (shape >= 0)
+        rc = bmv_sweep_lds_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, shape,
+                                  as_stream(stream));
+      if (rc != BMV_ERR_UNSUPPORTED || algo == 3) {
+        if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: LDS sweep does not cover this shape");
+        return rc;
+      }
+    }
+    rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, as_stream(stream));
     if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
     return rc;
   }

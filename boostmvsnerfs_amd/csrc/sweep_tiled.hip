@@ -72,11 +72,13 @@ __global__ void __launch_bounds__(256) sweep_nhwc_kernel(const float* __restrict
   const int k = blockIdx.x >> 3;
   const int d = k / blocks_per_plane;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wi = (k - d * blocks_per_plane) * 4 + wave;  // wave index inside this (band, plane)
-  const int yb = wi / groups_per_row;
+  // a workgroup is a 4-row x 16-column patch (one row per wave): the source rows two
+  // neighbouring target rows tap overlap, and the waves of one CU share them through its L1
+  const int t = k - d * blocks_per_plane;
+  const int yb = (t / groups_per_row) * 4 + wave;
   const int y = band * rows_per_band + yb;
   if (yb >= rows_per_band || y >= h) return;  // wave-uniform
-  const int x = (wi - yb * groups_per_row) * VPW + lane / CQ;
+  const int x = (t % groups_per_row) * VPW + lane / CQ;
   const int q = lane % CQ;
   const bool valid = x < w;
   const int xc = valid ? x : w - 1;
@@ -85,40 +87,62 @@ __global__ void __launch_bounds__(256) sweep_nhwc_kernel(const float* __restrict
   const float wm1 = (float)(Ws - 1), hm1 = (float)(Hs - 1);
   const float inv_half_w = 2.f / wm1, inv_half_h = 2.f / hm1;
 
-  // lane q of each quad projects the voxel into view q; the quad shares the results by DPP
-  float my_ix = 0.f, my_iy = 0.f;
-  if (q < S)
+  // Lane q of each quad does ALL the per-view geometry of view q (projection, floor, bounds,
+  // weights, byte offsets of the 4 taps); the quad then shares the 8 results by DPP, so the
+  // geometry costs each lane one view instead of S.
+  constexpr unsigned REC = C * 4;  // bytes per source pixel record
+  unsigned my_o[4] = {0, 0, 0, 0};
+  float my_w[4] = {0.f, 0.f, 0.f, 0.f};
+  if (q < S) {
+    float ix, iy;
     project_pixel(proj + ((size_t)b * S + q) * 12, (float)xc, (float)y, inv_depth, inv_half_w, inv_half_h, wm1, hm1,
-                  my_ix, my_iy);
+                  ix, iy);
+    Taps2 t = taps_zeros(ix, iy, Ws, Hs);
+    const unsigned vbase = (unsigned)q * (unsigned)(Hs * Ws) * REC;
+    my_o[0] = vbase + (unsigned)t.o00 * REC, my_o[1] = vbase + (unsigned)t.o01 * REC;
+    my_o[2] = vbase + (unsigned)t.o10 * REC, my_o[3] = vbase + (unsigned)t.o11 * REC;
+    my_w[0] = t.w00, my_w[1] = t.w01, my_w[2] = t.w10, my_w[3] = t.w11;
+  }
 
   float4 acc[QPL], acc2[QPL];
 #pragma unroll
   for (int p = 0; p < QPL; ++p) acc[p] = acc2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // 32-bit float4 indices off one scalar base (the launcher checks the batch item fits 2^31 floats)
-  const float4* fb = reinterpret_cast<const float4*>(feats + (size_t)b * S * Hs * Ws * C);
-  constexpr int C4 = C / 4;
-  const unsigned view_stride = (unsigned)(Hs * Ws) * C4;
-  auto one_view = [&](int s, float ix, float iy) {
-    Taps2 t = taps_zeros(ix, iy, Ws, Hs);
-    const unsigned base = (unsigned)s * view_stride + (unsigned)q * QPL;
-    const unsigned i00 = base + (unsigned)t.o00 * C4, i01 = base + (unsigned)t.o01 * C4;
-    const unsigned i10 = base + (unsigned)t.o10 * C4, i11 = base + (unsigned)t.o11 * C4;
+  // buffer loads: one scalar resource for this batch item + 32-bit byte offsets per lane
+  const size_t item_bytes = (size_t)S * Hs * Ws * REC;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(feats + (size_t)b * S * Hs * Ws * C), 0, (int)item_bytes, 0x00020000);
+  const unsigned lane_off = (unsigned)q * (16u * QPL);
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  auto one_view = [&](unsigned o0, unsigned o1, unsigned o2, unsigned o3, float w0, float w1, float w2, float w3) {
 #pragma unroll
     for (int p = 0; p < QPL; ++p) {
-      float4 a = fb[i00 + p], bq = fb[i01 + p], c = fb[i10 + p], e = fb[i11 + p];
-      float4 v = make_float4(a.x * t.w00, a.y * t.w00, a.z * t.w00, a.w * t.w00);
-      v = fma4(t.w01, bq, v);
-      v = fma4(t.w10, c, v);
-      v = fma4(t.w11, e, v);
+      i32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + lane_off + 16u * p, 0, 0);
+      i32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + lane_off + 16u * p, 0, 0);
+      i32x4 rc = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o2 + lane_off + 16u * p, 0, 0);
+      i32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o3 + lane_off + 16u * p, 0, 0);
+      float4 a = *reinterpret_cast<float4*>(&ra), bq = *reinterpret_cast<float4*>(&rb);
+      float4 c = *reinterpret_cast<float4*>(&rc), e = *reinterpret_cast<float4*>(&rd);
+      float4 v = make_float4(a.x * w0, a.y * w0, a.z * w0, a.w * w0);
+      v = fma4(w1, bq, v);
+      v = fma4(w2, c, v);
+      v = fma4(w3, e, v);
       acc[p].x += v.x, acc[p].y += v.y, acc[p].z += v.z, acc[p].w += v.w;
       acc2[p].x += v.x * v.x, acc2[p].y += v.y * v.y, acc2[p].z += v.z * v.z, acc2[p].w += v.w * v.w;
     }
   };
-  one_view(0, quad_bcast<0>(my_ix), quad_bcast<0>(my_iy));
-  if constexpr (S > 1) one_view(1, quad_bcast<1>(my_ix), quad_bcast<1>(my_iy));
-  if constexpr (S > 2) one_view(2, quad_bcast<2>(my_ix), quad_bcast<2>(my_iy));
-  if constexpr (S > 3) one_view(3, quad_bcast<3>(my_ix), quad_bcast<3>(my_iy));
+#define BMV_QB(SRC, v) quad_bcast<SRC>(v)
+#define BMV_QBU(SRC, v) (unsigned)__builtin_amdgcn_mov_dpp((int)(v), SRC * 0x55, 0xF, 0xF, true)
+#define BMV_VIEW(SRC)                                                                                       \
+  one_view(BMV_QBU(SRC, my_o[0]), BMV_QBU(SRC, my_o[1]), BMV_QBU(SRC, my_o[2]), BMV_QBU(SRC, my_o[3]),       \
+           BMV_QB(SRC, my_w[0]), BMV_QB(SRC, my_w[1]), BMV_QB(SRC, my_w[2]), BMV_QB(SRC, my_w[3]))
+  BMV_VIEW(0);
+  if constexpr (S > 1) BMV_VIEW(1);
+  if constexpr (S > 2) BMV_VIEW(2);
+  if constexpr (S > 3) BMV_VIEW(3);
+#undef BMV_VIEW
+#undef BMV_QB
+#undef BMV_QBU
 
   if (!valid) return;
   const float inv_s = 1.f / (float)S;
@@ -152,9 +176,10 @@ int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, b
 int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                           int D, int h, int w, float* out, hipStream_t stream) {
   if ((C != 16 && C != 32) || S < 2 || S > 4) return BMV_ERR_UNSUPPORTED;
+  if ((size_t)S * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;  // 32-bit buffer offsets
   int rows_per_band = (h + 7) / 8;
   int groups_per_row = (w + 15) / 16;
-  int blocks_per_plane = (rows_per_band * groups_per_row + 3) / 4;
+  int blocks_per_plane = ((rows_per_band + 3) / 4) * groups_per_row;
   dim3 grid(8u * (unsigned)(D * blocks_per_plane), B), block(256);
 #define SW(QPL, SV)                                                                                            \
   hipLaunchKernelGGL((sweep_nhwc_kernel<QPL, SV>), grid, block, 0, stream, feats, proj, dv, Hs, Ws, D, h, w, out, \

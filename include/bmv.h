@@ -57,7 +57,8 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
  * -> variance (B,C,D,h,w) = sum_s(x^2)/S - (sum_s(x)/S)^2, never materialising the
  * S warped volumes.  feat_layout: 0 = feats is (B,S,C,Hs,Ws) as the reference holds it,
  * 1 = channel-last (B,S,Hs,Ws,C) (bmv_nchw_to_nhwc converts).  algo: 0 = best kernel for
- * the layout, 1 = reference-layout direct gather (needs feat_layout 0). */
+ * the layout, 1 = reference-layout direct gather (feat_layout 0), 2 = channel-last direct
+ * gather, 3 = channel-last LDS-staged windows (2 and 3 need feat_layout 1). */
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
                            bmv_stream_t stream);

@@ -36,11 +36,16 @@ for lvl, L in levels.items():
     nhwc = ops.nchw_to_nhwc(feats)
     nbytes = 4 * (3 * L["C"] * Hs * Ws + L["C"] * L["D"] * h * w)
     for name, fn in (("nchw direct", lambda: ops.sweep_variance(feats, P, dv, algo=1)),
-                     ("channel-last", lambda: ops.sweep_variance(nhwc, P, dv, channels_last=True)),
+                     ("cl direct (TA)", lambda: ops.sweep_variance(nhwc, P, dv, channels_last=True, algo=2)),
+                     ("cl LDS-staged", lambda: ops.sweep_variance(nhwc, P, dv, channels_last=True, algo=3)),
                      ("transpose", lambda: ops.nchw_to_nhwc(feats))):
         out = torch.empty(1, L["C"], L["D"], h, w, device=dev)
-        for _ in range(5):
-            fn()
+        try:
+            for _ in range(5):
+                fn()
+        except RuntimeError as e:
+            print(f"level {lvl} {name:13s}: unsupported ({str(e).split(':')[-1].strip()})")
+            continue
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

@@ -203,3 +203,33 @@ def test_sweep_extreme_coordinates(ops):
     dv = torch.full((1, 4, 8, 10), 1e-9, device=DEV)
     var = ops.sweep_variance(feats, proj, dv, algo=1)
     assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_sweep_kernels_agree_at_scale(ops, level):
+    """All sweep kernels (reference-layout gather, channel-last gather, LDS-staged windows) against the
+    CPU oracle on BASELINE config-1 shapes (256x320), including a wide-baseline view whose epipolar
+    slide leaves the LDS window (global fallback path) and hypotheses that put a view behind the camera."""
+    from boostmvsnerfs_amd.synthetic import make_batch
+    from oracle import enerf as O
+    H, W = 256, 320
+    b = make_batch(H, W, seed=5)
+    b["src_exts"][0, 2, 0, 3] += 2.5           # view 2: large baseline -> long epipolar segments
+    cfgl = {0: dict(C=32, fs=0.25, vs=0.125, D=32), 1: dict(C=16, fs=0.5, vs=0.5, D=8)}[level]
+    Hs, Ws, h, w = int(H * cfgl["fs"]), int(W * cfgl["fs"]), int(H * cfgl["vs"]), int(W * cfgl["vs"])
+    torch.manual_seed(level)
+    feats = torch.randn(1, 3, cfgl["C"], Hs, Ws)
+    P = O.proj_mats(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"], cfgl["fs"], cfgl["vs"])
+    if level == 0:
+        dv, _ = O.depth_hypotheses_uniform(torch.tensor([[0.4, 8.0]]), cfgl["D"], h, w, True)
+    else:
+        dv = (3.0 + 2.0 * torch.rand(1, 1, h, w) + torch.linspace(-1.5, 1.5, cfgl["D"]).view(1, -1, 1, 1)).contiguous()
+    want = O.variance_volume(feats, P, dv)
+    fd, Pd, dvd = feats.to(DEV), P.to(DEV), dv.to(DEV)
+    for algo in (1, 2, 3, 0):
+        if algo == 3 and level == 0:
+            with pytest.raises(RuntimeError, match="LDS sweep does not cover"):
+                ops.sweep_variance(fd, Pd, dvd, algo=3)      # 2x source scale stays on the gather kernel
+            continue
+        got = ops.sweep_variance(fd, Pd, dvd, algo=algo)
+        assert_close(got, want, name=f"level {level} algo {algo}")
