@@ -78,6 +78,15 @@ SIGNATURES = {
     "bmv_mvs_mlp_fwd": [c_f, c_f, c_l, c_f, c_f],
     "bmv_mvs_render_fwd": [C.POINTER(MvsRenderArgs), c_f],
     "bmv_mvs_march_mask": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f],
+    "bmv_composite_bwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f],
+    "bmv_blend_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_vox_feat_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_img_feat_bwd": [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_sample_along_depth_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_build_rays_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_depth_regress_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_depth_values_cascade_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_sweep_variance_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_version": [],
 }
 

@@ -1,0 +1,165 @@
+"""torch.autograd.Function wrappers: HIP forward + HIP backward for every hot-path op that
+carries gradient in fine-tuning (SURVEY.md section 8 "Backward contract", BASELINE config 5).
+The training path materialises the per-sample tensors between ops (as the reference does);
+inference keeps using the fused kernels.
+"""
+import torch
+
+from . import ops
+
+
+class SweepVariance(torch.autograd.Function):
+    """a3+a4.  Gradient w.r.t. feats always, w.r.t. depth_values when they require it (level 1)."""
+
+    @staticmethod
+    def forward(ctx, feats, proj, depth_values, algo=0):
+        ctx.save_for_backward(feats, proj, depth_values)
+        return ops.sweep_variance(feats, proj, depth_values, algo=algo)
+
+    @staticmethod
+    def backward(ctx, d_var):
+        feats, proj, dv = ctx.saved_tensors
+        d_feats, d_dv = ops.sweep_variance_bwd(feats, proj, dv, d_var.contiguous(), ctx.needs_input_grad[2])
+        return d_feats, None, d_dv, None
+
+
+class DepthRegress(torch.autograd.Function):
+    """a5."""
+
+    @staticmethod
+    def forward(ctx, depth_prob, depth_values, depth_inv):
+        ctx.save_for_backward(depth_prob, depth_values)
+        ctx.inv = bool(depth_inv)
+        depth, std = ops.depth_regress(depth_prob, depth_values, depth_inv)
+        return depth, std
+
+    @staticmethod
+    def backward(ctx, d_depth, d_std):
+        prob, vals = ctx.saved_tensors
+        d_prob, d_vals = ops.depth_regress_bwd(prob, vals, d_depth.contiguous(), d_std.contiguous(), ctx.inv)
+        return d_prob, (d_vals if ctx.needs_input_grad[1] else None), None
+
+
+class DepthValuesCascade(torch.autograd.Function):
+    """a2 (cascade level): depth_values carries gradient to the previous level's depth / std;
+    the returned volume bounds are detached (enerf/utils.py:150)."""
+
+    @staticmethod
+    def forward(ctx, depth, std, near_far, h, w, D):
+        ctx.save_for_backward(depth, std, near_far)
+        dv, nf = ops.depth_values_cascade(depth, std, near_far, h, w, D)
+        ctx.mark_non_differentiable(nf)
+        return dv, nf
+
+    @staticmethod
+    def backward(ctx, d_dv, _d_nf):
+        depth, std, near_far = ctx.saved_tensors
+        d_depth, d_std = ops.depth_values_cascade_bwd(depth, std, near_far, d_dv.contiguous())
+        return d_depth, d_std, None, None, None, None
+
+
+class BuildRays(torch.autograd.Function):
+    """a6: gradient flows from the per-ray [near, far] (columns 8:10) to depth and std."""
+
+    @staticmethod
+    def forward(ctx, rays, depth, std, near_far, Hr, Wr, depth_inv):
+        ctx.save_for_backward(rays, depth, std, near_far)
+        ctx.cfg = (int(Hr), int(Wr), bool(depth_inv))
+        return ops.build_rays(rays, depth, std, near_far, Hr, Wr, depth_inv)
+
+    @staticmethod
+    def backward(ctx, d_rays12):
+        rays, depth, std, near_far = ctx.saved_tensors
+        Hr, Wr, inv = ctx.cfg
+        d_nf = d_rays12[..., 8:10].contiguous()
+        d_depth, d_std = ops.build_rays_bwd(rays, depth, std, near_far, d_nf, Hr, Wr, inv)
+        return None, d_depth, d_std, None, None, None, None
+
+
+class SampleAlongDepth(torch.autograd.Function):
+    """a7: world_xyz and the normalised depth coordinate carry gradient back to the ray bounds."""
+
+    @staticmethod
+    def forward(ctx, rays12, Ns, depth_inv):
+        ctx.save_for_backward(rays12)
+        ctx.cfg = (int(Ns), bool(depth_inv))
+        xyz, uvd, z = ops.sample_along_depth(rays12, Ns, depth_inv)
+        ctx.mark_non_differentiable(z)       # z_vals only feed the (detached) depth output
+        return xyz, uvd, z
+
+    @staticmethod
+    def backward(ctx, d_xyz, d_uvd, _d_z):
+        (rays12,) = ctx.saved_tensors
+        Ns, inv = ctx.cfg
+        d_nf = ops.sample_along_depth_bwd(rays12, d_xyz.contiguous(), d_uvd[..., 2].contiguous(), Ns, inv)
+        d_rays = torch.zeros_like(rays12)
+        d_rays[..., 8:10] = d_nf
+        return d_rays, None, None
+
+
+class VoxFeat(torch.autograd.Function):
+    """a9: gradient to the feature volume (scatter) and to the depth coordinate of uvd."""
+
+    @staticmethod
+    def forward(ctx, uvd01, volume):
+        ctx.save_for_backward(uvd01, volume)
+        return ops.vox_feat(uvd01, volume)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        uvd01, volume = ctx.saved_tensors
+        d_vol, d_d = ops.vox_feat_bwd(uvd01, volume, d_out.contiguous())
+        d_uvd = torch.zeros_like(uvd01)
+        d_uvd[..., 2] = d_d
+        return d_uvd, d_vol
+
+
+class ImgFeat(torch.autograd.Function):
+    """a10: gradient to the image features (scatter) and to the sample positions."""
+
+    @staticmethod
+    def forward(ctx, xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale):
+        ctx.save_for_backward(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext)
+        ctx.rs = float(render_scale)
+        return ops.img_feat(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        xyz, img, exts, ixts, tar = ctx.saved_tensors
+        d_img, d_xyz = ops.img_feat_bwd(xyz, img, exts, ixts, tar, ctx.rs, d_out.contiguous())
+        return d_xyz, d_img, None, None, None, None
+
+
+class Composite(torch.autograd.Function):
+    """a12."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, white_bkgd=False):
+        if white_bkgd:
+            raise NotImplementedError("white_bkgd backward")
+        ctx.save_for_backward(raw, z_vals)
+        rgb, depth, weights = ops.composite(raw, z_vals, False)
+        ctx.mark_non_differentiable(weights)
+        return rgb, depth, weights
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, _d_w):
+        raw, z = ctx.saved_tensors
+        # no host sync: an all-zero d_depth just costs the kernel its (cheap) softmax pass
+        return ops.composite_bwd(raw, z, d_rgb.contiguous(), d_depth.contiguous() if d_depth is not None else None), None, None
+
+
+class Blend(torch.autograd.Function):
+    """a16 with already-normalised masks (built under no_grad, boost_enerf/network.py:142-146)."""
+
+    @staticmethod
+    def forward(ctx, raws, masks, z_vals):
+        ctx.save_for_backward(raws, masks)
+        rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=False)
+        ctx.mark_non_differentiable(depth, weights)
+        return rgb, depth, weights
+
+    @staticmethod
+    def backward(ctx, d_rgb, _d_depth, _d_w):
+        raws, masks = ctx.saved_tensors
+        return ops.blend_bwd(raws, masks, d_rgb.contiguous()), None, None

@@ -1,0 +1,610 @@
+// Backward kernels of the ENeRF hot path (fine-tuning, BASELINE config 5; SURVEY.md section 8
+// "Backward contract").  Each kernel is the hand-derived adjoint of the forward kernel of the same
+// name; tests compare them with torch.autograd on the CPU oracle.  Scatter-adds are float atomics
+// (global_atomic_add_f32); gradient buffers are zero-initialised by the caller.
+#include "render_geom.hpp"
+
+namespace bmv {
+
+// ---------------------------------------------------------------------------
+// a12 raw2outputs backward.  d_rgb (N,3), d_depth (N) or null -> d_raw (N,Ns,4).
+// weights = softmax(alpha*T) is an output of the forward but never receives gradient in the
+// reference's losses (lib/train/losses/enerf.py:22-24); z_vals are detached (utils.py:629).
+// ---------------------------------------------------------------------------
+__global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ zv,
+                                     const float* __restrict__ d_rgb, const float* __restrict__ d_depth, long nrays,
+                                     int Ns, float* __restrict__ d_raw) {
+  long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrays) return;
+  const float* q = raw + r * Ns * 4;
+  float* dq = d_raw + r * Ns * 4;
+  const float g0 = d_rgb[r * 3], g1 = d_rgb[r * 3 + 1], g2 = d_rgb[r * 3 + 2];
+  // depth path: depth = sum_k softmax(w)_k z_k
+  float wmax = -INFINITY, den = 0.f, dotz = 0.f;
+  const float gd = d_depth ? d_depth[r] : 0.f;
+  if (d_depth) {
+    float T = 1.f;
+    for (int k = 0; k < Ns; ++k) {
+      float a = 1.f - expf(-q[k * 4 + 3]);
+      wmax = fmaxf(wmax, a * T);
+      T *= (1.f - a + 1e-10f);
+    }
+    T = 1.f;
+    for (int k = 0; k < Ns; ++k) {
+      float a = 1.f - expf(-q[k * 4 + 3]);
+      float e = expf(a * T - wmax);
+      den += e;
+      dotz += e * zv[r * Ns + k];
+      T *= (1.f - a + 1e-10f);
+    }
+    dotz /= den;  // = depth
+  }
+  // forward pass: park the exclusive transmittances T_k in the output buffer, then walk back
+  {
+    float Tf = 1.f;
+    for (int k = 0; k < Ns; ++k) {
+      dq[k * 4 + 3] = Tf;
+      Tf *= (1.f - (1.f - expf(-q[k * 4 + 3])) + 1e-10f);
+    }
+  }
+  float suffix = 0.f;  // suffix = sum_{j>k} d_T_j * T_j
+  for (int k = Ns - 1; k >= 0; --k) {
+    float a = 1.f - expf(-q[k * 4 + 3]);
+    float om = 1.f - a + 1e-10f;
+    float T = dq[k * 4 + 3];  // T_k (exclusive product)
+    float w = a * T;
+    float d_w = g0 * q[k * 4] + g1 * q[k * 4 + 1] + g2 * q[k * 4 + 2];
+    if (d_depth) {
+      float sm = expf(w - wmax) / den;
+      d_w += gd * sm * (zv[r * Ns + k] - dotz);
+    }
+    dq[k * 4] = w * g0, dq[k * 4 + 1] = w * g1, dq[k * 4 + 2] = w * g2;
+    float d_a = d_w * T - suffix / om;  // through w_k and through every later T_j
+    dq[k * 4 + 3] = d_a * (1.f - a);    // alpha = 1 - exp(-sigma)
+    suffix += d_w * a * T;              // d_T_k * T_k
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a16 raw2outputs_blend backward (masks already normalised, no gradient to masks or z).
+// raws (B,K,N,Ns,4), masks (B,K,N,Ns) -> d_raws.
+// ---------------------------------------------------------------------------
+__global__ void blend_bwd_kernel(const float* __restrict__ raws, const float* __restrict__ masks,
+                                 const float* __restrict__ d_rgb, int K, int N, int Ns, float* __restrict__ d_raws) {
+  int b = blockIdx.y;
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  size_t ks = (size_t)N * Ns;
+  const float* R = raws + ((size_t)b * K * N + n) * Ns * 4;
+  const float* M = masks + ((size_t)b * K * N + n) * Ns;
+  float* DR = d_raws + ((size_t)b * K * N + n) * Ns * 4;
+  const float g0 = d_rgb[((size_t)b * N + n) * 3], g1 = d_rgb[((size_t)b * N + n) * 3 + 1],
+              g2 = d_rgb[((size_t)b * N + n) * 3 + 2];
+  {  // park the exclusive transmittances T_s in the (k = 0) sigma slot of the output buffer
+    float Tf = 1.f;
+    for (int s = 0; s < Ns; ++s) {
+      float alpha = 0.f;
+      for (int k = 0; k < K; ++k) alpha += (1.f - expf(-R[(k * ks + s) * 4 + 3])) * M[k * ks + s];
+      DR[s * 4 + 3] = Tf;
+      Tf *= (1.f - alpha);
+    }
+  }
+  float suffix = 0.f;
+  for (int s = Ns - 1; s >= 0; --s) {
+    const float T = DR[s * 4 + 3];
+    float alpha = 0.f, A = 0.f;  // A = sum_k alpha_k m_k (c_k . g)
+    for (int k = 0; k < K; ++k) {
+      const float* q = R + (k * ks + s) * 4;
+      float ak = 1.f - expf(-q[3]), m = M[k * ks + s];
+      alpha += ak * m;
+      A += ak * m * (q[0] * g0 + q[1] * g1 + q[2] * g2);
+    }
+    float om = 1.f - alpha;
+    float om_safe = fabsf(om) > 1e-20f ? om : 1e-20f;
+    float d_alpha_shared = -suffix / om_safe;  // alpha_s only enters later transmittances
+    for (int k = 0; k < K; ++k) {
+      const float* q = R + (k * ks + s) * 4;
+      float* dq = DR + (k * ks + s) * 4;
+      float ak = 1.f - expf(-q[3]), m = M[k * ks + s];
+      float tam = T * ak * m;
+      dq[0] = tam * g0, dq[1] = tam * g1, dq[2] = tam * g2;
+      float d_ak = T * m * (q[0] * g0 + q[1] * g1 + q[2] * g2) + d_alpha_shared * m;
+      dq[3] = d_ak * (1.f - ak);
+    }
+    suffix += A * T;  // d_T_s * T_s with d_T_s = A
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a9 get_vox_feat backward: d_out (B,P,C) -> d_volume (atomics), d_d01 (B,P) (only the depth
+// coordinate of uvd carries gradient: u, v are pixel constants).
+// ---------------------------------------------------------------------------
+__global__ void vox_feat_bwd_kernel(const float* __restrict__ uvd01, const float* __restrict__ vol,
+                                    const float* __restrict__ d_out, int P, int C, int D, int h, int w,
+                                    float* __restrict__ d_vol, float* __restrict__ d_d01) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float* q = uvd01 + ((size_t)b * P + i) * 3;
+  float ix = unnorm(q[0] * 2.f - 1.f, w), iy = unnorm(q[1] * 2.f - 1.f, h), iz = unnorm(q[2] * 2.f - 1.f, D);
+  float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  bool ok = (fx >= -1.f) && (fx <= (float)(w - 1)) && (fy >= -1.f) && (fy <= (float)(h - 1)) && (fz >= -1.f) &&
+            (fz <= (float)(D - 1));
+  float gz = 0.f;
+  if (ok) {
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float ax = ix - fx, ay = iy - fy, az = iz - fz, ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy, ez = (fz + 1.f) - iz;
+    size_t cs = (size_t)D * h * w;
+    const float* v = vol + (size_t)b * C * cs;
+    float* dv = d_vol + (size_t)b * C * cs;
+    const float* go = d_out + ((size_t)b * P + i) * C;
+    for (int k = 0; k < 8; ++k) {
+      int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+      if (!(x >= 0 && x <= w - 1 && y >= 0 && y <= h - 1 && z >= 0 && z <= D - 1)) continue;
+      float wxy = (dx ? ax : ex) * (dy ? ay : ey), wgt = wxy * (dz ? az : ez);
+      size_t o = ((size_t)z * h + y) * w + x;
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float g = go[c];
+        atomicAdd(dv + c * cs + o, wgt * g);
+        acc += g * v[c * cs + o];
+      }
+      gz += (dz ? 1.f : -1.f) * wxy * acc;
+    }
+  }
+  // iz = ((2 d - 1) + 1) / 2 * (D - 1)  ->  d iz / d d01 = D - 1
+  d_d01[(size_t)b * P + i] = gz * (float)(D - 1);
+}
+
+// ---------------------------------------------------------------------------
+// a10 get_img_feat backward: d_out (B,P,S,C+4) -> d_img (B,S,C,H,W) (atomics), d_xyz (B,P,3).
+// ---------------------------------------------------------------------------
+// y = x / (|x| + eps): given dy -> dx
+__device__ __forceinline__ void unit_eps_bwd(const float* x, float eps, const float* dy, float* dx) {
+  float n = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  float s = n + eps;
+  float dot = x[0] * dy[0] + x[1] * dy[1] + x[2] * dy[2];
+  float k = n > 0.f ? dot / (s * s * n) : 0.f;
+  for (int j = 0; j < 3; ++j) dx[j] = dy[j] / s - x[j] * k;
+}
+
+__global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ img,
+                                    const float* __restrict__ src_exts, const float* __restrict__ src_ixts,
+                                    const float* __restrict__ tar_ext, float render_scale,
+                                    const float* __restrict__ d_out, int P, int S, int C, int H, int W,
+                                    float* __restrict__ d_img, float* __restrict__ d_xyz) {
+  extern __shared__ float smem[];
+  Cam* cams = reinterpret_cast<Cam*>(smem);
+  float* tar_c = smem + (sizeof(Cam) / 4) * S;
+  int b = blockIdx.y;
+  if ((int)threadIdx.x < S)
+    load_cam(src_exts + ((size_t)b * S + threadIdx.x) * 16, src_ixts + ((size_t)b * S + threadIdx.x) * 9, render_scale,
+             cams[threadIdx.x]);
+  if ((int)threadIdx.x == S) camera_centre(tar_ext + (size_t)b * 16, tar_c);
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float p[3] = {xyz[((size_t)b * P + i) * 3], xyz[((size_t)b * P + i) * 3 + 1], xyz[((size_t)b * P + i) * 3 + 2]};
+  float gp[3] = {0.f, 0.f, 0.f};
+  size_t plane = (size_t)H * W;
+  for (int s = 0; s < S; ++s) {
+    const Cam& cam = cams[s];
+    const float* go = d_out + (((size_t)b * P + i) * S + s) * (C + 4);
+    // ---- bilinear (border) part
+    float cx = p[0] * cam.E[0] + p[1] * cam.E[1] + p[2] * cam.E[2] + cam.E[3];
+    float cy = p[0] * cam.E[4] + p[1] * cam.E[5] + p[2] * cam.E[6] + cam.E[7];
+    float cz = p[0] * cam.E[8] + p[1] * cam.E[9] + p[2] * cam.E[10] + cam.E[11];
+    float qx = cx * cam.K[0] + cy * cam.K[1] + cz * cam.K[2];
+    float qy = cx * cam.K[3] + cy * cam.K[4] + cz * cam.K[5];
+    float qz = cx * cam.K[6] + cy * cam.K[7] + cz * cam.K[8];
+    float z = fmaxf(qz, 1e-6f);
+    float ix = unnorm((qx / z) / (float)(W - 1) * 2.f - 1.f, W), iy = unnorm((qy / z) / (float)(H - 1) * 2.f - 1.f, H);
+    // border clip: gradient passes only strictly inside [0, size-1] (aten clip_coordinates_set_grad)
+    float mx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f, my = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
+    float cix = fminf(fmaxf(ix, 0.f), (float)(W - 1)), ciy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    float fx = floorf(cix), fy = floorf(ciy);
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    bool vx1 = x1 <= W - 1, vy1 = y1 <= H - 1;
+    float ax = cix - fx, ay = ciy - fy, ex = (fx + 1.f) - cix, ey = (fy + 1.f) - ciy;
+    const float* f = img + ((size_t)b * S + s) * C * plane;
+    float* df = d_img + ((size_t)b * S + s) * C * plane;
+    float gix = 0.f, giy = 0.f;
+    size_t o00 = (size_t)y0 * W + x0, o01 = o00 + (vx1 ? 1 : 0), o10 = o00 + (vy1 ? W : 0), o11 = o10 + (vx1 ? 1 : 0);
+    for (int c = 0; c < C; ++c) {
+      float g = go[c];
+      const float* fc = f + c * plane;
+      float v00 = fc[o00], v01 = vx1 ? fc[o01] : 0.f, v10 = vy1 ? fc[o10] : 0.f, v11 = (vx1 && vy1) ? fc[o11] : 0.f;
+      atomicAdd(df + c * plane + o00, ex * ey * g);
+      if (vx1) atomicAdd(df + c * plane + o01, ax * ey * g);
+      if (vy1) atomicAdd(df + c * plane + o10, ex * ay * g);
+      if (vx1 && vy1) atomicAdd(df + c * plane + o11, ax * ay * g);
+      gix += g * ((v01 - v00) * ey + (v11 - v10) * ay);
+      giy += g * ((v10 - v00) * ex + (v11 - v01) * ax);
+    }
+    gix *= mx, giy *= my;
+    // ix = (qx / z): the normalise / unnormalise pair cancels exactly in the derivative
+    float gqx = gix / z, gqy = giy / z;
+    float gqz = (qz > 1e-6f) ? -(gix * qx + giy * qy) / (z * z) : 0.f;
+    float gcx = gqx * cam.K[0] + gqy * cam.K[3] + gqz * cam.K[6];
+    float gcy = gqx * cam.K[1] + gqy * cam.K[4] + gqz * cam.K[7];
+    float gcz = gqx * cam.K[2] + gqy * cam.K[5] + gqz * cam.K[8];
+    gp[0] += gcx * cam.E[0] + gcy * cam.E[4] + gcz * cam.E[8];
+    gp[1] += gcx * cam.E[1] + gcy * cam.E[5] + gcz * cam.E[9];
+    gp[2] += gcx * cam.E[2] + gcy * cam.E[6] + gcz * cam.E[10];
+    // ---- direction feature [ (a-b)/max(|a-b|,1e-6), a.b ],  a = unit(x - c_tar), b = unit(x - c_src)
+    float xa[3], xb[3], a[3], bb[3];
+    float na = 0.f, nb = 0.f;
+    for (int j = 0; j < 3; ++j) {
+      xa[j] = p[j] - tar_c[j], xb[j] = p[j] - cam.c[j];
+      na += xa[j] * xa[j], nb += xb[j] * xb[j];
+    }
+    na = sqrtf(na) + 1e-6f, nb = sqrtf(nb) + 1e-6f;
+    float dfv[3], nd = 0.f;
+    for (int j = 0; j < 3; ++j) {
+      a[j] = xa[j] / na, bb[j] = xb[j] / nb;
+      dfv[j] = a[j] - bb[j];
+      nd += dfv[j] * dfv[j];
+    }
+    nd = sqrtf(nd);
+    const float* gd = go + C;  // gradients of the 4 direction components
+    float g_df[3];
+    if (nd > 1e-6f) {  // dirn = df / |df|
+      float dot = dfv[0] * gd[0] + dfv[1] * gd[1] + dfv[2] * gd[2];
+      for (int j = 0; j < 3; ++j) g_df[j] = gd[j] / nd - dfv[j] * dot / (nd * nd * nd);
+    } else {
+      for (int j = 0; j < 3; ++j) g_df[j] = gd[j] / 1e-6f;
+    }
+    float ga[3], gb[3], gxa[3], gxb[3];
+    for (int j = 0; j < 3; ++j) {
+      ga[j] = g_df[j] + gd[3] * bb[j];
+      gb[j] = -g_df[j] + gd[3] * a[j];
+    }
+    unit_eps_bwd(xa, 1e-6f, ga, gxa);
+    unit_eps_bwd(xb, 1e-6f, gb, gxb);
+    for (int j = 0; j < 3; ++j) gp[j] += gxa[j] + gxb[j];
+  }
+  float* o = d_xyz + ((size_t)b * P + i) * 3;
+  o[0] = gp[0], o[1] = gp[1], o[2] = gp[2];
+}
+
+// ---------------------------------------------------------------------------
+// a7 sample_along_depth backward: d_xyz (B,N,Ns,3), d_dn (B,N,Ns) -> d_rays[..., 8:10] (B,N,2)
+// (ray near / far; the volume bounds in columns 10-11 are detached, utils.py:150).
+// ---------------------------------------------------------------------------
+__global__ void sample_along_depth_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ d_xyz,
+                                              const float* __restrict__ d_dn, long nrays, int Ns, int depth_inv,
+                                              float* __restrict__ d_near_far) {
+  long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrays) return;
+  const float* ry = rays + r * 12;
+  float rn = ry[8], rf = ry[9], vn = ry[10], vf = ry[11];
+  float g_rn = 0.f, g_rf = 0.f;
+  for (int k = 0; k < Ns; ++k) {
+    float t = Ns == 1 ? 0.5f : linspace01(k, Ns);
+    float z = rn + (rf - rn) * t;
+    const float* gx = d_xyz + (r * Ns + k) * 3;
+    float gd = gx[0] * ry[3] + gx[1] * ry[4] + gx[2] * ry[5];
+    float gz;
+    if (depth_inv) {
+      gz = z > 1e-6f ? -gd / (z * z) : 0.f;
+      gz += -d_dn[r * Ns + k] / fmaxf(vn - vf, 1e-6f);
+    } else {
+      gz = gd + d_dn[r * Ns + k] / fmaxf(vf - vn, 1e-6f);
+    }
+    g_rn += gz * (1.f - t);
+    g_rf += gz * t;
+  }
+  d_near_far[r * 2] = g_rn, d_near_far[r * 2 + 1] = g_rf;
+}
+
+// scatter of a bilinear (align_corners) upsample at one destination pixel
+__device__ __forceinline__ void upsample_scatter(float* __restrict__ g, int W, const Lerp1& ly, const Lerp1& lx, float v) {
+  atomicAdd(g + ly.i0 * W + lx.i0, ly.l0 * lx.l0 * v);
+  atomicAdd(g + ly.i0 * W + lx.i1, ly.l0 * lx.l1 * v);
+  atomicAdd(g + ly.i1 * W + lx.i0, ly.l1 * lx.l0 * v);
+  atomicAdd(g + ly.i1 * W + lx.i1, ly.l1 * lx.l1 * v);
+}
+
+// ---------------------------------------------------------------------------
+// a6 build_rays backward: d_near_far (B,N,2) (ray near / far) -> d_depth, d_std (B,hv,wv) (atomics).
+// ---------------------------------------------------------------------------
+__global__ void build_rays_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ depth,
+                                      const float* __restrict__ std_, const float* __restrict__ near_far,
+                                      const float* __restrict__ d_nf, int N, int hv, int wv, int Hr, int Wr,
+                                      int depth_inv, float* __restrict__ d_depth, float* __restrict__ d_std) {
+  int b = blockIdx.y;
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* r = rays + ((size_t)b * N + n) * 8;
+  size_t hw = (size_t)hv * wv;
+  int x = min(max((int)r[6], 0), Wr - 1), y = min(max((int)r[7], 0), Hr - 1);
+  Lerp1 ly = upsample_axis(y, hv, Hr), lx = upsample_axis(x, wv, Wr);
+  if (Hr == hv && Wr == wv) {
+    ly.i0 = ly.i1 = y, lx.i0 = lx.i1 = x;
+    ly.l0 = lx.l0 = 1.f, ly.l1 = lx.l1 = 0.f;
+  }
+  float dep = upsample_fetch(depth + b * hw, wv, ly, lx), sd = upsample_fetch(std_ + b * hw, wv, ly, lx);
+  float vn = upsample_fetch(near_far + b * 2 * hw, wv, ly, lx), vf = upsample_fetch(near_far + b * 2 * hw + hw, wv, ly, lx);
+  float g_rn = d_nf[((size_t)b * N + n) * 2], g_rf = d_nf[((size_t)b * N + n) * 2 + 1];
+  float g_dep = 0.f, g_sd = 0.f;
+  if (depth_inv) {  // rn = min(dep+sd, vn), rf = max(dep-sd, vf)
+    if (!(dep + sd > vn)) g_dep += g_rn, g_sd += g_rn;
+    if (!(dep - sd < vf)) g_dep += g_rf, g_sd -= g_rf;
+  } else {          // rn = max(dep-sd, vn), rf = min(dep+sd, vf)
+    if (!(dep - sd < vn)) g_dep += g_rn, g_sd -= g_rn;
+    if (!(dep + sd > vf)) g_dep += g_rf, g_sd += g_rf;
+  }
+  upsample_scatter(d_depth + b * hw, wv, ly, lx, g_dep);
+  upsample_scatter(d_std + b * hw, wv, ly, lx, g_sd);
+}
+
+// ---------------------------------------------------------------------------
+// a5 depth_regression backward: d_depth, d_std (B,h,w) -> d_prob, d_values (B,D,h,w)
+// ---------------------------------------------------------------------------
+__global__ void depth_regress_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ dvals,
+                                         const float* __restrict__ g_depth, const float* __restrict__ g_std, int D,
+                                         int hw, int depth_inv, float* __restrict__ d_prob,
+                                         float* __restrict__ d_values) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  const float* p = prob + (size_t)b * D * hw + i;
+  const float* v = dvals + (size_t)b * D * hw + i;
+  float mx = -INFINITY;
+  for (int d = 0; d < D; ++d) mx = fmaxf(mx, p[(size_t)d * hw]);
+  float den = 0.f;
+  for (int d = 0; d < D; ++d) den += expf(p[(size_t)d * hw] - mx);
+  float mean = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float val = v[(size_t)d * hw];
+    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+    mean += expf(p[(size_t)d * hw] - mx) / den * val;
+  }
+  float var = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float val = v[(size_t)d * hw];
+    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+    var += expf(p[(size_t)d * hw] - mx) / den * (val - mean) * (val - mean);
+  }
+  float gd = g_depth[(size_t)b * hw + i], gs = g_std[(size_t)b * hw + i];
+  float gvar = var > 1e-10f ? gs / (2.f * sqrtf(var)) : 0.f;
+  // sum_d p_d (v_d - mean) = 0, so the variance does not feed back into d_mean
+  float dotp = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float val = v[(size_t)d * hw];
+    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+    float pd = expf(p[(size_t)d * hw] - mx) / den;
+    dotp += pd * (gd * val + gvar * (val - mean) * (val - mean));
+  }
+  for (int d = 0; d < D; ++d) {
+    float raw = v[(size_t)d * hw];
+    float val = depth_inv ? 1.f / fmaxf(raw, 1e-6f) : raw;
+    float pd = expf(p[(size_t)d * hw] - mx) / den;
+    float gp = gd * val + gvar * (val - mean) * (val - mean);
+    d_prob[(size_t)b * D * hw + (size_t)d * hw + i] = pd * (gp - dotp);
+    float gv = pd * (gd + 2.f * gvar * (val - mean));
+    if (depth_inv) gv = raw > 1e-6f ? -gv / (raw * raw) : 0.f;
+    d_values[(size_t)b * D * hw + (size_t)d * hw + i] = gv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a2 get_depth_values (cascade) backward: d_depth_values (B,D,h,w) -> d_depth, d_std (B,h0,w0) (atomics)
+// ---------------------------------------------------------------------------
+__global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
+                                                const float* __restrict__ near_far, const float* __restrict__ g_dv,
+                                                int h0, int w0, int h, int w, int D, float* __restrict__ d_depth,
+                                                float* __restrict__ d_std) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int hw = h * w;
+  if (i >= hw) return;
+  int y = i / w, x = i - y * w;
+  Lerp1 ly = upsample_axis(y, h0, h), lx = upsample_axis(x, w0, w);
+  size_t o = (size_t)b * h0 * w0;
+  float dep = upsample_fetch(depth + o, w0, ly, lx), sd = upsample_fetch(std_ + o, w0, ly, lx);
+  float nf0 = upsample_fetch(near_far + o * 2, w0, ly, lx), nf1 = upsample_fetch(near_far + o * 2 + (size_t)h0 * w0, w0, ly, lx);
+  float hi = dep + sd, lo = dep - sd;
+  bool hi_free = !(hi > nf0), lo_free = !(lo < nf1);
+  if (!hi_free) hi = nf0;
+  if (!lo_free) lo = nf1;
+  float g_near = 0.f, g_far = 0.f;
+  float step = D > 1 ? 1.f / (float)(D - 1) : 0.f;
+  for (int d = 0; d < D; ++d) {
+    float t = d < D / 2 ? (float)d * step : 1.f - (float)(D - 1 - d) * step;
+    float g = g_dv[((size_t)b * D + d) * hw + i];
+    g_near += g * (1.f - t);
+    g_far += g * t;
+  }
+  float g_hi = -g_near / (hi * hi), g_lo = -g_far / (lo * lo);
+  float g_dep = (hi_free ? g_hi : 0.f) + (lo_free ? g_lo : 0.f);
+  float g_sd = (hi_free ? g_hi : 0.f) - (lo_free ? g_lo : 0.f);
+  upsample_scatter(d_depth + o, w0, ly, lx, g_dep);
+  upsample_scatter(d_std + o, w0, ly, lx, g_sd);
+}
+
+// ---------------------------------------------------------------------------
+// a3+a4 sweep backward: d_var (B,C,D,h,w) -> d_feats (B,S,C,Hs,Ws) (atomics), d_depth_values (B,D,h,w) or null.
+// One thread per voxel: the S warped values per channel are recomputed (never stored by the forward).
+// ---------------------------------------------------------------------------
+template <int CB, int S>
+__global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict__ feats,
+                                                         const float* __restrict__ proj,
+                                                         const float* __restrict__ dv,
+                                                         const float* __restrict__ g_var, int C, int Hs, int Ws, int D,
+                                                         int h, int w, float* __restrict__ d_feats,
+                                                         float* __restrict__ d_dv) {
+  int b = blockIdx.z;
+  int c0 = blockIdx.y * CB;
+  size_t nvox = (size_t)D * h * w;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  int x = (int)(i % w), y = (int)((i / w) % h);
+  float depth = dv[(size_t)b * nvox + i];
+  size_t plane = (size_t)Hs * Ws;
+  Taps2 tp[S];
+  float ex[S], ey[S], ax[S], ay[S], pxs[S], pys[S], pzs[S];
+  bool vx0[S], vx1[S], vy0[S], vy1[S];
+  for (int s = 0; s < S; ++s) {
+    const float* P = proj + ((size_t)b * S + s) * 12;
+    float px = P[0] * x + P[1] * y + P[2] + P[3] / depth;
+    float py = P[4] * x + P[5] * y + P[6] + P[7] / depth;
+    float pz = P[8] * x + P[9] * y + P[10] + P[11] / depth;
+    pxs[s] = px, pys[s] = py, pzs[s] = pz;
+    float z = fmaxf(pz, 1e-6f);
+    float ix = unnorm((px / z) / ((float)(Ws - 1) * 0.5f) - 1.f, Ws), iy = unnorm((py / z) / ((float)(Hs - 1) * 0.5f) - 1.f, Hs);
+    tp[s] = taps_zeros(ix, iy, Ws, Hs);
+    float fx = floorf(ix), fy = floorf(iy);
+    ex[s] = (fx + 1.f) - ix, ey[s] = (fy + 1.f) - iy, ax[s] = ix - fx, ay[s] = iy - fy;
+    int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Ws), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hs);
+    vx0[s] = x0 >= 0 && x0 <= Ws - 1, vx1[s] = x0 + 1 >= 0 && x0 + 1 <= Ws - 1;
+    vy0[s] = y0 >= 0 && y0 <= Hs - 1, vy1[s] = y0 + 1 >= 0 && y0 + 1 <= Hs - 1;
+  }
+  float gix[S], giy[S];
+  for (int s = 0; s < S; ++s) gix[s] = giy[s] = 0.f;
+  for (int c = 0; c < CB; ++c) {
+    float v[S][4], wv[S], mean = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* f = feats + (((size_t)b * S + s) * C + c0 + c) * plane;
+      v[s][0] = f[tp[s].o00], v[s][1] = f[tp[s].o01], v[s][2] = f[tp[s].o10], v[s][3] = f[tp[s].o11];
+      wv[s] = v[s][0] * tp[s].w00 + v[s][1] * tp[s].w01 + v[s][2] * tp[s].w10 + v[s][3] * tp[s].w11;
+      mean += wv[s];
+    }
+    mean /= (float)S;
+    float g = g_var[((size_t)b * C + c0 + c) * nvox + i];
+    for (int s = 0; s < S; ++s) {
+      float gw = (2.f / (float)S) * g * (wv[s] - mean);  // d var / d warped_s
+      float* df = d_feats + (((size_t)b * S + s) * C + c0 + c) * plane;
+      if (tp[s].w00 != 0.f) atomicAdd(df + tp[s].o00, tp[s].w00 * gw);
+      if (tp[s].w01 != 0.f) atomicAdd(df + tp[s].o01, tp[s].w01 * gw);
+      if (tp[s].w10 != 0.f) atomicAdd(df + tp[s].o10, tp[s].w10 * gw);
+      if (tp[s].w11 != 0.f) atomicAdd(df + tp[s].o11, tp[s].w11 * gw);
+      if (d_dv) {  // d warped / d (ix, iy): only in-bounds taps contribute (zeros padding)
+        float a00 = (vx0[s] && vy0[s]) ? v[s][0] : 0.f, a01 = (vx1[s] && vy0[s]) ? v[s][1] : 0.f;
+        float a10 = (vx0[s] && vy1[s]) ? v[s][2] : 0.f, a11 = (vx1[s] && vy1[s]) ? v[s][3] : 0.f;
+        gix[s] += gw * ((a01 - a00) * ey[s] + (a11 - a10) * ay[s]);
+        giy[s] += gw * ((a10 - a00) * ex[s] + (a11 - a01) * ax[s]);
+      }
+    }
+  }
+  if (d_dv) {
+    float gdepth = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* P = proj + ((size_t)b * S + s) * 12;
+      float z = fmaxf(pzs[s], 1e-6f);
+      // ix = px / z (normalise / unnormalise cancel); p = A + T / depth
+      float gpx = gix[s] / z, gpy = giy[s] / z;
+      float gpz = pzs[s] > 1e-6f ? -(gix[s] * pxs[s] + giy[s] * pys[s]) / (z * z) : 0.f;
+      gdepth += -(gpx * P[3] + gpy * P[7] + gpz * P[11]) / (depth * depth);
+    }
+    atomicAdd(d_dv + (size_t)b * nvox + i, gdepth);  // channel blocks of one voxel add up
+  }
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+extern "C" {
+
+int bmv_composite_bwd(const float* raw, const float* z_vals, const float* d_rgb, const float* d_depth, long nrays,
+                      int Ns, float* d_raw, bmv_stream_t stream) {
+  BMV_REQUIRE(raw && z_vals && d_rgb && d_raw, "bmv_composite_bwd: null pointer");
+  BMV_REQUIRE(nrays >= 0 && Ns > 0, "bmv_composite_bwd: bad shape");
+  if (nrays == 0) return BMV_OK;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(cdiv(nrays, 256)), dim3(256), 0, as_stream(stream), raw, z_vals, d_rgb,
+                     d_depth, nrays, Ns, d_raw);
+  BMV_LAUNCH_END("bmv_composite_bwd");
+}
+
+int bmv_blend_bwd(const float* raws, const float* masks, const float* d_rgb, int B, int K, int N, int Ns,
+                  float* d_raws, bmv_stream_t stream) {
+  BMV_REQUIRE(raws && masks && d_rgb && d_raws, "bmv_blend_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && K > 0 && N >= 0 && Ns > 0, "bmv_blend_bwd: bad shape");
+  if (N == 0) return BMV_OK;
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), raws, masks, d_rgb, K, N,
+                     Ns, d_raws);
+  BMV_LAUNCH_END("bmv_blend_bwd");
+}
+
+int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
+                     int w, float* d_volume, float* d_d01, bmv_stream_t stream) {
+  BMV_REQUIRE(uvd01 && volume && d_out && d_volume && d_d01, "bmv_vox_feat_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && P >= 0 && C > 0 && D > 0 && h > 0 && w > 0, "bmv_vox_feat_bwd: bad shape");
+  if (P == 0) return BMV_OK;
+  hipLaunchKernelGGL(vox_feat_bwd_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, as_stream(stream), uvd01, volume, d_out,
+                     P, C, D, h, w, d_volume, d_d01);
+  BMV_LAUNCH_END("bmv_vox_feat_bwd");
+}
+
+int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C, int H,
+                     int W, float* d_img, float* d_xyz, bmv_stream_t stream) {
+  BMV_REQUIRE(xyz && img_feat_rgb && src_exts && src_ixts && tar_ext && d_out && d_img && d_xyz,
+              "bmv_img_feat_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "bmv_img_feat_bwd: bad shape");
+  if (P == 0) return BMV_OK;
+  hipLaunchKernelGGL(img_feat_bwd_kernel, dim3(cdiv(P, 256), B), dim3(256), sizeof(Cam) * S + 16, as_stream(stream),
+                     xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, P, S, C, H, W, d_img, d_xyz);
+  BMV_LAUNCH_END("bmv_img_feat_bwd");
+}
+
+int bmv_sample_along_depth_bwd(const float* rays, const float* d_xyz, const float* d_dn, int B, int N, int Ns,
+                               int depth_inv, float* d_near_far, bmv_stream_t stream) {
+  BMV_REQUIRE(rays && d_xyz && d_dn && d_near_far, "bmv_sample_along_depth_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && N >= 0 && Ns > 0, "bmv_sample_along_depth_bwd: bad shape");
+  long nrays = (long)B * N;
+  if (nrays == 0) return BMV_OK;
+  hipLaunchKernelGGL(sample_along_depth_bwd_kernel, dim3(cdiv(nrays, 256)), dim3(256), 0, as_stream(stream), rays, d_xyz,
+                     d_dn, nrays, Ns, depth_inv, d_near_far);
+  BMV_LAUNCH_END("bmv_sample_along_depth_bwd");
+}
+
+int bmv_build_rays_bwd(const float* rays, const float* depth, const float* std_, const float* near_far,
+                       const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
+                       float* d_depth, float* d_std, bmv_stream_t stream) {
+  BMV_REQUIRE(rays && depth && std_ && near_far && d_near_far && d_depth && d_std, "bmv_build_rays_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && N >= 0 && hv > 0 && wv > 0 && Hr > 0 && Wr > 0, "bmv_build_rays_bwd: bad shape");
+  if (N == 0) return BMV_OK;
+  hipLaunchKernelGGL(build_rays_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), rays, depth, std_,
+                     near_far, d_near_far, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std);
+  BMV_LAUNCH_END("bmv_build_rays_bwd");
+}
+
+int bmv_depth_regress_bwd(const float* depth_prob, const float* depth_values, const float* d_depth,
+                          const float* d_std, int B, int D, int h, int w, int depth_inv, float* d_prob,
+                          float* d_values, bmv_stream_t stream) {
+  BMV_REQUIRE(depth_prob && depth_values && d_depth && d_std && d_prob && d_values, "bmv_depth_regress_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bmv_depth_regress_bwd: bad shape");
+  hipLaunchKernelGGL(depth_regress_bwd_kernel, dim3(cdiv(h * w, 128), B), dim3(128), 0, as_stream(stream), depth_prob,
+                     depth_values, d_depth, d_std, D, h * w, depth_inv, d_prob, d_values);
+  BMV_LAUNCH_END("bmv_depth_regress_bwd");
+}
+
+int bmv_depth_values_cascade_bwd(const float* depth, const float* std_, const float* near_far,
+                                 const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
+                                 float* d_depth, float* d_std, bmv_stream_t stream) {
+  BMV_REQUIRE(depth && std_ && near_far && d_depth_values && d_depth && d_std, "bmv_depth_values_cascade_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0 && h0 > 0 && w0 > 0, "bmv_depth_values_cascade_bwd: bad shape");
+  hipLaunchKernelGGL(depth_values_cascade_bwd_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, as_stream(stream), depth,
+                     std_, near_far, d_depth_values, h0, w0, h, w, D, d_depth, d_std);
+  BMV_LAUNCH_END("bmv_depth_values_cascade_bwd");
+}
+
+int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_variance,
+                           int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
+                           float* d_depth_values, bmv_stream_t stream) {
+  BMV_REQUIRE(feats && proj && depth_values && d_variance && d_feats, "bmv_sweep_variance_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "bmv_sweep_variance_bwd: bad shape");
+  if (S != 3 || C % 8 != 0) {
+    set_error("bmv_sweep_variance_bwd: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  size_t nvox = (size_t)D * h * w;
+  hipLaunchKernelGGL((sweep_bwd_kernel<8, 3>), dim3(cdiv(nvox, 256), C / 8, B), dim3(256), 0, as_stream(stream), feats,
+                     proj, depth_values, d_variance, C, Hs, Ws, D, h, w, d_feats, d_depth_values);
+  BMV_LAUNCH_END("bmv_sweep_variance_bwd");
+}
+
+}  // extern "C"

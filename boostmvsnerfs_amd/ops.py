@@ -387,3 +387,108 @@ def mvs_march_mask(rays, src_exts, src_ixts, Ns, inv_w, inv_h):
                                       dptr(_c(src_ixts), "src_ixts"), N, int(Ns), V, float(inv_w), float(inv_h),
                                       dptr(z), dptr(mask), stream()), "mvs_march_mask")
     return z, mask
+
+
+# ======================================================================= backward kernels (fine-tuning)
+def composite_bwd(raw, z_vals, d_rgb, d_depth=None):
+    Ns = raw.shape[-2]
+    nrays = raw.numel() // (Ns * 4)
+    d_raw = torch.empty_like(raw, memory_format=torch.contiguous_format)
+    lib = _lib.load()
+    _lib.check(lib.bmv_composite_bwd(dptr(_c(raw), "raw"), dptr(_c(z_vals), "z_vals"), dptr(_c(d_rgb), "d_rgb"),
+                                     dptr(_c(d_depth), "d_depth") if d_depth is not None else None, nrays, Ns,
+                                     dptr(d_raw), stream()), "composite_bwd")
+    return d_raw
+
+
+def blend_bwd(raws, masks, d_rgb):
+    B, K, N, Ns = raws.shape[:4]
+    d_raws = torch.empty_like(raws, memory_format=torch.contiguous_format)
+    lib = _lib.load()
+    _lib.check(lib.bmv_blend_bwd(dptr(_c(raws), "raws"), dptr(_c(masks).reshape(B, K, N, Ns), "masks"),
+                                 dptr(_c(d_rgb), "d_rgb"), B, K, N, Ns, dptr(d_raws), stream()), "blend_bwd")
+    return d_raws
+
+
+def vox_feat_bwd(uvd01, volume, d_out):
+    B, P = uvd01.shape[:2]
+    _, C_, D, h, w = volume.shape
+    d_vol = torch.zeros_like(volume, memory_format=torch.contiguous_format)
+    d_d = torch.empty(B, P, device=volume.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_vox_feat_bwd(dptr(_c(uvd01), "uvd"), dptr(_c(volume), "volume"), dptr(_c(d_out), "d_out"), B, P,
+                                    C_, D, h, w, dptr(d_vol), dptr(d_d), stream()), "vox_feat_bwd")
+    return d_vol, d_d
+
+
+def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out):
+    B, S, C_, H, W = img_feat_rgb.shape
+    pts = _c(xyz).reshape(B, -1, 3)
+    P = pts.shape[1]
+    d_img = torch.zeros_like(img_feat_rgb, memory_format=torch.contiguous_format)
+    d_xyz = torch.empty(B, P, 3, device=xyz.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_img_feat_bwd(dptr(pts, "xyz"), dptr(_c(img_feat_rgb), "img"), dptr(_c(src_exts), "src_exts"),
+                                    dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"), float(render_scale),
+                                    dptr(_c(d_out), "d_out"), B, P, S, C_, H, W, dptr(d_img), dptr(d_xyz), stream()),
+               "img_feat_bwd")
+    return d_img, d_xyz.reshape(xyz.shape)
+
+
+def sample_along_depth_bwd(rays12, d_xyz, d_dn, Ns, depth_inv):
+    B, N = rays12.shape[:2]
+    d_nf = torch.empty(B, N, 2, device=rays12.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_sample_along_depth_bwd(dptr(_c(rays12), "rays"), dptr(_c(d_xyz), "d_xyz"), dptr(_c(d_dn), "d_dn"),
+                                              B, N, int(Ns), int(bool(depth_inv)), dptr(d_nf), stream()),
+               "sample_along_depth_bwd")
+    return d_nf
+
+
+def build_rays_bwd(rays, depth, std, near_far, d_nf, Hr, Wr, depth_inv):
+    B, N = rays.shape[:2]
+    hv, wv = depth.shape[-2:]
+    d_depth = torch.zeros_like(depth, memory_format=torch.contiguous_format)
+    d_std = torch.zeros_like(std, memory_format=torch.contiguous_format)
+    lib = _lib.load()
+    _lib.check(lib.bmv_build_rays_bwd(dptr(_c(rays), "rays"), dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                      dptr(_c(near_far), "near_far"), dptr(_c(d_nf), "d_nf"), B, N, hv, wv, int(Hr),
+                                      int(Wr), int(bool(depth_inv)), dptr(d_depth), dptr(d_std), stream()),
+               "build_rays_bwd")
+    return d_depth, d_std
+
+
+def depth_regress_bwd(depth_prob, depth_values, d_depth, d_std, depth_inv):
+    B, D, h, w = depth_values.shape
+    d_prob = torch.empty_like(depth_values)
+    d_vals = torch.empty_like(depth_values)
+    lib = _lib.load()
+    _lib.check(lib.bmv_depth_regress_bwd(dptr(_c(depth_prob), "prob"), dptr(_c(depth_values), "values"),
+                                         dptr(_c(d_depth), "d_depth"), dptr(_c(d_std), "d_std"), B, D, h, w,
+                                         int(bool(depth_inv)), dptr(d_prob), dptr(d_vals), stream()),
+               "depth_regress_bwd")
+    return d_prob, d_vals
+
+
+def depth_values_cascade_bwd(depth, std, near_far, d_dv):
+    B, h0, w0 = depth.shape
+    _, D, h, w = d_dv.shape
+    d_depth = torch.zeros_like(depth, memory_format=torch.contiguous_format)
+    d_std = torch.zeros_like(std, memory_format=torch.contiguous_format)
+    lib = _lib.load()
+    _lib.check(lib.bmv_depth_values_cascade_bwd(dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                                dptr(_c(near_far), "near_far"), dptr(_c(d_dv), "d_dv"), B, h0, w0, h, w,
+                                                D, dptr(d_depth), dptr(d_std), stream()), "depth_values_cascade_bwd")
+    return d_depth, d_std
+
+
+def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad):
+    B, S, C_, Hs, Ws = feats.shape
+    _, D, h, w = depth_values.shape
+    d_feats = torch.zeros_like(feats, memory_format=torch.contiguous_format)
+    d_dv = torch.zeros_like(depth_values) if want_depth_grad else None
+    lib = _lib.load()
+    _lib.check(lib.bmv_sweep_variance_bwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
+                                          dptr(_c(depth_values), "depth_values"), dptr(_c(d_var), "d_var"), B, S, C_,
+                                          Hs, Ws, D, h, w, dptr(d_feats), dptr(d_dv), stream()), "sweep_variance_bwd")
+    return d_feats, d_dv

@@ -166,6 +166,34 @@ typedef struct {
 } bmv_render_args;
 int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
 
+/* ======================= backward (fine-tuning, SURVEY.md 8 "Backward contract") =======================
+ * Adjoint of the forward entry point of the same name; gradient buffers that receive scatter-adds
+ * (d_volume, d_img, d_depth, d_std, d_feats, d_depth_values) must be zero-initialised by the caller. */
+int bmv_composite_bwd(const float* raw, const float* z_vals, const float* d_rgb, const float* d_depth /*nullable*/,
+                      long nrays, int Ns, float* d_raw, bmv_stream_t stream);
+int bmv_blend_bwd(const float* raws, const float* masks /*normalised*/, const float* d_rgb, int B, int K, int N, int Ns,
+                  float* d_raws, bmv_stream_t stream);
+int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
+                     int w, float* d_volume, float* d_d01, bmv_stream_t stream);
+int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C, int H,
+                     int W, float* d_img, float* d_xyz, bmv_stream_t stream);
+int bmv_sample_along_depth_bwd(const float* rays, const float* d_xyz, const float* d_dn, int B, int N, int Ns,
+                               int depth_inv, float* d_near_far /*(B,N,2)*/, bmv_stream_t stream);
+int bmv_build_rays_bwd(const float* rays, const float* depth, const float* std, const float* near_far,
+                       const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
+                       float* d_depth, float* d_std, bmv_stream_t stream);
+int bmv_depth_regress_bwd(const float* depth_prob, const float* depth_values, const float* d_depth,
+                          const float* d_std, int B, int D, int h, int w, int depth_inv, float* d_prob,
+                          float* d_values, bmv_stream_t stream);
+int bmv_depth_values_cascade_bwd(const float* depth, const float* std, const float* near_far,
+                                 const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
+                                 float* d_depth, float* d_std, bmv_stream_t stream);
+/* feats in the reference layout (B,S,C,Hs,Ws); d_depth_values may be NULL (level 0: hypotheses are constants) */
+int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_variance,
+                           int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
+                           float* d_depth_values, bmv_stream_t stream);
+
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
 
 /* ---- a18 Network.get_proj_mats            lib/networks/mvsnerf/network.py:1070-1090

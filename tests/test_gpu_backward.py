@@ -1,0 +1,124 @@
+"""Backward kernels vs torch.autograd on the CPU oracle (fine-tuning path, BASELINE config 5)."""
+import pytest
+import torch
+
+from conftest import assert_close, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GTOL = dict(rtol=2e-3, atol_scale=2e-3)    # gradients: sums of many products, scatter-add order not fixed
+
+
+def leaf(t):
+    return t.detach().clone().requires_grad_(True)
+
+
+def test_composite_and_blend_bwd():
+    from boostmvsnerfs_amd import autograd as A
+    from oracle import enerf as O
+    torch.manual_seed(0)
+    for Ns in (2, 8, 32):
+        raw = torch.rand(1, 301, Ns, 4) * torch.tensor([1, 1, 1, 3.0])
+        z = torch.rand(1, 301, Ns) + 2
+        g_rgb, g_depth = torch.randn(1, 301, 3), torch.randn(1, 301)
+        r = leaf(raw)
+        out = O.composite(r, z)
+        (out["rgb"] * g_rgb).sum().add((out["depth"] * g_depth).sum()).backward()
+        rg = leaf(raw.to(DEV))
+        rgb, depth, _ = A.Composite.apply(rg, z.to(DEV))
+        ((rgb * g_rgb.to(DEV)).sum() + (depth * g_depth.to(DEV)).sum()).backward()
+        assert_close(rg.grad, r.grad, name=f"d_raw Ns={Ns}", **GTOL)
+    K, N, Ns = 3, 257, 4
+    raws = torch.rand(2, K, N, Ns, 4) * torch.tensor([1, 1, 1, 2.0])
+    masks = O.normalise_masks(torch.randint(0, 4, (2, K, N, Ns)).float() / 3)
+    z = torch.rand(2, K, N, Ns) + 2
+    g = torch.randn(2, N, 3)
+    r = leaf(raws)
+    (O.blend(r, masks, z)["rgb"] * g).sum().backward()
+    rg = leaf(raws.to(DEV))
+    (A.Blend.apply(rg, masks.to(DEV), z.to(DEV))[0] * g.to(DEV)).sum().backward()
+    assert_close(rg.grad, r.grad, name="d_raws", **GTOL)
+
+
+def test_lookup_and_sampler_bwd(enerf_fx):
+    from boostmvsnerfs_amd import autograd as A
+    from oracle import enerf as O
+    b = enerf_fx.batch()
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    torch.manual_seed(1)
+    for lvl, inv in ((1, False), (0, True)):
+        rs = c.render_scale[lvl]
+        Hr, Wr = int(H * rs), int(W * rs)
+        depth, std = enerf_fx.t(f"cap/depth_regression#{lvl}.0"), enerf_fx.t(f"cap/depth_regression#{lvl}.1") * 0.3
+        nf = enerf_fx.t(f"cap/get_depth_values#{lvl}.1")
+        vol = enerf_fx.t(f"cap/cost_reg_{lvl}#0.0")
+        img = torch.cat([enerf_fx.t(f"cap/feature_net#0.{0 if lvl == 0 else 2}")[None], enerf_fx.t(f"cap/unpreprocess#{lvl}")], 2)
+        Ns = c.num_samples[lvl]
+
+        def run(dev, mods):
+            d, s, v, im = (leaf(t.to(dev)) for t in (depth, std, vol, img))
+            bb = {k: (t.to(dev) if torch.is_tensor(t) else t) for k, t in b.items()}
+            if mods is O:
+                rays = O.rays_with_bounds(bb[f"rays_{lvl}"], d, s, nf.to(dev), rs / c.volume_scale[lvl], inv)
+                xyz, uvd, z = O.sample_points(rays, Ns, inv)
+                uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3)
+                vox = O.vox_lookup(uvd01, v)
+                feat = O.img_lookup(xyz, im, bb["src_exts"], bb["src_ixts"], bb["tar_ext"], rs)
+            else:
+                rays = mods.BuildRays.apply(bb[f"rays_{lvl}"], d, s, nf.to(dev), Hr, Wr, inv)
+                xyz, uvd, z = mods.SampleAlongDepth.apply(rays, Ns, inv)
+                uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3)
+                vox = mods.VoxFeat.apply(uvd01, v)
+                feat = mods.ImgFeat.apply(xyz, im, bb["src_exts"], bb["src_ixts"], bb["tar_ext"], rs)
+            torch.manual_seed(7)
+            gv, gf = torch.randn(vox.shape), torch.randn(feat.shape)
+            ((vox * gv.to(dev)).sum() + (feat * gf.to(dev)).sum()).backward()
+            return d.grad, s.grad, v.grad, im.grad
+
+        want = run("cpu", O)
+        got = run(DEV, A)
+        for name, g, w_ in zip(("d_depth", "d_std", "d_volume", "d_img"), got, want):
+            assert_close(g, w_, name=f"{name} level {lvl}", **GTOL)
+
+
+def test_depth_bwd(enerf_fx):
+    from boostmvsnerfs_amd import autograd as A
+    from oracle import enerf as O
+    torch.manual_seed(2)
+    for lvl, inv in ((0, True), (1, False)):
+        prob, vals = enerf_fx.t(f"cap/cost_reg_{lvl}#0.1"), enerf_fx.t(f"cap/get_depth_values#{lvl}.0")
+        g1, g2 = torch.randn(prob.shape[0], *prob.shape[2:]), torch.randn(prob.shape[0], *prob.shape[2:])
+        p, v = leaf(prob), leaf(vals)
+        d, s = O.depth_regress(p, v, inv)
+        ((d * g1).sum() + (s * g2).sum()).backward()
+        pg, vg = leaf(prob.to(DEV)), leaf(vals.to(DEV))
+        d2, s2 = A.DepthRegress.apply(pg, vg, inv)
+        ((d2 * g1.to(DEV)).sum() + (s2 * g2.to(DEV)).sum()).backward()
+        assert_close(pg.grad, p.grad, name=f"d_prob{lvl}", **GTOL)
+        assert_close(vg.grad, v.grad, name=f"d_values{lvl}", **GTOL)
+    depth, std = enerf_fx.t("cap/depth_regression#0.0"), enerf_fx.t("cap/depth_regression#0.1") * 0.2
+    nf0 = enerf_fx.t("cap/get_depth_values#0.1")
+    g = torch.randn(1, 8, 32, 48)
+    d, s = leaf(depth), leaf(std)
+    (O.depth_hypotheses_cascade(d, s, nf0, 4.0, 8, True, False)[0] * g).sum().backward()
+    dg, sg = leaf(depth.to(DEV)), leaf(std.to(DEV))
+    (A.DepthValuesCascade.apply(dg, sg, nf0.to(DEV), 32, 48, 8)[0] * g.to(DEV)).sum().backward()
+    assert_close(dg.grad, d.grad, name="cascade d_depth", **GTOL)
+    assert_close(sg.grad, s.grad, name="cascade d_std", **GTOL)
+
+
+def test_sweep_bwd(enerf_fx):
+    from boostmvsnerfs_amd import autograd as A
+    from oracle import enerf as O
+    torch.manual_seed(3)
+    feats = {0: enerf_fx.t("cap/feature_net#0.0")[None], 1: enerf_fx.t("cap/feature_net#0.1")[None]}
+    for lvl in range(2):
+        P, dv = enerf_fx.t(f"cap/get_proj_mats#{lvl}"), enerf_fx.t(f"cap/get_depth_values#{lvl}.0")
+        g = torch.randn(1, feats[lvl].shape[2], *dv.shape[1:])
+        f, d = leaf(feats[lvl]), leaf(dv)
+        (O.variance_volume(f, P, d) * g).sum().backward()
+        fg, dg = leaf(feats[lvl].to(DEV)), leaf(dv.to(DEV))
+        (A.SweepVariance.apply(fg, P.to(DEV), dg) * g.to(DEV)).sum().backward()
+        assert_close(fg.grad, f.grad, name=f"d_feats{lvl}", **GTOL)
+        assert_close(dg.grad, d.grad, name=f"d_depth_values{lvl}", rtol=5e-3, atol_scale=5e-3)
