@@ -492,3 +492,42 @@ def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad):
                                           dptr(_c(depth_values), "depth_values"), dptr(_c(d_var), "d_var"), B, S, C_,
                                           Hs, Ws, D, h, w, dptr(d_feats), dptr(d_dv), stream()), "sweep_variance_bwd")
     return d_feats, d_dv
+
+
+def nerf_pack_bwd_weights(tensors, feat_ch):
+    lib = _lib.load()
+    n = lib.bmv_nerf_bwd_blob_size(int(feat_ch))
+    if n < 0:
+        _lib.check(n, "nerf_bwd_blob_size")
+    out = torch.empty(n, device=tensors[0].device, dtype=torch.float32)
+    held = [_c(t.detach()) for t in tensors]
+    params = _lib.NerfParams(*[dptr(t, f"nerf param {i}") for i, t in enumerate(held)])
+    _lib.check(lib.bmv_nerf_pack_bwd_weights(C.byref(params), int(feat_ch), dptr(out), stream()), "nerf_pack_bwd_weights")
+    return out
+
+
+def nerf_bwd_rows(feat_ch):
+    lib = _lib.load()
+    ir = C.c_int(0)
+    r = lib.bmv_nerf_bwd_rows(int(feat_ch), C.byref(ir))
+    if r < 0:
+        _lib.check(r, "nerf_bwd_rows")
+    return r, ir.value
+
+
+def nerf_mlp_bwd(vox_feat_t, img_feat_rgb_dir, d_out, blob_fwd, blob_bwd, feat_ch):
+    """-> rows (R,P), d_vox (8,P), d_img (3,IR,P), vecs (160)."""
+    npts = vox_feat_t.numel() // 8
+    R, IR = nerf_bwd_rows(feat_ch)
+    dev = vox_feat_t.device
+    rows = torch.empty(R, npts, device=dev, dtype=torch.float32)
+    d_vox = torch.empty(8, npts, device=dev, dtype=torch.float32)
+    d_img = torch.zeros(3, IR, npts, device=dev, dtype=torch.float32)
+    vecs = torch.zeros(160, device=dev, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"nerf_mlp_bwd[feat={feat_ch}]"):
+        rc = lib.bmv_nerf_mlp_bwd(dptr(_c(vox_feat_t), "vox_feat"), dptr(_c(img_feat_rgb_dir), "img"),
+                                  dptr(_c(d_out), "d_out"), dptr(blob_fwd, "blob_fwd"), dptr(blob_bwd, "blob_bwd"),
+                                  int(feat_ch), npts, dptr(rows), dptr(d_vox), dptr(d_img), dptr(vecs), stream())
+    _lib.check(rc, "nerf_mlp_bwd")
+    return rows, d_vox, d_img, vecs

@@ -194,6 +194,20 @@ int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* d
                            int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
                            float* d_depth_values, bmv_stream_t stream);
 
+/* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89).  The kernel recomputes the forward of every
+ * 32-sample tile and back-propagates the data path on the matrix cores; it writes
+ *   rows  (R, P)           pre-activation gradients + the hidden activations the weight gradients need,
+ *   d_vox (8, P), d_img (3, IR, P)   input gradients, [row][sample] layout,
+ *   vecs  (160)            weight gradients of color.2 (64) | sigma (64) | agg_w_fc (32), accumulated (zero it first).
+ * Weight gradients of the wide layers are library GEMMs over the sample dimension on the host side
+ * (boostmvsnerfs_amd/autograd.py: dW = rows_block @ activations^T).  R / IR: bmv_nerf_bwd_rows(). */
+int bmv_nerf_bwd_blob_size(int feat_ch);
+int bmv_nerf_bwd_rows(int feat_ch, int* d_img_rows);
+int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* params, int feat_ch, float* blob, bmv_stream_t stream);
+int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* d_out, const float* blob_fwd,
+                     const float* blob_bwd, int feat_ch, long npts, float* rows, float* d_vox, float* d_img,
+                     float* vecs, bmv_stream_t stream);
+
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
 
 /* ---- a18 Network.get_proj_mats            lib/networks/mvsnerf/network.py:1070-1090

@@ -1,0 +1,43 @@
+"""MLP backward (MFMA data path + GEMM weight gradients) vs torch.autograd on the CPU oracle."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("lvl,feat_ch", [(1, 8), (0, 32)])
+def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch):
+    from boostmvsnerfs_amd import autograd as A, ops
+    from oracle import enerf as O
+    sd = enerf_fx.group("sd")
+    prefix = f"nerf_{lvl}."
+    names = [f"{prefix}{n}.{k}" for n in ops.NERF_PARAM_ORDER for k in ("weight", "bias")]
+    P = 1003                                            # ragged: not a multiple of the 32-sample tile
+    vox = enerf_fx.t(f"cap/get_vox_feat#{lvl}")[:, :P].contiguous()
+    img = enerf_fx.t(f"cap/get_img_feat#{lvl}")[:, :P].contiguous()
+    torch.manual_seed(4)
+    g = torch.randn(1, P, 4)
+    # CPU oracle + autograd
+    sd_cpu = {k: v.detach().clone().requires_grad_(k in names) for k, v in sd.items()}
+    v_c, i_c = vox.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    out_c = O.nerf_mlp(sd_cpu, prefix, v_c, i_c)
+    (out_c * g).sum().backward()
+    # HIP
+    params = [sd[n].to(DEV).clone().requires_grad_(True) for n in names]
+    v_g, i_g = vox.to(DEV).requires_grad_(True), img.to(DEV).requires_grad_(True)
+    out_g = A.NerfMLP.apply(v_g, i_g, feat_ch, *params)
+    assert_close(out_g, out_c, name="forward")
+    (out_g * g.to(DEV)).sum().backward()
+    assert_close(v_g.grad, v_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_vox_feat")
+    assert_close(i_g.grad, i_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_img_feat")
+    # agg_w_fc.bias only shifts the logits of a softmax: its gradient is exactly 0 in real arithmetic and pure
+    # rounding noise in fp32, so the absolute floor is tied to the scale of the whole parameter gradient
+    gmax = max(float(sd_cpu[n].grad.abs().max()) for n in names)
+    for n, p in zip(names, params):
+        want = sd_cpu[n].grad
+        err = (p.grad.cpu() - want).abs()
+        tol = 2e-3 * want.abs() + 2e-3 * float(want.pow(2).mean().sqrt()) + 1e-6 * gmax
+        assert bool((err <= tol).all()), f"grad {n}: worst {float(err.max()):.3e} (scale {gmax:.3e})"
