@@ -131,12 +131,17 @@ class Network(enerf_network.Network):
         utils.py:639-667); mask normalisation over K happens inside the kernel."""
         if cfg.enerf.white_bkgd:
             raise NotImplementedError          # as the reference (utils.py:660-661)
-        rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=True)
+        if torch.is_grad_enabled():             # fine-tuning: masks are constants (built under no_grad)
+            from ...autograd import Blend
+            with torch.no_grad():
+                tot = masks.sum(1, keepdim=True)
+                masks = torch.where(tot > 0, masks / tot, torch.full_like(masks, 1.0 / masks.shape[1]))
+            rgb, depth, weights = Blend.apply(raws, masks, z_vals)
+        else:
+            rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=True)
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
     def forward(self, batch):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training (backward kernels) is not part of this build yet")
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
         cc = cfg.enerf.cas_config
@@ -156,7 +161,8 @@ class Network(enerf_network.Network):
         for i in range(cc.num):
             raws, zs, ms = [], [], []
             stacks = None
-            if cc.render_if[i] and B == 1:      # K render launches write straight into the stacked buffers
+            train = torch.is_grad_enabled()
+            if cc.render_if[i] and B == 1 and not train:   # K render launches write straight into the stacked buffers
                 n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
                 stacks = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
                           torch.empty(1, K, n_i, ns_i, device=dev))
@@ -167,7 +173,10 @@ class Network(enerf_network.Network):
                 if not cc.render_if[i]:
                     continue
                 im_feat = feats[f"level_{cc.render_im_feat_level[i]}"][bi, ids]
-                if stacks is not None and self.ray_range is None:
+                if train:
+                    raw, z, m = self.render_level_train(i, states[k], im_feat, views, batch, mode=1)
+                    raws.append(raw), zs.append(z), ms.append(m)
+                elif stacks is not None and self.ray_range is None:
                     self.render_level(i, states[k], im_feat, views, batch, mode=1, outs=tuple(t[:, k] for t in stacks))
                 else:
                     raw, z, m = self.render_level(i, states[k], im_feat, views, batch, mode=1)

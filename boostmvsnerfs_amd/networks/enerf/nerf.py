@@ -64,6 +64,8 @@ class NeRF(nn.Module):
 
     def forward(self, vox_feat, img_feat_rgb_dir):
         """vox_feat (B,P,8), img_feat_rgb_dir (B,P,3,feat_ch+4) -> (B,P,4) = [rgb, sigma]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward of the HIP MLP is not implemented yet; call under torch.no_grad()")
+        if torch.is_grad_enabled():
+            from ...autograd import NerfMLP
+            params = [t for lin in self._linears() for t in (lin.weight, lin.bias)]
+            return NerfMLP.apply(vox_feat, img_feat_rgb_dir, self.feat_ch - 3, *params)
         return ops.nerf_mlp(vox_feat, img_feat_rgb_dir, self.packed_weights(), self.feat_ch - 3)

@@ -17,6 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ... import autograd as A
 from ... import ops
 from ...config import cfg
 from .cnn import CostRegNet, FeatureNet, MinCostRegNet
@@ -64,18 +65,57 @@ class Network(nn.Module):
         h, w = int(H * cc.volume_scale[i]), int(W * cc.volume_scale[i])
         D = cc.volume_planes[i]
         st = LevelState()
+        train = torch.is_grad_enabled()       # fine-tuning: autograd Functions (HIP forward + HIP backward)
         if prev is None or prev.depth is None:
             st.depth_values, st.near_far = ops.depth_values_uniform(batch["near_far"], D, h, w, cc.depth_inv[i])
         else:
             if not cc.depth_inv[i - 1] or cc.depth_inv[i]:
                 raise NotImplementedError("cascade levels must go disparity -> depth")
-            st.depth_values, st.near_far = ops.depth_values_cascade(prev.depth, prev.std, prev.near_far, h, w, D)
+            if train:
+                st.depth_values, st.near_far = A.DepthValuesCascade.apply(prev.depth, prev.std, prev.near_far, h, w, D)
+            else:
+                st.depth_values, st.near_far = ops.depth_values_cascade(prev.depth, prev.std, prev.near_far, h, w, D)
         proj = ops.proj_mats(src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"], cc.im_feat_scale[i],
                              cc.volume_scale[i])
-        variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
+        if train:
+            variance = A.SweepVariance.apply(feats_i, proj, st.depth_values, self.sweep_algo)
+        else:
+            variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
         st.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
-        st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
+        if train:
+            st.depth, st.std = A.DepthRegress.apply(depth_prob, st.depth_values, cc.depth_inv[i])
+        else:
+            st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
         return st
+
+    # ------------------------------------------------------------------ training renderer (unfused, differentiable)
+    def render_level_train(self, i, st, im_feat, views, batch, mode=0):
+        """Same maths as render_level through the per-op autograd Functions: the per-sample tensors are
+        materialised between ops (as the reference does) so every op has a HIP backward
+        (backward contract)."""
+        cc = cfg.enerf.cas_config
+        src_inps, src_exts, src_ixts = views
+        B = src_inps.shape[0]
+        H, W = src_inps.shape[-2:]
+        rs = cc.render_scale[i]
+        Hr, Wr = int(H * rs), int(W * rs)
+        if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
+            raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
+        Ns, inv = cc.num_samples[i], cc.depth_inv[i]
+        nerf = getattr(self, f"nerf_{i}")
+        rays12 = A.BuildRays.apply(batch[f"rays_{i}"], st.depth, st.std, st.near_far, Hr, Wr, inv)
+        xyz, uvd, z = A.SampleAlongDepth.apply(rays12, Ns, inv)
+        uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(B, -1, 3)
+        vox = A.VoxFeat.apply(uvd01, st.feature_volume)
+        img = torch.cat([im_feat, ops.unpreprocess(src_inps, Hr, Wr)], 2)
+        feat = A.ImgFeat.apply(xyz, img, src_exts, src_ixts, batch["tar_ext"], rs)
+        params = [t for lin in nerf._linears() for t in (lin.weight, lin.bias)]
+        raw = A.NerfMLP.apply(vox, feat, nerf.feat_ch - 3, *params).reshape(B, -1, Ns, 4)
+        if mode == 1:
+            with torch.no_grad():
+                mask = ops.mask_viewport(xyz, src_exts, src_ixts, Wr - 1, Hr - 1).view(B, -1, Ns)
+            return raw, z, mask
+        return A.Composite.apply(raw, z, cfg.enerf.white_bkgd)
 
     # ------------------------------------------------------------------ fused renderer of one level
     def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None):
@@ -117,19 +157,17 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training (backward kernels) is not part of this build yet; "
-                                      "call under torch.no_grad() / eval()")
         cc = cfg.enerf.cas_config
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         feats = self.forward_feat(batch["src_inps"])
+        render = self.render_level_train if torch.is_grad_enabled() else self.render_level
         ret = {}
         st = None
         for i in range(cc.num):
             st = self.level_front(i, feats[f"level_{i}"], views, batch, st)
             if not cc.render_if[i]:
                 continue
-            rgb, depth, weights = self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)
+            rgb, depth, weights = render(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)
             ret_i = {"rgb": rgb, "depth": depth, "weights": weights,
                      "depth_mvs": torch.reciprocal(st.depth) if cc.depth_inv[i] else st.depth, "std": st.std}
             if os.environ.get("BMV_CHECK_NAN") == "1" and bool(rgb.isnan().any()):

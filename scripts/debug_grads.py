@@ -1,0 +1,59 @@
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from conftest import load_fixture, tiny_cfg
+from boostmvsnerfs_amd.config import set_cfg
+from boostmvsnerfs_amd.networks.enerf.network import Network
+from boostmvsnerfs_amd.train import NetworkWrapper
+from oracle import enerf as O
+fx = load_fixture("enerf_tiny")
+cfg = set_cfg(tiny_cfg(fx, "enerf_pretrain"))
+sd = fx.group("sd")
+batch = fx.batch()
+g = torch.Generator().manual_seed(0)
+for i in range(2):
+    batch[f"rgb_{i}"] = torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=g)
+cc = cfg.enerf.cas_config
+leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+out = O.enerf_forward(leaves, batch, cfg)
+loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - batch[f"rgb_{i}"]) ** 2).mean() for i in range(2))
+loss.backward()
+net = Network(); net.load_state_dict(sd); net = net.cuda().eval()
+bg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+_, l2, _ = NetworkWrapper(net)(bg); l2.backward()
+print("loss", float(loss), float(l2))
+for k, p in net.named_parameters():
+    w = leaves[k].grad; gg = p.grad.cpu()
+    rel = float((gg - w).norm() / (w.norm() + 1e-30))
+    print(f"{k:45s} |w|={float(w.norm()):.3e} rel_l2={rel:.2e} max|w|={float(w.abs().max()):.2e} maxerr={float((gg-w).abs().max()):.2e}")
+
+# ---- second pass: gradients at the level-0 depth / std and level-1 depth_values
+print("---- intermediates")
+leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+cap = {}
+out = O.enerf_forward(leaves, batch, cfg, capture=cap)
+for k in ("depth_0", "std_0", "depth_values_1", "depth_1", "std_1", "depth_prob_0"):
+    cap[k].retain_grad()
+loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - batch[f"rgb_{i}"]) ** 2).mean() for i in range(2))
+loss.backward()
+net.zero_grad()
+states = []
+orig = net.level_front
+def lf(*a, **k):
+    st = orig(*a, **k)
+    for t in (st.depth, st.std, st.depth_values):
+        if t.requires_grad:
+            t.retain_grad()
+    states.append(st)
+    return st
+net.level_front = lf
+_, l3, _ = NetworkWrapper(net)(bg); l3.backward()
+def cmp(name, g, w):
+    g = g.cpu()
+    print(f"{name:16s} |w|={float(w.norm()):.3e} rel_l2={float((g-w).norm()/(w.norm()+1e-30)):.2e}")
+cmp("d_depth_0", states[0].depth.grad, cap["depth_0"].grad)
+cmp("d_std_0", states[0].std.grad, cap["std_0"].grad)
+cmp("d_dv_1", states[1].depth_values.grad, cap["depth_values_1"].grad)
+cmp("d_depth_1", states[1].depth.grad, cap["depth_1"].grad)
+cmp("d_std_1", states[1].std.grad, cap["std_1"].grad)

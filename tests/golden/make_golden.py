@@ -265,5 +265,36 @@ def gen_boost_mvsnerf():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "enerf"
-    {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf, "mvsnerf": gen_mvsnerf,
-     "boost_mvsnerf": gen_boost_mvsnerf}[which]()
+    if which != "enerf_grads":
+        {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf, "mvsnerf": gen_mvsnerf,
+         "boost_mvsnerf": gen_boost_mvsnerf}[which]()
+
+
+def gen_enerf_grads():
+    """Gradients of the reference itself (fine-tune loss, eval-mode batch norm) for the backward contract."""
+    from boostmvsnerfs_amd.synthetic import make_batch
+    cfg = load_reference("configs/exps/evaluate/enerf/free_eval.yaml")
+    from lib.networks.enerf import network
+    cfg.enerf.cas_config.volume_planes = list(TINY_PLANES)
+    cfg.enerf.cas_config.render_if = [True, True]
+    torch.manual_seed(0)
+    net = perturb_(network.Network().eval())
+    batch = make_batch(TINY_H, TINY_W, n_views=3, seed=0)
+    g = torch.Generator().manual_seed(0)
+    targets = {i: torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=g) for i in range(2)}
+    out = net(batch)
+    w = [0.1, 1.0]                                       # dtu_pretrain.yaml:47 loss_weight
+    loss = sum(w[i] * ((out[f"rgb_level{i}"] - targets[i]) ** 2).mean() for i in range(2))
+    loss.backward()
+    blob = {"extra/loss": np.asarray(float(loss))}
+    for i in range(2):
+        blob[f"in/rgb_{i}"] = targets[i].numpy()
+    for k, p in net.named_parameters():
+        blob["grad/" + k] = p.grad.numpy()
+    path = os.path.join(HERE, "enerf_tiny_grads.npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "enerf_grads":
+    gen_enerf_grads()
