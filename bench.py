@@ -50,6 +50,10 @@ WORKLOADS = {
     "mvsnerf_224x352_32planes": dict(net="mvsnerf", preset="mvsnerf_eval", H=224, W=352, samples=32, views=3),
     "mvsnerf_ours_224x352_128planes_k4": dict(net="boost_mvsnerf", preset="mvsnerf_ours_eval", H=224, W=352,
                                               samples=128, views=6, k_best=4),                       # configs[3]
+    # configs[4]: per-scene fine-tune step (forward + backward + Adam), both levels rendered, DDP over RCCL for N>1
+    "enerf_ours_ft_480x736_6src_k4": dict(net="boost_enerf", preset="enerf_ours_ft", H=480, W=736, planes=[64, 8],
+                                          views=6, k_best=4, train=True),
+    "enerf_ft_512x640_3src": dict(net="enerf", preset="enerf_pretrain", H=512, W=640, planes=[64, 8], views=3, train=True),
 }
 
 
@@ -69,6 +73,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--miopen-find", type=int, default=1,
+                    help="1: let MIOpen search its convolution solvers once (torch.backends.cudnn.benchmark)")
     return ap.parse_args()
 
 
@@ -153,6 +159,7 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # the CNN stacks run on MIOpen
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -170,14 +177,33 @@ def main():
         net.ray_range = sharding.ray_slice(N, world, rank)
     gather = sharding.TileGather(world, N if args.shard == "views" else None, dev) if world > 1 else None
 
-    def step():
-        with torch.no_grad():
-            out = net(batch)
-        if gather is not None:
-            if args.shard == "views":
-                return gather.all_gather_frames(out[rgb_key], out[depth_key])
-            return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
-        return out
+    if wl.get("train"):
+        # fine-tune step (trainer.py:44-63): every rank trains on its own target view, DDP averages the
+        # gradients over RCCL (bucketed all-reduce overlapped with backward); no tile gather in training
+        from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
+        gen = torch.Generator().manual_seed(rank)
+        for i in range(cc.num):
+            batch[f"rgb_{i}"] = torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=gen).to(dev)
+        net.train()
+        wrapper = NetworkWrapper(net)
+        if world > 1:
+            wrapper = torch.nn.parallel.DistributedDataParallel(
+                torch.nn.SyncBatchNorm.convert_sync_batchnorm(wrapper), device_ids=[local_rank],
+                output_device=local_rank, find_unused_parameters=True)
+        optimizer = make_optimizer(net)
+        gather = None
+
+        def step():
+            return train_step(wrapper, optimizer, batch)
+    else:
+        def step():
+            with torch.no_grad():
+                out = net(batch)
+            if gather is not None:
+                if args.shard == "views":
+                    return gather.all_gather_frames(out[rgb_key], out[depth_key])
+                return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
+            return out
 
     for _ in range(args.warmup):
         step()

@@ -9,6 +9,8 @@ so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .conv3d_wgrad import Conv3d, ConvTranspose3d   # MIOpen forward / data grad, slice-GEMM weight grad
+
 
 class _ConvBN(nn.Module):
     """conv (no bias) -> batch norm -> ReLU; children named `conv` and `bn`."""
@@ -27,11 +29,11 @@ def cbr2(cin, cout, k=3, stride=1, pad=1):
 
 
 def cbr3(cin, cout, stride=1):
-    return _ConvBN(nn.Conv3d, nn.BatchNorm3d, cin, cout, 3, stride, 1)
+    return _ConvBN(Conv3d, nn.BatchNorm3d, cin, cout, 3, stride, 1)
 
 
 def up3(cin, cout):
-    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
+    return nn.Sequential(ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
                          nn.BatchNorm3d(cout))
 
 
@@ -78,8 +80,8 @@ class _CostReg(nn.Module):
             self.conv7 = up3(64, 32)
         self.conv9 = up3(32, 16)
         self.conv11 = up3(16, 8)
-        self.depth_conv = nn.Sequential(nn.Conv3d(8, 1, 3, padding=1, bias=False))
-        self.feat_conv = nn.Sequential(nn.Conv3d(8, 8, 3, padding=1, bias=False))
+        self.depth_conv = nn.Sequential(Conv3d(8, 1, 3, padding=1, bias=False))
+        self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
 
     def forward(self, x):
         s0 = self.conv0(x)

@@ -1,0 +1,94 @@
+"""3-D convolutions whose WEIGHT gradient is 27 slice-GEMMs instead of MIOpen's conv3d
+backward-weights solvers.
+
+Measured on MI355X / ROCm 7.2 (scripts/probe_conv3d.py): MIOpen picks `naive_conv_*_wrw_ncdhw`
+or a 40 ms CK batched-GEMM for every 3x3x3 fp32 layer of the cost regularisers (308 ms per
+CostRegNet backward, >90 % of a fine-tune step; its exhaustive find mode takes >15 min).  The weight
+gradient of a k^3 convolution is k^3 small GEMMs over the voxel dimension,
+    dW[:, :, kd, kh, kw] = dY (Co x P) @ X_shift(kd,kh,kw)^T (P x Ci),
+which rocBLAS does in microseconds.  Forward and the data gradient stay on MIOpen.
+SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter
+names are unchanged (subclasses of nn.Conv3d / nn.ConvTranspose3d).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _slice_gemm_wgrad(big, small, stride, k=3):
+    """big: (Cb, Db, Hb, Wb) already zero-padded; small: (Cs, Ds, Hs, Ws).
+    Returns G (Cs, Cb, k, k, k) with G[s, b, kd, kh, kw] = sum_p small[s, p] * big[b, stride*p + (kd,kh,kw)]."""
+    Cs, Ds, Hs, Ws = small.shape
+    Cb = big.shape[0]
+    sm = small.reshape(Cs, -1)
+    out = torch.empty(Cs, Cb, k, k, k, device=small.device, dtype=small.dtype)
+    for kd in range(k):
+        for kh in range(k):
+            for kw in range(k):
+                sl = big[:, kd:kd + stride * Ds:stride, kh:kh + stride * Hs:stride, kw:kw + stride * Ws:stride]
+                out[:, :, kd, kh, kw] = sm @ sl.reshape(Cb, -1).t()
+    return out
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return F.conv3d(x, w, None, stride, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        s = ctx.stride
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [s] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = 0
+            for b in range(x.shape[0]):
+                xp = F.pad(x[b], (1, 1, 1, 1, 1, 1))
+                gw = gw + _slice_gemm_wgrad(xp, gy[b], s)          # (Co, Ci, 3,3,3)
+        return gx, gw, None
+
+
+class _ConvT3dFn(torch.autograd.Function):
+    """ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = F.conv3d(gy, w, None, 2, 1)                        # adjoint of the transposed conv
+        if ctx.needs_input_grad[1]:
+            gw = 0
+            for b in range(x.shape[0]):
+                # y[o] += x[i] * w[k] with o = 2 i - 1 + k  ->  dW[ci, co, k] = sum_i x[ci, i] * dY[co, 2 i - 1 + k]
+                gp = F.pad(gy[b], (1, 1, 1, 1, 1, 1))
+                gw = gw + _slice_gemm_wgrad(gp, x[b], 2)            # (Ci, Co, 3,3,3)
+        return gx, gw
+
+
+class Conv3d(nn.Conv3d):
+    def forward(self, x):
+        if (torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None and self.kernel_size == (3, 3, 3)
+                and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1
+                and self.stride[0] == self.stride[1] == self.stride[2]):
+            return _Conv3dFn.apply(x, self.weight, self.stride[0])
+        return super().forward(x)
+
+
+class ConvTranspose3d(nn.ConvTranspose3d):
+    def forward(self, x, output_size=None):
+        if (torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None and output_size is None
+                and self.kernel_size == (3, 3, 3) and self.stride == (2, 2, 2) and self.padding == (1, 1, 1)
+                and self.output_padding == (1, 1, 1) and self.groups == 1):
+            return _ConvT3dFn.apply(x, self.weight)
+        return super().forward(x, output_size)
