@@ -205,6 +205,19 @@ def main():
                 return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
             return out
 
+    # MIOpen's solver search writes its per-user find-db: rank 0 searches first with a collective-free forward,
+    # the other ranks then hit the finished db instead of N processes searching (and locking the db) at once.
+    if world > 1 and args.miopen_find and not wl.get("train"):
+        def local_forward():
+            with torch.no_grad():
+                net(batch)
+            torch.cuda.synchronize()
+        if rank == 0:
+            local_forward()
+        dist.barrier()
+        if rank != 0:
+            local_forward()
+        dist.barrier()
     for _ in range(args.warmup):
         step()
     ktimer.reset()

@@ -21,13 +21,19 @@ def _slice_gemm_wgrad(big, small, stride, k=3):
     Cs, Ds, Hs, Ws = small.shape
     Cb = big.shape[0]
     sm = small.reshape(Cs, -1)
-    out = torch.empty(Cs, Cb, k, k, k, device=small.device, dtype=small.dtype)
+    P = sm.shape[1]
+    # gather the k^3 shifted views into one (k^3 * Cb, P) matrix (k^3 strided copies), then ONE GEMM with the
+    # voxel dimension as its K: (k^3 Cb x P) @ (P x Cs).  27 separate (Cs x P)(P x Cb) GEMMs ran at < 0.4 TB/s.
+    cols = torch.empty(k * k * k, Cb, P, device=small.device, dtype=small.dtype)
+    i = 0
     for kd in range(k):
         for kh in range(k):
             for kw in range(k):
                 sl = big[:, kd:kd + stride * Ds:stride, kh:kh + stride * Hs:stride, kw:kw + stride * Ws:stride]
-                out[:, :, kd, kh, kw] = sm @ sl.reshape(Cb, -1).t()
-    return out
+                cols[i].view(Cb, Ds, Hs, Ws).copy_(sl)
+                i += 1
+    g = cols.view(k * k * k * Cb, P) @ sm.t()                       # (k^3 * Cb, Cs)
+    return g.view(k, k, k, Cb, Cs).permute(4, 3, 0, 1, 2).contiguous()
 
 
 class _Conv3dFn(torch.autograd.Function):
