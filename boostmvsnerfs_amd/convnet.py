@@ -1,0 +1,107 @@
+"""Host side of the convolution engine (csrc/conv.hip): weight packing with the eval-mode
+batch norm folded in, and tensor wrappers over bmv_conv_fwd / bmv_conv3d_transpose_fwd /
+bmv_fpn_topdown_fwd.
+
+The conv blocks of the reference (`ConvBnReLU`, `ConvBnReLU3D`, lib/networks/enerf/utils.py:10-33)
+become one launch each; their parameters stay ordinary nn.Module parameters with the reference's
+state-dict names (networks/enerf/cnn.py) and are re-packed only when one of them changes.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ktimer
+from ._lib import dptr, stream
+
+
+def fold_bn(weight, bn, out_dim=0):
+    """weight of a conv (out_dim=0) or transposed conv (out_dim=1) followed by eval-mode batch norm
+    -> (weight * gamma / sqrt(var + eps), beta - mean * gamma / sqrt(var + eps))."""
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean.detach() * scale
+    shape = [1] * weight.dim()
+    shape[out_dim] = -1
+    return weight.detach() * scale.view(shape), shift
+
+
+def pack_conv(weight, bias):
+    """weight (Cout,Cin,[kd,]kh,kw), bias (Cout) or None -> (wpack, bias16) in the layout of include/bmv.h:
+    wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]."""
+    Cout, Cin = weight.shape[:2]
+    taps = int(weight[0, 0].numel())
+    nt, nc = (Cout + 15) // 16, (Cin + 3) // 4
+    w = torch.zeros(nt * 16, nc * 4, taps, device=weight.device, dtype=torch.float32)
+    w[:Cout, :Cin] = weight.detach().reshape(Cout, Cin, taps).float()
+    wpack = w.view(nt, 16, nc, 4, taps).permute(0, 2, 4, 3, 1).contiguous()
+    b = torch.zeros(nt * 16, device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        b[:Cout] = bias.detach().float()
+    return wpack, b
+
+
+def pack_convT(weight, bias):
+    """ConvTranspose3d weight (Cin,Cout,3,3,3) -> the same blob layout with the roles of dims 0/1 swapped."""
+    return pack_conv(weight.detach().transpose(0, 1), bias)
+
+
+def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None):
+    """x (B,Cin,D,H,W) -> act(conv_transpose3d(x, k=3, stride=2, padding=1, output_padding=1) + bias) + skip."""
+    B, Cin, D, H, W = x.shape
+    shape = (B, Cout, 2 * D, 2 * H, 2 * W)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    assert out.shape == shape and out.is_contiguous()
+    if skip is not None:
+        assert skip.shape == shape and skip.is_contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"convT3d[{Cin}->{Cout},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv3d_transpose_fwd(dptr(x, "convT input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
+                                 dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout,
+                                 int(bool(relu)), stream())
+    _lib.check(rc, "convT3d_fwd")
+    return out
+
+
+def fpn_topdown(fine, coarse, weight, bias, out=None):
+    """bilinear_x2(coarse, align_corners=True) + conv1x1(fine, weight (C,Cf,1,1), bias) -> (B,C,H,W)."""
+    B, Cf, H, W = fine.shape
+    C = coarse.shape[1]
+    assert coarse.shape == (B, C, H // 2, W // 2)
+    if out is None:
+        out = torch.empty(B, C, H, W, device=fine.device, dtype=torch.float32)
+    w = weight.detach().reshape(C, Cf).contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"fpn_topdown[{Cf}->{C},{H}x{W}]"):
+        rc = lib.bmv_fpn_topdown_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"), dptr(w, "w"),
+                                     dptr(bias.detach().contiguous(), "bias"), dptr(out), B, Cf, C, H, W, stream())
+    _lib.check(rc, "fpn_topdown_fwd")
+    return out
+
+
+def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None):
+    """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
+    ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout))."""
+    is3d = x.dim() == 5
+    B, Cin = x.shape[:2]
+    D = x.shape[2] if is3d else 1
+    H, W = x.shape[-2:]
+    p, pd = k // 2, kd // 2
+    Do, Ho, Wo = (D + 2 * pd - kd) // stride + 1, (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+    if channels_last:
+        shape = (B, Do, Ho, Wo, Cout) if is3d else (B, Ho, Wo, Cout)
+    else:
+        shape = (B, Cout, Do, Ho, Wo) if is3d else (B, Cout, Ho, Wo)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    assert out.shape == shape and out.is_contiguous()
+    if skip is not None:
+        assert skip.shape == shape and skip.is_contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"conv[{Cin}->{Cout},k{kd}x{k}x{k},s{stride},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
+                              dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout, kd, k, stride,
+                              int(bool(relu)), int(bool(channels_last)), stream())
+    _lib.check(rc, "conv_fwd")
+    return out

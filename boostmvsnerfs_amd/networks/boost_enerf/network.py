@@ -71,6 +71,14 @@ class Network(enerf_network.Network):
         bi = torch.arange(ids.shape[0], device=ids.device)[:, None]
         return (batch["all_src_inps"][bi, ids], batch["all_src_exts"][bi, ids], batch["all_src_ixts"][bi, ids])
 
+    @staticmethod
+    def _pick_feats(f, bi, ids):
+        """f[bi, ids] that keeps a channel-last feature buffer channel-last (the sweep reads it without a transpose)."""
+        cl = f.permute(0, 1, 3, 4, 2)
+        if not f.is_contiguous() and cl.is_contiguous():
+            return cl[bi, ids].permute(0, 1, 4, 2, 3)
+        return f[bi, ids]
+
     # ------------------------------------------------------------------ view selection (a17)
     def calc_mask(self, src_views_id, batch, feats=None):
         """2-D visibility map of one triplet for every rendered level (network.py:22-69)."""
@@ -83,7 +91,7 @@ class Network(enerf_network.Network):
             pick = lambda f: f
         else:
             bi = torch.arange(B, device=ids.device)[:, None]
-            pick = lambda f: f[bi, ids]
+            pick = lambda f: self._pick_feats(f, bi, ids)
         H, W = views[0].shape[-2:]
         out, st = {}, None
         for i in range(cc.num):
@@ -169,7 +177,7 @@ class Network(enerf_network.Network):
             for k in range(K):
                 ids = sel[:, k]
                 views = self._pick(batch, ids)
-                states[k] = self.level_front(i, feats[f"level_{i}"][bi, ids], views, batch, states[k])
+                states[k] = self.level_front(i, self._pick_feats(feats[f"level_{i}"], bi, ids), views, batch, states[k])
                 if not cc.render_if[i]:
                     continue
                 im_feat = feats[f"level_{cc.render_im_feat_level[i]}"][bi, ids]

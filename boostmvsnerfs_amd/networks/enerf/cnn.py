@@ -6,10 +6,47 @@ Module/parameter names reproduce the reference's state-dict keys exactly
 (lib/networks/enerf/feature_net.py:4-36, cost_reg_net.py:4-86, utils.py:10-33)
 so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.
 """
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import convnet
 from .conv3d_wgrad import Conv3d, ConvTranspose3d   # MIOpen forward / data grad, slice-GEMM weight grad
+
+
+def _engine_ok(module, x):
+    """Inference (eval-mode batch norm, no autograd) on the GPU runs on the convolution engine
+    (csrc/conv.hip); training keeps the torch modules (MIOpen forward / data gradients)."""
+    return (not module.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and os.environ.get("BMV_CNN", "engine") != "torch")
+
+
+class _Packed:
+    """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
+    bump `_version`; `.to()` / `.cuda()` replace storage and change `data_ptr`)."""
+
+    def __init__(self):
+        self.key = None
+        self.blobs = None
+        self.tensors = None
+
+    def get(self, module, build):
+        if self.tensors is None:
+            self.tensors = list(module.parameters()) + list(module.buffers())
+        key = [t._version for t in self.tensors]
+        key.append(self.tensors[0].data_ptr())
+        key.append(self.tensors[-1].data_ptr())
+        if key != self.key:
+            self.tensors = list(module.parameters()) + list(module.buffers())    # buffers are replaced by .to()
+            self.blobs, self.key = build(), key
+        return self.blobs
+
+
+def _pack_cbr(m):
+    """_ConvBN -> (wpack, bias) with the batch norm folded in."""
+    return convnet.pack_conv(*convnet.fold_bn(m.conv.weight, m.bn))
 
 
 class _ConvBN(nn.Module):
@@ -51,12 +88,37 @@ class FeatureNet(nn.Module):
         self.lat0 = nn.Conv2d(8, 32, 1)
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
+        self._packed = _Packed()
 
     @staticmethod
     def _top_down(coarse, lateral):
         return F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + lateral
 
+    def _forward_engine(self, x):
+        """Same graph, one launch per conv block.  The two maps the plane sweeps read come out channel-last
+        (returned as (N,C,H,W) views of (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
+        P = self._packed.get(self, lambda: {
+            **{f"conv{i}.{j}": _pack_cbr(getattr(self, f"conv{i}")[j]) for i in range(3) for j in range(2)},
+            "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
+            "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
+            "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias)})
+        c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
+        c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
+        c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
+        c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
+        c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
+        c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
+        p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1)
+        p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
+        p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
+        f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last=True)
+        f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
+        p2_cl = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True)
+        return p2_cl.permute(0, 3, 1, 2), f1.permute(0, 3, 1, 2), f0
+
     def forward(self, x):
+        if _engine_ok(self, x):
+            return self._forward_engine(x)
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
@@ -82,8 +144,33 @@ class _CostReg(nn.Module):
         self.conv11 = up3(16, 8)
         self.depth_conv = nn.Sequential(Conv3d(8, 1, 3, padding=1, bias=False))
         self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
+        self._packed = _Packed()
+
+    def _forward_engine(self, x):
+        def build():
+            P = {f"conv{i}": _pack_cbr(getattr(self, f"conv{i}")) for i in range(5 + 2 * (self.depth == 3))}
+            for name in ("conv7", "conv9", "conv11")[3 - self.depth:]:
+                up = getattr(self, name)
+                P[name] = convnet.pack_convT(*convnet.fold_bn(up[0].weight, up[1], out_dim=1))
+            # feat_conv (8 ch) and depth_conv (1 ch) read the same tensor: one 9-channel convolution
+            P["heads"] = convnet.pack_conv(torch.cat([self.feat_conv[0].weight, self.depth_conv[0].weight], 0), None)
+            return P
+        P = self._packed.get(self, build)
+        s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
+        s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)
+        s2 = convnet.conv_fwd(convnet.conv_fwd(s1, *P["conv3"], 32, 3, 3, 2, relu=True), *P["conv4"], 32, 3, 3, relu=True)
+        y = s2
+        if self.depth == 3:
+            t = convnet.conv_fwd(convnet.conv_fwd(s2, *P["conv5"], 64, 3, 3, 2, relu=True), *P["conv6"], 64, 3, 3, relu=True)
+            y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2)
+        y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
+        y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
+        heads = convnet.conv_fwd(y, *P["heads"], 9, 3, 3)
+        return heads[:, :8], heads[:, 8]
 
     def forward(self, x):
+        if _engine_ok(self, x):
+            return self._forward_engine(x)
         s0 = self.conv0(x)
         s1 = self.conv2(self.conv1(s0))
         s2 = self.conv4(self.conv3(s1))

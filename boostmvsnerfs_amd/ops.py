@@ -77,6 +77,10 @@ def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=No
     channels_last=True.  With channels_last=None (default) a reference-layout input with C in
     {16, 32} is first put into the channel-last layout (one transpose kernel) and the fast
     channel-last sweep runs; algo=1 forces the reference-layout direct-gather kernel."""
+    if channels_last is None and feats.dim() == 5 and not feats.is_contiguous() and algo != 1:
+        cl = feats.permute(0, 1, 3, 4, 2)
+        if cl.is_contiguous():        # (B,S,C,Hs,Ws) view of a channel-last buffer (the conv engine writes it so)
+            feats, channels_last = cl, True
     if channels_last:
         B, S, Hs, Ws, C_ = feats.shape
     else:

@@ -1,0 +1,159 @@
+"""Convolution engine (csrc/conv.hip) against torch's fp32 convolutions on the same device: every
+kernel shape FeatureNet / MinCostRegNet / CostRegNet use, ragged sizes (tiles that hang over the
+border, W not a multiple of 16, Cin = 3, Cout in {1, 8, 9, 16, 32, 64}), fused bias / ReLU / skip,
+both output layouts.  Floating-point kernel: tolerance 1e-4 of the output scale (fp32 FMA chains in a
+different summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, want, tol=1e-4):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+CASES_2D = [  # Cin, Cout, k, stride, H, W
+    (3, 8, 3, 1, 37, 53), (8, 8, 3, 1, 64, 96), (8, 16, 5, 2, 64, 96), (16, 16, 3, 1, 32, 48),
+    (16, 32, 5, 2, 33, 47), (32, 32, 3, 1, 16, 24), (32, 32, 1, 1, 16, 24), (16, 32, 1, 1, 19, 21),
+    (32, 16, 3, 1, 32, 48), (32, 8, 3, 1, 40, 72),
+]
+CASES_3D = [  # Cin, Cout, stride, D, H, W
+    (32, 8, 1, 8, 8, 12), (16, 8, 1, 4, 32, 48), (8, 16, 2, 8, 8, 12), (16, 16, 1, 4, 4, 6), (16, 32, 2, 4, 4, 6),
+    (32, 32, 1, 2, 2, 3), (32, 64, 2, 2, 8, 12), (64, 64, 1, 1, 4, 6), (8, 9, 1, 5, 9, 19), (8, 1, 1, 8, 8, 12),
+    (8, 8, 1, 3, 17, 33),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,W", CASES_2D)
+def test_conv2d(Cin, Cout, k, stride, H, W):
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(2, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv2d(x, w, b, stride, k // 2)
+    wp, bp = convnet.pack_conv(w, b)
+    _close(convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride), want)
+    _close(convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride, relu=True), F.relu(want))
+    got = convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride, channels_last=True)
+    _close(got.permute(0, 3, 1, 2), want)
+
+
+@pytest.mark.parametrize("Cin,Cout,stride,D,H,W", CASES_3D)
+def test_conv3d(Cin, Cout, stride, D, H, W):
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + stride)
+    x = torch.randn(1, Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv3d(x, w, b, stride, 1)
+    wp, bp = convnet.pack_conv(w, b)
+    _close(convnet.conv_fwd(x, wp, bp, Cout, 3, 3, stride), want)
+    skip = torch.randn(want.shape, generator=g).to(DEV)
+    _close(convnet.conv_fwd(x, wp, bp, Cout, 3, 3, stride, relu=True, skip=skip), F.relu(want) + skip)
+    got = convnet.conv_fwd(x, wp, bp, Cout, 3, 3, stride, channels_last=True)
+    _close(got.permute(0, 4, 1, 2, 3), want)
+
+
+@pytest.mark.parametrize("Cin,Cout,D,H,W", [(64, 32, 1, 4, 6), (32, 16, 2, 8, 12), (16, 8, 4, 16, 24), (16, 8, 3, 5, 19),
+                                             (32, 16, 1, 1, 1)])
+def test_conv3d_transpose(Cin, Cout, D, H, W):
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cin + Cout + D)
+    x = torch.randn(1, Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (Cin * 27 / 8) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)
+    wp, bp = convnet.pack_convT(w, b)
+    _close(convnet.convT3d_fwd(x, wp, bp, Cout), want)
+    skip = torch.randn(want.shape, generator=g).to(DEV)
+    _close(convnet.convT3d_fwd(x, wp, bp, Cout, skip=skip), want + skip)
+    _close(convnet.convT3d_fwd(x, wp, bp, Cout, relu=True), F.relu(want))
+
+
+@pytest.mark.parametrize("Cf,H,W", [(8, 64, 96), (16, 32, 48), (16, 6, 70)])
+def test_fpn_topdown(Cf, H, W):
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cf + H)
+    fine = torch.randn(2, Cf, H, W, generator=g).to(DEV)
+    coarse = torch.randn(2, 32, H // 2, W // 2, generator=g).to(DEV)
+    w = torch.randn(32, Cf, 1, 1, generator=g).to(DEV)
+    b = torch.randn(32, generator=g).to(DEV)
+    want = F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(fine, w, b)
+    _close(convnet.fpn_topdown(fine, coarse, w, b), want)
+
+
+def _randomise_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def test_feature_net_engine_matches_torch_modules(monkeypatch):
+    from boostmvsnerfs_amd.networks.enerf.cnn import FeatureNet
+    torch.manual_seed(0)
+    net = FeatureNet()
+    _randomise_bn(net, 1)
+    net = net.to(DEV).eval()
+    x = torch.randn(3, 3, 64, 96, device=DEV)
+    with torch.no_grad():
+        got = net(x)
+        monkeypatch.setenv("BMV_CNN", "torch")
+        want = net(x)
+    assert not got[0].is_contiguous() and got[0].permute(0, 2, 3, 1).is_contiguous()      # sweep layout
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape
+        _close(g_, w_)
+    # a parameter update invalidates the packed weights
+    monkeypatch.delenv("BMV_CNN")
+    with torch.no_grad():
+        net.smooth0.bias.add_(1.0)
+        _close(net(x)[2], want[2] + 1.0)
+
+
+@pytest.mark.parametrize("cls,cin,shape", [("MinCostRegNet", 32, (8, 8, 12)), ("CostRegNet", 16, (8, 32, 48))])
+def test_cost_reg_engine_matches_torch_modules(monkeypatch, cls, cin, shape):
+    from boostmvsnerfs_amd.networks.enerf import cnn
+    torch.manual_seed(0)
+    net = getattr(cnn, cls)(cin)
+    _randomise_bn(net, 2)
+    net = net.to(DEV).eval()
+    x = torch.rand(1, cin, *shape, device=DEV)
+    with torch.no_grad():
+        feat, prob = net(x)
+        monkeypatch.setenv("BMV_CNN", "torch")
+        feat_t, prob_t = net(x)
+    assert feat.shape == feat_t.shape and prob.shape == prob_t.shape
+    _close(feat, feat_t)
+    _close(prob, prob_t)
+
+
+def test_fold_bn_matches_eval_batch_norm():
+    from boostmvsnerfs_amd import convnet
+    torch.manual_seed(0)
+    conv = torch.nn.Conv3d(8, 16, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm3d(16).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.normal_(), bn.running_mean.normal_(), bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(1, 8, 4, 8, 12, device=DEV)
+        want = F.relu(bn(conv(x)))
+        wp, bp = convnet.pack_conv(*convnet.fold_bn(conv.weight, bn))
+        _close(convnet.conv_fwd(x, wp, bp, 16, 3, 3, relu=True), want)
+
+
+def test_unsupported_shape_is_loud():
+    from boostmvsnerfs_amd import convnet
+    x = torch.zeros(1, 4, 8, 8, device=DEV)
+    wp, bp = convnet.pack_conv(torch.zeros(4, 4, 7, 7, device=DEV), None)
+    with pytest.raises(RuntimeError, match="not one of the shapes"):
+        convnet.conv_fwd(x, wp, bp, 4, 1, 7, 1)

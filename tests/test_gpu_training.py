@@ -104,6 +104,8 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     l2, stats = train_step(wrapper, opt, {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()})
     assert torch.isfinite(l2)
     # every parameter with a non-zero oracle gradient moves (a few heads sit behind dead ReLUs: exact zeros)
+    # (agg_w_fc.bias sits in front of a softmax over views: its gradient is 0 up to rounding noise on either side)
+    gmax = max(float(g.abs().max()) for g in want.values())
     for k, p in net.named_parameters():
-        if float(want[k].abs().max()) > 0:
+        if float(want[k].abs().max()) > 1e-6 * gmax:
             assert bool((p.detach() != before[k]).any()), f"{k} did not move"
