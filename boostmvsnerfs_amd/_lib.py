@@ -79,6 +79,7 @@ SIGNATURES = {
     "bmv_mvs_render_fwd": [C.POINTER(MvsRenderArgs), c_f],
     "bmv_mvs_march_mask": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f],
     "bmv_conv_wpack_floats": [c_i, c_i, c_i, c_i, c_i],
+    "bmv_conv_pairs_rows": [c_i, c_i, c_i, c_i],
     "bmv_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "bmv_conv3d_transpose_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "bmv_fpn_topdown_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

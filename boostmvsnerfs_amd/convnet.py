@@ -24,24 +24,36 @@ def fold_bn(weight, bn, out_dim=0):
     return weight.detach() * scale.view(shape), shift
 
 
-def pack_conv(weight, bias):
+def pack_conv(weight, bias, stride=1, allow_pair=True):
     """weight (Cout,Cin,[kd,]kh,kw), bias (Cout) or None -> (wpack, bias16) in the layout of include/bmv.h:
-    wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]."""
+    wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap], or the row-pair layout when the library pairs
+    output rows for this shape (Cout <= 8, 3x3 / 3x3x3, stride 1)."""
     Cout, Cin = weight.shape[:2]
+    k = weight.shape[-1]
+    kd = weight.shape[2] if weight.dim() == 5 else 1
     taps = int(weight[0, 0].numel())
     nt, nc = (Cout + 15) // 16, (Cin + 3) // 4
-    w = torch.zeros(nt * 16, nc * 4, taps, device=weight.device, dtype=torch.float32)
-    w[:Cout, :Cin] = weight.detach().reshape(Cout, Cin, taps).float()
-    wpack = w.view(nt, 16, nc, 4, taps).permute(0, 2, 4, 3, 1).contiguous()
-    b = torch.zeros(nt * 16, device=weight.device, dtype=torch.float32)
+    dev = weight.device
+    b = torch.zeros(nt * 16, device=dev, dtype=torch.float32)
     if bias is not None:
         b[:Cout] = bias.detach().float()
+    if allow_pair and _lib.load().bmv_conv_pairs_rows(Cout, kd, k, stride):
+        w8 = torch.zeros(8, nc * 4, kd, k, k, device=dev, dtype=torch.float32)
+        w8[:Cout, :Cin] = weight.detach().reshape(Cout, Cin, kd, k, k).float()
+        w8 = w8.view(8, nc, 4, kd, k, k).permute(1, 3, 4, 5, 2, 0)          # (nc, kd, ky, kx, 4, 8)
+        wp = torch.zeros(nc, kd, k + 1, k, 4, 16, device=dev, dtype=torch.float32)
+        wp[:, :, :k, :, :, :8] = w8                                         # output row y   meets filter row j
+        wp[:, :, 1:, :, :, 8:] = w8                                         # output row y+1 meets filter row j-1
+        return wp.view(1, nc, kd * (k + 1) * k, 4, 16).contiguous(), b
+    w = torch.zeros(nt * 16, nc * 4, taps, device=dev, dtype=torch.float32)
+    w[:Cout, :Cin] = weight.detach().reshape(Cout, Cin, taps).float()
+    wpack = w.view(nt, 16, nc, 4, taps).permute(0, 2, 4, 3, 1).contiguous()
     return wpack, b
 
 
 def pack_convT(weight, bias):
     """ConvTranspose3d weight (Cin,Cout,3,3,3) -> the same blob layout with the roles of dims 0/1 swapped."""
-    return pack_conv(weight.detach().transpose(0, 1), bias)
+    return pack_conv(weight.detach().transpose(0, 1), bias, allow_pair=False)
 
 
 def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None):

@@ -16,6 +16,10 @@
 // (2 channels x 16 x) fall on 32 distinct banks; the per-tap operand is `ds_read_b32 base + immediate`.
 // Tile loads are raw buffer loads whose per-thread slot offsets are computed once per block; out-of-image
 // slots (zero padding) and padded input channels use an out-of-range offset and come back as 0.
+//
+// Row pairing (Cout <= 8, stride 1): the 16 MFMA rows hold the 8 output channels of TWO adjacent output rows
+// y, y+1.  Input row y+j (j = 0..K) meets filter row j for output y and filter row j-1 for output y+1, so K+1
+// MFMAs per (kz, kx) produce two output rows: (K+1)/(2K) = 2/3 of the MFMAs of padding 8 channels to 16.
 #include "bmv_common.hpp"
 
 namespace bmv {
@@ -32,11 +36,12 @@ struct ConvArgs {
   int relu, channels_last;
 };
 
-template <int KD, int K, int S, int NCT, int R, bool IS3D>
+// MAP: 0 = 2-D (row groups along y), 1 = 3-D with the block's 4/NCT row groups along z, 2 = 3-D along y
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 struct ConvTile {
   static constexpr int NRG = 4 / NCT;  // row groups (waves per cout tile)
-  static constexpr int TZ = IS3D ? NRG : 1;
-  static constexpr int TY = IS3D ? R : NRG * R;
+  static constexpr int TZ = (MAP == 1) ? NRG : 1;
+  static constexpr int TY = (MAP == 1) ? R : NRG * R;
   static constexpr int TZH = (TZ - 1) * S + KD;
   static constexpr int TYH = (TY - 1) * S + K;
   static constexpr int RS = 15 * S + K;  // 16 outputs along x + halo
@@ -44,13 +49,15 @@ struct ConvTile {
   // stride 1: plane stride = 16 (mod 32); stride 2: odd  -> conflict-free operand reads
   static constexpr int PS = (S == 1) ? ((SLOTS + 15) / 32 * 32 + 16) : (SLOTS | 1);
   static constexpr int NSLOT = (SLOTS + 255) / 256;
-  static constexpr int TAPS = KD * K * K;
-  static constexpr int ROWBASE = IS3D ? S * TYH * RS : R * S * RS;  // LDS offset of one row group
+  static constexpr int TAPS = PAIR ? KD * (K + 1) * K : KD * K * K;
+  static constexpr int ROWBASE = (MAP == 1) ? S * TYH * RS : R * S * RS;  // LDS offset of one row group
+  static constexpr int NACC = PAIR ? R / 2 : R;
+  static_assert(!PAIR || (S == 1 && NCT == 1 && R % 2 == 0), "row pairing: stride 1, one cout tile, even rows");
 };
 
-template <int KD, int K, int S, int NCT, int R, bool IS3D>
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-  using T = ConvTile<KD, K, S, NCT, R, IS3D>;
+  using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   __shared__ float lds[4 * T::PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
@@ -83,9 +90,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int cot = blockIdx.y * NCT + ct;  // cout tile of this wave
   const float* wp = a.wpack + (size_t)cot * nchunk * (T::TAPS * 64) + lane;
 
-  f32x4 acc[R];
+  f32x4 acc[T::NACC];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < T::NACC; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float pre[4][T::NSLOT];
   auto load_tile = [&](int chunk) {
@@ -120,33 +127,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[(size_t)(chunk + 1) * (T::TAPS * 64) + t * 64];
     }
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int kd = 0; kd < KD; ++kd)
+      for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < K; ++kh)
+        for (int j = 0; j <= K; ++j)
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const float w = wv[(kd * K + kh) * K + kw];
+          for (int kw = 0; kw < K; ++kw) {
+            const float w = wv[(kd * (K + 1) + j) * K + kw];
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r], 0,
-                                                          0, 0);
-        }
+            for (int p = 0; p < R / 2; ++p)
+              acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + 2 * p + j) * T::RS + kw], acc[p], 0,
+                                                            0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const float w = wv[(kd * K + kh) * K + kw];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r],
+                                                            0, 0, 0);
+          }
+    }
   }
 
   // epilogue: lane = output x (lane & 15), registers = 4 consecutive output channels
   const int x = x0 + (lane & 15);
-  const int co0 = cot * 16 + 4 * (lane >> 4);
-  if (x >= a.Wo || co0 >= a.Cout) return;
+  const int g = lane >> 4;
+  const int co0 = PAIR ? 4 * (g & 1) : cot * 16 + 4 * g;
+  const int z = (MAP == 1) ? z0 + rg : z0;
+  if (x >= a.Wo || co0 >= a.Cout || z >= a.Do) return;
   float bs[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
-  const int z = IS3D ? z0 + rg : 0;
-  if (z >= a.Do) return;
+  const size_t cs = (size_t)a.Do * a.Ho * a.Wo;
+  const int ybase = (MAP == 1) ? y0 : y0 + rg * R;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int y = IS3D ? y0 + r : y0 + rg * R + r;
-    if (y >= a.Ho) break;
+  for (int r = 0; r < T::NACC; ++r) {
+    const int y = PAIR ? ybase + 2 * r + (g >> 1) : ybase + r;
+    if (y >= a.Ho) continue;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -165,7 +189,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
           if (co0 + j < a.Cout) a.out[o + j] = v[j] + (a.skip ? a.skip[o + j] : 0.f);
       }
     } else {
-      const size_t cs = (size_t)a.Do * a.Ho * a.Wo;
       const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + z) * a.Ho + y) * a.Wo + x;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -180,23 +203,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // parities of an input position are 1+2+2+4+2+4+4+8 = 27 taps: no MFMA on stuffed zeros.  A wave owns R input
 // rows x 16 input x and keeps the 8 parity accumulators of each; the two x parities of a lane are adjacent in
 // the output row and leave as one 8-byte store.  The U-Net skip add is the epilogue.
+// MAP as above (1: row groups along z, 2: along y).
 // ---------------------------------------------------------------------------------------------------
-template <int NCT, int R>
+template <int NCT, int R, int MAP>
 struct ConvTTile {
   static constexpr int NRG = 4 / NCT;
-  static constexpr int TZH = NRG + 1, TYH = R + 1, RS = 17;
+  static constexpr int TZ = (MAP == 1) ? NRG : 1;
+  static constexpr int TY = (MAP == 1) ? R : NRG * R;
+  static constexpr int TZH = TZ + 1, TYH = TY + 1, RS = 17;
   static constexpr int SLOTS = TZH * TYH * RS;
   static constexpr int PS = (SLOTS + 15) / 32 * 32 + 16;
   static constexpr int NSLOT = (SLOTS + 255) / 256;
+  static constexpr int ROWBASE = (MAP == 1) ? TYH * RS : R * RS;
 };
 
-template <int NCT, int R>
+template <int NCT, int R, int MAP>
 __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
-  using T = ConvTTile<NCT, R>;
+  using T = ConvTTile<NCT, R, MAP>;
   __shared__ float lds[4 * T::PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
-  const int ntx = (a.W + 15) / 16, nty = (a.H + R - 1) / R, ntz = (a.D + T::NRG - 1) / T::NRG;
+  const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY, ntz = (a.D + T::TZ - 1) / T::TZ;
   int bid = blockIdx.x;
   const int tx = bid % ntx;
   bid /= ntx;
@@ -204,7 +231,7 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
   bid /= nty;
   const int tz = bid % ntz;
   const int b = bid / ntz;
-  const int x0 = tx * 16, y0 = ty * R, z0 = tz * T::NRG;
+  const int x0 = tx * 16, y0 = ty * T::TY, z0 = tz * T::TZ;
   const int plane = a.D * a.H * a.W;
 
   unsigned goff[T::NSLOT];
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
   for (int t = 0; t < 27; ++t) wnext[t] = wp[t * 64];
 
-  const float* ap = lds + (lane >> 4) * T::PS + rg * (T::TYH * T::RS) + (lane & 15);
+  const float* ap = lds + (lane >> 4) * T::PS + rg * T::ROWBASE + (lane & 15);
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();
 #pragma unroll
@@ -284,40 +311,40 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
 
   const int m = x0 + (lane & 15);
   const int co0 = cot * 16 + 4 * (lane >> 4);
-  const int mz = z0 + rg;
+  const int mz = (MAP == 1) ? z0 + rg : z0;
   if (m >= a.W || co0 >= a.Cout || mz >= a.D) return;
   float bs[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
   const size_t cs = (size_t)a.Do * a.Ho * a.Wo;
+  const int ybase = (MAP == 1) ? y0 : y0 + rg * R;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int my = y0 + r;
-    if (my >= a.H) break;
+    const int my = ybase + r;
+    if (my >= a.H) continue;
+    // all skip values of this input row first: skip and out may alias as far as the compiler knows, and a
+    // load issued after a store would wait for it
+    float2 sk[4][4];
 #pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-      const int pz = q >> 2, py = (q >> 1) & 1;
-      const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + 2 * mz + pz) * a.Ho + 2 * my + py) * a.Wo + 2 * m;
+    for (int q = 0; q < 4; ++q) {
+      const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + 2 * mz + (q >> 1)) * a.Ho + 2 * my + (q & 1)) * a.Wo + 2 * m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        sk[q][j] = (a.skip && co0 + j < a.Cout) ? *reinterpret_cast<const float2*>(a.skip + o + j * cs)
+                                                 : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + 2 * mz + (q >> 1)) * a.Ho + 2 * my + (q & 1)) * a.Wo + 2 * m;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (co0 + j >= a.Cout) break;
-        float v0 = acc[r][q][j] + bs[j], v1 = acc[r][q + 1][j] + bs[j];
+        if (co0 + j >= a.Cout) continue;
+        float v0 = acc[r][2 * q][j] + bs[j], v1 = acc[r][2 * q + 1][j] + bs[j];
         if (a.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f);
-        if (a.skip) {
-          const float2 s = *reinterpret_cast<const float2*>(a.skip + o + j * cs);
-          v0 += s.x, v1 += s.y;
-        }
-        *reinterpret_cast<float2*>(a.out + o + j * cs) = make_float2(v0, v1);
+        *reinterpret_cast<float2*>(a.out + o + j * cs) = make_float2(v0 + sk[q][j].x, v1 + sk[q][j].y);
       }
     }
   }
-}
-
-template <int NCT, int R>
-static void launch_convT(const ConvArgs& a, hipStream_t st) {
-  using T = ConvTTile<NCT, R>;
-  dim3 grid(cdiv(a.W, 16) * cdiv(a.H, R) * cdiv(a.D, T::NRG) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
-  hipLaunchKernelGGL((convT3d_mfma_kernel<NCT, R>), grid, dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -346,32 +373,72 @@ __global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restric
   }
 }
 
-template <int KD, int K, int S, int NCT, int R, bool IS3D>
+// ---------------------------------------------------------------------------------------------------
+// Launch selection.  Big tiles (R rows per wave, all cout tiles of a layer in one block so the LDS tile is
+// shared) when they still give every CU a few blocks; otherwise small tiles, one cout tile per block
+// (grid.y walks the cout tiles): the deep U-Net levels have a few thousand voxels only.
+// ---------------------------------------------------------------------------------------------------
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
+static unsigned conv_blocks(const ConvArgs& a) {
+  using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
+  return cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B * cdiv(cdiv(a.Cout, 16), NCT);
+}
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
-  using T = ConvTile<KD, K, S, NCT, R, IS3D>;
-  const unsigned ntx = cdiv(a.Wo, 16), nty = cdiv(a.Ho, T::TY), ntz = cdiv(a.Do, T::TZ);
-  const unsigned ncot = cdiv(a.Cout, 16);
-  dim3 grid(ntx * nty * ntz * a.B, cdiv(ncot, NCT));
-  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, IS3D>), grid, dim3(256), 0, st, a);
+  using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
+  dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
+  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR>), grid, dim3(256), 0, st, a);
 }
 
-template <int KD, int K, int S, int R, bool IS3D>
-static void launch_conv_nct(const ConvArgs& a, hipStream_t st) {
+constexpr unsigned kEnoughBlocks = 512;  // 2 per CU
+
+// RB / RS: rows per wave of the big / small tiling
+template <int KD, int K, int S, int RB, int RS_, bool IS3D>
+static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int MB = IS3D ? 1 : 0;   // big tiles: row groups along z for volumes
+  constexpr int MS = IS3D ? 2 : 0;   // small tiles: one z slice
   const unsigned ncot = cdiv(a.Cout, 16);
-  if (ncot == 1)
-    launch_conv<KD, K, S, 1, R, IS3D>(a, st);
-  else if (ncot == 2)
-    launch_conv<KD, K, S, 2, R, IS3D>(a, st);
-  else
-    launch_conv<KD, K, S, 4, R, IS3D>(a, st);
+  if constexpr (S == 1 && K == 3) {
+    if (a.Cout <= 8) {               // row pairing
+      if (conv_blocks<KD, K, S, 1, RB, MB, true>(a) >= kEnoughBlocks)
+        return launch_conv<KD, K, S, 1, RB, MB, true>(a, st);
+      return launch_conv<KD, K, S, 1, 2, MS, true>(a, st);
+    }
+  }
+  if (ncot == 1 && conv_blocks<KD, K, S, 1, RB, MB, false>(a) >= kEnoughBlocks)
+    return launch_conv<KD, K, S, 1, RB, MB, false>(a, st);
+  if (ncot == 2 && conv_blocks<KD, K, S, 2, RB, MB, false>(a) >= kEnoughBlocks)
+    return launch_conv<KD, K, S, 2, RB, MB, false>(a, st);
+  if (ncot >= 3 && conv_blocks<KD, K, S, 4, RB, MB, false>(a) >= kEnoughBlocks)
+    return launch_conv<KD, K, S, 4, RB, MB, false>(a, st);
+  if (conv_blocks<KD, K, S, 1, RS_, MB, false>(a) >= kEnoughBlocks)
+    return launch_conv<KD, K, S, 1, RS_, MB, false>(a, st);
+  launch_conv<KD, K, S, 1, 1, MS, false>(a, st);
+}
+
+template <int NCT, int R, int MAP>
+static unsigned convT_blocks(const ConvArgs& a) {
+  using T = ConvTTile<NCT, R, MAP>;
+  return cdiv(a.W, 16) * cdiv(a.H, T::TY) * cdiv(a.D, T::TZ) * a.B * cdiv(cdiv(a.Cout, 16), NCT);
+}
+template <int NCT, int R, int MAP>
+static void launch_convT(const ConvArgs& a, hipStream_t st) {
+  using T = ConvTTile<NCT, R, MAP>;
+  dim3 grid(cdiv(a.W, 16) * cdiv(a.H, T::TY) * cdiv(a.D, T::TZ) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
+  hipLaunchKernelGGL((convT3d_mfma_kernel<NCT, R, MAP>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace bmv
 
 extern "C" {
 
-int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int kh, int kw) {
-  return ((Cout + 15) / 16) * ((Cin + 3) / 4) * kd * kh * kw * 64;
+int bmv_conv_pairs_rows(int Cout, int kd, int k, int stride) {
+  return (Cout <= 8 && stride == 1 && k == 3 && (kd == 1 || kd == 3)) ? 1 : 0;
+}
+
+int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride) {
+  const int taps = bmv_conv_pairs_rows(Cout, kd, k, stride) ? kd * (k + 1) * k : kd * k * k;
+  return ((Cout + 15) / 16) * ((Cin + 3) / 4) * taps * 64;
 }
 
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
@@ -390,23 +457,23 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   a.relu = relu, a.channels_last = out_channels_last;
   hipStream_t st = as_stream(stream);
   if (kd == 1 && k == 3 && stride == 1)
-    launch_conv_nct<1, 3, 1, 8, false>(a, st);
+    dispatch_conv<1, 3, 1, 8, 2, false>(a, st);
   else if (kd == 1 && k == 5 && stride == 2)
-    launch_conv_nct<1, 5, 2, 4, false>(a, st);
+    dispatch_conv<1, 5, 2, 4, 2, false>(a, st);
   else if (kd == 1 && k == 1 && stride == 1)
-    launch_conv_nct<1, 1, 1, 8, false>(a, st);
+    dispatch_conv<1, 1, 1, 8, 2, false>(a, st);
   else if (kd == 3 && k == 3 && stride == 1)
-    launch_conv_nct<3, 3, 1, 8, true>(a, st);
+    dispatch_conv<3, 3, 1, 8, 2, true>(a, st);
   else if (kd == 3 && k == 3 && stride == 2)
-    launch_conv_nct<3, 3, 2, 4, true>(a, st);
+    dispatch_conv<3, 3, 2, 4, 2, true>(a, st);
   else
     BMV_REQUIRE(false, "conv: kernel (%d,%d,%d) stride %d is not one of the shapes of FeatureNet / CostRegNet", kd, k,
                 k, stride);
   BMV_LAUNCH_END("conv_fwd");
 }
 
-int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
-                    int D, int H, int W, int Cout, int relu, bmv_stream_t stream) {
+int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B,
+                             int Cin, int D, int H, int W, int Cout, int relu, bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(in && wpack && bias && out, "convT3d: null pointer");
   BMV_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "convT3d: bad shape");
@@ -417,11 +484,12 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
   a.Do = 2 * D, a.Ho = 2 * H, a.Wo = 2 * W;
   a.relu = relu, a.channels_last = 0;
   hipStream_t st = as_stream(stream);
-  const unsigned ncot = cdiv(Cout, 16);
-  if (ncot == 1)
-    launch_convT<1, 4>(a, st);
+  if (convT_blocks<1, 4, 1>(a) >= kEnoughBlocks)
+    launch_convT<1, 4, 1>(a, st);
+  else if (convT_blocks<1, 2, 1>(a) >= kEnoughBlocks)
+    launch_convT<1, 2, 1>(a, st);
   else
-    launch_convT<2, 4>(a, st);
+    launch_convT<1, 1, 2>(a, st);
   BMV_LAUNCH_END("convT3d_fwd");
 }
 

@@ -46,7 +46,7 @@ class _Packed:
 
 def _pack_cbr(m):
     """_ConvBN -> (wpack, bias) with the batch norm folded in."""
-    return convnet.pack_conv(*convnet.fold_bn(m.conv.weight, m.bn))
+    return convnet.pack_conv(*convnet.fold_bn(m.conv.weight, m.bn), stride=m.conv.stride[0])
 
 
 class _ConvBN(nn.Module):

@@ -284,8 +284,13 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
  * (kd,k) in {(1,1),(1,3),(1,5 stride 2),(3,3)}.  out = act(conv(in) + bias) + skip, planar (B,Cout,Do,Ho,Wo)
  * or channel-last (B,Do,Ho,Wo,Cout) (the sweep's feature layout); skip (nullable) has out's layout.
  * wpack: bmv_conv_wpack_floats() floats laid out [ceil(Cout/16)][ceil(Cin/4)][tap][4][16], zero padded:
- *   wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]  (tap = (kz*k + ky)*k + kx). */
-int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int kh, int kw);
+ *   wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]  (tap = (kz*k + ky)*k + kx).
+ * Row pairing (bmv_conv_pairs_rows() == 1: Cout <= 8, 3x3 / 3x3x3, stride 1): the 16 rows are the 8 output
+ * channels of two adjacent output rows and tap = (kz*(k+1) + j)*k + kx walks the k+1 input rows j they touch:
+ *   wpack[0][c][tap][kk][o]     = weight[o][4 c + kk][kz][j][kx]      (j < k,  o < 8)
+ *   wpack[0][c][tap][kk][8 + o] = weight[o][4 c + kk][kz][j - 1][kx]  (j >= 1, o < 8), zero elsewhere. */
+int bmv_conv_pairs_rows(int Cout, int kd, int k, int stride);
+int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride);
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                  int D, int H, int W, int Cout, int kd, int k, int stride, int relu, int out_channels_last,
                  bmv_stream_t stream);

@@ -57,7 +57,7 @@ def main():
         x = torch.randn(B, Cin, *sp, device="cuda")
         w = torch.randn(Cout, Cin, *([k] * nd), device="cuda") / (Cin * k ** nd) ** 0.5
         b = torch.randn(Cout, device="cuda")
-        wp, bp = convnet.pack_conv(w, b)
+        wp, bp = convnet.pack_conv(w, b, s)
         kd = k if nd == 3 else 1
         conv = F.conv3d if nd == 3 else F.conv2d
         with torch.no_grad():

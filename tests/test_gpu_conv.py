@@ -37,7 +37,7 @@ def test_conv2d(Cin, Cout, k, stride, H, W):
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
     b = torch.randn(Cout, generator=g).to(DEV)
     want = F.conv2d(x, w, b, stride, k // 2)
-    wp, bp = convnet.pack_conv(w, b)
+    wp, bp = convnet.pack_conv(w, b, stride)
     _close(convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride), want)
     _close(convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride, relu=True), F.relu(want))
     got = convnet.conv_fwd(x, wp, bp, Cout, 1, k, stride, channels_last=True)
@@ -52,7 +52,7 @@ def test_conv3d(Cin, Cout, stride, D, H, W):
     w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).to(DEV)
     b = torch.randn(Cout, generator=g).to(DEV)
     want = F.conv3d(x, w, b, stride, 1)
-    wp, bp = convnet.pack_conv(w, b)
+    wp, bp = convnet.pack_conv(w, b, stride)
     _close(convnet.conv_fwd(x, wp, bp, Cout, 3, 3, stride), want)
     skip = torch.randn(want.shape, generator=g).to(DEV)
     _close(convnet.conv_fwd(x, wp, bp, Cout, 3, 3, stride, relu=True, skip=skip), F.relu(want) + skip)
@@ -60,7 +60,25 @@ def test_conv3d(Cin, Cout, stride, D, H, W):
     _close(got.permute(0, 4, 1, 2, 3), want)
 
 
-@pytest.mark.parametrize("Cin,Cout,D,H,W", [(64, 32, 1, 4, 6), (32, 16, 2, 8, 12), (16, 8, 4, 16, 24), (16, 8, 3, 5, 19),
+@pytest.mark.parametrize("nd,B,Cin,Cout,k,stride,sp", [
+    # BASELINE configs[1] layer shapes that select the big tilings (>= 512 blocks)
+    (2, 3, 3, 8, 3, 1, (512, 640)), (2, 3, 8, 16, 5, 2, (512, 640)), (2, 3, 32, 16, 3, 1, (256, 320)),
+    (2, 3, 32, 32, 3, 1, (128, 160)), (2, 3, 32, 32, 1, 1, (128, 160)),
+    (3, 1, 32, 8, 3, 1, (64, 64, 80)), (3, 1, 8, 16, 3, 2, (8, 256, 320)), (3, 1, 16, 16, 3, 1, (4, 128, 160)),
+    (3, 1, 8, 9, 3, 1, (8, 256, 320)), (3, 1, 32, 32, 3, 1, (16, 64, 80)), (3, 1, 32, 64, 3, 2, (16, 64, 160)),
+])
+def test_conv_full_size_layers(nd, B, Cin, Cout, k, stride, sp):
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, *sp, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, *([k] * nd), generator=g) / (Cin * k ** nd) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = (F.conv3d if nd == 3 else F.conv2d)(x, w, b, stride, k // 2)
+    wp, bp = convnet.pack_conv(w, b, stride)
+    _close(convnet.conv_fwd(x, wp, bp, Cout, k if nd == 3 else 1, k, stride), want)
+
+
+@pytest.mark.parametrize("Cin,Cout,D,H,W", [(16, 8, 4, 128, 160), (32, 16, 8, 32, 40), (64, 32, 1, 4, 6), (32, 16, 2, 8, 12), (16, 8, 4, 16, 24), (16, 8, 3, 5, 19),
                                              (32, 16, 1, 1, 1)])
 def test_conv3d_transpose(Cin, Cout, D, H, W):
     from boostmvsnerfs_amd import convnet
