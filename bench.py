@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
     ap.add_argument("--miopen-find", type=int, default=1,
                     help="1: let MIOpen search its convolution solvers once (torch.backends.cudnn.benchmark)")
     return ap.parse_args()
@@ -222,6 +223,9 @@ def main():
         step()
     ktimer.reset()
     ktimer.enabled = not args.no_kernel_events
+    # HIP events around the kernels the roofline objects are built from; --all-kernel-events times every launch
+    # (two event records per launch: ~0.3 ms of host time per frame, the frame is then host-bound)
+    ktimer.only = None if args.all_kernel_events else ("sweep_variance", "render_rays", "mvs_render", "mvs_sweep")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbmv.so")
+LIB_PATH = os.environ.get("BMV_LIB_PATH") or os.path.join(_HERE, "libbmv.so")   # override: kernel experiments only
 
 _lib = None
 
