@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--sweep-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N>1, views sharding: wait for each frame's all-gather before rendering the next frame")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
     ap.add_argument("--miopen-find", type=int, default=1,
@@ -202,7 +204,10 @@ def main():
                 out = net(batch)
             if gather is not None:
                 if args.shard == "views":
-                    return gather.all_gather_frames(out[rgb_key], out[depth_key])
+                    if args.sync_gather:
+                        return gather.all_gather_frames(out[rgb_key], out[depth_key])
+                    # the exchange of frame i runs on RCCL's stream under the kernels of frame i+1
+                    return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
                 return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
             return out
 
@@ -233,6 +238,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather is not None:
+        gather.flush()                 # every exchange issued in the timed region completes inside it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -311,6 +318,8 @@ def main():
                        "volume_planes": list(cc.volume_planes) if "planes" in wl else None,
                        "num_samples": list(cc.num_samples), "render_if": list(cc.render_if),
                        "k_best": wl.get("k_best"), "shard": args.shard if world > 1 else "none",
+                       "gather": ("none" if world == 1 or wl.get("train") else
+                                  "sync" if args.sync_gather or args.shard == "rays" else "pipelined (1 frame)"),
                        "weights": "random init (seed 0)"},
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
         }

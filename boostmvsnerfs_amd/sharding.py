@@ -56,6 +56,43 @@ class TileGather:
         dist.all_gather_into_tensor(recv, send, group=self.group)
         return recv.view(self.world, n, 4)
 
+    # ---- pipelined variant: the exchange of frame i overlaps the rendering of frame i+1 --------------------
+    def all_gather_frames_pipelined(self, rgb, depth):
+        """Same exchange, issued asynchronously on the collective's own stream with double-buffered tiles.
+        Returns the frames gathered by the PREVIOUS call (None on the first): a renderer streams frames, so the
+        all-gather of frame i rides under the kernels of frame i+1 instead of stalling the compute stream.
+        `flush()` returns the last gathered frames."""
+        n = rgb.shape[-2]
+        if getattr(self, "_pipe", None) is None or self._pipe[0][0].shape[0] != n:
+            dev = rgb.device
+            self._pipe = [(torch.empty(n, 4, device=dev), torch.empty(self.world * n, 4, device=dev)) for _ in range(2)]
+            self._work = [None, None]
+            self._step = 0
+        slot = self._step & 1
+        self._step += 1
+        if self._work[slot] is not None:       # this slot's previous exchange (two calls ago) must be done
+            self._work[slot].wait()
+        send, recv = self._pipe[slot]
+        send[:, :3] = rgb.reshape(n, 3)
+        send[:, 3] = depth.reshape(n)
+        self._work[slot] = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        prev = slot ^ 1
+        if self._work[prev] is None:
+            return None
+        self._work[prev].wait()
+        return self._pipe[prev][1].view(self.world, n, 4)
+
+    def flush(self):
+        """Wait for every exchange in flight; returns the most recent gathered frames (or None)."""
+        if getattr(self, "_pipe", None) is None or self._step == 0:
+            return None
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        last = (self._step - 1) & 1
+        n = self._pipe[last][0].shape[0]
+        return self._pipe[last][1].view(self.world, n, 4)
+
     def all_gather_ray_tiles(self, rgb, depth, n_rays):
         """rays sharding: this rank's tile (1,n_r,3)/(1,n_r) -> full frame (n_rays, 4).
         Tiles differ by at most one ray; they are padded to the largest for a single collective."""

@@ -52,6 +52,18 @@ def _worker(rank, world, port, n_rays, q):
         frames = sharding.TileGather(world).all_gather_frames(mine["rgb"], mine["depth"])
         ok_views = all(torch.equal(frames[r, :, :3], full["rgb"][0] * (r + 1)) and
                        torch.equal(frames[r, :, 3], full["depth"][0] + r) for r in range(world))
+        # pipelined views sharding (bench.py default): call i returns the frames of call i-1, flush() the last
+        tp = sharding.TileGather(world)
+        got = []
+        for i in range(4):
+            g = tp.all_gather_frames_pipelined(full["rgb"] * (rank + 1 + 10 * i), full["depth"] + rank + i)
+            got.append(None if g is None else g.clone())      # the two tile buffers are reused every other call
+        assert got[0] is None
+        got = got[1:] + [tp.flush()]
+        ok_pipe = got[0] is not None and all(
+            torch.equal(got[i][r, :, :3], full["rgb"][0] * (r + 1 + 10 * i)) and
+            torch.equal(got[i][r, :, 3], full["depth"][0] + r + i) for i in range(4) for r in range(world))
+        ok_views = ok_views and ok_pipe and sharding.TileGather(world).flush() is None
         q.put((rank, bool(ok_rays), bool(ok_views), tuple(frame.shape), tuple(frames.shape)))
     finally:
         dist.destroy_process_group()
