@@ -1,0 +1,100 @@
+"""HIP-graph replay of `Network.forward` for a resident batch.
+
+A frame is ~45 short launches; issued one by one from Python the host needs about as long as the GPU
+(and cannot run far enough ahead for the two-stream overlap of networks/enerf/network.py to happen).
+`FrameGraph` captures one forward pass -- including its second-stream fork/join -- into HIP graphs and
+replays them: the host cost of a frame drops to three calls.
+
+The capture is CUT at one plane-sweep launch (by default the last one, the level-1 sweep): graph A
+holds everything before it, graph B everything after it, and the sweep itself stays an ordinary launch
+between them, so HIP events on the stream can time exactly that kernel inside a timed region
+(bench.py's `roofline`).  `cut=None` captures the frame as one graph.
+
+The batch tensors are the graph's static inputs: refresh them in place (`copy_`) between replays.  The
+returned dict holds the static output tensors of the captured pass.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ktimer, ops
+
+
+class FrameGraph:
+    def __init__(self, net, batch, cut=-1, warmup=2):
+        self.net, self.batch = net, batch
+        self.cut = cut
+        self.graphs = []
+        self.sweep_args = None
+        self.out = None
+        self._capture(warmup)
+
+    # ------------------------------------------------------------------ capture
+    def _count_sweeps(self):
+        calls = []
+
+        def hook(*a):
+            calls.append(torch.cuda.current_stream())
+            return None
+        ops.sweep_hook = hook
+        try:
+            with torch.no_grad():
+                self.net(self.batch)
+        finally:
+            ops.sweep_hook = None
+        return calls
+
+    def _capture(self, warmup):
+        was_enabled, ktimer.enabled = ktimer.enabled, False
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream), torch.no_grad():
+                for _ in range(warmup):              # allocator pools, packed weights, side stream: all warm
+                    self.net(self.batch)
+                cut_index = None
+                if self.cut is not None:
+                    calls = self._count_sweeps()
+                    idx = self.cut if self.cut >= 0 else len(calls) + self.cut
+                    # only a launch on the capture stream itself can split the capture
+                    if 0 <= idx < len(calls) and calls[idx] == stream:
+                        cut_index = idx
+                torch.cuda.synchronize()
+                seen = [0]
+                g_a = torch.cuda.CUDAGraph()
+                self.graphs = [g_a]
+
+                def hook(feats, proj, depth_values, algo, out, channels_last):
+                    i = seen[0]
+                    seen[0] += 1
+                    if i != cut_index:
+                        return None
+                    self.graphs[-1].capture_end()
+                    res = ops._sweep_variance(feats, proj, depth_values, algo, out, channels_last)   # eager, static buffers
+                    self.sweep_args = (feats, proj, depth_values, algo, res, channels_last)
+                    g_b = torch.cuda.CUDAGraph()
+                    self.graphs.append(g_b)
+                    g_b.capture_begin(pool=g_a.pool(), capture_error_mode="thread_local")
+                    return res
+                ops.sweep_hook = hook
+                try:
+                    g_a.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        self.out = self.net(self.batch)
+                    finally:
+                        self.graphs[-1].capture_end()
+                finally:
+                    ops.sweep_hook = None
+        finally:
+            ktimer.enabled = was_enabled
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ replay
+    def replay(self):
+        self.graphs[0].replay()
+        if self.sweep_args is not None:
+            f, p, dv, algo, out, cl = self.sweep_args
+            ops._sweep_variance(f, p, dv, algo, out, cl)      # times itself through ktimer when enabled
+            self.graphs[1].replay()
+        return self.out

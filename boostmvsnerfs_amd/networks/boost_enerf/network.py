@@ -56,6 +56,7 @@ class Network(enerf_network.Network):
         super().__init__()
         self.view_selection_outputs = None
         self.capture = None
+        self._sel_cache = {}
         if not preprocess:
             path = os.path.join(cfg.result_dir, "view_selection.json")
             if not os.path.exists(path):
@@ -155,13 +156,20 @@ class Network(enerf_network.Network):
         cc = cfg.enerf.cas_config
         dev = batch["all_src_inps"].device
         B, N = batch["all_src_inps"].shape[:2]
-        trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)
-        k_best = torch.tensor([self.view_selection_outputs[f"{s}_{v}"]
-                               for s, v in zip(batch["meta"]["scene"], batch["meta"]["tar_view"])], device=dev)
         K = int(cc.k_best)
-        if k_best.shape[1] < K:
-            raise ValueError(f"view_selection.json holds {k_best.shape[1]} volumes per target, cfg k_best={K}")
-        sel = trip[k_best[:, :K]]                                   # (B,K,3)
+        # (B,K,3) view ids of the K cost volumes; cached on the device per (targets, N, K): no host->device copy
+        # on the frame path, and the forward stays capturable as a HIP graph
+        key = (tuple(f"{s}_{v}" for s, v in zip(batch["meta"]["scene"], batch["meta"]["tar_view"])), N, K, str(dev))
+        sel = self._sel_cache.get(key)
+        if sel is None:
+            trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)
+            k_best = torch.tensor([self.view_selection_outputs[t] for t in key[0]], device=dev)
+            if k_best.shape[1] < K:
+                raise ValueError(f"view_selection.json holds {k_best.shape[1]} volumes per target, cfg k_best={K}")
+            sel = trip[k_best[:, :K]]                               # (B,K,3)
+            if len(self._sel_cache) > 64:
+                self._sel_cache.clear()
+            self._sel_cache[key] = sel
         feats = self.forward_feat(batch["all_src_inps"])            # all N views once
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K

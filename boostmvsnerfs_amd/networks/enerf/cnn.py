@@ -16,6 +16,10 @@ from ... import convnet
 from .conv3d_wgrad import Conv3d, ConvTranspose3d   # MIOpen forward / data grad, slice-GEMM weight grad
 
 
+def engine_ok(module, x):
+    return _engine_ok(module, x)
+
+
 def _engine_ok(module, x):
     """Inference (eval-mode batch norm, no autograd) on the GPU runs on the convolution engine
     (csrc/conv.hip); training keeps the torch modules (MIOpen forward / data gradients)."""
@@ -94,14 +98,17 @@ class FeatureNet(nn.Module):
     def _top_down(coarse, lateral):
         return F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + lateral
 
-    def _forward_engine(self, x):
-        """Same graph, one launch per conv block.  The two maps the plane sweeps read come out channel-last
-        (returned as (N,C,H,W) views of (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
-        P = self._packed.get(self, lambda: {
+    def _blobs(self):
+        return self._packed.get(self, lambda: {
             **{f"conv{i}.{j}": _pack_cbr(getattr(self, f"conv{i}")[j]) for i in range(3) for j in range(2)},
             "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
             "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias)})
+
+    def engine_bottom_up(self, x):
+        """Encoder + top layer: (c0, c1, p2 planar, p2 channel-last).  The coarsest map is all the level-0 cost
+        volume needs, so a caller can start that cascade level while `engine_top_down` is still running."""
+        P = self._blobs()
         c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
         c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
         c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
@@ -109,12 +116,24 @@ class FeatureNet(nn.Module):
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
         c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
         p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1)
+        p2_cl = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True)
+        return c0, c1, p2, p2_cl.permute(0, 3, 1, 2)
+
+    def engine_top_down(self, c0, c1, p2):
+        """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar)."""
+        P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
         p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
         f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last=True)
         f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
-        p2_cl = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True)
-        return p2_cl.permute(0, 3, 1, 2), f1.permute(0, 3, 1, 2), f0
+        return f1.permute(0, 3, 1, 2), f0
+
+    def _forward_engine(self, x):
+        """Same graph, one launch per conv block.  The two maps the plane sweeps read come out channel-last
+        (returned as (N,C,H,W) views of (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
+        c0, c1, p2, p2_cl = self.engine_bottom_up(x)
+        f1, f0 = self.engine_top_down(c0, c1, p2)
+        return p2_cl, f1, f0
 
     def forward(self, x):
         if _engine_ok(self, x):

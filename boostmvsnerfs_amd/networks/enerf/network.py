@@ -20,7 +20,7 @@ import torch.nn as nn
 from ... import autograd as A
 from ... import ops
 from ...config import cfg
-from .cnn import CostRegNet, FeatureNet, MinCostRegNet
+from .cnn import CostRegNet, FeatureNet, MinCostRegNet, engine_ok
 from .nerf import NeRF
 
 
@@ -44,6 +44,9 @@ class Network(nn.Module):
         # optional intra-frame ray sharding (boostmvsnerfs_amd/sharding.py): render rays [begin, end) only
         self.ray_range = None
         self.sweep_algo = 0
+        # inference: run the level-0 cascade chain on a second stream under FeatureNet's top-down path
+        self.overlap_front = os.environ.get("BMV_OVERLAP", "1") == "1"
+        self._side_stream = None
 
     # ------------------------------------------------------------------ 2-D features
     def forward_feat(self, x):
@@ -155,16 +158,49 @@ class Network(nn.Module):
 
     batchify_rays = render_rays
 
+    # ------------------------------------------------------------------ overlapped front end (inference)
+    def _front_overlapped(self, batch, views):
+        """FeatureNet's coarsest map is all the level-0 cost volume needs: the level-0 chain (sweep, 3-D
+        regulariser, depth regression: ~20 short launches that fill a fraction of the chip) runs on a second
+        HIP stream while the main stream finishes FeatureNet's top-down path (4 large launches).
+        Returns (feats, level-0 state); the main stream has waited for the side stream."""
+        x = batch["src_inps"]
+        B, V, C, H, W = x.shape
+        fn = self.feature_net
+        c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        level0 = p2_cl.reshape(B, V, -1, H // 4, W // 4)
+        with torch.cuda.stream(side):
+            st0 = self.level_front(0, level0, views, batch, None)
+        f1, f0 = fn.engine_top_down(c0, c1, p2)
+        main.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():   # (a graph capture owns its memory pool)
+            for name in LevelState.__slots__:    # allocated under the side stream, consumed on the main one
+                t = getattr(st0, name)
+                if t is not None:
+                    t.record_stream(main)
+        feats = {"level_0": level0, "level_1": f1.reshape(B, V, -1, H // 2, W // 2),
+                 "level_2": f0.reshape(B, V, -1, H, W)}
+        return feats, st0
+
     # ------------------------------------------------------------------ forward
     def forward(self, batch):
         cc = cfg.enerf.cas_config
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
-        feats = self.forward_feat(batch["src_inps"])
+        st0 = None
+        if self.overlap_front and engine_ok(self.feature_net, batch["src_inps"]):
+            feats, st0 = self._front_overlapped(batch, views)
+        else:
+            feats = self.forward_feat(batch["src_inps"])
         render = self.render_level_train if torch.is_grad_enabled() else self.render_level
         ret = {}
         st = None
         for i in range(cc.num):
-            st = self.level_front(i, feats[f"level_{i}"], views, batch, st)
+            st = st0 if (i == 0 and st0 is not None) else self.level_front(i, feats[f"level_{i}"], views, batch, st)
             if not cc.render_if[i]:
                 continue
             rgb, depth, weights = render(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)

@@ -72,11 +72,22 @@ def nchw_to_nhwc(x):
     return out
 
 
+sweep_hook = None     # framegraph.FrameGraph: lets a graph capture step around one sweep launch
+
+
 def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
     """feats: (B,S,C,Hs,Ws) in the reference layout, or channel-last (B,S,Hs,Ws,C) when
     channels_last=True.  With channels_last=None (default) a reference-layout input with C in
     {16, 32} is first put into the channel-last layout (one transpose kernel) and the fast
     channel-last sweep runs; algo=1 forces the reference-layout direct-gather kernel."""
+    if sweep_hook is not None:
+        r = sweep_hook(feats, proj, depth_values, algo, out, channels_last)
+        if r is not None:
+            return r
+    return _sweep_variance(feats, proj, depth_values, algo, out, channels_last)
+
+
+def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
     if channels_last is None and feats.dim() == 5 and not feats.is_contiguous() and algo != 1:
         cl = feats.permute(0, 1, 3, 4, 2)
         if cl.is_contiguous():        # (B,S,C,Hs,Ws) view of a channel-last buffer (the conv engine writes it so)
