@@ -56,7 +56,12 @@ def pack_convT(weight, bias):
     return pack_conv(weight.detach().transpose(0, 1), bias, allow_pair=False)
 
 
-def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None):
+def _slope(relu, slope):
+    """activation v > 0 ? v : s * v of the C ABI: relu=True -> 0, slope given -> leaky ReLU, neither -> 1 (identity)."""
+    return float(slope) if slope is not None else (0.0 if relu else 1.0)
+
+
+def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None, slope=None):
     """x (B,Cin,D,H,W) -> act(conv_transpose3d(x, k=3, stride=2, padding=1, output_padding=1) + bias) + skip."""
     B, Cin, D, H, W = x.shape
     shape = (B, Cout, 2 * D, 2 * H, 2 * W)
@@ -70,7 +75,7 @@ def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None):
     with ktimer.region(f"convT3d[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv3d_transpose_fwd(dptr(x, "convT input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                                  dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout,
-                                 int(bool(relu)), stream())
+                                 _slope(relu, slope), stream())
     _lib.check(rc, "convT3d_fwd")
     return out
 
@@ -91,7 +96,7 @@ def fpn_topdown(fine, coarse, weight, bias, out=None):
     return out
 
 
-def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None):
+def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):
     """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
     ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout))."""
     is3d = x.dim() == 5
@@ -114,6 +119,6 @@ def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, chann
     with ktimer.region(f"conv[{Cin}->{Cout},k{kd}x{k}x{k},s{stride},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                               dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout, kd, k, stride,
-                              int(bool(relu)), int(bool(channels_last)), stream())
+                              _slope(relu, slope), int(bool(channels_last)), stream())
     _lib.check(rc, "conv_fwd")
     return out

@@ -33,7 +33,8 @@ struct ConvArgs {
   const float* skip;   // nullable, layout of out
   float* out;          // (B, Cout, Do, Ho, Wo) or channel-last (B, Do, Ho, Wo, Cout)
   int B, Cin, D, H, W, Cout, Do, Ho, Wo;
-  int relu, channels_last;
+  float slope;  // activation: v > 0 ? v : slope * v  (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky ReLU)
+  int channels_last;
 };
 
 // MAP: 0 = 2-D (row groups along y), 1 = 3-D with the block's 4/NCT row groups along z, 2 = 3-D along y
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = acc[r][j] + bs[j];
-      if (a.relu) v[j] = fmaxf(v[j], 0.f);
+      v[j] = fmaxf(v[j], 0.f) + a.slope * fminf(v[j], 0.f);
     }
     if (a.channels_last) {
       const size_t o = ((((size_t)b * a.Do + z) * a.Ho + y) * a.Wo + x) * a.Cout + co0;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
       for (int j = 0; j < 4; ++j) {
         if (co0 + j >= a.Cout) continue;
         float v0 = acc[r][2 * q][j] + bs[j], v1 = acc[r][2 * q + 1][j] + bs[j];
-        if (a.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f);
+        v0 = fmaxf(v0, 0.f) + a.slope * fminf(v0, 0.f), v1 = fmaxf(v1, 0.f) + a.slope * fminf(v1, 0.f);
         *reinterpret_cast<float2*>(a.out + o + j * cs) = make_float2(v0 + sk[q][j].x, v1 + sk[q][j].y);
       }
     }
@@ -442,7 +443,7 @@ int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride) {
 }
 
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
-                 int D, int H, int W, int Cout, int kd, int k, int stride, int relu, int out_channels_last,
+                 int D, int H, int W, int Cout, int kd, int k, int stride, float act_slope, int out_channels_last,
                  bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(in && wpack && bias && out, "conv: null pointer");
@@ -454,7 +455,7 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = Cout;
   const int p = k / 2, pd = kd / 2;
   a.Do = (D + 2 * pd - kd) / stride + 1, a.Ho = (H + 2 * p - k) / stride + 1, a.Wo = (W + 2 * p - k) / stride + 1;
-  a.relu = relu, a.channels_last = out_channels_last;
+  a.slope = act_slope, a.channels_last = out_channels_last;
   hipStream_t st = as_stream(stream);
   if (kd == 1 && k == 3 && stride == 1)
     dispatch_conv<1, 3, 1, 8, 2, false>(a, st);
@@ -473,7 +474,7 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
 }
 
 int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B,
-                             int Cin, int D, int H, int W, int Cout, int relu, bmv_stream_t stream) {
+                             int Cin, int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(in && wpack && bias && out, "convT3d: null pointer");
   BMV_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "convT3d: bad shape");
@@ -482,7 +483,7 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
   a.in = in, a.wpack = wpack, a.bias = bias, a.skip = skip, a.out = out;
   a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = Cout;
   a.Do = 2 * D, a.Ho = 2 * H, a.Wo = 2 * W;
-  a.relu = relu, a.channels_last = 0;
+  a.slope = act_slope, a.channels_last = 0;
   hipStream_t st = as_stream(stream);
   if (convT_blocks<1, 4, 1>(a) >= kEnoughBlocks)
     launch_convT<1, 4, 1>(a, st);

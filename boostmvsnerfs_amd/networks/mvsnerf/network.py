@@ -17,7 +17,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ... import convnet
 from ...config import cfg
+from ..enerf.cnn import _Packed, _engine_ok
 
 PAD = 24   # network.py:1016, 1106
 
@@ -72,9 +74,23 @@ class FeatureNet(nn.Module):
         self.conv1 = nn.Sequential(_c2(8, 16, 5, 2, 2), _c2(16, 16), _c2(16, 16))
         self.conv2 = nn.Sequential(_c2(16, 32, 5, 2, 2), _c2(32, 32), _c2(32, 32))
         self.toplayer = nn.Conv2d(32, 32, 1)
+        self._packed = _Packed()
+
+    def _forward_engine(self, x):
+        """Inference on the convolution engine (csrc/conv.hip): one launch per conv + ABN block."""
+        blocks = [m for seq in (self.conv0, self.conv1, self.conv2) for m in seq]
+        P = self._packed.get(self, lambda: [
+            *[convnet.pack_conv(*convnet.fold_bn(m.conv.weight, m.bn), stride=m.conv.stride[0]) for m in blocks],
+            convnet.pack_conv(self.toplayer.weight, self.toplayer.bias)])
+        for m, (wp, bp) in zip(blocks, P):
+            x = convnet.conv_fwd(x, wp, bp, m.conv.out_channels, 1, m.conv.kernel_size[0], m.conv.stride[0],
+                                 slope=m.bn.slope)
+        return convnet.conv_fwd(x, *P[-1], 32, 1, 1)
 
     def forward(self, x):
         B, V, C, H, W = x.shape
+        if _engine_ok(self, x):
+            return self._forward_engine(x.reshape(B * V, C, H, W)).view(B, V, 32, H // 4, W // 4)
         y = self.toplayer(self.conv2(self.conv1(self.conv0(x.reshape(B * V, C, H, W)))))
         return y.view(B, V, 32, H // 4, W // 4)
 
@@ -89,8 +105,33 @@ class CostRegNet(nn.Module):
         self.conv3, self.conv4 = _c3(16, 32, 2), _c3(32, 32)
         self.conv5, self.conv6 = _c3(32, 64, 2), _c3(64, 64)
         self.conv7, self.conv9, self.conv11 = _up3(64, 32), _up3(32, 16), _up3(16, 8)
+        self._packed = _Packed()
+
+    def _forward_engine(self, x):
+        def build():
+            P = {f"conv{i}": convnet.pack_conv(*convnet.fold_bn(getattr(self, f"conv{i}").conv.weight,
+                                                                 getattr(self, f"conv{i}").bn),
+                                               stride=getattr(self, f"conv{i}").conv.stride[0]) for i in range(7)}
+            for name in ("conv7", "conv9", "conv11"):
+                up = getattr(self, name)
+                P[name] = convnet.pack_convT(*convnet.fold_bn(up[0].weight, up[1], out_dim=1))
+            return P
+        P = self._packed.get(self, build)
+        sl = self.conv0.bn.slope
+
+        def cb(name, t, cout, stride=1):
+            return convnet.conv_fwd(t, *P[name], cout, 3, 3, stride, slope=sl)
+        s0 = cb("conv0", x, 8)
+        s1 = cb("conv2", cb("conv1", s0, 16, 2), 16)
+        s2 = cb("conv4", cb("conv3", s1, 32, 2), 32)
+        t = cb("conv6", cb("conv5", s2, 64, 2), 64)
+        y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2, slope=sl)
+        y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1, slope=sl)
+        return convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0, slope=sl)
 
     def forward(self, x):
+        if _engine_ok(self, x):
+            return self._forward_engine(x)
         s0 = self.conv0(x)
         s1 = self.conv2(self.conv1(s0))
         s2 = self.conv4(self.conv3(s1))

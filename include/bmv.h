@@ -281,7 +281,9 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
  * and passes its shift (or the conv bias) as `bias`.
  *
  * bmv_conv_fwd: in (B,Cin,D,H,W) planar (D = 1, kd = 1 for 2-D), zero padding k/2, stride 1|2, kernels
- * (kd,k) in {(1,1),(1,3),(1,5 stride 2),(3,3)}.  out = act(conv(in) + bias) + skip, planar (B,Cout,Do,Ho,Wo)
+ * (kd,k) in {(1,1),(1,3),(1,5 stride 2),(3,3)}.  act(v) = v > 0 ? v : act_slope * v (1 = none, 0 = ReLU, 0.01 =
+ * InPlaceABN's leaky ReLU of the MVSNeRF stacks, mvsnerf/network.py:699-779).
+ * out = act(conv(in) + bias) + skip, planar (B,Cout,Do,Ho,Wo)
  * or channel-last (B,Do,Ho,Wo,Cout) (the sweep's feature layout); skip (nullable) has out's layout.
  * wpack: bmv_conv_wpack_floats() floats laid out [ceil(Cout/16)][ceil(Cin/4)][tap][4][16], zero padded:
  *   wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]  (tap = (kz*k + ky)*k + kx).
@@ -292,7 +294,7 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
 int bmv_conv_pairs_rows(int Cout, int kd, int k, int stride);
 int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride);
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
-                 int D, int H, int W, int Cout, int kd, int k, int stride, int relu, int out_channels_last,
+                 int D, int H, int W, int Cout, int kd, int k, int stride, float act_slope, int out_channels_last,
                  bmv_stream_t stream);
 
 /* ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + folded batch norm of the U-Net
@@ -300,7 +302,7 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
  * in (B,Cin,D,H,W) -> out = act(convT(in) + bias) + skip, (B,Cout,2D,2H,2W) planar.
  * wpack as bmv_conv_fwd with wpack[t][c][tap][k][o] = weight[4 c + k][16 t + o][tap]  (torch's (Cin,Cout,3,3,3)). */
 int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
-                    int D, int H, int W, int Cout, int relu, bmv_stream_t stream);
+                    int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream);
 
 /* FPN top-down step (feature_net.py:24-36 `_upsample_add` + lat1 / lat0):
  * out (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2), align_corners=True) + conv1x1(fine (B,Cf,H,W); w (C,Cf)) + bias */

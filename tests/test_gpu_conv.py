@@ -110,7 +110,7 @@ def _randomise_bn(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for m in net.modules():
-            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) or hasattr(m, "running_var"):
                 m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
                 m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
@@ -154,6 +154,34 @@ def test_cost_reg_engine_matches_torch_modules(monkeypatch, cls, cin, shape):
     assert feat.shape == feat_t.shape and prob.shape == prob_t.shape
     _close(feat, feat_t)
     _close(prob, prob_t)
+
+
+def test_leaky_slope_and_mvsnerf_stacks(monkeypatch):
+    """InPlaceABN's leaky ReLU (slope 0.01) as the epilogue; MVSNeRF's FeatureNet / CostRegNet
+    (mvsnerf/network.py:699-779: 41 input channels, three stride-2 levels) against their torch modules."""
+    from boostmvsnerfs_amd import convnet
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    set_cfg(make_cfg("mvsnerf_eval"))
+    from boostmvsnerfs_amd.networks.mvsnerf import network as M
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 8, 4, 9, 21, generator=g).to(DEV)
+    w = (torch.randn(16, 8, 3, 3, 3, generator=g) / 15).to(DEV)
+    b = torch.randn(16, generator=g).to(DEV)
+    wp, bp = convnet.pack_conv(w, b)
+    _close(convnet.conv_fwd(x, wp, bp, 16, 3, 3, slope=0.01), F.leaky_relu(F.conv3d(x, w, b, 1, 1), 0.01))
+    torch.manual_seed(0)
+    feat, reg = M.FeatureNet(), M.CostRegNet(41)
+    _randomise_bn(feat, 3), _randomise_bn(reg, 4)
+    feat, reg = feat.to(DEV).eval(), reg.to(DEV).eval()
+    img = torch.randn(1, 3, 3, 64, 96, device=DEV)
+    vol = torch.rand(1, 41, 8, 40, 48, device=DEV)
+    with torch.no_grad():
+        got_f, got_r = feat(img), reg(vol)
+        monkeypatch.setenv("BMV_CNN", "torch")
+        want_f, want_r = feat(img), reg(vol)
+    assert got_f.shape == want_f.shape and got_r.shape == want_r.shape
+    _close(got_f, want_f)
+    _close(got_r, want_r)
 
 
 def test_fold_bn_matches_eval_batch_norm():
