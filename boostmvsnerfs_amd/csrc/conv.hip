@@ -9,6 +9,10 @@
 // into the weights on the host, its shift / the conv bias, the ReLU and the U-Net skip add are the epilogue,
 // so a conv block is ONE launch and activations are written once.
 //
+// Tried and rejected (measured): staging 2-4 k-steps (8-16 channels) per barrier pair instead of one -- slower for
+// every layer class (small tilings 733 -> 778 us over all layers, big 2-D tilings 86 -> 111 us for 32 -> 8): the
+// larger stage costs more in resident blocks per CU than it saves in exposed load latency.
+//
 // Orientation (as the MLP of render.hip): weights are the A operand (rows = 16 output channels), the
 // activations are the B operand (columns = 16 consecutive output x), one k-step = 4 input channels of one
 // filter tap.  Activations stay in the reference's planar layout (B,C,D,H,W): an input tile with its halo is
@@ -20,8 +24,6 @@
 // Row pairing (Cout <= 8, stride 1): the 16 MFMA rows hold the 8 output channels of TWO adjacent output rows
 // y, y+1.  Input row y+j (j = 0..K) meets filter row j for output y and filter row j-1 for output y+1, so K+1
 // MFMAs per (kz, kx) produce two output rows: (K+1)/(2K) = 2/3 of the MFMAs of padding 8 channels to 16.
-#include <stdlib.h>
-
 #include "bmv_common.hpp"
 
 namespace bmv {
@@ -58,14 +60,10 @@ struct ConvTile {
   static_assert(!PAIR || (S == 1 && NCT == 1 && R % 2 == 0), "row pairing: stride 1, one cout tile, even rows");
 };
 
-// CK = k-steps (4 input channels each) staged in LDS per barrier pair.  Measured: CK = 4 (2 for stride 2) on the small
-// tilings of the deep U-Net levels is SLOWER than CK = 1 (733 -> 778 us over all layers of config 2): the larger
-// stage costs more in resident blocks per CU than it saves in exposed load latency.  Every launch uses CK = 1.
-template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, int CK = 1>
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
-  constexpr int CH = 4 * CK;  // channels per stage
-  __shared__ float lds[CH * T::PS];
+  __shared__ float lds[4 * T::PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
   const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + T::TY - 1) / T::TY, ntz = (a.Do + T::TZ - 1) / T::TZ;
@@ -93,26 +91,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
 
-  const int nk = (a.Cin + 3) / 4;            // k-steps; the weight blob has one 64-float row per (k-step, tap)
-  const int nstage = (nk + CK - 1) / CK;
-  const int cot = blockIdx.y * NCT + ct;     // cout tile of this wave
-  const float* wp = a.wpack + (size_t)cot * nk * (T::TAPS * 64) + lane;
+  const int nchunk = (a.Cin + 3) / 4;
+  const int cot = blockIdx.y * NCT + ct;  // cout tile of this wave
+  const float* wp = a.wpack + (size_t)cot * nchunk * (T::TAPS * 64) + lane;
 
   f32x4 acc[T::NACC];
 #pragma unroll
   for (int r = 0; r < T::NACC; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float pre[CH][T::NSLOT];
-  auto load_tile = [&](int stage) {
+  float pre[4][T::NSLOT];
+  auto load_tile = [&](int chunk) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int ch = stage * CH + c;          // channels past Cin (padding of the last k-step / stage) read as 0
-      const bool chok = ch < a.Cin;           // block-uniform
-      const unsigned cb = chok ? 4u * (unsigned)(ch * plane) : 0u;
+    for (int c = 0; c < 4; ++c) {
+      const unsigned cb = 4u * (unsigned)((chunk * 4 + c) * plane);
 #pragma unroll
       for (int j = 0; j < T::NSLOT; ++j)
-        pre[c][j] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, chok ? goff[j] + cb : 0x80000000u, 0, 0));
+        pre[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff[j] + cb, 0, 0));
     }
   };
   load_tile(0);
@@ -121,55 +115,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
   for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[t * 64];
 
-  const float* ap0 = lds + (lane >> 4) * T::PS + rg * T::ROWBASE + (lane & 15) * S;
-  for (int stage = 0; stage < nstage; ++stage) {
+  const float* ap = lds + (lane >> 4) * T::PS + rg * T::ROWBASE + (lane & 15) * S;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();  // every wave is done with the previous tile
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int j = 0; j < T::NSLOT; ++j)
         if ((j + 1) * 256 <= T::SLOTS || tid + 256 * j < T::SLOTS) lds[c * T::PS + tid + 256 * j] = pre[c][j];
+    float wv[T::TAPS];
+#pragma unroll
+    for (int t = 0; t < T::TAPS; ++t) wv[t] = wnext[t];
     __syncthreads();
-    if (stage + 1 < nstage) load_tile(stage + 1);  // in flight during the MFMAs below
+    if (chunk + 1 < nchunk) {  // next tile and next weights are in flight during the MFMAs below
+      load_tile(chunk + 1);
 #pragma unroll
-    for (int kc = 0; kc < CK; ++kc) {
-      const int ks = stage * CK + kc;
-      if (ks >= nk) break;  // block-uniform
-      float wv[T::TAPS];
+      for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[(size_t)(chunk + 1) * (T::TAPS * 64) + t * 64];
+    }
+    if constexpr (PAIR) {
 #pragma unroll
-      for (int t = 0; t < T::TAPS; ++t) wv[t] = wnext[t];
-      if (ks + 1 < nk) {
+      for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-        for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[(size_t)(ks + 1) * (T::TAPS * 64) + t * 64];
-      }
-      const float* ap = ap0 + kc * 4 * T::PS;
-      if constexpr (PAIR) {
+        for (int j = 0; j <= K; ++j)
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd)
+          for (int kw = 0; kw < K; ++kw) {
+            const float w = wv[(kd * (K + 1) + j) * K + kw];
 #pragma unroll
-          for (int j = 0; j <= K; ++j)
+            for (int p = 0; p < R / 2; ++p)
+              acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + 2 * p + j) * T::RS + kw], acc[p], 0,
+                                                            0, 0);
+          }
+    } else {
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-              const float w = wv[(kd * (K + 1) + j) * K + kw];
+      for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-              for (int p = 0; p < R / 2; ++p)
-                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + 2 * p + j) * T::RS + kw], acc[p],
-                                                              0, 0, 0);
-            }
-      } else {
+        for (int kh = 0; kh < K; ++kh)
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd)
+          for (int kw = 0; kw < K; ++kw) {
+            const float w = wv[(kd * K + kh) * K + kw];
 #pragma unroll
-          for (int kh = 0; kh < K; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-              const float w = wv[(kd * K + kh) * K + kw];
-#pragma unroll
-              for (int r = 0; r < R; ++r)
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r],
-                                                              0, 0, 0);
-            }
-      }
+            for (int r = 0; r < R; ++r)
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r],
+                                                            0, 0, 0);
+          }
     }
   }
 
@@ -400,11 +388,11 @@ static unsigned conv_blocks(const ConvArgs& a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   return cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B * cdiv(cdiv(a.Cout, 16), NCT);
 }
-template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, int CK = 1>
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
-  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR, CK>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR>), grid, dim3(256), 0, st, a);
 }
 
 constexpr unsigned kEnoughBlocks = 512;  // 2 per CU
@@ -417,11 +405,18 @@ static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const unsigned ncot = cdiv(a.Cout, 16);
   if constexpr (S == 1 && K == 3) {
     if (a.Cout <= 8) {               // row pairing
-      if (conv_blocks<KD, K, S, 1, RB, MB, true>(a) >= kEnoughBlocks)
+      if (conv_blocks<KD, K, S, 1, RB, MB, true>(a) >= kEnoughBlocks) {
+        // measured inside the frame (bench.py, graph replay): 4 rows per wave win for the 3 -> 8 / 8 -> 8 full-resolution
+        // 2-D layers (more resident blocks), 8 rows for 32-channel inputs and the volumes (fewer halo loads)
+        if (!IS3D && a.Cin <= 8) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
         return launch_conv<KD, K, S, 1, RB, MB, true>(a, st);
+      }
       return launch_conv<KD, K, S, 1, 2, MS, true>(a, st);
     }
   }
+  constexpr int RH = RB == 8 ? 4 : RB;  // feat_conv + depth_conv (9 channels on a full-size volume): 4 rows per wave
+  if (IS3D && ncot == 1 && conv_blocks<KD, K, S, 1, RH, MB, false>(a) >= kEnoughBlocks)
+    return launch_conv<KD, K, S, 1, RH, MB, false>(a, st);
   if (ncot == 1 && conv_blocks<KD, K, S, 1, RB, MB, false>(a) >= kEnoughBlocks)
     return launch_conv<KD, K, S, 1, RB, MB, false>(a, st);
   if (ncot == 2 && conv_blocks<KD, K, S, 2, RB, MB, false>(a) >= kEnoughBlocks)
