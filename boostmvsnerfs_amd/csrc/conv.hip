@@ -30,6 +30,11 @@ namespace bmv {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int x = bid & 7, per = n >> 3, rem = n & 7;      // XCD x runs workgroups x, x+8, ...: per + (x < rem) of them
+  return x * per + min(x, rem) + (bid >> 3);
+}
+
 struct ConvArgs {
   const float* in;     // (B, Cin, D, H, W)
   const float* wpack;  // [cout tile][cin chunk of 4][tap][4][16]
@@ -67,7 +72,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
   const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + T::TY - 1) / T::TY, ntz = (a.Do + T::TZ - 1) / T::TZ;
-  int bid = blockIdx.x;
+  // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles so that the
+  // halo rows / planes neighbouring tiles share are served by one L2
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % ntx;
   bid /= ntx;
   const int ty = bid % nty;
@@ -229,7 +236,9 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
   const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY, ntz = (a.D + T::TZ - 1) / T::TZ;
-  int bid = blockIdx.x;
+  // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles so that the
+  // halo rows / planes neighbouring tiles share are served by one L2
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % ntx;
   bid /= ntx;
   const int ty = bid % nty;
