@@ -34,7 +34,8 @@ class RenderArgs(C.Structure):
                 + [(n, C.c_int) for n in ("B", "N", "S", "feat_ch", "Ns", "depth_inv", "hv", "wv", "Dv", "Hr", "Wr")]
                 + [("render_scale", C.c_float)]
                 + [(n, C.c_int) for n in ("rgb_affine", "white_bkgd", "mode", "ray_begin", "ray_end")]
-                + [(n, C.c_void_p) for n in ("out0", "out1", "out2")])
+                + [(n, C.c_void_p) for n in ("out0", "out1", "out2")]
+                + [("view_ids", C.c_void_p), ("n_all", C.c_int)])
 
 
 class MvsMlpParams(C.Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],
+    "bmv_sweep_variance_views_fwd": [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_nchw_to_nhwc": [c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_depth_regress_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_build_rays": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
@@ -131,14 +133,14 @@ def check(rc, what=""):
         raise RuntimeError(f"libbmv {what} failed (code {rc}): {msg}")
 
 
-def dptr(t, name="tensor"):
-    """Device pointer of a contiguous fp32 CUDA tensor (validated)."""
+def dptr(t, name="tensor", dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor of `dtype` (fp32 unless stated; validated)."""
     if t is None:
         return None
     if not torch.is_tensor(t):
         raise TypeError(f"{name}: expected a tensor, got {type(t)}")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: the BoostMVSNeRFs hot path runs on the GPU only (tensor is on {t.device}); "
                            "there is no CPU fallback")

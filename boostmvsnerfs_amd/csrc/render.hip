@@ -110,8 +110,10 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
     for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
       const Cam& cam = rc->cam[i];
       Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
-      const float* fp = a.im_feat + ((size_t)b * 3 + i) * FEAT_CH * plane;
-      const float* cp = a.rgb_src + ((size_t)b * 3 + i) * 3 * plane;
+      // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
+      const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
+      const float* fp = a.im_feat + vslot * FEAT_CH * plane;
+      const float* cp = a.rgb_src + vslot * 3 * plane;
 #pragma unroll
       for (int j = 0; j < L::KFC; ++j) {
         int c = 2 * j + h;  // channel of [feature, rgb]
@@ -260,6 +262,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   BMV_REQUIRE(a->ray_begin >= 0 && a->ray_end <= a->N && a->ray_begin <= a->ray_end,
               "bmv_render_rays_fwd: ray range [%d,%d) outside [0,%d)", a->ray_begin, a->ray_end, a->N);
   BMV_REQUIRE(a->mode == 0 || a->mode == 1, "bmv_render_rays_fwd: mode=%d", a->mode);
+  BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
   if (a->ray_begin == a->ray_end) return BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
 #define RENDER_CASE(FC, NSV, INVV)                                                                                  \

@@ -328,9 +328,23 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
 }
 
 int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                          int D, int h, int w, float* out, hipStream_t stream);
+                          int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
 int bmv_sweep_lds_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                          int D, int h, int w, float* out, int shape, hipStream_t stream);
+
+int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, int n_all, const float* proj,
+                                 const float* depth_values, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                                 float* variance, bmv_stream_t stream) {
+  BMV_REQUIRE(feats_all && view_ids && proj && depth_values && variance, "bmv_sweep_variance_views_fwd: null pointer");
+  BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
+              "bmv_sweep_variance_views_fwd: bad shape");
+  int rc = bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
+                                 as_stream(stream));
+  if (rc == BMV_ERR_UNSUPPORTED)
+    set_error("bmv_sweep_variance_views_fwd: needs channel-last features with C in {16, 32} and 2..4 views (C=%d, S=%d)", C,
+              S);
+  return rc;
+}
 
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
@@ -357,7 +371,8 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
         return rc;
       }
     }
-    rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, as_stream(stream));
+    rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                               as_stream(stream));
     if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
     return rc;
   }

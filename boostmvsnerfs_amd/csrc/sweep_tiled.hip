@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(256) sweep_nhwc_kernel(const float* __restrict
                                                           const float* __restrict__ proj,
                                                           const float* __restrict__ dv, int Hs, int Ws, int D, int h,
                                                           int w, float* __restrict__ out, int rows_per_band,
-                                                          int groups_per_row, int blocks_per_plane) {
+                                                          int groups_per_row, int blocks_per_plane,
+                                                          const int* __restrict__ view_ids, int n_all) {
   static_assert(S >= 1 && S <= 4, "one quad lane projects one view");
   constexpr int CQ = 4, VPW = 64 / CQ, C = 4 * CQ * QPL;
   const int b = blockIdx.y;
@@ -98,7 +99,8 @@ __global__ void __launch_bounds__(256) sweep_nhwc_kernel(const float* __restrict
     project_pixel(proj + ((size_t)b * S + q) * 12, (float)xc, (float)y, inv_depth, inv_half_w, inv_half_h, wm1, hm1,
                   ix, iy);
     Taps2 t = taps_zeros(ix, iy, Ws, Hs);
-    const unsigned vbase = (unsigned)q * (unsigned)(Hs * Ws) * REC;
+    // view q of this cost volume inside the feature tensor: q, or view_ids[b*S + q] of an (B, n_all, ...) tensor
+    const unsigned vbase = (unsigned)(view_ids ? view_ids[b * S + q] : q) * (unsigned)(Hs * Ws) * REC;
     my_o[0] = vbase + (unsigned)t.o00 * REC, my_o[1] = vbase + (unsigned)t.o01 * REC;
     my_o[2] = vbase + (unsigned)t.o10 * REC, my_o[3] = vbase + (unsigned)t.o11 * REC;
     my_w[0] = t.w00, my_w[1] = t.w01, my_w[2] = t.w10, my_w[3] = t.w11;
@@ -109,9 +111,10 @@ __global__ void __launch_bounds__(256) sweep_nhwc_kernel(const float* __restrict
   for (int p = 0; p < QPL; ++p) acc[p] = acc2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // buffer loads: one scalar resource for this batch item + 32-bit byte offsets per lane
-  const size_t item_bytes = (size_t)S * Hs * Ws * REC;
+  const int item_views = view_ids ? n_all : S;
+  const size_t item_bytes = (size_t)item_views * Hs * Ws * REC;
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(feats + (size_t)b * S * Hs * Ws * C), 0, (int)item_bytes, 0x00020000);
+      const_cast<float*>(feats + (size_t)b * item_views * Hs * Ws * C), 0, (int)item_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)q * (16u * QPL);
   using i32x4 = __attribute__((ext_vector_type(4))) int;
   auto one_view = [&](unsigned o0, unsigned o1, unsigned o2, unsigned o3, float w0, float w1, float w2, float w3) {
@@ -174,16 +177,16 @@ int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, b
 
 // Channel-last sweep.  Returns BMV_ERR_UNSUPPORTED for channel counts it has no kernel for.
 int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                          int D, int h, int w, float* out, hipStream_t stream) {
+                          int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream) {
   if ((C != 16 && C != 32) || S < 2 || S > 4) return BMV_ERR_UNSUPPORTED;
-  if ((size_t)S * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+  if ((size_t)(view_ids ? n_all : S) * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;  // 32-bit offsets
   int rows_per_band = (h + 7) / 8;
   int groups_per_row = (w + 15) / 16;
   int blocks_per_plane = ((rows_per_band + 3) / 4) * groups_per_row;
   dim3 grid(8u * (unsigned)(D * blocks_per_plane), B), block(256);
 #define SW(QPL, SV)                                                                                            \
   hipLaunchKernelGGL((sweep_nhwc_kernel<QPL, SV>), grid, block, 0, stream, feats, proj, dv, Hs, Ws, D, h, w, out, \
-                     rows_per_band, groups_per_row, blocks_per_plane)
+                     rows_per_band, groups_per_row, blocks_per_plane, view_ids, n_all)
   if (C == 16) {
     if (S == 2) SW(1, 2); else if (S == 3) SW(1, 3); else SW(1, 4);
   } else {

@@ -33,7 +33,7 @@ class FrameGraph:
     def _count_sweeps(self):
         calls = []
 
-        def hook(*a):
+        def hook(impl, args, kwargs):
             calls.append(torch.cuda.current_stream())
             return None
         ops.sweep_hook = hook
@@ -64,14 +64,14 @@ class FrameGraph:
                 g_a = torch.cuda.CUDAGraph()
                 self.graphs = [g_a]
 
-                def hook(feats, proj, depth_values, algo, out, channels_last):
+                def hook(impl, args, kwargs):
                     i = seen[0]
                     seen[0] += 1
                     if i != cut_index:
                         return None
                     self.graphs[-1].capture_end()
-                    res = ops._sweep_variance(feats, proj, depth_values, algo, out, channels_last)   # eager, static buffers
-                    self.sweep_args = (feats, proj, depth_values, algo, res, channels_last)
+                    res = impl(*args, **kwargs)                      # eager, on static buffers
+                    self.sweep_args = (impl, args, {**kwargs, "out": res})
                     g_b = torch.cuda.CUDAGraph()
                     self.graphs.append(g_b)
                     g_b.capture_begin(pool=g_a.pool(), capture_error_mode="thread_local")
@@ -94,7 +94,7 @@ class FrameGraph:
     def replay(self):
         self.graphs[0].replay()
         if self.sweep_args is not None:
-            f, p, dv, algo, out, cl = self.sweep_args
-            ops._sweep_variance(f, p, dv, algo, out, cl)      # times itself through ktimer when enabled
+            impl, args, kwargs = self.sweep_args
+            impl(*args, **kwargs)                             # times itself through ktimer when enabled
             self.graphs[1].replay()
         return self.out

@@ -174,16 +174,37 @@ class Network(enerf_network.Network):
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K
         ret = {}
+        train = torch.is_grad_enabled()
+        # Inference with the engine's channel-last feature maps: the sweep and render kernels pick each volume's three
+        # views out of the all-views tensors by index -- no gathered copies of images / feature maps per volume
+        # (those copies were 15 % of a K = 4 frame); only the 4x4 / 3x3 camera matrices are gathered, once per volume.
+        by_index = (not train and all(cc.render_scale[i] == 1.0 for i in range(cc.num) if cc.render_if[i])
+                    and all(not feats[f"level_{i}"].is_contiguous()
+                            and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous() for i in range(cc.num)))
+        if by_index:
+            sel32 = sel.to(torch.int32)
+            cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
         for i in range(cc.num):
             raws, zs, ms = [], [], []
             stacks = None
-            train = torch.is_grad_enabled()
             if cc.render_if[i] and B == 1 and not train:   # K render launches write straight into the stacked buffers
                 n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
                 stacks = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
                           torch.empty(1, K, n_i, ns_i, device=dev))
             for k in range(K):
                 ids = sel[:, k]
+                if by_index:
+                    vid = sel32[:, k]
+                    views = (batch["all_src_inps"], *cams[k])
+                    states[k] = self.level_front(i, feats[f"level_{i}"], views, batch, states[k], view_ids=vid)
+                    if not cc.render_if[i]:
+                        continue
+                    im_feat = feats[f"level_{cc.render_im_feat_level[i]}"]
+                    o = tuple(t[:, k] for t in stacks) if (stacks is not None and self.ray_range is None) else None
+                    r = self.render_level(i, states[k], im_feat, views, batch, mode=1, outs=o, view_ids=vid)
+                    if o is None:
+                        raws.append(r[0]), zs.append(r[1]), ms.append(r[2])
+                    continue
                 views = self._pick(batch, ids)
                 states[k] = self.level_front(i, self._pick_feats(feats[f"level_{i}"], bi, ids), views, batch, states[k])
                 if not cc.render_if[i]:

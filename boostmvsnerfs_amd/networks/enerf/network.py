@@ -61,9 +61,11 @@ class Network(nn.Module):
                 "level_2": fine.reshape(B, V, -1, H, W)}
 
     # ------------------------------------------------------------------ cost volume of one level
-    def level_front(self, i, feats_i, views, batch, prev):
+    def level_front(self, i, feats_i, views, batch, prev, view_ids=None):
         """Plane sweep + regulariser + depth regression (network.py:81-90).
-        `views` = (src_inps, src_exts, src_ixts) of the S views of this cost volume."""
+        `views` = (src_inps, src_exts, src_ixts) of the S views of this cost volume.  With `view_ids` (B,S) int32
+        (inference), `feats_i` and `src_inps` hold ALL source views and the kernels pick the volume's views by index
+        (no gathered copies); src_exts / src_ixts are the S picked ones either way."""
         cc = cfg.enerf.cas_config
         src_inps, src_exts, src_ixts = views
         H, W = src_inps.shape[-2:]
@@ -84,6 +86,8 @@ class Network(nn.Module):
                              cc.volume_scale[i])
         if train:
             variance = A.SweepVariance.apply(feats_i, proj, st.depth_values, self.sweep_algo)
+        elif view_ids is not None:
+            variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values)
         else:
             variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
         st.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
@@ -123,9 +127,9 @@ class Network(nn.Module):
         return A.Composite.apply(raw, z, cfg.enerf.white_bkgd)
 
     # ------------------------------------------------------------------ fused renderer of one level
-    def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None):
+    def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None, view_ids=None):
         """rays -> pixels (mode 0) or raw MLP outputs + depths + visibility (mode 1)
-        (network.py:24-55, boost_enerf/network.py:123-161)."""
+        (network.py:24-55, boost_enerf/network.py:123-161).  `view_ids`: see level_front (needs render_scale 1)."""
         cc = cfg.enerf.cas_config
         src_inps, src_exts, src_ixts = views
         H, W = src_inps.shape[-2:]
@@ -136,6 +140,8 @@ class Network(nn.Module):
         if rs == 1.0:
             rgb_src, affine = src_inps, True
         else:
+            if view_ids is not None:
+                raise ValueError("view_ids need render_scale 1 (the resized colour maps are per cost volume)")
             rgb_src, affine = ops.unpreprocess(src_inps, Hr, Wr), False
         nerf = getattr(self, f"nerf_{i}")
         rays = batch[f"rays_{i}"]
@@ -148,7 +154,7 @@ class Network(nn.Module):
                                 src_ixts, batch["tar_ext"], nerf.packed_weights(), feat_ch=nerf.feat_ch - 3,
                                 Ns=cc.num_samples[i], depth_inv=cc.depth_inv[i], Hr=Hr, Wr=Wr, render_scale=rs,
                                 rgb_affine=affine, white_bkgd=cfg.enerf.white_bkgd, mode=mode,
-                                ray_range=(c0, min(c0 + chunk, end)), outs=outs)
+                                ray_range=(c0, min(c0 + chunk, end)), outs=outs, view_ids=view_ids)
             outs = o      # every chunk writes its own ray slice of the same buffers
         if (begin, end) != (0, N):
             outs = tuple(t[:, begin:end] for t in outs)

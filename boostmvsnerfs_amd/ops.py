@@ -72,7 +72,7 @@ def nchw_to_nhwc(x):
     return out
 
 
-sweep_hook = None     # framegraph.FrameGraph: lets a graph capture step around one sweep launch
+sweep_hook = None     # framegraph.FrameGraph: hook(impl, args, kwargs) lets a graph capture step around one sweep launch
 
 
 def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
@@ -81,10 +81,41 @@ def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=No
     {16, 32} is first put into the channel-last layout (one transpose kernel) and the fast
     channel-last sweep runs; algo=1 forces the reference-layout direct-gather kernel."""
     if sweep_hook is not None:
-        r = sweep_hook(feats, proj, depth_values, algo, out, channels_last)
+        r = sweep_hook(_sweep_variance, (feats, proj, depth_values), dict(algo=algo, out=out, channels_last=channels_last))
         if r is not None:
             return r
     return _sweep_variance(feats, proj, depth_values, algo, out, channels_last)
+
+
+def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
+    """Plane sweep over the S views `view_ids` (B,S) int32 picked from feats_all = ALL source views: a
+    (B,n_all,C,Hs,Ws) view of a channel-last (B,n_all,Hs,Ws,C) buffer (what FeatureNet's engine path returns).
+    No gathered copy of the feature maps is made."""
+    if sweep_hook is not None:
+        r = sweep_hook(_sweep_variance_views, (feats_all, view_ids, proj, depth_values), dict(out=out))
+        if r is not None:
+            return r
+    return _sweep_variance_views(feats_all, view_ids, proj, depth_values, out)
+
+
+def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
+    cl = feats_all.permute(0, 1, 3, 4, 2) if feats_all.dim() == 5 else None
+    if cl is None or not cl.is_contiguous():
+        raise ValueError("sweep_variance_views needs a (B,n_all,C,Hs,Ws) view of channel-last feature maps")
+    B, n_all, Hs, Ws, C_ = cl.shape
+    S = view_ids.shape[1]
+    if view_ids.dtype != torch.int32 or view_ids.shape[0] != B:
+        raise ValueError("view_ids must be int32 (B,S)")
+    _, D, h, w = depth_values.shape
+    if out is None:
+        out = torch.empty(B, C_, D, h, w, device=cl.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]"):
+        rc = lib.bmv_sweep_variance_views_fwd(dptr(cl, "feats_all"), dptr(_c(view_ids), "view_ids", torch.int32), n_all,
+                                              dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"), B, S, C_,
+                                              Hs, Ws, D, h, w, dptr(out), stream())
+    _lib.check(rc, "sweep_variance_views")
+    return out
 
 
 def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
@@ -247,10 +278,12 @@ def blend(raws, masks, z_vals, normalise):
 
 
 def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext, blob, *, feat_ch,
-                Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None, outs=None):
+                Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None, outs=None,
+                view_ids=None):
     """Fused a6..a12 (+a14).  mode 0 -> (rgb, depth, weights); mode 1 -> (raw, z_vals, mask).
     ray_range=(begin, end) renders only those rays; the outputs keep the full (B,N,...) shape and
-    only that slice is written."""
+    only that slice is written.  view_ids (B,S) int32: im_feat / rgb_src hold ALL n_all source views and the
+    cost volume's view i is view_ids[b, i] (src_exts / src_ixts are already the S picked ones)."""
     B, N = rays.shape[:2]
     S = src_exts.shape[1]
     _, _, Dv, hv, wv = volume.shape
@@ -285,6 +318,13 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     a.rgb_affine, a.white_bkgd, a.mode = int(bool(rgb_affine)), int(bool(white_bkgd)), int(mode)
     a.ray_begin, a.ray_end = int(begin), int(end)
     a.out0, a.out1, a.out2 = dptr(o0), dptr(o1), dptr(o2)
+    if view_ids is not None:
+        if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S) or im_feat.shape[1] != rgb_src.shape[1]:
+            raise ValueError("render_rays: view_ids must be int32 (B,S); im_feat / rgb_src must hold the same n_all views")
+        view_ids = _c(view_ids)
+        a.view_ids, a.n_all = dptr(view_ids, "view_ids", torch.int32), int(im_feat.shape[1])
+    else:
+        a.view_ids, a.n_all = None, 0
     lib = _lib.load()
     with ktimer.region(f"render_rays[feat={feat_ch},Ns={Ns},mode={mode}]"):
         rc = lib.bmv_render_rays_fwd(C.byref(a), stream())

@@ -62,6 +62,12 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
                            bmv_stream_t stream);
+/* Same sweep over S views PICKED from a channel-last tensor of all views: feats_all (B,n_all,Hs,Ws,C), view s of batch
+ * item b is feats_all[b, view_ids[b*S + s]] (boost_enerf/network.py:178-192 builds every cost volume from a
+ * triplet of the N source views; no gathered copy of the feature maps is made).  proj (B,S,3,4) is per picked view. */
+int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, int n_all, const float* proj,
+                                 const float* depth_values, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                                 float* variance, bmv_stream_t stream);
 /* (n,C,H,W) -> (n,H,W,C), C % 4 == 0: puts the 2-D features into the sweep's channel-last layout */
 int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, bmv_stream_t stream);
 
@@ -163,6 +169,8 @@ typedef struct {
   float* out0;            /* rgb  | raw    */
   float* out1;            /* depth| z_vals */
   float* out2;            /* weights | mask */
+  const int* view_ids;    /* NULL, or (B,S): im_feat / rgb_src are (B,n_all,...) and view i is view_ids[b*S + i] */
+  int n_all;
 } bmv_render_args;
 int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
 
