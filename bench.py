@@ -225,9 +225,10 @@ def main():
         if rank != 0:
             local_forward()
         dist.barrier()
-    # warm-up (eager); the fused renderer is timed here for `roofline_mfma` because it sits inside a graph later
+    # warm-up (eager); the fused renderer is timed here for `roofline_mfma` because it sits inside a graph later (and
+    # the sweeps, used only when a workload's graph has no eager sweep: K volumes on K streams)
     ktimer.reset()
-    ktimer.enabled, ktimer.only = not args.no_kernel_events, ("render_rays", "mvs_render")
+    ktimer.enabled, ktimer.only = not args.no_kernel_events, ("render_rays", "mvs_render", "sweep_variance", "mvs_sweep")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -57,6 +57,8 @@ class Network(enerf_network.Network):
         self.view_selection_outputs = None
         self.capture = None
         self._sel_cache = {}
+        self._streams = []
+        self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
         if not preprocess:
             path = os.path.join(cfg.result_dir, "view_selection.json")
             if not os.path.exists(path):
@@ -150,6 +152,50 @@ class Network(enerf_network.Network):
             rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=True)
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
+    def _forward_parallel(self, batch, feats, sel, sel32, cams, K):
+        """The K cost volumes are independent until the fusion: each one's chain (sweeps, regularisers, depth
+        regression, render in MLP-only mode) runs on its own HIP stream; the deep U-Net levels are launches of a few
+        dozen workgroups that fill the chip only together.  The main stream joins them before the blend."""
+        cc = cfg.enerf.cas_config
+        dev = batch["all_src_inps"].device
+        main = torch.cuda.current_stream()
+        while len(self._streams) < K:
+            self._streams.append(torch.cuda.Stream())
+        stacks = {}
+        for i in range(cc.num):
+            if cc.render_if[i]:
+                n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
+                stacks[i] = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
+                             torch.empty(1, K, n_i, ns_i, device=dev))
+        first = {}
+        for k in range(K):
+            s = self._streams[k]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                vid = sel32[:, k]
+                views = (batch["all_src_inps"], *cams[k])
+                st = None
+                for i in range(cc.num):
+                    st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid)
+                    if cc.render_if[i]:
+                        self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch, mode=1,
+                                          outs=tuple(t[:, k] for t in stacks[i]), view_ids=vid)
+                        if k == 0:
+                            first[i] = (st.depth, st.std)
+        for k in range(K):
+            main.wait_stream(self._streams[k])
+        ret = {}
+        for i, (raws, zs, ms) in stacks.items():
+            out = self.merge_mlp_outputs(raws, ms, zs)
+            depth0, std0 = first[i]                                 # depth_mvs / std come from volume 0 only
+            if not torch.cuda.is_current_stream_capturing():
+                depth0.record_stream(main), std0.record_stream(main)
+            out["depth_mvs"] = torch.reciprocal(depth0) if cc.depth_inv[i] else depth0
+            out["std"] = std0
+            ret.update({f"{k_}_level{i}": v for k_, v in out.items()})
+        batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
+        return ret
+
     def forward(self, batch):
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
@@ -184,6 +230,8 @@ class Network(enerf_network.Network):
         if by_index:
             sel32 = sel.to(torch.int32)
             cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
+            if self.parallel_volumes and B == 1 and self.ray_range is None and self.capture is None:
+                return self._forward_parallel(batch, feats, sel, sel32, cams, K)
         for i in range(cc.num):
             raws, zs, ms = [], [], []
             stacks = None

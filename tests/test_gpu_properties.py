@@ -73,6 +73,36 @@ def test_sweep_symmetries_full_size(full, level):
     assert float(var_0.abs().max()) <= 1e-5 * float(f.pow(2).max())
 
 
+def test_views_by_index_equals_gathered_views_full_size(full):
+    """bmv_sweep_variance_views_fwd / view_ids of the render kernel (boost path: every cost volume picks 3 of the N
+    source views) == the same kernels on gathered copies of those views, bit for bit."""
+    from boostmvsnerfs_amd import ops
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    cfg, net, _ = full
+    cc = cfg.enerf.cas_config
+    batch = clone_batch(make_batch(H, W, n_views=5, seed=1), DEV)
+    ids = torch.tensor([[3, 0, 4]], device=DEV)
+    ids32 = ids.to(torch.int32)
+    bi = torch.arange(1, device=DEV)[:, None]
+    with torch.no_grad():
+        feats = net.forward_feat(batch["all_src_inps"])
+        exts, ixts = batch["all_src_exts"][bi, ids], batch["all_src_ixts"][bi, ids]
+        picked = (batch["all_src_inps"][bi, ids], exts, ixts)
+        by_index = (batch["all_src_inps"], exts, ixts)
+        f1 = feats["level_1"]
+        assert not f1.is_contiguous() and f1.permute(0, 1, 3, 4, 2).is_contiguous()
+        st_a = st_b = None
+        for i in range(cc.num):
+            fa = feats[f"level_{i}"].permute(0, 1, 3, 4, 2)[bi, ids].permute(0, 1, 4, 2, 3)
+            st_a = net.level_front(i, fa, picked, batch, st_a)
+            st_b = net.level_front(i, feats[f"level_{i}"], by_index, batch, st_b, view_ids=ids32)
+            assert torch.equal(st_a.depth, st_b.depth) and torch.equal(st_a.feature_volume, st_b.feature_volume)
+        out_a = net.render_level(1, st_a, feats["level_2"][bi, ids], picked, batch)
+        out_b = net.render_level(1, st_b, feats["level_2"], by_index, batch, view_ids=ids32)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+
+
 def test_depth_regression_ranges_full_size(full):
     cfg, net, batch = full
     _, (st0, st1), _ = _front(net, batch, cfg)
