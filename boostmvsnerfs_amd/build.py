@@ -18,11 +18,7 @@ LIB = os.path.join(HERE, "libbmv.so")
 SOURCES = ["sweep.hip", "sweep_tiled.hip", "sweep_lds.hip", "sample.hip", "render.hip", "mvs.hip", "backward.hip", "mlp_bwd.hip", "conv.hip"]
 HEADERS = ["bmv_common.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# render.hip only: fp32 `/` compiles to v_rcp sequences (<= 2.5 ulp) instead of the IEEE-correct expansion (~10 VALU
-# instructions per division; the fused renderer has 67 of them per 32 samples and is co-limited by VALU issue):
-# 4 orders of magnitude inside the 1e-3 parity bar, measured -12 us on the renderer.  The standalone ops and the
-# backward kernels keep exact division (their tests hold tighter tolerances on near-cancelling quantities).
-EXTRA_FLAGS = {"render.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]}
+EXTRA_FLAGS = {}    # per-file flags
 
 
 def _hipcc():

@@ -6,6 +6,13 @@
 
 #include "../../include/bmv.h"
 
+// fp32 division of the per-sample geometry.  Exact by default (the standalone ops and their tests); render.hip
+// defines it as a * v_rcp_f32(b) (1 ulp): the fused renderer is co-limited by VALU issue and had 67 IEEE division
+// expansions (~10 instructions each) per 32 samples.
+#ifndef BMV_DIV
+#define BMV_DIV(a, b) ((a) / (b))
+#endif
+
 namespace bmv {
 
 void set_error(const char* fmt, ...);
@@ -94,12 +101,53 @@ __device__ __forceinline__ Taps2 taps_border(float ix, float iy, int W, int H) {
   return t;
 }
 
+// p[i] for a 32-bit BYTE offset: `wave-uniform pointer + zero-extended 32-bit lane offset` is one addressing mode of
+// global_load (scalar base + vector offset); an element index would need a 64-bit shift-add per load.
+__device__ __forceinline__ float ld_byte_off(const float* __restrict__ p, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off);
+}
+// The same through a buffer resource: scalar descriptor + 32-bit lane byte offset + scalar byte offset (the channel
+// plane): no vector ALU work per load at all.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, size_t bytes) {
+  // the pointer is wave-uniform by construction; say so (readfirstlane), or every load through the descriptor is
+  // wrapped in a waterfall loop
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  float* q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float tap_fetch_buf(__amdgpu_buffer_rsrc_t r, const Taps2& t, unsigned soff) {
+  float v = ld_buf(r, (unsigned)t.o00, soff) * t.w00;
+  v += ld_buf(r, (unsigned)t.o01, soff) * t.w01;
+  v += ld_buf(r, (unsigned)t.o10, soff) * t.w10;
+  v += ld_buf(r, (unsigned)t.o11, soff) * t.w11;
+  return v;
+}
+// taps whose offsets were pre-multiplied by 4 (tap_bytes)
+__device__ __forceinline__ float tap_fetch_bytes(const float* __restrict__ p, const Taps2& t) {
+  float v = ld_byte_off(p, (unsigned)t.o00) * t.w00;
+  v += ld_byte_off(p, (unsigned)t.o01) * t.w01;
+  v += ld_byte_off(p, (unsigned)t.o10) * t.w10;
+  v += ld_byte_off(p, (unsigned)t.o11) * t.w11;
+  return v;
+}
+__device__ __forceinline__ void tap_bytes(Taps2& t, int extra_elems) {
+  t.o00 = (t.o00 + extra_elems) * 4, t.o01 = (t.o01 + extra_elems) * 4;
+  t.o10 = (t.o10 + extra_elems) * 4, t.o11 = (t.o11 + extra_elems) * 4;
+}
+
 __device__ __forceinline__ float tap_fetch(const float* __restrict__ p, const Taps2& t) {
   // same accumulation order as aten's grid_sampler_2d: nw, ne, sw, se
-  float v = p[t.o00] * t.w00;
-  v += p[t.o01] * t.w01;
-  v += p[t.o10] * t.w10;
-  v += p[t.o11] * t.w11;
+  // offsets are >= 0 (taps_* clamp them into the plane): unsigned indices let the loads take the uniform plane
+  // pointer as a scalar base + 32-bit lane offset instead of a 64-bit address computed per load
+  float v = p[(unsigned)t.o00] * t.w00;
+  v += p[(unsigned)t.o01] * t.w01;
+  v += p[(unsigned)t.o10] * t.w10;
+  v += p[(unsigned)t.o11] * t.w11;
   return v;
 }
 

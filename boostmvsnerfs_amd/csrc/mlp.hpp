@@ -229,7 +229,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   {
     float m = fmaxf(aw[0], fmaxf(aw[1], aw[2]));
     float e0 = __expf(aw[0] - m), e1 = __expf(aw[1] - m), e2 = __expf(aw[2] - m);
-    float inv = 1.f / (e0 + e1 + e2);
+    float inv = BMV_DIV(1.f, e0 + e1 + e2);
     aw[0] = e0 * inv, aw[1] = e1 * inv, aw[2] = e2 * inv;
   }
   // agg.fc (nerf.py:90): 32 -> 16
@@ -316,7 +316,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   {
     float m = fmaxf(cl[0], fmaxf(cl[1], cl[2]));
     float e0 = __expf(cl[0] - m), e1 = __expf(cl[1] - m), e2 = __expf(cl[2] - m);
-    float inv = 1.f / (e0 + e1 + e2);
+    float inv = BMV_DIV(1.f, e0 + e1 + e2);
     cl[0] = e0 * inv, cl[1] = e1 * inv, cl[2] = e2 * inv;
   }
   // blend the sampled source colours: channels FEAT_CH + {0,1,2} sit at

@@ -8,6 +8,7 @@
 // sample's geometry; the gathers are split between them by channel parity, which
 // is exactly the k-slot order the MLP wants (mlp.hpp).  The MLP weights sit in
 // LDS once per workgroup (4 waves) and the workgroup walks tiles grid-stride.
+#define BMV_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))   // see bmv_common.hpp
 #include "mlp.hpp"
 #include "render_geom.hpp"
 
@@ -83,6 +84,16 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
   const float* vol = a.volume + (size_t)b * 8 * a.Dv * hwv;
   const float inv_w = (float)(a.Wr - 1), inv_h = (float)(a.Hr - 1);
 
+  // buffer descriptors of the gathered tensors (wave-uniform, built once): loads are descriptor + 32-bit offsets
+  const __amdgpu_buffer_rsrc_t rs_vol = make_rsrc(vol, (size_t)8 * a.Dv * hwv * 4);
+  __amdgpu_buffer_rsrc_t rs_f[3], rs_c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
+    const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
+    rs_f[i] = make_rsrc(a.im_feat + vslot * FEAT_CH * plane, (size_t)FEAT_CH * plane * 4);
+    rs_c[i] = make_rsrc(a.rgb_src + vslot * 3 * plane, (size_t)3 * plane * 4);
+  }
   const int nrays = a.ray_end - a.ray_begin;
   const int ntiles = (nrays + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
@@ -99,10 +110,15 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
 
     float fin[3][L::KF], dir[3][4], vox[4], res[4];
     {  // a9: trilinear lookup, this half's 4 channels
-      Taps3 t3 = taps3_zeros(px / inv_w, py / inv_h, dn, a.wv, a.hv, a.Dv);
-      size_t cs = (size_t)a.Dv * hwv;
+      Taps3 t3 = taps3_zeros(BMV_DIV(px, inv_w), BMV_DIV(py, inv_h), dn, a.wv, a.hv, a.Dv);
+      const size_t cs = (size_t)a.Dv * hwv;
+      // the half's channel offset (h * cs) goes into the 32-bit tap offsets once: every load is then
+      // `wave-uniform plane pointer + 32-bit lane offset` instead of a 64-bit per-lane address
+      const int hoff = h ? (int)cs : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch(vol + (size_t)(2 * j + h) * cs, t3);
+      for (int k = 0; k < 8; ++k) t3.o[k] = (t3.o[k] + hoff) * 4;   // byte offsets (a volume stays below 2 GiB)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch_buf(rs_vol, t3, (unsigned)(2 * j) * (unsigned)cs * 4u);
     }
     BMV_FENCE();
     float vis = 0.f;
@@ -110,20 +126,18 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
     for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
       const Cam& cam = rc->cam[i];
       Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
-      // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
-      const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
-      const float* fp = a.im_feat + vslot * FEAT_CH * plane;
-      const float* cp = a.rgb_src + vslot * 3 * plane;
+      Taps2 t2h = t2;  // same taps as byte offsets, one channel plane further for the odd half
+      tap_bytes(t2h, h ? (int)plane : 0);
 #pragma unroll
       for (int j = 0; j < L::KFC; ++j) {
         int c = 2 * j + h;  // channel of [feature, rgb]
         float v = 0.f;
         if (2 * j + 1 < FEAT_CH) {  // both halves read a feature channel
-          v = tap_fetch(fp + (size_t)c * plane, t2);
+          v = tap_fetch_buf(rs_f[i], t2h, (unsigned)(2 * j) * (unsigned)plane * 4u);
         } else if (2 * j >= FEAT_CH) {  // colour channels (the last slot of half 1 is padding)
           int cc = c - FEAT_CH;
           if (cc < 3) {
-            v = tap_fetch(cp + (size_t)cc * plane, t2);
+            v = tap_fetch_buf(rs_c[i], t2h, (unsigned)(2 * j - FEAT_CH) * (unsigned)plane * 4u);
             if (a.rgb_affine) v = v * 0.5f + 0.5f;
           }
         }
@@ -171,7 +185,7 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
     float e = __expf(w - wmax), den = e;
 #pragma unroll
     for (int m = 1; m < NS; m <<= 1) den += __shfl_xor(den, m, NS);
-    float sm = e / den;
+    float sm = BMV_DIV(e, den);
     float dz = sm * z, acc = sm;
 #pragma unroll
     for (int m = 1; m < NS; m <<= 1) {

@@ -79,12 +79,12 @@ __device__ __forceinline__ void sample_point(const float* o, const float* d, flo
                                              int k, int Ns, bool depth_inv, float& z, float* xyz, float& dn) {
   z = Ns == 1 ? rn + (rf - rn) * 0.5f : rn + (rf - rn) * linspace01(k, Ns);
   if (depth_inv) {
-    float iz = 1.f / fmaxf(z, 1e-6f);
+    float iz = BMV_DIV(1.f, fmaxf(z, 1e-6f));
     xyz[0] = o[0] + d[0] * iz, xyz[1] = o[1] + d[1] * iz, xyz[2] = o[2] + d[2] * iz;
-    dn = (vn - z) / fmaxf(vn - vf, 1e-6f);
+    dn = BMV_DIV(vn - z, fmaxf(vn - vf, 1e-6f));
   } else {
     xyz[0] = o[0] + d[0] * z, xyz[1] = o[1] + d[1] * z, xyz[2] = o[2] + d[2] * z;
-    dn = (z - vn) / fmaxf(vf - vn, 1e-6f);
+    dn = BMV_DIV(z - vn, fmaxf(vf - vn, 1e-6f));
   }
 }
 
@@ -119,10 +119,22 @@ __device__ __forceinline__ Taps3 taps3_zeros(float u01, float v01, float d01, in
   }
   return t;
 }
+__device__ __forceinline__ float tap3_fetch_buf(__amdgpu_buffer_rsrc_t r, const Taps3& t, unsigned soff) {  // byte offsets
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += ld_buf(r, (unsigned)t.o[k], soff) * t.w[k];
+  return v;
+}
+__device__ __forceinline__ float tap3_fetch_bytes(const float* __restrict__ p, const Taps3& t) {   // offsets in bytes
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += ld_byte_off(p, (unsigned)t.o[k]) * t.w[k];
+  return v;
+}
 __device__ __forceinline__ float tap3_fetch(const float* __restrict__ p, const Taps3& t) {
   float v = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v += p[t.o[k]] * t.w[k];
+  for (int k = 0; k < 8; ++k) v += p[(unsigned)t.o[k]] * t.w[k];
   return v;
 }
 
@@ -136,8 +148,8 @@ __device__ __forceinline__ Taps2 project_taps(const Cam& cam, const float* xyz, 
   float qy = cx * cam.K[3] + cy * cam.K[4] + cz * cam.K[5];
   float qz = cx * cam.K[6] + cy * cam.K[7] + cz * cam.K[8];
   float z = fmaxf(qz, 1e-6f);
-  float gx = (qx / z) / (float)(W - 1) * 2.f - 1.f;
-  float gy = (qy / z) / (float)(H - 1) * 2.f - 1.f;
+  float gx = BMV_DIV(BMV_DIV(qx, z), (float)(W - 1)) * 2.f - 1.f;
+  float gy = BMV_DIV(BMV_DIV(qy, z), (float)(H - 1)) * 2.f - 1.f;
   return taps_border(unnorm(gx, W), unnorm(gy, H), W, H);
 }
 
@@ -157,14 +169,14 @@ __device__ __forceinline__ void dir_feature(const float* xyz, const float* tar_c
   float df[3], nd = 0.f, dot = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    a[k] /= na;
-    b[k] /= nb;
+    a[k] = BMV_DIV(a[k], na);
+    b[k] = BMV_DIV(b[k], nb);
     df[k] = a[k] - b[k];
     nd += df[k] * df[k];
     dot += a[k] * b[k];
   }
   nd = fmaxf(sqrtf(nd), 1e-6f);
-  out4[0] = df[0] / nd, out4[1] = df[1] / nd, out4[2] = df[2] / nd, out4[3] = dot;
+  out4[0] = BMV_DIV(df[0], nd), out4[1] = BMV_DIV(df[1], nd), out4[2] = BMV_DIV(df[2], nd), out4[3] = dot;
 }
 
 // a14: is the point inside the viewport of this source view (full-res K, render-res W-1,H-1)?
@@ -176,7 +188,7 @@ __device__ __forceinline__ float visible(const Cam& cam, const float* xyz, float
   float px = cx * cam.Kf[0] + cy * cam.Kf[1] + cz * cam.Kf[2];
   float py = cx * cam.Kf[3] + cy * cam.Kf[4] + cz * cam.Kf[5];
   float pz = cx * cam.Kf[6] + cy * cam.Kf[7] + cz * cam.Kf[8];
-  float u = px / pz / inv_w, v = py / pz / inv_h;
+  float u = BMV_DIV(BMV_DIV(px, pz), inv_w), v = BMV_DIV(BMV_DIV(py, pz), inv_h);
   return (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f && pz > 0.f) ? 1.f : 0.f;
 }
 
