@@ -3,6 +3,8 @@
 // Reference: lib/networks/enerf/utils.py:35-153, 324-351, 722-731.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "bmv_common.hpp"
 
 namespace bmv {
@@ -331,6 +333,14 @@ int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv
                           int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
 int bmv_sweep_lds_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                          int D, int h, int w, float* out, int shape, hipStream_t stream);
+int bmv_sweep_split_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
+                           int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
+// split-geometry kernel (sweep_split.hip) by default: 26.9 / 27.4 us vs 31.4 / 29.0 us (level 0 / 1, config 2);
+// BMV_SWEEP_SPLIT=0 selects the all-quad-layout kernel of sweep_tiled.hip
+static bool prefer_split() {
+  static const bool v = !(getenv("BMV_SWEEP_SPLIT") && atoi(getenv("BMV_SWEEP_SPLIT")) == 0);
+  return v;
+}
 
 int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, int n_all, const float* proj,
                                  const float* depth_values, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
@@ -338,8 +348,11 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
   BMV_REQUIRE(feats_all && view_ids && proj && depth_values && variance, "bmv_sweep_variance_views_fwd: null pointer");
   BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_views_fwd: bad shape");
-  int rc = bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
-                                 as_stream(stream));
+  int rc = prefer_split()
+               ? bmv_sweep_split_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
+                                        as_stream(stream))
+               : bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
+                                       as_stream(stream));
   if (rc == BMV_ERR_UNSUPPORTED)
     set_error("bmv_sweep_variance_views_fwd: needs channel-last features with C in {16, 32} and 2..4 views (C=%d, S=%d)", C,
               S);
@@ -371,8 +384,11 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
         return rc;
       }
     }
-    rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                               as_stream(stream));
+    rc = (prefer_split() && algo != 3)
+             ? bmv_sweep_split_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                      as_stream(stream))
+             : bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                     as_stream(stream));
     if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
     return rc;
   }
