@@ -103,6 +103,34 @@ def test_views_by_index_equals_gathered_views_full_size(full):
         assert torch.equal(a, b)
 
 
+def test_batch_of_two_equals_two_batches_of_one():
+    """Every kernel takes the batch dimension in its grid: a B = 2 forward is bit-identical to the two B = 1 forwards
+    (different cameras / rays per item)."""
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    from boostmvsnerfs_amd.config import get_cfg
+    prev = get_cfg()
+    cfg = make_cfg("enerf_pretrain")                      # both levels rendered
+    cfg.enerf.cas_config.volume_planes = [16, 8]
+    set_cfg(cfg)
+    try:
+        torch.manual_seed(0)
+        net = Network().eval().to(DEV)
+        b2 = clone_batch(make_batch(64, 96, n_views=3, seed=0, B=2), DEV)
+        with torch.no_grad():
+            both = net(b2)
+            singles = []
+            for i in range(2):
+                bi = {k: (v[i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in b2.items()}
+                singles.append(net(bi))
+    finally:
+        set_cfg(prev)                                     # the module-scope `full` fixture reads the global cfg
+    assert {"rgb_level0", "rgb_level1"} <= set(both)
+    for k, v in both.items():
+        assert torch.equal(v, torch.cat([s[k] for s in singles], 0)), k
+
+
 def test_depth_regression_ranges_full_size(full):
     cfg, net, batch = full
     _, (st0, st1), _ = _front(net, batch, cfg)
