@@ -348,11 +348,13 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
   BMV_REQUIRE(feats_all && view_ids && proj && depth_values && variance, "bmv_sweep_variance_views_fwd: null pointer");
   BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_views_fwd: bad shape");
-  int rc = prefer_split()
-               ? bmv_sweep_split_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
-                                        as_stream(stream))
-               : bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
-                                       as_stream(stream));
+  int rc = BMV_ERR_UNSUPPORTED;
+  if (prefer_split())
+    rc = bmv_sweep_split_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
+                                as_stream(stream));
+  if (rc == BMV_ERR_UNSUPPORTED)
+    rc = bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
+                               as_stream(stream));
   if (rc == BMV_ERR_UNSUPPORTED)
     set_error("bmv_sweep_variance_views_fwd: needs channel-last features with C in {16, 32} and 2..4 views (C=%d, S=%d)", C,
               S);
@@ -384,11 +386,13 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
         return rc;
       }
     }
-    rc = (prefer_split() && algo != 3)
-             ? bmv_sweep_split_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                      as_stream(stream))
-             : bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                     as_stream(stream));
+    rc = BMV_ERR_UNSUPPORTED;
+    if (prefer_split())
+      rc = bmv_sweep_split_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                  as_stream(stream));
+    if (rc == BMV_ERR_UNSUPPORTED)   // (source maps beyond the split kernel's 28-bit tap offsets, or BMV_SWEEP_SPLIT=0)
+      rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                 as_stream(stream));
     if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
     return rc;
   }

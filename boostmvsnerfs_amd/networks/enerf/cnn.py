@@ -36,6 +36,9 @@ class _Packed:
         self.blobs = None
         self.tensors = None
 
+    def invalidate(self):
+        self.key = self.tensors = None
+
     def get(self, module, build):
         if self.tensors is None:
             self.tensors = list(module.parameters()) + list(module.buffers())
@@ -97,6 +100,10 @@ class FeatureNet(nn.Module):
     @staticmethod
     def _top_down(coarse, lateral):
         return F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + lateral
+
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .float(): buffers are replaced, storage moves
+        self._packed.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _blobs(self):
         return self._packed.get(self, lambda: {
@@ -164,6 +171,10 @@ class _CostReg(nn.Module):
         self.depth_conv = nn.Sequential(Conv3d(8, 1, 3, padding=1, bias=False))
         self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
         self._packed = _Packed()
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _forward_engine(self, x):
         def build():
