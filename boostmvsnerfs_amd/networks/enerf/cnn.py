@@ -22,7 +22,11 @@ def engine_ok(module, x):
 
 def _engine_ok(module, x):
     """Inference (eval-mode batch norm, no autograd) on the GPU runs on the convolution engine
-    (csrc/conv.hip); training keeps the torch modules (MIOpen forward / data gradients)."""
+    (csrc/conv.hip); training keeps the torch modules (MIOpen forward / data gradients).
+    CPU tensors are refused like everywhere else on the path: there is no CPU fallback."""
+    if not x.is_cuda:
+        raise RuntimeError(f"{type(module).__name__}: the BoostMVSNeRFs hot path runs on the GPU only (input is on "
+                           f"{x.device}); there is no CPU fallback")
     return (not module.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
             and os.environ.get("BMV_CNN", "engine") != "torch")
 

@@ -56,3 +56,12 @@ def test_ops_refuse_cpu_tensors():
     from boostmvsnerfs_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.depth_regress(torch.zeros(1, 4, 2, 2), torch.ones(1, 4, 2, 2), True)
+
+
+def test_cnn_modules_refuse_cpu_tensors():
+    import torch
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    set_cfg(make_cfg("enerf_eval"))
+    from boostmvsnerfs_amd.networks.enerf.cnn import FeatureNet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FeatureNet().eval()(torch.zeros(1, 3, 32, 32))
