@@ -24,6 +24,8 @@
 // Row pairing (Cout <= 8, stride 1): the 16 MFMA rows hold the 8 output channels of TWO adjacent output rows
 // y, y+1.  Input row y+j (j = 0..K) meets filter row j for output y and filter row j-1 for output y+1, so K+1
 // MFMAs per (kz, kx) produce two output rows: (K+1)/(2K) = 2/3 of the MFMAs of padding 8 channels to 16.
+#include <stdlib.h>
+
 #include "bmv_common.hpp"
 
 namespace bmv {
@@ -388,6 +390,137 @@ __global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Split-K tiling for the deep U-Net levels (a few thousand voxels, 32-64 channels): with one 4-row x 16-column
+// tile per workgroup those launches are a few hundred workgroups whose waves each walk ALL k-steps in sequence,
+// exposing one global-load latency per k-step (measured 16-30 % MFMA-pipe occupancy).  Here every wave covers all
+// 4 rows of the tile but only every 4th k-step (4 input channels) of a 16-channel LDS stage; the 4 partial sums meet
+// in LDS and wave r finishes row r.  The dependent chain per wave is 4x shorter.
+// ---------------------------------------------------------------------------------------------------
+template <int KD, int K, int S, bool IS3D>
+struct SplitKTile {
+  static constexpr int TY = 4;
+  static constexpr int TZH = KD, TYH = (TY - 1) * S + K, RS = 15 * S + K;
+  static constexpr int SLOTS = TZH * TYH * RS;
+  static constexpr int PS = (S == 1) ? ((SLOTS + 15) / 32 * 32 + 16) : (SLOTS | 1);
+  static constexpr int NSLOT = (SLOTS + 255) / 256;
+  static constexpr int TAPS = KD * K * K;
+};
+
+template <int KD, int K, int S, bool IS3D>
+__global__ __launch_bounds__(256) void conv_splitk_kernel(ConvArgs a) {
+  using T = SplitKTile<KD, K, S, IS3D>;
+  __shared__ float lds[16 * T::PS];
+  __shared__ f32x4 red[4][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + 3) / 4;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int ty = bid % nty;
+  bid /= nty;
+  const int z0 = bid % a.Do;
+  const int b = bid / a.Do;
+  const int x0 = tx * 16, y0 = ty * 4;
+  const int ix0 = x0 * S - K / 2, iy0 = y0 * S - K / 2, iz0 = z0 * S - KD / 2;
+  const int plane = a.D * a.H * a.W;
+
+  unsigned goff[T::NSLOT];
+#pragma unroll
+  for (int j = 0; j < T::NSLOT; ++j) {
+    const int slot = tid + 256 * j;
+    const int sx = slot % T::RS, t = slot / T::RS, sy = t % T::TYH, sz = t / T::TYH;
+    const int gx = ix0 + sx, gy = iy0 + sy, gz = iz0 + sz;
+    const bool ok = (slot < T::SLOTS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D);
+    goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
+  }
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
+  const int nk = (a.Cin + 3) / 4, nstage = (nk + 3) / 4;
+  const int cot = blockIdx.y;
+  const float* wp = a.wpack + (size_t)cot * nk * (T::TAPS * 64) + lane;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* ap = lds + (wave * 4 + (lane >> 4)) * T::PS + (lane & 15) * S;
+  for (int stage = 0; stage < nstage; ++stage) {
+    // 16 channels of the tile; channels past Cin (last stage) must read as 0: the offsets stay below 2^31 because
+    // (Cin + 15) * plane * 4 is checked on the host
+    float pre[16][T::NSLOT];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int ch = stage * 16 + c;
+      const unsigned cb = 4u * (unsigned)(ch * plane);
+#pragma unroll
+      for (int j = 0; j < T::NSLOT; ++j)
+        pre[c][j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ch < a.Cin ? goff[j] + cb : 0x80000000u, 0, 0));
+    }
+    const int ks = stage * 4 + wave;  // this wave's k-step
+    float wv[T::TAPS];
+    if (ks < nk) {
+#pragma unroll
+      for (int t = 0; t < T::TAPS; ++t) wv[t] = wp[(size_t)ks * (T::TAPS * 64) + t * 64];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+      for (int j = 0; j < T::NSLOT; ++j)
+        if ((j + 1) * 256 <= T::SLOTS || tid + 256 * j < T::SLOTS) lds[c * T::PS + tid + 256 * j] = pre[c][j];
+    __syncthreads();
+    if (ks < nk) {
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const float w = wv[(kd * K + kh) * K + kw];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r], 0,
+                                                            0, 0);
+          }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  const f32x4 sum = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
+
+  // wave r finishes row r: lane = output x, registers = 4 consecutive output channels
+  const int x = x0 + (lane & 15), y = y0 + wave;
+  const int co0 = cot * 16 + 4 * (lane >> 4);
+  if (x >= a.Wo || y >= a.Ho || co0 >= a.Cout) return;
+  const size_t cs = (size_t)a.Do * a.Ho * a.Wo;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = sum[j] + a.bias[co0 + j];
+    v[j] = fmaxf(v[j], 0.f) + a.slope * fminf(v[j], 0.f);
+  }
+  if (a.channels_last) {
+    const size_t o = ((((size_t)b * a.Do + z0) * a.Ho + y) * a.Wo + x) * a.Cout + co0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (co0 + j < a.Cout) a.out[o + j] = v[j] + (a.skip ? a.skip[o + j] : 0.f);
+  } else {
+    const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + z0) * a.Ho + y) * a.Wo + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (co0 + j < a.Cout) a.out[o + j * cs] = v[j] + (a.skip ? a.skip[o + j * cs] : 0.f);
+  }
+}
+
+template <int KD, int K, int S, bool IS3D>
+static void launch_splitk(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, 4) * a.Do * a.B, cdiv(a.Cout, 16));
+  hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D>), grid, dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Launch selection.  Big tiles (R rows per wave, all cout tiles of a layer in one block so the LDS tile is
 // shared) when they still give every CU a few blocks; otherwise small tiles, one cout tile per block
 // (grid.y walks the cout tiles): the deep U-Net levels have a few thousand voxels only.
@@ -405,6 +538,10 @@ static void launch_conv(const ConvArgs& a, hipStream_t st) {
 }
 
 constexpr unsigned kEnoughBlocks = 512;  // 2 per CU
+static bool splitk_enabled() {
+  static const bool v = !(getenv("BMV_CONV_SPLITK") && atoi(getenv("BMV_CONV_SPLITK")) == 0);
+  return v;
+}
 
 // RB / RS: rows per wave of the big / small tiling
 template <int KD, int K, int S, int RB, int RS_, bool IS3D>
@@ -434,6 +571,8 @@ static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
     return launch_conv<KD, K, S, 4, RB, MB, false>(a, st);
   if (conv_blocks<KD, K, S, 1, RS_, MB, false>(a) >= kEnoughBlocks)
     return launch_conv<KD, K, S, 1, RS_, MB, false>(a, st);
+  // measured inside the frame (bench.py): 292.4 -> 296.8 Mray/s with Cin >= 16, 295.3 with Cin >= 32
+  if (a.Cin >= 16 && splitk_enabled()) return launch_splitk<KD, K, S, IS3D>(a, st);
   launch_conv<KD, K, S, 1, 1, MS, false>(a, st);
 }
 
