@@ -520,6 +520,102 @@ static void launch_splitk(const ConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D>), grid, dim3(256), 0, st, a);
 }
 
+// Split-K form of the transposed convolution for the deep levels: one input row x 16 input x per workgroup, wave w takes
+// every 4th k-step of a 16-channel stage with all 8 parity accumulators, the partial sums meet in LDS and wave w
+// finishes output row pair (pz, py) = (w >> 1, w & 1).
+__global__ __launch_bounds__(256) void convT3d_splitk_kernel(ConvArgs a) {
+  constexpr int RS = 17, SLOTS = 2 * 2 * RS, PS = (SLOTS + 15) / 32 * 32 + 16;
+  __shared__ float lds[16 * PS];
+  __shared__ f32x4 red[4][8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntx = (a.W + 15) / 16;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int my = bid % a.H;
+  bid /= a.H;
+  const int mz = bid % a.D;
+  const int b = bid / a.D;
+  const int x0 = tx * 16;
+  const int plane = a.D * a.H * a.W;
+  unsigned goff = 0x80000000u;
+  if (tid < SLOTS) {
+    const int sx = tid % RS, t = tid / RS, sy = t & 1, sz = t >> 1;
+    const int gx = x0 + sx, gy = my + sy, gz = mz + sz;
+    if (gx < a.W && gy < a.H && gz < a.D) goff = 4u * (unsigned)((gz * a.H + gy) * a.W + gx);
+  }
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
+  const int nk = (a.Cin + 3) / 4, nstage = (nk + 3) / 4;
+  const int cot = blockIdx.y;
+  const float* wp = a.wpack + (size_t)cot * nk * (27 * 64) + lane;
+  f32x4 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = lds + (wave * 4 + (lane >> 4)) * PS + (lane & 15);
+  for (int stage = 0; stage < nstage; ++stage) {
+    float pre[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int ch = stage * 16 + c;
+      pre[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             rsrc, ch < a.Cin ? goff + 4u * (unsigned)(ch * plane) : 0x80000000u, 0, 0));
+    }
+    const int ks = stage * 4 + wave;
+    float wv[27];
+    if (ks < nk) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t) wv[t] = wp[(size_t)ks * (27 * 64) + t * 64];
+    }
+    __syncthreads();
+    if (tid < SLOTS) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) lds[c * PS + tid] = pre[c];
+    }
+    __syncthreads();
+    if (ks < nk) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+#pragma unroll
+        for (int dz = 0; dz <= pz; ++dz)
+#pragma unroll
+          for (int dy = 0; dy <= py; ++dy)
+#pragma unroll
+            for (int dx = 0; dx <= px; ++dx) {
+              const int kz = pz ? 2 * dz : 1, oz = pz ? 1 - dz : 0;
+              const int ky = py ? 2 * dy : 1, oy = py ? 1 - dy : 0;
+              const int kx = px ? 2 * dx : 1, ox = px ? 1 - dx : 0;
+              acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[(kz * 3 + ky) * 3 + kx], ap[(oz * 2 + oy) * RS + ox],
+                                                            acc[q], 0, 0, 0);
+            }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[wave][q][lane] = acc[q];
+  __syncthreads();
+  const int q0 = 2 * wave;  // this wave finishes parities (pz, py) = (wave >> 1, wave & 1), px = 0 and 1
+  const f32x4 s0 = red[0][q0][lane] + red[1][q0][lane] + red[2][q0][lane] + red[3][q0][lane];
+  const f32x4 s1 = red[0][q0 + 1][lane] + red[1][q0 + 1][lane] + red[2][q0 + 1][lane] + red[3][q0 + 1][lane];
+  const int m = x0 + (lane & 15);
+  const int co0 = cot * 16 + 4 * (lane >> 4);
+  if (m >= a.W || co0 >= a.Cout) return;
+  const size_t cs = (size_t)a.Do * a.Ho * a.Wo;
+  const size_t o = ((((size_t)b * a.Cout + co0) * a.Do + 2 * mz + (wave >> 1)) * a.Ho + 2 * my + (wave & 1)) * a.Wo + 2 * m;
+  float2 sk[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    sk[j] = (a.skip && co0 + j < a.Cout) ? *reinterpret_cast<const float2*>(a.skip + o + j * cs) : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (co0 + j >= a.Cout) continue;
+    float v0 = s0[j] + a.bias[co0 + j], v1 = s1[j] + a.bias[co0 + j];
+    v0 = fmaxf(v0, 0.f) + a.slope * fminf(v0, 0.f), v1 = fmaxf(v1, 0.f) + a.slope * fminf(v1, 0.f);
+    *reinterpret_cast<float2*>(a.out + o + j * cs) = make_float2(v0 + sk[j].x, v1 + sk[j].y);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Launch selection.  Big tiles (R rows per wave, all cout tiles of a layer in one block so the LDS tile is
 // shared) when they still give every CU a few blocks; otherwise small tiles, one cout tile per block
@@ -648,7 +744,10 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
     launch_convT<1, 4, 1>(a, st);
   else if (convT_blocks<1, 2, 1>(a) >= kEnoughBlocks)
     launch_convT<1, 2, 1>(a, st);
-  else
+  else if (Cin >= 16 && splitk_enabled()) {
+    dim3 grid(cdiv(W, 16) * H * D * B, cdiv(Cout, 16));
+    hipLaunchKernelGGL(convT3d_splitk_kernel, grid, dim3(256), 0, st, a);
+  } else
     launch_convT<1, 1, 2>(a, st);
   BMV_LAUNCH_END("convT3d_fwd");
 }
