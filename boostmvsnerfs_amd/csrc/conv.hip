@@ -132,14 +132,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < T::NSLOT; ++j)
         if ((j + 1) * 256 <= T::SLOTS || tid + 256 * j < T::SLOTS) lds[c * T::PS + tid + 256 * j] = pre[c][j];
+    // Row-paired kernels (36 taps) read the k-step's weights straight from L2 / L1 -- issued before the barrier,
+    // consumed after it: a register double-buffer for them costs 36 VGPRs = one resident workgroup per CU (measured
+    // +1 % frames/s without it).  The 27-tap kernels keep the double-buffer (measured -0.3 % without).
     float wv[T::TAPS];
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int t = 0; t < T::TAPS; ++t) wv[t] = wnext[t];
+      for (int t = 0; t < T::TAPS; ++t) wv[t] = wp[(size_t)chunk * (T::TAPS * 64) + t * 64];
+    } else {
+#pragma unroll
+      for (int t = 0; t < T::TAPS; ++t) wv[t] = wnext[t];
+    }
     __syncthreads();
-    if (chunk + 1 < nchunk) {  // next tile and next weights are in flight during the MFMAs below
+    if (chunk + 1 < nchunk) {  // the next tile (and weights) are in flight during the MFMAs below
       load_tile(chunk + 1);
+      if constexpr (!PAIR) {
 #pragma unroll
-      for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[(size_t)(chunk + 1) * (T::TAPS * 64) + t * 64];
+        for (int t = 0; t < T::TAPS; ++t) wnext[t] = wp[(size_t)(chunk + 1) * (T::TAPS * 64) + t * 64];
+      }
     }
     if constexpr (PAIR) {
 #pragma unroll
