@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int p = 0; p < R / 2; ++p)
               acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + 2 * p + j) * T::RS + kw], acc[p], 0,
                                                             0, 0);
+            // keep the accumulators rotating (the scheduler otherwise chains 3-4 MFMAs on one accumulator, each
+            // waiting out the 40-cycle dependent latency); memory instructions may still move across
+            __builtin_amdgcn_sched_barrier(0x0090);
           }
     } else {
 #pragma unroll
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int r = 0; r < R; ++r)
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r],
                                                             0, 0, 0);
+            if constexpr (R <= 4) __builtin_amdgcn_sched_barrier(0x0090);   // as above: few accumulators, keep them rotating
           }
     }
   }
