@@ -77,8 +77,10 @@ def parse():
                     help="N>1, views sharding: wait for each frame's all-gather before rendering the next frame")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
-    ap.add_argument("--miopen-find", type=int, default=1,
-                    help="1: let MIOpen search its convolution solvers once (torch.backends.cudnn.benchmark)")
+    ap.add_argument("--miopen-find", type=int, default=0,
+                    help="1: let MIOpen search its convolution solvers (torch.backends.cudnn.benchmark).  Only the "
+                         "training workloads still run convolutions on MIOpen (inference uses csrc/conv.hip), and "
+                         "its search for the 3-D fp32 backward solvers takes > 15 min: off by default")
     return ap.parse_args()
 
 
@@ -163,7 +165,7 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # the CNN stacks run on MIOpen
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # training-mode convolutions run on MIOpen
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
