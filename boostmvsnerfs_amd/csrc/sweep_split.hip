@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(256) sweep_split_kernel(const float* __restric
   const size_t cstride = (size_t)D * hw;
   using i32x4 = __attribute__((ext_vector_type(4))) int;
 
+#pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (r >= rows_left) break;  // wave-uniform
+    if (r >= rows_left) continue;  // wave-uniform
     float4 acc[QPL], acc2[QPL];
 #pragma unroll
     for (int p = 0; p < QPL; ++p) acc[p] = acc2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
