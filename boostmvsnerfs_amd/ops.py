@@ -27,6 +27,18 @@ def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):
     return out
 
 
+def make_rays(tar_ext, tar_ixt, H, W, scale=1.0):
+    """batch['rays_i'] of the full-image branch of `build_rays` (lib/datasets/enerf_utils.py:25-31, 62-71), built on
+    the device from the target camera: (B, int(H*scale) * int(W*scale), 8) = [origin | direction | x, y]."""
+    B = tar_ext.shape[0]
+    h, w = int(H * scale), int(W * scale)
+    rays = torch.empty(B, h * w, 8, device=tar_ext.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_make_rays(dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), B, int(H), int(W),
+                                 float(scale), dptr(rays), stream()), "make_rays")
+    return rays
+
+
 def depth_values_uniform(near_far, D, h, w, depth_inv):
     B = near_far.shape[0]
     dv = torch.empty(B, D, h, w, device=near_far.device, dtype=torch.float32)

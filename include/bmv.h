@@ -317,6 +317,13 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
                         int Cf, int C, int H, int W, bmv_stream_t stream);
 
+/* ==== section 8(f) rank 4: target rays on the device ======================================================
+ * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,
+ * tar_ixt (B,3,3), render scale -> rays (B, h*w, 8) = [origin | direction | x, y], h = int(H*scale), w = int(W*scale):
+ * the layout of batch['rays_i'].  float64 inside like the numpy original, rounded to float32 once. */
+int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int H, int W, float scale, float* rays,
+                  bmv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,23 @@ def test_sweep_kernels_agree_at_scale(ops, level):
             continue
         got = ops.sweep_variance(fd, Pd, dvd, algo=algo)
         assert_close(got, want, name=f"level {level} algo {algo}")
+
+
+def test_make_rays_matches_the_dataset_ray_builder():
+    """bmv_make_rays vs the numpy restatement of `build_rays` (lib/datasets/enerf_utils.py:25-31, 62-71) the synthetic
+    batches are built with: both render scales, two different target cameras in one batch."""
+    import numpy as np
+    from boostmvsnerfs_amd import ops
+    from boostmvsnerfs_amd.synthetic import make_batch, make_rays
+    H, W = 96, 160
+    b = make_batch(H, W, n_views=3, seed=3, B=2)
+    ext, ixt = b["tar_ext"].numpy().astype(np.float64), b["tar_ixt"].numpy().astype(np.float64)
+    for scale in (1.0, 0.25):
+        got = ops.make_rays(b["tar_ext"].to(DEV), b["tar_ixt"].to(DEV), H, W, scale).cpu()
+        want = torch.from_numpy(np.stack([make_rays(ext[i], ixt[i], H, W, scale) for i in range(2)]))
+        assert got.shape == want.shape == (2, int(H * scale) * int(W * scale), 8)
+        assert torch.equal(got[..., 6:], want[..., 6:])                       # pixel coordinates
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+        # and they are what the batch carries
+        key = "rays_1" if scale == 1.0 else "rays_0"
+        assert float((got - b[key]).abs().max()) <= 1e-6 * float(want.abs().max())
