@@ -84,7 +84,7 @@ SIGNATURES = {
     "bmv_conv_pairs_rows": [c_i, c_i, c_i, c_i],
     "bmv_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f],
     "bmv_conv3d_transpose_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
-    "bmv_fpn_topdown_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "bmv_fpn_topdown_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "bmv_make_rays": [c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f],
     "bmv_composite_bwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f],
     "bmv_blend_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],

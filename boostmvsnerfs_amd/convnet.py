@@ -88,10 +88,13 @@ def fpn_topdown(fine, coarse, weight, bias, out=None):
     if out is None:
         out = torch.empty(B, C, H, W, device=fine.device, dtype=torch.float32)
     w = weight.detach().reshape(C, Cf).contiguous()
+    # a (B,C,h,w) view of a channel-last (B,h,w,C) buffer is read in place (the coarsest FPN map exists only so)
+    cl = (not coarse.is_contiguous()) and coarse.permute(0, 2, 3, 1).is_contiguous()
+    coarse_mem = coarse.permute(0, 2, 3, 1) if cl else coarse.contiguous()
     lib = _lib.load()
     with ktimer.region(f"fpn_topdown[{Cf}->{C},{H}x{W}]"):
-        rc = lib.bmv_fpn_topdown_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"), dptr(w, "w"),
-                                     dptr(bias.detach().contiguous(), "bias"), dptr(out), B, Cf, C, H, W, stream())
+        rc = lib.bmv_fpn_topdown_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse_mem, "coarse"), dptr(w, "w"),
+                                     dptr(bias.detach().contiguous(), "bias"), dptr(out), B, Cf, C, H, W, int(cl), stream())
     _lib.check(rc, "fpn_topdown_fwd")
     return out
 

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
 // Memory-bound (writes 32 channels per pixel); a thread owns one pixel and walks the output channels, the
 // 1x1 weights are wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------------------
-template <int CF>
+template <int CF, bool COARSE_CL>
 __global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int C, int H, int W) {
@@ -398,7 +398,14 @@ __global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restric
     float v = bias[c];
 #pragma unroll
     for (int i = 0; i < CF; ++i) v = fmaf(w[c * CF + i], f[i], v);
-    v += upsample_fetch(coarse + ((size_t)b * C + c) * hwc, Wc, ly, lx);
+    if constexpr (COARSE_CL) {   // coarse is (B, Hc, Wc, C): the channel-last map the plane sweep reads
+      const float* cp = coarse + (size_t)b * hwc * C + c;
+      const size_t sC = (size_t)C;
+      v += ly.l0 * (lx.l0 * cp[(ly.i0 * Wc + lx.i0) * sC] + lx.l1 * cp[(ly.i0 * Wc + lx.i1) * sC]) +
+           ly.l1 * (lx.l0 * cp[(ly.i1 * Wc + lx.i0) * sC] + lx.l1 * cp[(ly.i1 * Wc + lx.i1) * sC]);
+    } else {
+      v += upsample_fetch(coarse + ((size_t)b * C + c) * hwc, Wc, ly, lx);
+    }
     out[((size_t)b * C + c) * hw + (size_t)y * W + x] = v;
   }
 }
@@ -767,16 +774,20 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
 }
 
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
-                        int Cf, int C, int H, int W, bmv_stream_t stream) {
+                        int Cf, int C, int H, int W, int coarse_channels_last, bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(fine && coarse && w && bias && out, "fpn_topdown: null pointer");
   BMV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_topdown: bad shape");
   dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
   hipStream_t st = as_stream(stream);
-  if (Cf == 8)
-    hipLaunchKernelGGL(fpn_topdown_kernel<8>, grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+  if (Cf == 8 && !coarse_channels_last)
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+  else if (Cf == 16 && !coarse_channels_last)
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+  else if (Cf == 8)
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
   else if (Cf == 16)
-    hipLaunchKernelGGL(fpn_topdown_kernel<16>, grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");

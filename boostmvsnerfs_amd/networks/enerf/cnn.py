@@ -117,8 +117,9 @@ class FeatureNet(nn.Module):
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias)})
 
     def engine_bottom_up(self, x):
-        """Encoder + top layer: (c0, c1, p2 planar, p2 channel-last).  The coarsest map is all the level-0 cost
-        volume needs, so a caller can start that cascade level while `engine_top_down` is still running."""
+        """Encoder + top layer: (c0, c1, p2, p2) with p2 a (N,32,H/4,W/4) view of the channel-last buffer the level-0
+        sweep reads.  The coarsest map is all the level-0 cost volume needs, so a caller can start that cascade level
+        while `engine_top_down` is still running."""
         P = self._blobs()
         c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
         c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
@@ -126,9 +127,9 @@ class FeatureNet(nn.Module):
         c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
         c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
-        p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1)
-        p2_cl = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True)
-        return c0, c1, p2, p2_cl.permute(0, 3, 1, 2)
+        # the coarsest map is written once, channel-last (the level-0 sweep's layout); the top-down step reads it so
+        p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
+        return c0, c1, p2, p2
 
     def engine_top_down(self, c0, c1, p2):
         """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar)."""

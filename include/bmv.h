@@ -313,9 +313,10 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
                     int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream);
 
 /* FPN top-down step (feature_net.py:24-36 `_upsample_add` + lat1 / lat0):
- * out (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2), align_corners=True) + conv1x1(fine (B,Cf,H,W); w (C,Cf)) + bias */
+ * out (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2), align_corners=True) + conv1x1(fine (B,Cf,H,W); w (C,Cf)) + bias;
+ * coarse_channels_last: coarse is (B,H/2,W/2,C) (the coarsest map is kept only in the sweep's layout) */
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
-                        int Cf, int C, int H, int W, bmv_stream_t stream);
+                        int Cf, int C, int H, int W, int coarse_channels_last, bmv_stream_t stream);
 
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,
