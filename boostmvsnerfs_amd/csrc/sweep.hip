@@ -335,8 +335,16 @@ int bmv_sweep_lds_launch(const float* feats, const float* proj, const float* dv,
                          int D, int h, int w, float* out, int shape, hipStream_t stream);
 int bmv_sweep_split_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                            int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
+int bmv_sweep_win_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
+                         int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
+                         hipStream_t stream);
 // split-geometry kernel (sweep_split.hip) by default: 26.9 / 27.4 us vs 31.4 / 29.0 us (level 0 / 1, config 2);
 // BMV_SWEEP_SPLIT=0 selects the all-quad-layout kernel of sweep_tiled.hip
+// windowed kernel (sweep_win.hip) first unless BMV_SWEEP_WIN=0
+static bool prefer_win() {
+  static const bool v = !(getenv("BMV_SWEEP_WIN") && atoi(getenv("BMV_SWEEP_WIN")) == 0);
+  return v;
+}
 static bool prefer_split() {
   static const bool v = !(getenv("BMV_SWEEP_SPLIT") && atoi(getenv("BMV_SWEEP_SPLIT")) == 0);
   return v;
@@ -349,7 +357,10 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
   BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_views_fwd: bad shape");
   int rc = BMV_ERR_UNSUPPORTED;
-  if (prefer_split())
+  if (prefer_win())
+    rc = bmv_sweep_win_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
+                              as_stream(stream));
+  if (rc == BMV_ERR_UNSUPPORTED && prefer_split())
     rc = bmv_sweep_split_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
                                 as_stream(stream));
   if (rc == BMV_ERR_UNSUPPORTED)
@@ -368,7 +379,8 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
   BMV_REQUIRE(B > 0 && S > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_fwd: bad shape");
   BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
-  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) || ((algo == 2 || algo == 3) && feat_layout == 1),
+  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) ||
+                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || (algo >= 40 && algo < 100)) && feat_layout == 1),
               "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d", algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
   if (feat_layout == 1) {
@@ -387,7 +399,15 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
       }
     }
     rc = BMV_ERR_UNSUPPORTED;
-    if (prefer_split())
+    if (algo == 4 || algo >= 40 || (algo == 0 && prefer_win())) {   // LDS-staged exact windows (sweep_win.hip)
+      rc = bmv_sweep_win_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                algo >= 40 ? algo - 40 : -1, as_stream(stream));
+      if (rc != BMV_ERR_UNSUPPORTED || algo != 0) {
+        if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: windowed sweep does not cover this shape / variant");
+        return rc;
+      }
+    }
+    if (prefer_split() || algo == 5)
       rc = bmv_sweep_split_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
                                   as_stream(stream));
     if (rc == BMV_ERR_UNSUPPORTED)   // (source maps beyond the split kernel's 28-bit tap offsets, or BMV_SWEEP_SPLIT=0)

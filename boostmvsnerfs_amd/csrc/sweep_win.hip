@@ -1,0 +1,510 @@
+// Plane sweep with LDS-staged source windows (a3+a4, channel-last features, C in {16, 32}).
+// Reference: lib/networks/enerf/utils.py:57-95 (homo_warp), :324-351 (build_feature_volume).
+//
+// Why: the gather kernels (sweep_tiled.hip, sweep_split.hip) fetch every bilinear tap as its own 16-byte-per-lane
+// request through the vector L1 -- 503 MB of tap traffic per launch at config 2, which the texture path cannot move in
+// less than ~13 us whatever HBM does.  Here the texels a tile of voxels needs are copied into LDS ONCE per view by
+// LDS-DMA (coalesced row pieces of 1 KB, no VGPR round trip) and every tap is a ds_read_b128 (256 B/clk/CU).
+//
+// Decomposition.  A workgroup owns TXW x TYH target pixels x DP depth planes x 16 channels (a 32-channel level is
+// two workgroups, one per channel half: a record is then 64 of the 128 bytes of a source pixel).
+//   lane = one voxel with its 16 channels (sum / sum of squares: 32 accumulators); a wave is 64 consecutive voxels
+//          of one plane (TXW = 32: two rows of 32), so every store instruction writes whole 128-byte lines of the
+//          (B,C,D,h,w) volume and the 16-lane groups of a ds_read_b128 read neighbouring records;
+//   1. geometry: every lane projects its voxel into the S views once and keeps (first tap | share bits, 4 axis
+//      weights with the zero-padding validity folded in) per view;
+//   2. window:   the EXACT bounding box of the taps that carry weight, per view, by a DPP wave reduction + one LDS
+//      exchange (the depth hypotheses vary per pixel, so corner voxels do not bound it);
+//   3. fill:     the box goes to LDS as 16-record pieces, NB windows in flight (views are processed in turn and
+//      the fill of view s+1 runs under the blend of view s);
+//   4. blend:    16 ds_read_b128 per voxel and view; a wave with a tap outside the staged box (box larger than the
+//      LDS budget) gathers that view from global memory instead -- correctness never depends on the window;
+//   5. variance written once.
+// Bank conflicts: 16 lanes reading the same 16-byte slice of 16 neighbouring 64-byte records would hit 4 of the 16
+// four-bank groups, so slice q of record r sits at slot q ^ ((r >> 2) & 3); the DMA writes LDS linearly, so the
+// permutation is applied to the per-lane SOURCE address.
+#include <stdlib.h>
+
+#include "bmv_common.hpp"
+
+namespace bmv {
+
+namespace {
+
+__device__ __forceinline__ float4 ld4_lds(const char* base, unsigned byte) {
+  return *reinterpret_cast<const float4*>(base + byte);
+}
+
+// min and max over every 16-lane row (4 DPP steps each; the two chains fill each other's DPP wait states)
+__device__ __forceinline__ void row_min_max(float& lo, float& hi) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(lo), "+v"(hi));
+}
+// min and max over every group of 8 lanes (3 DPP steps), two pairs at once
+__device__ __forceinline__ void oct_min_max2(float& lo0, float& hi0, float& lo1, float& hi1) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+}
+
+}  // namespace
+
+struct WinArgs {
+  const float* feats;
+  const float* proj;
+  const float* dv;
+  float* out;
+  const int* view_ids;
+  int n_all, C, Hs, Ws, D, h, w;
+  int tiles_x, tyb, pgroups, chalves, cap;
+  int flags;   // ablation switches (BMV_SWEEP_WIN_FLAGS, tuning only): 1 no fill, 2 no blend, 4 no store
+};
+
+#ifndef BMV_WIN_WPE
+#define BMV_WIN_WPE 4
+#endif
+
+template <int TXW, int TYH, int DP, int S, int NB>
+__global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(BMV_WIN_WPE, 8)))
+sweep_win_kernel(const WinArgs a) {
+  constexpr int NT = TXW * TYH * DP, NW = NT / 64;
+  static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
+  static_assert((TXW * TYH) % 64 == 0, "a wave covers 64 voxels of ONE plane");
+  static_assert(8 * S <= 64, "corner lanes");
+  __shared__ float2 slots[NW];
+  extern __shared__ __attribute__((aligned(64))) char win[];  // NB windows of cap records (64 B each)
+
+  unsigned long long st[12];   // tuning: phase time stamps (flags & 64), shader clock
+#define BMV_STAMP(i)                                       \
+  if (a.flags & 64) {                                      \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    st[i] = __builtin_amdgcn_s_memtime();                  \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) st[i] = 0;
+  BMV_STAMP(0)
+  const int b = blockIdx.y;
+  const int band = blockIdx.x & 7;
+  int kk = blockIdx.x >> 3;
+  const int chh = kk % a.chalves;
+  kk /= a.chalves;
+  const int pg = kk % a.pgroups;
+  kk /= a.pgroups;
+  const int tx = kk % a.tiles_x;
+  const int ty = band * a.tyb + kk / a.tiles_x;
+  if (ty * TYH >= a.h) return;  // whole workgroup, before any barrier
+  const int C = a.C, Hs = a.Hs, Ws = a.Ws, D = a.D, h = a.h, w = a.w;
+  const unsigned REC = (unsigned)C * 4u;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = tid % TXW, ly = (tid / TXW) % TYH, ld = tid / (TXW * TYH);
+  const int x = tx * TXW + lx, y = ty * TYH + ly, d = pg * DP + ld;
+  const bool inb = (x < w) & (y < h) & (d < D);
+  const int xc = min(x, w - 1), yc = min(y, h - 1), dc = min(d, D - 1);
+  const size_t hw = (size_t)h * w;
+
+  // corner lanes (lane < 8 S): corner (lane & 7) of the tile box in (x, y, 1/depth), view lane >> 3; their
+  // projection rows are fetched now, under the latency of the depth load
+  const int cview = min(lane >> 3, S - 1);
+  float cP[12];
+  {
+    const float* Pc = a.proj + ((size_t)b * S + cview) * 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cP[j] = Pc[j];
+  }
+  const float inv_depth = __builtin_amdgcn_rcpf(a.dv[((size_t)b * D + dc) * hw + (size_t)yc * w + xc]);
+
+  // ---- 1. range of 1/depth over the workgroup
+  float ilo = inv_depth, ihi = inv_depth;
+  if (a.flags & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BMV_STAMP(1)
+  row_min_max(ilo, ihi);
+  {
+    auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    const float l0 = rl(ilo, 0), l1 = rl(ilo, 16), l2 = rl(ilo, 32), l3 = rl(ilo, 48);
+    const float h0 = rl(ihi, 0), h1 = rl(ihi, 16), h2 = rl(ihi, 32), h3 = rl(ihi, 48);
+    ilo = fminf(fminf(l0, l1), fminf(l2, l3)), ihi = fmaxf(fmaxf(h0, h1), fmaxf(h2, h3));
+  }
+  if (NW > 1) {
+    if (lane == 0) slots[wave] = make_float2(ilo, ihi);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const float2 v = slots[k];
+      ilo = fminf(ilo, v.x), ihi = fmaxf(ihi, v.y);
+    }
+  }
+
+  BMV_STAMP(2)
+  // ---- 2. tap window per view: a projected coordinate is a ratio of affine functions of (x, y, 1/depth), so over the
+  // tile's box its extremes sit on the 8 corners (as long as the box stays in front of the camera: otherwise the
+  // window is "everything", gets clipped to the LDS budget and the waves fall back to global gathers)
+  int wx[S], wy[S], wcols[S], wrows[S];
+  {
+    const int bx0 = tx * TXW, bx1 = min(bx0 + TXW, w) - 1, by0 = ty * TYH, by1 = min(by0 + TYH, h) - 1;
+    const float X = (float)((lane & 1) ? bx1 : bx0), Y = (float)((lane & 2) ? by1 : by0), I = (lane & 4) ? ihi : ilo;
+    const float px = cP[0] * X + cP[1] * Y + cP[2] + cP[3] * I;
+    const float py = cP[4] * X + cP[5] * Y + cP[6] + cP[7] * I;
+    const float pz = cP[8] * X + cP[9] * Y + cP[10] + cP[11] * I;
+    const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
+    const bool bad = !(pz > 1e-6f);
+    const float u = px * iz, v = py * iz;
+    float ulo = bad ? -INFINITY : u, uhi = bad ? INFINITY : u, vlo = bad ? -INFINITY : v, vhi = bad ? INFINITY : v;
+    oct_min_max2(ulo, uhi, vlo, vhi);
+    // texel range [floor(lo), floor(hi) + 1] with a rounding margin, clipped to the image
+    const float fWs = (float)Ws, fHs = (float)Hs;
+    const int x_lo = (int)fminf(fmaxf(floorf(ulo - 0.01f), 0.f), fWs), x_hi = (int)fminf(fmaxf(floorf(uhi + 0.01f) + 1.f, -1.f), fWs - 1.f);
+    const int y_lo = (int)fminf(fmaxf(floorf(vlo - 0.01f), 0.f), fHs), y_hi = (int)fminf(fmaxf(floorf(vhi + 0.01f) + 1.f, -1.f), fHs - 1.f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int xlo = __builtin_amdgcn_readlane(x_lo, 8 * s), xhi = __builtin_amdgcn_readlane(x_hi, 8 * s);
+      const int ylo = __builtin_amdgcn_readlane(y_lo, 8 * s), yhi = __builtin_amdgcn_readlane(y_hi, 8 * s);
+      const bool empty = (xhi < xlo) | (yhi < ylo);
+      const int wc = empty ? 0 : min(xhi - xlo + 1, a.cap);
+      const int wr = empty ? 0 : min(yhi - ylo + 1, a.cap / max(wc, 1));
+      wx[s] = empty ? 0 : xlo, wy[s] = empty ? 0 : ylo, wcols[s] = wc, wrows[s] = wr;
+    }
+  }
+
+  BMV_STAMP(3)
+  const int item_views = a.view_ids ? a.n_all : S;
+  const char* fbytes = reinterpret_cast<const char*>(a.feats + (size_t)b * item_views * Hs * Ws * C);
+  unsigned vbase[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    vbase[s] = (unsigned)(a.view_ids ? a.view_ids[b * S + s] : s) * (unsigned)(Hs * Ws) * REC + (unsigned)chh * 64u;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(fbytes), 0, (int)((size_t)item_views * Hs * Ws * REC), 0x00020000);
+
+  // ---- 3. fill: piece p = records [16p, 16p + 16) of the row-major window; lane = (record, slot).  Reads past the
+  // window stay inside the buffer descriptor (or return 0) and land in LDS nobody reads.
+  const int lrec = lane >> 2;
+  const unsigned lslice = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;  // slice stored at this lane's slot
+  auto issue_fill = [&](int s, int buf) {
+    const int wc = wcols[s], ntex = wc * wrows[s];
+    if (ntex == 0 || (a.flags & 1)) return;
+    const int npieces = (ntex + 15) >> 4;
+    const unsigned origin = vbase[s] + (unsigned)(wy[s] * Ws + wx[s]) * REC + lslice;
+    char* dst = win + (size_t)buf * a.cap * 64;
+    // (row, col) of this lane's record in the wave's first piece, then advanced by 16 NW records per piece
+    int L = wave * 16 + lrec;
+    int row = (int)((float)L * (1.f / (float)wc));
+    int col = L - row * wc;
+    if (col >= wc) col -= wc, ++row;
+    if (col < 0) col += wc, --row;
+    const int drow = (16 * NW) / wc, dcol = (16 * NW) - drow * wc;   // scalar
+    for (int p = wave; p < npieces; p += NW) {
+      const unsigned off = origin + (unsigned)(row * Ws + col) * REC;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, (int)off, 0,
+                                           0, 0);
+      col += dcol, row += drow;
+      if (col >= wc) col -= wc, ++row;
+    }
+  };
+
+  // ---- 4. geometry of this voxel in every view
+  unsigned og[S];            // cx | cy << 14 | share-x << 28 | share-y << 29 | no-tap << 31
+  float wx0[S], wx1[S], wy0[S], wy1[S];
+  {
+    const float fx = (float)xc, fy = (float)yc;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float* P = a.proj + ((size_t)b * S + s) * 12;
+      const float px = P[0] * fx + P[1] * fy + P[2] + P[3] * inv_depth;
+      const float py = P[4] * fx + P[5] * fy + P[6] + P[7] * inv_depth;
+      const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] * inv_depth;
+      const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
+      // uv / ((W-1)/2) - 1 followed by grid_sample's ((g+1)/2) (W-1) is the identity up to rounding
+      const float ix = px * iz, iy = py * iz;
+      const float flx = floorf(ix), fly = floorf(iy);
+      // clamp before the int conversion (also maps NaN into range): anything outside ends with both taps invalid
+      const int tx0 = (int)__builtin_amdgcn_fmed3f(flx, -2.f, (float)Ws), ty0 = (int)__builtin_amdgcn_fmed3f(fly, -2.f, (float)Hs);
+      const bool vx0 = ((unsigned)tx0 < (unsigned)Ws) & inb, vx1 = ((unsigned)(tx0 + 1) < (unsigned)Ws) & inb;
+      const bool vy0 = (unsigned)ty0 < (unsigned)Hs, vy1 = (unsigned)(ty0 + 1) < (unsigned)Hs;
+      const float ax = ix - flx, ay = iy - fly, ex = 1.f - ax, ey = 1.f - ay;
+      wx0[s] = vx0 ? ex : 0.f, wx1[s] = vx1 ? ax : 0.f;
+      wy0[s] = vy0 ? ey : 0.f, wy1[s] = vy1 ? ay : 0.f;
+      const bool any = (vx0 | vx1) & (vy0 | vy1);
+      // a tap outside the image has weight 0 and is parked on its in-image neighbour
+      const int cx = vx0 ? tx0 : tx0 + 1, cy = vy0 ? ty0 : ty0 + 1;
+      const unsigned bits = ((vx0 & vx1) ? 1u << 28 : 0u) | ((vy0 & vy1) ? 1u << 29 : 0u);
+      og[s] = any ? ((unsigned)cx | (unsigned)cy << 14 | bits) : 0x80000000u;
+    }
+  }
+
+  BMV_STAMP(4)
+  float4 acc[4], acc2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = acc2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+  auto blend = [&](int q, float4 t00, float4 t01, float4 t10, float4 t11, float w00, float w01, float w10,
+                   float w11) {
+    float4 v;
+    v.x = t00.x * w00 + t01.x * w01 + t10.x * w10 + t11.x * w11;
+    v.y = t00.y * w00 + t01.y * w01 + t10.y * w10 + t11.y * w11;
+    v.z = t00.z * w00 + t01.z * w01 + t10.z * w10 + t11.z * w11;
+    v.w = t00.w * w00 + t01.w * w01 + t10.w * w10 + t11.w * w11;
+    acc[q].x += v.x, acc[q].y += v.y, acc[q].z += v.z, acc[q].w += v.w;
+    acc2[q].x += v.x * v.x, acc2[q].y += v.y * v.y, acc2[q].z += v.z * v.z, acc2[q].w += v.w * v.w;
+  };
+
+  auto compute = [&](int s, int buf) {
+    if (a.flags & 2) return;
+    const unsigned o = og[s];
+    const bool any = (int)o >= 0;
+    if (!__any(any)) return;   // no voxel of the wave sees this view: it contributes 0 to both sums
+    const int wc = wcols[s];
+    const int rx = any ? (int)(o & 0x3fffu) - wx[s] : 0, ry = any ? (int)((o >> 14) & 0x3fffu) - wy[s] : 0;
+    const int shx = (int)((o >> 28) & 1u), shy = (int)((o >> 29) & 1u);
+    const float w00 = wx0[s] * wy0[s], w01 = wx1[s] * wy0[s], w10 = wx0[s] * wy1[s], w11 = wx1[s] * wy1[s];
+    const bool slow = ((rx | ry) < 0) | (rx + shx >= wc) | (ry + shy >= wrows[s]);
+    if (__builtin_expect(__any(slow), 0)) {
+      if (a.flags & 16) return;
+      // a tap outside the staged box (box clipped by the LDS budget): this wave gathers the view from global memory
+      const unsigned g00 = vbase[s] + (unsigned)((ry + wy[s]) * Ws + rx + wx[s]) * REC;
+      const unsigned gdx = shx ? REC : 0u, gdy = shy ? (unsigned)Ws * REC : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        i32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g00 + 16u * q, 0, 0);
+        i32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g00 + gdx + 16u * q, 0, 0);
+        i32x4 rc = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g00 + gdy + 16u * q, 0, 0);
+        i32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g00 + gdx + gdy + 16u * q, 0, 0);
+        blend(q, *reinterpret_cast<float4*>(&ra), *reinterpret_cast<float4*>(&rb), *reinterpret_cast<float4*>(&rc),
+              *reinterpret_cast<float4*>(&rd), w00, w01, w10, w11);
+        __builtin_amdgcn_sched_barrier(0);   // one slice in flight: this path is rare, registers matter more
+      }
+    } else {
+      const unsigned boff = (unsigned)buf * (unsigned)a.cap * 64u;   // multiple of 64: commutes with the slot XOR
+      const unsigned L00 = (unsigned)(ry * wc + rx), L01 = L00 + (unsigned)shx;
+      const unsigned L10 = L00 + (shy ? (unsigned)wc : 0u), L11 = L10 + (unsigned)shx;
+      const unsigned b00 = boff + ((L00 << 6) | (((L00 >> 2) & 3u) << 4)), b01 = boff + ((L01 << 6) | (((L01 >> 2) & 3u) << 4));
+      const unsigned b10 = boff + ((L10 << 6) | (((L10 >> 2) & 3u) << 4)), b11 = boff + ((L11 << 6) | (((L11 >> 2) & 3u) << 4));
+      // two slices in flight: the reads of slice q + 1 are issued before the blend of slice q
+      float4 t00 = ld4_lds(win, b00), t01 = ld4_lds(win, b01), t10 = ld4_lds(win, b10), t11 = ld4_lds(win, b11);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 n00, n01, n10, n11;
+        if (q < 3) {
+          const unsigned m = (unsigned)(q + 1) << 4;
+          n00 = ld4_lds(win, b00 ^ m), n01 = ld4_lds(win, b01 ^ m), n10 = ld4_lds(win, b10 ^ m), n11 = ld4_lds(win, b11 ^ m);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        blend(q, t00, t01, t10, t11, w00, w01, w10, w11);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < 3) t00 = n00, t01 = n01, t10 = n10, t11 = n11;
+      }
+    }
+  };
+
+  // ---- 3+5. views in turn, NB windows in flight
+  int issued = 0, landed = 0;
+#pragma unroll
+  for (; issued < (NB < S ? NB : S); ++issued) issue_fill(issued, issued);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    if (s >= landed) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      landed = issued;
+    }
+    if (s == 0) { BMV_STAMP(5) } else if (s == 1) { BMV_STAMP(7) } else if (s == 2) { BMV_STAMP(9) }
+    compute(s, s % NB);
+    if (s == 0) { BMV_STAMP(6) } else if (s == 1) { BMV_STAMP(8) } else if (s == 2) { BMV_STAMP(10) }
+    if (issued < S && issued == s + NB) {
+      __syncthreads();  // every wave is done with window s % NB
+      issue_fill(issued, s % NB);
+      ++issued;
+    }
+  }
+
+  if (a.flags & 64) {
+    if (tid == 0) {
+      float* o = a.out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+      o[0] = (float)(unsigned)(st[0] & 0xffffffu), o[1] = (float)(unsigned)((st[0] >> 24) & 0xffffffu);
+#pragma unroll
+      for (int i = 1; i < 11; ++i) o[i + 1] = (float)(unsigned)(st[i] - st[0]);
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[12] = (float)(xcc & 0xf);
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      o[13] = (float)((hwid >> 8) & 0xf);   // CU id within the shader array
+      o[14] = (float)((hwid >> 13) & 0x7);  // SE id
+    }
+    return;
+  }
+  if (a.flags & 32) {   // debug: window of view 0 / 1 and the depth range instead of the variance
+    acc2[0] = make_float4((float)wcols[0] * S, (float)wrows[0] * S, (float)wx[0] * S, (float)wy[0] * S);
+    acc2[1] = make_float4((float)wcols[1] * S, (float)wrows[1] * S, (float)wx[1] * S, (float)wy[1] * S);
+    acc2[2] = make_float4(ilo * S, ihi * S, inv_depth * S, (float)(og[0] & 0x3fff) * S);
+    acc2[3] = make_float4((float)((og[0] >> 14) & 0x3fff) * S, (float)(og[0] >> 28) * S, wx0[0] * S, wy0[0] * S);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ---- 6. variance: scalar channel offsets, one dword per lane and channel (a wave writes whole 128-byte lines)
+  if (inb && !(a.flags & 4)) {
+    const float inv_s = 1.f / (float)S;
+    const unsigned cstride = (unsigned)(D * hw) * 4u;
+    __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + (size_t)b * C * D * hw, 0, (int)((size_t)C * D * hw * 4), 0x00020000);
+    const unsigned voff = (unsigned)((size_t)d * hw + (size_t)y * w + x) * 4u;
+    unsigned soff = (unsigned)chh * 16u * cstride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m;
+      m = acc[q].x * inv_s;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].x * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+      soff += cstride;
+      m = acc[q].y * inv_s;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].y * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+      soff += cstride;
+      m = acc[q].z * inv_s;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].z * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+      soff += cstride;
+      m = acc[q].w * inv_s;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].w * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+      soff += cstride;
+    }
+  }
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+namespace {
+
+struct Variant {
+  int txw, tyh, dp, nb, cap;
+};
+// tuning table (algo 40 + i); caps in 64-byte records, multiples of 16
+const Variant kVariants[] = {
+    {32, 8, 1, 1, 448},   // 0
+    {32, 8, 2, 1, 640},   // 1
+    {32, 8, 2, 2, 640},   // 2
+    {32, 4, 2, 1, 448},   // 3
+    {32, 4, 2, 2, 448},   // 4
+    {32, 8, 4, 1, 1024},  // 5
+    {32, 8, 4, 2, 1024},  // 6
+    {32, 2, 4, 2, 640},   // 7
+    {16, 4, 8, 1, 448},   // 8
+    {16, 4, 8, 2, 448},   // 9
+    {16, 4, 16, 1, 608},  // 10
+    {16, 4, 16, 2, 608},  // 11
+    {16, 4, 4, 2, 320},   // 12
+    {32, 2, 8, 2, 640},   // 13
+    {32, 4, 1, 1, 256},   // 14
+    {32, 2, 2, 2, 320},   // 15
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+template <int TXW, int TYH, int DP, int S, int NB>
+int launch_one(const WinArgs& a, int B, hipStream_t stream) {
+  auto kern = sweep_win_kernel<TXW, TYH, DP, S, NB>;
+  const size_t lds = (size_t)NB * a.cap * 64;
+  static size_t allowed = 0;
+  if (lds > allowed) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return BMV_ERR_UNSUPPORTED;
+    }
+    allowed = lds;
+  }
+  dim3 grid(8u * (unsigned)(a.chalves * a.pgroups * a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  return BMV_OK;
+}
+
+template <int TXW, int TYH, int DP, int NB>
+int launch_s(const WinArgs& a, int B, int S, hipStream_t stream) {
+  if (S == 3) return launch_one<TXW, TYH, DP, 3, NB>(a, B, stream);
+  if (S == 2) return launch_one<TXW, TYH, DP, 2, NB>(a, B, stream);
+  if (S == 4) return launch_one<TXW, TYH, DP, 4, NB>(a, B, stream);
+  return BMV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs,
+                                    int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
+                                    hipStream_t stream) {
+  if ((C != 16 && C != 32) || S < 2 || S > 4) return BMV_ERR_UNSUPPORTED;
+  if ((size_t)(view_ids ? n_all : S) * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;
+  if (Hs >= (1 << 14) - 2 || Ws >= (1 << 14) - 2) return BMV_ERR_UNSUPPORTED;  // 14-bit tap coordinates
+  if ((size_t)C * D * h * w * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;        // 32-bit volume offsets
+  if (variant < 0) {
+    // default by the source / volume scale: same resolution (cascade level 1: neighbours in a plane share texels)
+    // or finer source (level 0: the planes of a pixel share texels along its epipolar line)
+    variant = (float)Ws / (float)w <= 1.5f ? 2 : 9;
+  }
+  if (variant >= kNumVariants) return BMV_ERR_UNSUPPORTED;
+  Variant v = kVariants[variant];
+  if (const char* e = getenv("BMV_SWEEP_WIN_CAP")) {
+    int c = atoi(e);
+    if (c >= 16) v.cap = (c + 15) & ~15;
+  }
+  WinArgs a;
+  a.feats = feats, a.proj = proj, a.dv = dv, a.out = out, a.view_ids = view_ids, a.n_all = n_all;
+  a.C = C, a.Hs = Hs, a.Ws = Ws, a.D = D, a.h = h, a.w = w;
+  a.tiles_x = (w + v.txw - 1) / v.txw;
+  const int tiles_y = (h + v.tyh - 1) / v.tyh;
+  a.tyb = (tiles_y + 7) / 8;
+  a.pgroups = (D + v.dp - 1) / v.dp;
+  a.chalves = C / 16;
+  a.cap = v.cap;
+  a.flags = 0;
+  if (const char* e = getenv("BMV_SWEEP_WIN_FLAGS")) a.flags = atoi(e);
+  int rc = BMV_ERR_UNSUPPORTED;
+#define V(TXW, TYH, DP, NB) \
+  if (v.txw == TXW && v.tyh == TYH && v.dp == DP && v.nb == NB) rc = launch_s<TXW, TYH, DP, NB>(a, B, S, stream);
+  V(32, 8, 1, 1)
+  V(32, 8, 2, 1)
+  V(32, 8, 2, 2)
+  V(32, 4, 2, 1)
+  V(32, 4, 2, 2)
+  V(32, 8, 4, 1)
+  V(32, 8, 4, 2)
+  V(32, 2, 4, 2)
+  V(16, 4, 8, 1)
+  V(16, 4, 8, 2)
+  V(16, 4, 16, 1)
+  V(16, 4, 16, 2)
+  V(16, 4, 4, 2)
+  V(32, 2, 8, 2)
+  V(32, 4, 1, 1)
+  V(32, 2, 2, 2)
+#undef V
+  if (rc != BMV_OK) return rc;
+  BMV_LAUNCH_END("bmv_sweep_variance_fwd(win)");
+}

@@ -143,7 +143,7 @@ def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=N
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=feats.device, dtype=torch.float32)
     layout = 1 if channels_last else 0
-    if channels_last is None and algo in (0, 2, 3) and C_ in (16, 32):
+    if channels_last is None and algo != 1 and C_ in (16, 32):
         feats = nchw_to_nhwc(feats)
         layout = 1
     lib = _lib.load()

@@ -58,7 +58,9 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
  * S warped volumes.  feat_layout: 0 = feats is (B,S,C,Hs,Ws) as the reference holds it,
  * 1 = channel-last (B,S,Hs,Ws,C) (bmv_nchw_to_nhwc converts).  algo: 0 = best kernel for
  * the layout, 1 = reference-layout direct gather (feat_layout 0), 2 = channel-last direct
- * gather, 3 = channel-last LDS-staged windows (2 and 3 need feat_layout 1). */
+ * gather, 3 = channel-last LDS-staged corner windows (round 1), 4 = channel-last LDS-staged exact windows
+ * (sweep_win.hip: the default for C in {16, 32}), 5 = channel-last split-geometry gather; 40 + i = tuning variant i of
+ * algo 4 (2..5 and 40+ need feat_layout 1). */
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
                            bmv_stream_t stream);

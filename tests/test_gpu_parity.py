@@ -203,6 +203,11 @@ def test_sweep_extreme_coordinates(ops):
     dv = torch.full((1, 4, 8, 10), 1e-9, device=DEV)
     var = ops.sweep_variance(feats, proj, dv, algo=1)
     assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
+    # channel-last kernels (16 channels): the windowed kernel sees an EMPTY tap box for every view
+    feats16 = torch.randn(1, 3, 16, 16, 20, device=DEV)
+    for algo in (4, 5, 2):
+        var = ops.sweep_variance(feats16, proj, dv, algo=algo)
+        assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0, algo
 
 
 @pytest.mark.parametrize("level", [0, 1])
@@ -226,13 +231,42 @@ def test_sweep_kernels_agree_at_scale(ops, level):
         dv = (3.0 + 2.0 * torch.rand(1, 1, h, w) + torch.linspace(-1.5, 1.5, cfgl["D"]).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
     fd, Pd, dvd = feats.to(DEV), P.to(DEV), dv.to(DEV)
-    for algo in (1, 2, 3, 0):
+    for algo in (1, 2, 3, 4, 5, 0) + tuple(range(40, 56)):
         if algo == 3 and level == 0:
             with pytest.raises(RuntimeError, match="LDS sweep does not cover"):
                 ops.sweep_variance(fd, Pd, dvd, algo=3)      # 2x source scale stays on the gather kernel
             continue
         got = ops.sweep_variance(fd, Pd, dvd, algo=algo)
         assert_close(got, want, name=f"level {level} algo {algo}")
+    # windowed kernel with an LDS budget far below the tap boxes: clipped windows + the global fallback per wave
+    import os
+    os.environ["BMV_SWEEP_WIN_CAP"] = "48"
+    try:
+        for algo in (4, 41, 49):
+            assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} algo {algo} cap 48")
+    finally:
+        del os.environ["BMV_SWEEP_WIN_CAP"]
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 16, 37, 53, 5, 19, 45), (2, 4, 32, 40, 24, 7, 21, 13), (1, 3, 16, 9, 7, 3, 33, 70)])
+def test_sweep_windowed_ragged_shapes(ops, shape):
+    """Windowed kernel on sizes that are not multiples of its tiles (partial tiles in x, y and planes), 2 and 4
+    views, batch 2, a source smaller than one window piece, vs the CPU oracle."""
+    from oracle import enerf as O
+    B, S, C, Hs, Ws, D, h, w = shape
+    torch.manual_seed(sum(shape))
+    feats = torch.randn(B, S, C, Hs, Ws)
+    P = torch.zeros(B, S, 3, 4)
+    for b in range(B):
+        for s in range(S):
+            sx, sy = Ws / w, Hs / h
+            P[b, s] = torch.tensor([[sx, 0.05 * s, 0.3 * s, 4.0 * (s - 1)], [-0.04 * s, sy, 0.2 * b, 3.0 * (1 - s)],
+                                    [0.0, 0.0, 1.0, 0.05 * s]])
+    dv = (2.0 + torch.rand(B, 1, h, w) + torch.linspace(0.0, 3.0, D).view(1, -1, 1, 1)).contiguous()
+    want = O.variance_volume(feats, P, dv)
+    for algo in (4, 40, 42, 46, 49, 51, 5):
+        got = ops.sweep_variance(feats.to(DEV), P.to(DEV), dv.to(DEV), algo=algo)
+        assert_close(got, want, name=f"shape {shape} algo {algo}")
 
 
 def test_make_rays_matches_the_dataset_ray_builder():
