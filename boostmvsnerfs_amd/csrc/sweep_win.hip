@@ -83,11 +83,15 @@ struct WinArgs {
   const int* view_ids;
   int n_all, C, Hs, Ws, D, h, w;
   int tiles_x, tyb, pgroups, chalves, cap;
+  unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1: n / tiles_x = umulhi(n, magic) for n < 2^16
   int flags;   // ablation switches (BMV_SWEEP_WIN_FLAGS, tuning only): 1 no fill, 2 no blend, 4 no store
 };
 
 #ifndef BMV_WIN_WPE
 #define BMV_WIN_WPE 4
+#endif
+#ifndef BMV_WIN_TAPBUF
+#define BMV_WIN_TAPBUF 2
 #endif
 
 template <int TXW, int TYH, int DP, int S, int NB>
@@ -101,24 +105,30 @@ sweep_win_kernel(const WinArgs a) {
   extern __shared__ __attribute__((aligned(64))) char win[];  // NB windows of cap records (64 B each)
 
   unsigned long long st[12];   // tuning: phase time stamps (flags & 64), shader clock
+#ifdef BMV_WIN_STAMPS
 #define BMV_STAMP(i)                                       \
   if (a.flags & 64) {                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
     st[i] = __builtin_amdgcn_s_memtime();                  \
     __builtin_amdgcn_sched_barrier(0);                     \
   }
+#else
+#define BMV_STAMP(i)
+#endif
 #pragma unroll
   for (int i = 0; i < 12; ++i) st[i] = 0;
   BMV_STAMP(0)
-  const int b = blockIdx.y;
+  // grid = (8 bands x channel halves x plane groups, tile columns x tile rows of a band, batch); blockIdx.x % 8 = the
+  // band = the XCD whose L2 holds that band's source rows.  The scalar unit is shared by the whole CU: no integer
+  // divisions here (a runtime s_div is ~40 scalar instructions), only shifts and one multiply-high
+  const int b = blockIdx.z;
   const int band = blockIdx.x & 7;
-  int kk = blockIdx.x >> 3;
-  const int chh = kk % a.chalves;
-  kk /= a.chalves;
-  const int pg = kk % a.pgroups;
-  kk /= a.pgroups;
-  const int tx = kk % a.tiles_x;
-  const int ty = band * a.tyb + kk / a.tiles_x;
+  const int kx = blockIdx.x >> 3;
+  const int chh = kx & (a.chalves - 1);          // chalves is 1 or 2
+  const int pg = kx >> (a.chalves - 1);
+  const int j = (int)__umulhi((unsigned)blockIdx.y, (unsigned)a.tiles_x_magic);   // blockIdx.y / tiles_x
+  const int tx = blockIdx.y - j * a.tiles_x;
+  const int ty = band * a.tyb + j;
   if (ty * TYH >= a.h) return;  // whole workgroup, before any barrier
   const int C = a.C, Hs = a.Hs, Ws = a.Ws, D = a.D, h = a.h, w = a.w;
   const unsigned REC = (unsigned)C * 4u;
@@ -145,7 +155,9 @@ sweep_win_kernel(const WinArgs a) {
 
   // ---- 1. range of 1/depth over the workgroup
   float ilo = inv_depth, ihi = inv_depth;
+#ifdef BMV_WIN_STAMPS
   if (a.flags & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   BMV_STAMP(1)
   row_min_max(ilo, ihi);
   {
@@ -168,7 +180,7 @@ sweep_win_kernel(const WinArgs a) {
   // ---- 2. tap window per view: a projected coordinate is a ratio of affine functions of (x, y, 1/depth), so over the
   // tile's box its extremes sit on the 8 corners (as long as the box stays in front of the camera: otherwise the
   // window is "everything", gets clipped to the LDS budget and the waves fall back to global gathers)
-  int wx[S], wy[S], wcols[S], wrows[S];
+  int wx[S], wy[S], wcols[S], wrows[S], wdrow[S], wdcol[S];
   {
     const int bx0 = tx * TXW, bx1 = min(bx0 + TXW, w) - 1, by0 = ty * TYH, by1 = min(by0 + TYH, h) - 1;
     const float X = (float)((lane & 1) ? bx1 : bx0), Y = (float)((lane & 2) ? by1 : by0), I = (lane & 4) ? ihi : ilo;
@@ -180,18 +192,27 @@ sweep_win_kernel(const WinArgs a) {
     const float u = px * iz, v = py * iz;
     float ulo = bad ? -INFINITY : u, uhi = bad ? INFINITY : u, vlo = bad ? -INFINITY : v, vhi = bad ? INFINITY : v;
     oct_min_max2(ulo, uhi, vlo, vhi);
-    // texel range [floor(lo), floor(hi) + 1] with a rounding margin, clipped to the image
+    // texel range [floor(lo), floor(hi) + 1] with a rounding margin, clipped to the image; clipped to the LDS budget;
+    // all on the corner lanes (vector ALU), the scalar unit only receives the results
     const float fWs = (float)Ws, fHs = (float)Hs;
     const int x_lo = (int)fminf(fmaxf(floorf(ulo - 0.01f), 0.f), fWs), x_hi = (int)fminf(fmaxf(floorf(uhi + 0.01f) + 1.f, -1.f), fWs - 1.f);
     const int y_lo = (int)fminf(fmaxf(floorf(vlo - 0.01f), 0.f), fHs), y_hi = (int)fminf(fmaxf(floorf(vhi + 0.01f) + 1.f, -1.f), fHs - 1.f);
+    const bool empty = (x_hi < x_lo) | (y_hi < y_lo);
+    const int wc_l = empty ? 0 : min(x_hi - x_lo + 1, a.cap);
+    int fit = (int)((float)a.cap * __builtin_amdgcn_rcpf((float)max(wc_l, 1)));   // cap / wc, fixed up below
+    fit += ((fit + 1) * wc_l <= a.cap) ? 1 : 0;
+    fit -= (fit * wc_l > a.cap) ? 1 : 0;
+    const int wr_l = empty ? 0 : min(y_hi - y_lo + 1, fit);
+    // per piece a wave's records advance by 16 NW: (rows, columns) of that step
+    int drow_l = (int)((float)(16 * NW) * __builtin_amdgcn_rcpf((float)max(wc_l, 1)));
+    drow_l += ((drow_l + 1) * wc_l <= 16 * NW) ? 1 : 0;
+    drow_l -= (drow_l * wc_l > 16 * NW) ? 1 : 0;
+    const int dcol_l = 16 * NW - drow_l * wc_l;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      const int xlo = __builtin_amdgcn_readlane(x_lo, 8 * s), xhi = __builtin_amdgcn_readlane(x_hi, 8 * s);
-      const int ylo = __builtin_amdgcn_readlane(y_lo, 8 * s), yhi = __builtin_amdgcn_readlane(y_hi, 8 * s);
-      const bool empty = (xhi < xlo) | (yhi < ylo);
-      const int wc = empty ? 0 : min(xhi - xlo + 1, a.cap);
-      const int wr = empty ? 0 : min(yhi - ylo + 1, a.cap / max(wc, 1));
-      wx[s] = empty ? 0 : xlo, wy[s] = empty ? 0 : ylo, wcols[s] = wc, wrows[s] = wr;
+      wx[s] = __builtin_amdgcn_readlane(empty ? 0 : x_lo, 8 * s), wy[s] = __builtin_amdgcn_readlane(empty ? 0 : y_lo, 8 * s);
+      wcols[s] = __builtin_amdgcn_readlane(wc_l, 8 * s), wrows[s] = __builtin_amdgcn_readlane(wr_l, 8 * s);
+      wdrow[s] = __builtin_amdgcn_readlane(drow_l, 8 * s), wdcol[s] = __builtin_amdgcn_readlane(dcol_l, 8 * s);
     }
   }
 
@@ -208,91 +229,118 @@ sweep_win_kernel(const WinArgs a) {
   // ---- 3. fill: piece p = records [16p, 16p + 16) of the row-major window; lane = (record, slot).  Reads past the
   // window stay inside the buffer descriptor (or return 0) and land in LDS nobody reads.
   const int lrec = lane >> 2;
-  const unsigned lslice = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;  // slice stored at this lane's slot
+  // slice q of window record r sits at slot q ^ ((r >> 2) & 3); a piece starts at a multiple of 16 records, so the
+  // slice this lane fetches for its slot (lane & 3) is the same for every piece
+  const unsigned lslice = (unsigned)((lane ^ (lane >> 4)) & 3) * 16u;
   auto issue_fill = [&](int s, int buf) {
     const int wc = wcols[s], ntex = wc * wrows[s];
     if (ntex == 0 || (a.flags & 1)) return;
     const int npieces = (ntex + 15) >> 4;
-    const unsigned origin = vbase[s] + (unsigned)(wy[s] * Ws + wx[s]) * REC + lslice;
     char* dst = win + (size_t)buf * a.cap * 64;
-    // (row, col) of this lane's record in the wave's first piece, then advanced by 16 NW records per piece
-    int L = wave * 16 + lrec;
+    // (row, col) of this lane's record in the wave's first piece; per piece the record index advances by 16 NW =
+    // (drow, dcol) of the window, i.e. by a constant byte step plus one extra row whenever the column wraps
+    const int L = wave * 16 + lrec;
     int row = (int)((float)L * (1.f / (float)wc));
     int col = L - row * wc;
     if (col >= wc) col -= wc, ++row;
     if (col < 0) col += wc, --row;
-    const int drow = (16 * NW) / wc, dcol = (16 * NW) - drow * wc;   // scalar
+    unsigned off = vbase[s] + (unsigned)((wy[s] + row) * Ws + wx[s] + col) * REC + lslice;
+    const unsigned step = (unsigned)(wdrow[s] * Ws + wdcol[s]) * REC, wrap = (unsigned)(Ws - wc) * REC;
+    const int dcol = wdcol[s];
     for (int p = wave; p < npieces; p += NW) {
-      const unsigned off = origin + (unsigned)(row * Ws + col) * REC;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, (int)off, 0,
-                                           0, 0);
-      col += dcol, row += drow;
-      if (col >= wc) col -= wc, ++row;
+                                               0, 0);
+      col += dcol, off += step;
+      if (col >= wc) col -= wc, off += wrap;
     }
   };
-
-  // ---- 4. geometry of this voxel in every view
-  unsigned og[S];            // cx | cy << 14 | share-x << 28 | share-y << 29 | no-tap << 31
-  float wx0[S], wx1[S], wy0[S], wy1[S];
-  {
-    const float fx = (float)xc, fy = (float)yc;
+  int issued = 0, landed = 0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float* P = a.proj + ((size_t)b * S + s) * 12;
-      const float px = P[0] * fx + P[1] * fy + P[2] + P[3] * inv_depth;
-      const float py = P[4] * fx + P[5] * fy + P[6] + P[7] * inv_depth;
-      const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] * inv_depth;
-      const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
-      // uv / ((W-1)/2) - 1 followed by grid_sample's ((g+1)/2) (W-1) is the identity up to rounding
-      const float ix = px * iz, iy = py * iz;
-      const float flx = floorf(ix), fly = floorf(iy);
-      // clamp before the int conversion (also maps NaN into range): anything outside ends with both taps invalid
-      const int tx0 = (int)__builtin_amdgcn_fmed3f(flx, -2.f, (float)Ws), ty0 = (int)__builtin_amdgcn_fmed3f(fly, -2.f, (float)Hs);
-      const bool vx0 = ((unsigned)tx0 < (unsigned)Ws) & inb, vx1 = ((unsigned)(tx0 + 1) < (unsigned)Ws) & inb;
-      const bool vy0 = (unsigned)ty0 < (unsigned)Hs, vy1 = (unsigned)(ty0 + 1) < (unsigned)Hs;
-      const float ax = ix - flx, ay = iy - fly, ex = 1.f - ax, ey = 1.f - ay;
-      wx0[s] = vx0 ? ex : 0.f, wx1[s] = vx1 ? ax : 0.f;
-      wy0[s] = vy0 ? ey : 0.f, wy1[s] = vy1 ? ay : 0.f;
-      const bool any = (vx0 | vx1) & (vy0 | vy1);
-      // a tap outside the image has weight 0 and is parked on its in-image neighbour
-      const int cx = vx0 ? tx0 : tx0 + 1, cy = vy0 ? ty0 : ty0 + 1;
-      const unsigned bits = ((vx0 & vx1) ? 1u << 28 : 0u) | ((vy0 & vy1) ? 1u << 29 : 0u);
-      og[s] = any ? ((unsigned)cx | (unsigned)cy << 14 | bits) : 0x80000000u;
-    }
-  }
+  for (; issued < (NB < S ? NB : S); ++issued) issue_fill(issued, issued);
 
+  // ---- 4. geometry of this voxel in every view, reduced to what the blend needs: the LDS byte addresses of the two
+  // upper taps (flags in the 4 free low bits of the first: 1 = lower row exists, 2 = a tap lies outside the staged
+  // window, 4 = some tap carries weight) and the 4 bilinear weights with the zero padding folded in
+  struct Taps {
+    float ix, iy, ax, ay;
+    int cx, cy, shx, shy;
+    bool vx0, vx1, vy0, vy1, any;
+  };
+  const float fxc = (float)xc, fyc = (float)yc;
+  auto project = [&](int s, float inv_depth) {
+    Taps t;
+    const float* P = a.proj + ((size_t)b * S + s) * 12;
+    const float px = P[0] * fxc + P[1] * fyc + P[2] + P[3] * inv_depth;
+    const float py = P[4] * fxc + P[5] * fyc + P[6] + P[7] * inv_depth;
+    const float pz = P[8] * fxc + P[9] * fyc + P[10] + P[11] * inv_depth;
+    const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
+    // uv / ((W-1)/2) - 1 followed by grid_sample's ((g+1)/2) (W-1) is the identity up to rounding
+    t.ix = px * iz, t.iy = py * iz;
+    const float flx = floorf(t.ix), fly = floorf(t.iy);
+    // clamp before the int conversion (also maps NaN into range): anything outside ends with both taps invalid
+    const int tx0 = (int)__builtin_amdgcn_fmed3f(flx, -2.f, (float)Ws), ty0 = (int)__builtin_amdgcn_fmed3f(fly, -2.f, (float)Hs);
+    t.vx0 = ((unsigned)tx0 < (unsigned)Ws) & inb, t.vx1 = ((unsigned)(tx0 + 1) < (unsigned)Ws) & inb;
+    t.vy0 = (unsigned)ty0 < (unsigned)Hs, t.vy1 = (unsigned)(ty0 + 1) < (unsigned)Hs;
+    t.ax = t.ix - flx, t.ay = t.iy - fly;
+    t.any = (t.vx0 | t.vx1) & (t.vy0 | t.vy1);
+    // a tap outside the image has weight 0 and is parked on its in-image neighbour
+    t.cx = t.vx0 ? tx0 : tx0 + 1, t.cy = t.vy0 ? ty0 : ty0 + 1;
+    t.shx = (t.vx0 & t.vx1) ? 1 : 0, t.shy = (t.vy0 & t.vy1) ? 1 : 0;
+    return t;
+  };
+  unsigned b00, b01, b10, b11;
+  float w00, w01, w10, w11;
+  auto geometry = [&](int s) {
+    const Taps t = project(s, inv_depth);
+    const float wx0 = t.vx0 ? 1.f - t.ax : 0.f, wx1 = t.vx1 ? t.ax : 0.f;
+    const float wy0 = t.vy0 ? 1.f - t.ay : 0.f, wy1 = t.vy1 ? t.ay : 0.f;
+    w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    int rx = t.cx - wx[s], ry = t.cy - wy[s];
+    const bool inwin = ((rx | ry) >= 0) & (rx + t.shx < wcols[s]) & (ry + t.shy < wrows[s]);
+    const bool slow = t.any & !inwin;
+    if (!t.any | slow) rx = ry = 0;   // parked on the window origin (a slow wave never reads LDS for this view)
+    const int shx = (t.any & !slow) ? t.shx : 0;
+    const int shy = (t.any & !slow) ? t.shy : 0;
+    const unsigned boff = (unsigned)(s % NB) * (unsigned)a.cap * 64u;
+    const unsigned L00 = (unsigned)(ry * wcols[s] + rx), L01 = L00 + (unsigned)shx;
+    const unsigned L10 = L00 + (shy ? (unsigned)wcols[s] : 0u), L11 = L10 + (unsigned)shx;
+    b00 = (boff + (L00 << 6)) | (((L00 >> 2) & 3u) << 4) | (slow ? 2u : 0u) | (t.any ? 4u : 0u);
+    b01 = (boff + (L01 << 6)) | (((L01 >> 2) & 3u) << 4);
+    b10 = (boff + (L10 << 6)) | (((L10 >> 2) & 3u) << 4);
+    b11 = (boff + (L11 << 6)) | (((L11 >> 2) & 3u) << 4);
+  };
   BMV_STAMP(4)
+
   float4 acc[4], acc2[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = acc2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   using i32x4 = __attribute__((ext_vector_type(4))) int;
 
-  auto blend = [&](int q, float4 t00, float4 t01, float4 t10, float4 t11, float w00, float w01, float w10,
-                   float w11) {
+  auto blend = [&](int q, float4 t00, float4 t01, float4 t10, float4 t11, float a00, float a01, float a10,
+                   float a11) {
     float4 v;
-    v.x = t00.x * w00 + t01.x * w01 + t10.x * w10 + t11.x * w11;
-    v.y = t00.y * w00 + t01.y * w01 + t10.y * w10 + t11.y * w11;
-    v.z = t00.z * w00 + t01.z * w01 + t10.z * w10 + t11.z * w11;
-    v.w = t00.w * w00 + t01.w * w01 + t10.w * w10 + t11.w * w11;
+    v.x = t00.x * a00 + t01.x * a01 + t10.x * a10 + t11.x * a11;
+    v.y = t00.y * a00 + t01.y * a01 + t10.y * a10 + t11.y * a11;
+    v.z = t00.z * a00 + t01.z * a01 + t10.z * a10 + t11.z * a11;
+    v.w = t00.w * a00 + t01.w * a01 + t10.w * a10 + t11.w * a11;
     acc[q].x += v.x, acc[q].y += v.y, acc[q].z += v.z, acc[q].w += v.w;
     acc2[q].x += v.x * v.x, acc2[q].y += v.y * v.y, acc2[q].z += v.z * v.z, acc2[q].w += v.w * v.w;
   };
 
-  auto compute = [&](int s, int buf) {
+  auto compute = [&](int s) {
     if (a.flags & 2) return;
-    const unsigned o = og[s];
-    const bool any = (int)o >= 0;
-    if (!__any(any)) return;   // no voxel of the wave sees this view: it contributes 0 to both sums
-    const int wc = wcols[s];
-    const int rx = any ? (int)(o & 0x3fffu) - wx[s] : 0, ry = any ? (int)((o >> 14) & 0x3fffu) - wy[s] : 0;
-    const int shx = (int)((o >> 28) & 1u), shy = (int)((o >> 29) & 1u);
-    const float w00 = wx0[s] * wy0[s], w01 = wx1[s] * wy0[s], w10 = wx0[s] * wy1[s], w11 = wx1[s] * wy1[s];
-    const bool slow = ((rx | ry) < 0) | (rx + shx >= wc) | (ry + shy >= wrows[s]);
-    if (__builtin_expect(__any(slow), 0)) {
+    const unsigned f = b00;
+    if (!__any((f & 4u) != 0)) return;   // no voxel of the wave sees this view: it contributes 0 to both sums
+    if (__builtin_expect(__any((f & 2u) != 0), 0)) {
       if (a.flags & 16) return;
-      // a tap outside the staged box (box clipped by the LDS budget): this wave gathers the view from global memory
-      const unsigned g00 = vbase[s] + (unsigned)((ry + wy[s]) * Ws + rx + wx[s]) * REC;
-      const unsigned gdx = shx ? REC : 0u, gdy = shy ? (unsigned)Ws * REC : 0u;
+      // a tap outside the staged box (box clipped by the LDS budget, or a view partly behind the camera): this wave
+      // gathers the view from global memory, from its own geometry
+      float inv_depth2 = inv_depth;
+      asm volatile("" : "+v"(inv_depth2));   // not a common subexpression of the first projection: nothing stays live
+      const Taps t = project(s, inv_depth2);
+      const int gx = t.any ? t.cx : 0, gy = t.any ? t.cy : 0;
+      const unsigned g00 = vbase[s] + (unsigned)(gy * Ws + gx) * REC;
+      const unsigned gdx = (t.any && t.shx) ? REC : 0u, gdy = (t.any && t.shy) ? (unsigned)Ws * REC : 0u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         i32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g00 + 16u * q, 0, 0);
@@ -304,41 +352,44 @@ sweep_win_kernel(const WinArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // one slice in flight: this path is rare, registers matter more
       }
     } else {
-      const unsigned boff = (unsigned)buf * (unsigned)a.cap * 64u;   // multiple of 64: commutes with the slot XOR
-      const unsigned L00 = (unsigned)(ry * wc + rx), L01 = L00 + (unsigned)shx;
-      const unsigned L10 = L00 + (shy ? (unsigned)wc : 0u), L11 = L10 + (unsigned)shx;
-      const unsigned b00 = boff + ((L00 << 6) | (((L00 >> 2) & 3u) << 4)), b01 = boff + ((L01 << 6) | (((L01 >> 2) & 3u) << 4));
-      const unsigned b10 = boff + ((L10 << 6) | (((L10 >> 2) & 3u) << 4)), b11 = boff + ((L11 << 6) | (((L11 >> 2) & 3u) << 4));
+      const unsigned a00 = f & ~15u, a01 = b01, a10 = b10, a11 = b11;
+#if BMV_WIN_TAPBUF == 2
       // two slices in flight: the reads of slice q + 1 are issued before the blend of slice q
-      float4 t00 = ld4_lds(win, b00), t01 = ld4_lds(win, b01), t10 = ld4_lds(win, b10), t11 = ld4_lds(win, b11);
+      float4 t00 = ld4_lds(win, a00), t01 = ld4_lds(win, a01), t10 = ld4_lds(win, a10), t11 = ld4_lds(win, a11);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 n00, n01, n10, n11;
         if (q < 3) {
           const unsigned m = (unsigned)(q + 1) << 4;
-          n00 = ld4_lds(win, b00 ^ m), n01 = ld4_lds(win, b01 ^ m), n10 = ld4_lds(win, b10 ^ m), n11 = ld4_lds(win, b11 ^ m);
+          n00 = ld4_lds(win, a00 ^ m), n01 = ld4_lds(win, a01 ^ m), n10 = ld4_lds(win, a10 ^ m), n11 = ld4_lds(win, a11 ^ m);
         }
         __builtin_amdgcn_sched_barrier(0);
         blend(q, t00, t01, t10, t11, w00, w01, w10, w11);
         __builtin_amdgcn_sched_barrier(0);
         if (q < 3) t00 = n00, t01 = n01, t10 = n10, t11 = n11;
       }
+#else
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned m = (unsigned)q << 4;
+        blend(q, ld4_lds(win, a00 ^ m), ld4_lds(win, a01 ^ m), ld4_lds(win, a10 ^ m), ld4_lds(win, a11 ^ m), w00, w01, w10, w11);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
   };
 
-  // ---- 3+5. views in turn, NB windows in flight
-  int issued = 0, landed = 0;
-#pragma unroll
-  for (; issued < (NB < S ? NB : S); ++issued) issue_fill(issued, issued);
+  // ---- 5. views in turn, NB windows in flight
 #pragma unroll
   for (int s = 0; s < S; ++s) {
+    geometry(s);   // under the latency of this view's fill
     if (s >= landed) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       landed = issued;
     }
     if (s == 0) { BMV_STAMP(5) } else if (s == 1) { BMV_STAMP(7) } else if (s == 2) { BMV_STAMP(9) }
-    compute(s, s % NB);
+    compute(s);
     if (s == 0) { BMV_STAMP(6) } else if (s == 1) { BMV_STAMP(8) } else if (s == 2) { BMV_STAMP(10) }
     if (issued < S && issued == s + NB) {
       __syncthreads();  // every wave is done with window s % NB
@@ -347,6 +398,7 @@ sweep_win_kernel(const WinArgs a) {
     }
   }
 
+#ifdef BMV_WIN_STAMPS
   if (a.flags & 64) {
     if (tid == 0) {
       float* o = a.out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
@@ -363,11 +415,12 @@ sweep_win_kernel(const WinArgs a) {
     }
     return;
   }
+#endif
   if (a.flags & 32) {   // debug: window of view 0 / 1 and the depth range instead of the variance
     acc2[0] = make_float4((float)wcols[0] * S, (float)wrows[0] * S, (float)wx[0] * S, (float)wy[0] * S);
     acc2[1] = make_float4((float)wcols[1] * S, (float)wrows[1] * S, (float)wx[1] * S, (float)wy[1] * S);
-    acc2[2] = make_float4(ilo * S, ihi * S, inv_depth * S, (float)(og[0] & 0x3fff) * S);
-    acc2[3] = make_float4((float)((og[0] >> 14) & 0x3fff) * S, (float)(og[0] >> 28) * S, wx0[0] * S, wy0[0] * S);
+    acc2[2] = make_float4(ilo * S, ihi * S, inv_depth * S, (float)(b00 >> 6) * S);
+    acc2[3] = make_float4((float)(b00 & 63u) * S, (float)(b01 >> 6) * S, w00 * S, w11 * S);
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -441,7 +494,7 @@ int launch_one(const WinArgs& a, int B, hipStream_t stream) {
     }
     allowed = lds;
   }
-  dim3 grid(8u * (unsigned)(a.chalves * a.pgroups * a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
+  dim3 grid(8u * (unsigned)(a.chalves * a.pgroups), (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   return BMV_OK;
 }
@@ -466,7 +519,7 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   if (variant < 0) {
     // default by the source / volume scale: same resolution (cascade level 1: neighbours in a plane share texels)
     // or finer source (level 0: the planes of a pixel share texels along its epipolar line)
-    variant = (float)Ws / (float)w <= 1.5f ? 2 : 9;
+    variant = (float)Ws / (float)w <= 1.5f ? 0 : 9;
   }
   if (variant >= kNumVariants) return BMV_ERR_UNSUPPORTED;
   Variant v = kVariants[variant];
@@ -483,6 +536,8 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   a.pgroups = (D + v.dp - 1) / v.dp;
   a.chalves = C / 16;
   a.cap = v.cap;
+  a.tiles_x_magic = (unsigned)(((unsigned long long)1 << 32) / (unsigned)a.tiles_x) + 1u;
+  if (a.tiles_x * a.tyb >= 65536) return BMV_ERR_UNSUPPORTED;
   a.flags = 0;
   if (const char* e = getenv("BMV_SWEEP_WIN_FLAGS")) a.flags = atoi(e);
   int rc = BMV_ERR_UNSUPPORTED;

