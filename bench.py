@@ -5,8 +5,13 @@
 
 Metric (BASELINE.json): rendered Mray/s (512x640 target, 3 source views, 64 depth
 planes) = rays rendered by the whole job per second of `Network.forward(batch)`,
-the sync-bracketed call the reference times in run.py:117-123.  A step is one
-forward over one synthetic batch already resident in HBM.
+bracketed the way the reference's evaluate loop brackets it (run.py:113-129:
+synchronize -> t0 -> network(batch) -> synchronize, one step at a time).  A step is
+one forward over one synthetic batch already resident in HBM; EVERY timed step ends
+with a device synchronize, so `value` is the run.py number, not a pipelined one.
+The forward that is timed is the HIP-graph replay of the frame (`config.launch`);
+`value_extra` reports the same bracket around the eager `net(batch)` a drop-in
+run.py would call, and the un-synchronised (pipelined) replay rate.
 
 N > 1 (one process per GPU, torch.distributed over RCCL): independent target
 views are sharded across ranks -- every rank renders its own target frame of the
@@ -57,6 +62,9 @@ WORKLOADS = {
 }
 
 
+_SELECTION = None   # triplet indices of the K cost volumes (boost workloads)
+
+
 def sweep_bytes(S, C, Hs, Ws, D, h, w):
     """read every source feature map once + write the variance volume once."""
     return 4 * (S * C * Hs * Ws + C * D * h * w)
@@ -75,6 +83,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="1: replay the frame as HIP graphs (inference workloads)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N>1, views sharding: wait for each frame's all-gather before rendering the next frame")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="do not synchronize after every timed step (the un-bracketed replay rate; NOT the run.py metric)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
     ap.add_argument("--miopen-find", type=int, default=0,
@@ -119,11 +129,13 @@ def build(args, rank, dev):
         else:
             from boostmvsnerfs_amd.networks.boost_mvsnerf.network import Network
         pre = Network(preprocess=True).eval().to(dev)           # offline view selection (untimed, run.py:39-85)
+        global _SELECTION
         with torch.no_grad():
             sel = pre.forward_view_selection(clone_batch(batch_cpu, dev))
         key = next(iter(sel))
         if len(sel[key]) < cc.k_best:                            # degenerate synthetic geometry: pad the cover
             sel[key] = (sel[key] + [i for i in range(20) if i not in sel[key]])[: cc.k_best]
+        _SELECTION = sel[key]
         with open(os.path.join(cfg.result_dir, "view_selection.json"), "w") as f:
             json.dump(sel, f)
         torch.manual_seed(0)
@@ -137,20 +149,52 @@ def build(args, rank, dev):
     return cfg, wl, net, sd_cpu, batch_cpu, clone_batch(batch_cpu, dev), level
 
 
-def cpu_baseline(args, cfg, wl, state_dict, batch_cpu):
-    """The oracle (CPU port of the reference path) on this host's cores: one full frame."""
+def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
+    """The oracle (CPU port of the reference path) on this host's cores.  ENeRF / MVSNeRF: one full frame.  The
+    K-volume workloads: a bounded ray sample -- the front end (features, K cost volumes, regularisers) is run in full,
+    the per-ray part on two strided ray subsets, and the frame time is the linear extrapolation t(N) of t(n)."""
     from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
     H, W = wl["H"], wl["W"]
-    if wl["net"] != "enerf":
-        return None     # bounded-sample baselines for the K-volume / MVSNeRF workloads: see DESIGN.md
-    from oracle import enerf as O   # checker / baseline only
-    with torch.no_grad():
-        O.enerf_forward(state_dict, make_batch(64, 96), cfg)              # page-in / thread-pool warm-up
+    N = H * W
+    threads = torch.get_num_threads()
+
+    def timed(fn):
         t0 = time.perf_counter()
-        O.enerf_forward(state_dict, clone_batch(batch_cpu), cfg)
-        dt = time.perf_counter() - t0
-    return {"value": H * W / dt / 1e6, "unit": "Mray/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 frame {H}x{W} (whole workload), oracle/enerf.py torch-CPU fp32, {dt:.2f} s",
+        with torch.no_grad():
+            fn()
+        return time.perf_counter() - t0
+
+    if wl["net"] == "enerf":
+        from oracle import enerf as O   # checker / baseline only
+        timed(lambda: O.enerf_forward(state_dict, make_batch(64, 96), cfg))          # page-in / thread-pool warm-up
+        dt = timed(lambda: O.enerf_forward(state_dict, clone_batch(batch_cpu), cfg))
+        sample = f"1 frame {H}x{W} (whole workload), oracle/enerf.py torch-CPU fp32, {dt:.2f} s"
+    elif wl["net"] == "mvsnerf" and wl["samples"] <= 32:
+        from oracle import mvsnerf as M
+        dt = timed(lambda: M.mvsnerf_forward(state_dict, clone_batch(batch_cpu), cfg))
+        sample = f"1 frame {H}x{W} x {wl['samples']} samples (whole workload), oracle/mvsnerf.py torch-CPU fp32, {dt:.2f} s"
+    else:
+        k_best = list(sel)[: wl.get("k_best", 1)] if sel is not None else None
+
+        def run(stride):
+            b = clone_batch(batch_cpu)
+            if wl["net"] in ("mvsnerf", "boost_mvsnerf"):
+                from oracle import mvsnerf as M
+                b["rays_0"] = b["rays_0"][:, ::stride].contiguous()
+                if wl["net"] == "mvsnerf":
+                    return timed(lambda: M.mvsnerf_forward(state_dict, b, cfg)), b["rays_0"].shape[1]
+                return timed(lambda: M.boost_mvsnerf_forward(state_dict, b, cfg, k_best)), b["rays_0"].shape[1]
+            from oracle import enerf as O
+            for i in range(cfg.enerf.cas_config.num):
+                b[f"rays_{i}"] = b[f"rays_{i}"][:, ::stride].contiguous()
+            return timed(lambda: O.boost_enerf_forward(state_dict, b, cfg, k_best)), b[f"rays_{cfg.enerf.cas_config.num - 1}"].shape[1]
+        strides = (64, 32) if wl["net"] != "boost_enerf" else (8, 4)
+        (t1, n1), (t2, n2) = run(strides[0]), run(strides[1])
+        per_ray = max((t2 - t1) / (n2 - n1), 0.0)
+        dt = t1 + per_ray * (N - n1)
+        sample = (f"front end in full + rays ::{strides[0]} ({n1} rays, {t1:.2f} s) and ::{strides[1]} ({n2} rays, {t2:.2f} s), "
+                  f"frame time extrapolated linearly in the ray count to {N} rays = {dt:.1f} s; oracle torch-CPU fp32")
+    return {"value": N / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port", "sample": sample,
             "host_cpus": os.cpu_count()}
 
 
@@ -227,24 +271,24 @@ def main():
         if rank != 0:
             local_forward()
         dist.barrier()
-    # warm-up (eager); the fused renderer is timed here for `roofline_mfma` because it sits inside a graph later (and
-    # the sweeps, used only when a workload's graph has no eager sweep: K volumes on K streams)
+    # ---- warm-up (eager).  The first step pays module loads / allocator growth: kernel events start after it.
     ktimer.reset()
-    ktimer.enabled, ktimer.only = not args.no_kernel_events, ("render_rays", "mvs_render", "sweep_variance", "mvs_sweep")
-    for _ in range(args.warmup):
+    ktimer.only = ("render_rays", "mvs_render", "sweep_variance", "mvs_sweep")
+    for i in range(args.warmup):
+        ktimer.enabled = (not args.no_kernel_events) and i > 0
         step()
     torch.cuda.synchronize()
     warm_kernels = ktimer.summary()
     ktimer.enabled = False
     # Inference workloads: replay the frame as HIP graphs (the ~45 launches of a frame cost the host about as long
-    # as the GPU needs to run them).  The level-1 sweep stays an ordinary launch between the two graphs so the
-    # HIP events of `roofline` time it inside the timed region.  Falls back to eager launches if capture fails.
+    # as the GPU needs to run them).  The plane sweeps stay ordinary launches between the graphs so the HIP events
+    # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
     eager_step = step
     if args.graph and not wl.get("train") and not args.all_kernel_events and wl["net"] in ("enerf", "boost_enerf"):
         try:
             from boostmvsnerfs_amd.framegraph import FrameGraph
-            fg = FrameGraph(net, batch, cut=None if args.no_kernel_events else -1)
+            fg = FrameGraph(net, batch, cut=None if args.no_kernel_events else "all")
             replay = fg.replay
 
             def step():   # noqa: F811
@@ -258,12 +302,42 @@ def main():
                 return out
             for _ in range(2):
                 step()
-            graph_note = f"{len(fg.graphs)} graph(s)" + (" + eager level-1 sweep" if fg.sweep_args is not None else "")
+            graph_note = f"{len(fg.graphs)} graph(s)" + (f" + {len(fg.sweeps)} eager plane sweep(s)" if fg.sweeps else "")
         except Exception as e:   # keep the eager path: the bench must still produce its line
             print(f"[bench] HIP-graph capture failed, staying eager: {type(e).__name__}: {e}", file=sys.stderr)
             graph_note = f"capture failed ({type(e).__name__})"
             step = eager_step
             torch.cuda.synchronize()
+
+    def bracketed(fn, iters):
+        """run.py:113-129: synchronize, t0, network(batch), synchronize, per step; the first iteration is dropped."""
+        times = []
+        for _ in range(iters + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return sum(times[1:]) / iters
+
+    extra = {}
+    if not wl.get("train"):
+        n_x = max(5, min(args.steps, 20))
+        t_eager = bracketed(eager_step, n_x)
+        extra["sync_bracketed_eager"] = {"value": N * (world if args.shard == "views" else 1) / t_eager / 1e6, "ms_per_step": t_eager * 1e3,
+                                         "what": "run.py:113-129 bracket around the eager net(batch) (what a drop-in run.py calls)"}
+        if step is not eager_step:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_x):
+                step()
+            if gather is not None:
+                gather.flush()
+            torch.cuda.synchronize()
+            t_pipe = (time.perf_counter() - t0) / n_x
+            extra["pipelined_replay"] = {"value": N * (world if args.shard == "views" else 1) / t_pipe / 1e6, "ms_per_step": t_pipe * 1e3,
+                                         "what": "graph replays issued back to back, one synchronize at the end (not the metric)"}
+
     ktimer.reset()
     ktimer.enabled = not args.no_kernel_events
     # HIP events around the kernels the roofline objects are built from; --all-kernel-events times every launch
@@ -276,6 +350,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if not wl.get("train") and not args.pipelined:
+            if gather is not None:
+                gather.flush()
+            torch.cuda.synchronize()       # the reference's per-step bracket (run.py:117-123)
     if gather is not None:
         gather.flush()                 # every exchange issued in the timed region completes inside it
     torch.cuda.synchronize()
@@ -293,6 +371,7 @@ def main():
         frames = args.steps * (world if args.shard == "views" else 1)
         value = frames * N / dt / 1e6
         ks = ktimer.summary()
+        ks_timed = set(ks)
         for name, v in warm_kernels.items():          # graph mode: the renderer's events come from the eager warm-up
             ks.setdefault(name, v)
         kernels = {name: {"launches": n, "avg_us": mean_ms * 1e3, "min_us": min_ms * 1e3}
@@ -300,26 +379,32 @@ def main():
         roofline = mfma = None
         if wl["net"] in ("enerf", "boost_enerf"):
             planes = cc.volume_planes
-            # ---- roofline of the plane-sweep kernel (level 1 launch: the larger one)
+            # ---- roofline of the plane-sweep kernel: both cascade levels, the WORSE one is the headline object
+            pmc = {}
+            try:    # rocprofv3 --pmc passes on the frame's own sweep inputs (profiles/README.md, scripts/prof_sweep_once.py)
+                pmc = json.load(open(os.path.join(REPO, "profiles", "sweep_pmc.json"))).get(args.workload, {})
+            except Exception:
+                pmc = {}
+            levels = {}
+            n_src = cfg.enerf.cost_volume_input_views if wl["net"] == "boost_enerf" else wl["views"]
             for lvl, C in ((0, 32), (1, 16)):
                 h, w = int(H * cc.volume_scale[lvl]), int(W * cc.volume_scale[lvl])
                 name = f"sweep_variance[C={C},D={planes[lvl]},{h}x{w}]"
                 if name in kernels:
-                    nb = sweep_bytes(3, C, int(H * cc.im_feat_scale[lvl]), int(W * cc.im_feat_scale[lvl]), planes[lvl], h, w)
-                    kernels[name].update({"algorithmic_bytes": nb, "GB/s": nb / kernels[name]["avg_us"] / 1e3})
-                    if lvl == 1:
-                        k = kernels[name]
-                        traffic = None
-                        pmc = os.path.join(REPO, "profiles", "sweep_pmc.json")   # rocprofv3 --pmc passes (profiles/README.md)
-                        if os.path.exists(pmc):
-                            try:
-                                traffic = json.load(open(pmc)).get(args.workload, {}).get("sweep_level1_hbm_bytes")
-                            except Exception:
-                                traffic = None
-                        roofline = {"bound": "hbm", "kernel": "sweep_variance level 1 (a3+a4 fused plane sweep)",
-                                    "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": k["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": nb,
-                                    "avg_us": k["avg_us"], "launches": k["launches"]}
+                    nb = sweep_bytes(n_src, C, int(H * cc.im_feat_scale[lvl]), int(W * cc.im_feat_scale[lvl]), planes[lvl], h, w)
+                    k = kernels[name]
+                    k.update({"algorithmic_bytes": nb, "GB/s": nb / k["avg_us"] / 1e3})
+                    levels[f"level{lvl}"] = {"achieved": k["GB/s"], "frac": k["GB/s"] / HBM_PEAK_GBS, "avg_us": k["avg_us"],
+                                             "min_us": k["min_us"], "launches": k["launches"], "algorithmic_bytes": nb,
+                                             "traffic": pmc.get(f"sweep_level{lvl}_hbm_bytes"),
+                                             "timed": "HIP events in the timed region" if name in ks_timed else "HIP events in the eager warm-up"}
+            if levels:
+                worst = min(levels, key=lambda n: levels[n]["frac"])
+                L = levels[worst]
+                roofline = {"bound": "hbm", "kernel": f"sweep_variance {worst} (a3+a4 fused plane sweep; the worse of the two cascade levels)",
+                            "achieved": L["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": L["frac"],
+                            "traffic": L["traffic"], "algorithmic_bytes": L["algorithmic_bytes"], "avg_us": L["avg_us"],
+                            "launches": L["launches"], "levels": levels}
             rname = next((n for n in kernels if n.startswith("render_rays[feat=8")), None)
             if rname:
                 rays_launch = N // world if (args.shard == "rays" and world > 1) else N
@@ -359,12 +444,17 @@ def main():
                        "num_samples": list(cc.num_samples), "render_if": list(cc.render_if),
                        "k_best": wl.get("k_best"), "shard": args.shard if world > 1 else "none",
                        "gather": ("none" if world == 1 or wl.get("train") else
-                                  "sync" if args.sync_gather or args.shard == "rays" else "pipelined (1 frame)"),
-                       "weights": "random init (seed 0)", "launch": graph_note},
+                                  "sync" if args.sync_gather or args.shard == "rays" or not args.pipelined
+                                  else "pipelined (1 frame)"),
+                       "weights": "random init (seed 0)", "launch": graph_note,
+                       "bracket": ("train step" if wl.get("train") else "pipelined: one synchronize after the K steps" if args.pipelined
+                                   else "run.py:117-123: device synchronize after every step")},
+            # `value` is the aggregate over all ranks (the metric's "per GPU" names the 1-GPU headline config)
+            "value_per_gpu": value / world, "value_extra": extra,
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline and (headline or args.cpu_baseline):
-            cb = cpu_baseline(args, cfg, wl, sd_cpu, batch_cpu)
+        if world == 1 and not args.no_cpu_baseline and (headline or args.cpu_baseline) and not wl.get("train"):
+            cb = cpu_baseline(args, cfg, wl, sd_cpu, batch_cpu, _SELECTION)
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

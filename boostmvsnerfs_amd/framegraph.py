@@ -5,9 +5,9 @@ A frame is ~45 short launches; issued one by one from Python the host needs abou
 `FrameGraph` captures one forward pass -- including its second-stream fork/join -- into HIP graphs and
 replays them: the host cost of a frame drops to three calls.
 
-The capture is CUT at one plane-sweep launch (by default the last one, the level-1 sweep): graph A
-holds everything before it, graph B everything after it, and the sweep itself stays an ordinary launch
-between them, so HIP events on the stream can time exactly that kernel inside a timed region
+The capture is CUT at plane-sweep launches (`cut=-1`: the last one, the level-1 sweep; `cut="all"`: every
+sweep issued on the capture stream): the graphs hold everything between them and the sweeps themselves
+stay ordinary launches, so HIP events on the stream can time exactly those kernels inside a timed region
 (bench.py's `roofline`).  `cut=None` captures the frame as one graph.
 
 The batch tensors are the graph's static inputs: refresh them in place (`copy_`) between replays.  The
@@ -25,7 +25,7 @@ class FrameGraph:
         self.net, self.batch = net, batch
         self.cut = cut
         self.graphs = []
-        self.sweep_args = None
+        self.sweeps = []            # (impl, args, kwargs) of the eager sweep launched after graph i
         self.out = None
         self._capture(warmup)
 
@@ -52,13 +52,15 @@ class FrameGraph:
             with torch.cuda.stream(stream), torch.no_grad():
                 for _ in range(warmup):              # allocator pools, packed weights, side stream: all warm
                     self.net(self.batch)
-                cut_index = None
+                cut_index = set()
                 if self.cut is not None:
                     calls = self._count_sweeps()
-                    idx = self.cut if self.cut >= 0 else len(calls) + self.cut
+                    if self.cut == "all":
+                        wanted = range(len(calls))
+                    else:
+                        wanted = [self.cut if self.cut >= 0 else len(calls) + self.cut]
                     # only a launch on the capture stream itself can split the capture
-                    if 0 <= idx < len(calls) and calls[idx] == stream:
-                        cut_index = idx
+                    cut_index = {i for i in wanted if 0 <= i < len(calls) and calls[i] == stream}
                 torch.cuda.synchronize()
                 seen = [0]
                 g_a = torch.cuda.CUDAGraph()
@@ -67,11 +69,11 @@ class FrameGraph:
                 def hook(impl, args, kwargs):
                     i = seen[0]
                     seen[0] += 1
-                    if i != cut_index:
+                    if i not in cut_index:
                         return None
                     self.graphs[-1].capture_end()
                     res = impl(*args, **kwargs)                      # eager, on static buffers
-                    self.sweep_args = (impl, args, {**kwargs, "out": res})
+                    self.sweeps.append((impl, args, {**kwargs, "out": res}))
                     g_b = torch.cuda.CUDAGraph()
                     self.graphs.append(g_b)
                     g_b.capture_begin(pool=g_a.pool(), capture_error_mode="thread_local")
@@ -91,10 +93,14 @@ class FrameGraph:
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ replay
+    @property
+    def sweep_args(self):
+        """The last eager sweep (None if the frame is one graph)."""
+        return self.sweeps[-1] if self.sweeps else None
+
     def replay(self):
         self.graphs[0].replay()
-        if self.sweep_args is not None:
-            impl, args, kwargs = self.sweep_args
+        for (impl, args, kwargs), g in zip(self.sweeps, self.graphs[1:]):
             impl(*args, **kwargs)                             # times itself through ktimer when enabled
-            self.graphs[1].replay()
+            g.replay()
         return self.out
