@@ -338,6 +338,34 @@ def main():
             extra["pipelined_replay"] = {"value": N * (world if args.shard == "views" else 1) / t_pipe / 1e6, "ms_per_step": t_pipe * 1e3,
                                          "what": "graph replays issued back to back, one synchronize at the end (not the metric)"}
 
+    if not wl.get("train") and world == 1:
+        # the reference's loaders hand over HOST tensors (run.py:114-116 moves them every frame): the same bracket with
+        # the batch copied from pinned host memory each step, with the rays copied too / built on the device instead
+        host = {k: v.cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
+        ray_keys = [k for k in host if k.startswith("rays_")]
+
+        def from_host(device_rays):
+            def fn():
+                for k, v in host.items():
+                    if device_rays and k in ray_keys:
+                        batch.pop(k, None)              # Network.ensure_rays rebuilds them from tar_ext / tar_ixt
+                    else:
+                        if k not in batch:
+                            batch[k] = torch.empty_like(v, device=dev)
+                        batch[k].copy_(v, non_blocking=True)
+                return eager_step()
+            return fn
+        for name, dr in (("host_batch_sync_eager", False), ("host_batch_device_rays_sync_eager", True)):
+            t_h = bracketed(from_host(dr), n_x)
+            extra[name] = {"value": N / t_h / 1e6, "ms_per_step": t_h * 1e3,
+                           "what": "run.py bracket incl. the host->device copy of the batch (PCIe), eager forward"
+                                   + ("; rays built on the device (bmv_make_rays) instead of copied" if dr else "")}
+        for k, v in host.items():                       # leave the resident batch as the graphs captured it
+            if k not in batch:
+                batch[k] = torch.empty_like(v, device=dev)
+            batch[k].copy_(v)
+        torch.cuda.synchronize()
+
     ktimer.reset()
     ktimer.enabled = not args.no_kernel_events
     # HIP events around the kernels the roofline objects are built from; --all-kernel-events times every launch

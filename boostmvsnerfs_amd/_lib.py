@@ -70,6 +70,7 @@ SIGNATURES = {
     "bmv_nerf_mlp_fwd": [c_f, c_f, c_f, c_i, c_l, c_f, c_f],
     "bmv_composite_fwd": [c_f, c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_f],
     "bmv_mask_viewport": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_i, c_f, c_f],
+    "bmv_ndc_coords": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_f, c_f],
     "bmv_blend_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
     "bmv_render_rays_fwd": [C.POINTER(RenderArgs), c_f],
     "bmv_mvs_proj_mats": [c_f, c_f, c_i, c_i, c_f, c_f],
@@ -85,7 +86,7 @@ SIGNATURES = {
     "bmv_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f],
     "bmv_conv3d_transpose_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "bmv_fpn_topdown_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
-    "bmv_make_rays": [c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f],
+    "bmv_make_rays": [c_f, c_f, c_i, c_i, c_i, C.c_double, c_f, c_f],
     "bmv_composite_bwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f],
     "bmv_blend_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_vox_feat_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],

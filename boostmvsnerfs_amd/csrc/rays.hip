@@ -78,13 +78,11 @@ __global__ void __launch_bounds__(256) make_rays_kernel(const float* __restrict_
 
 using namespace bmv;
 
-extern "C" int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int H, int W, float scale, float* rays,
+extern "C" int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int h, int w, double scale, float* rays,
                              bmv_stream_t stream) {
   BMV_REQUIRE(tar_ext && tar_ixt && rays, "bmv_make_rays: null pointer");
-  BMV_REQUIRE(B > 0 && H > 0 && W > 0 && scale > 0.f, "bmv_make_rays: bad shape");
-  const int h = (int)(H * (double)scale), w = (int)(W * (double)scale);
-  BMV_REQUIRE(h > 0 && w > 0, "bmv_make_rays: scale %g leaves no pixels", (double)scale);
+  BMV_REQUIRE(B > 0 && h > 0 && w > 0 && scale > 0.0, "bmv_make_rays: bad shape (h=%d, w=%d, scale=%g)", h, w, scale);
   hipLaunchKernelGGL(make_rays_kernel, dim3(cdiv((long)h * w, 256), B), dim3(256), 0, as_stream(stream), tar_ext, tar_ixt,
-                     (double)scale, h, w, rays);
+                     scale, h, w, rays);
   BMV_LAUNCH_END("bmv_make_rays");
 }

@@ -179,16 +179,23 @@ __device__ __forceinline__ void dir_feature(const float* xyz, const float* tar_c
   out4[0] = BMV_DIV(df[0], nd), out4[1] = BMV_DIV(df[1], nd), out4[2] = BMV_DIV(df[2], nd), out4[3] = dot;
 }
 
-// a14: is the point inside the viewport of this source view (full-res K, render-res W-1,H-1)?
-__device__ __forceinline__ float visible(const Cam& cam, const float* xyz, float inv_w, float inv_h) {
+// a14 get_ndc_coords (enerf/utils.py:490-508): p = K (R x + T); (p.x / p.z / (W-1), p.y / p.z / (H-1), p.z) with the
+// full-resolution K and the render-resolution (W-1, H-1) the reference passes
+__device__ __forceinline__ void ndc_coords(const Cam& cam, const float* xyz, float inv_w, float inv_h, float& u, float& v,
+                                           float& pz) {
   float cx = xyz[0] * cam.E[0] + xyz[1] * cam.E[1] + xyz[2] * cam.E[2];
   float cy = xyz[0] * cam.E[4] + xyz[1] * cam.E[5] + xyz[2] * cam.E[6];
   float cz = xyz[0] * cam.E[8] + xyz[1] * cam.E[9] + xyz[2] * cam.E[10];
   cx += cam.E[3], cy += cam.E[7], cz += cam.E[11];
   float px = cx * cam.Kf[0] + cy * cam.Kf[1] + cz * cam.Kf[2];
   float py = cx * cam.Kf[3] + cy * cam.Kf[4] + cz * cam.Kf[5];
-  float pz = cx * cam.Kf[6] + cy * cam.Kf[7] + cz * cam.Kf[8];
-  float u = BMV_DIV(BMV_DIV(px, pz), inv_w), v = BMV_DIV(BMV_DIV(py, pz), inv_h);
+  pz = cx * cam.Kf[6] + cy * cam.Kf[7] + cz * cam.Kf[8];
+  u = BMV_DIV(BMV_DIV(px, pz), inv_w), v = BMV_DIV(BMV_DIV(py, pz), inv_h);
+}
+// a14: is the point inside the viewport of this source view (full-res K, render-res W-1,H-1)?
+__device__ __forceinline__ float visible(const Cam& cam, const float* xyz, float inv_w, float inv_h) {
+  float u, v, pz;
+  ndc_coords(cam, xyz, inv_w, inv_h, u, v, pz);
   return (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f && pz > 0.f) ? 1.f : 0.f;
 }
 

@@ -112,6 +112,23 @@ __global__ void mask_viewport_kernel(const float* __restrict__ xyz, const float*
   mask[(size_t)b * P + i] = acc / (float)V;
 }
 
+// a14 get_ndc_coords for one source view per batch item
+__global__ void ndc_coords_kernel(const float* __restrict__ xyz, const float* __restrict__ src_ext,
+                                  const float* __restrict__ src_ixt, float inv_w, float inv_h, int P,
+                                  float* __restrict__ ndc) {
+  __shared__ Cam cam;
+  int b = blockIdx.y;
+  if (threadIdx.x == 0) load_cam(src_ext + (size_t)b * 16, src_ixt + (size_t)b * 9, 1.f, cam);
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float p[3] = {xyz[((size_t)b * P + i) * 3], xyz[((size_t)b * P + i) * 3 + 1], xyz[((size_t)b * P + i) * 3 + 2]};
+  float u, v, pz;
+  ndc_coords(cam, p, inv_w, inv_h, u, v, pz);
+  float* o = ndc + ((size_t)b * P + i) * 3;
+  o[0] = u, o[1] = v, o[2] = pz;
+}
+
 // a12: one thread per ray (Ns is 2..128; the fused renderer uses wave shuffles instead).
 __global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ zv, long nrays, int Ns,
                                  int white_bkgd, float* __restrict__ rgb, float* __restrict__ depth,
@@ -257,6 +274,16 @@ int bmv_mask_viewport(const float* xyz, const float* src_exts, const float* src_
   hipLaunchKernelGGL(mask_viewport_kernel, dim3(cdiv(P, 256), B), dim3(256), sizeof(Cam) * V, as_stream(stream), xyz,
                      src_exts, src_ixts, inv_w, inv_h, P, V, mask);
   BMV_LAUNCH_END("bmv_mask_viewport");
+}
+
+int bmv_ndc_coords(const float* xyz, const float* src_ext, const float* src_ixt, float inv_w, float inv_h, int B, int P,
+                   float* ndc, bmv_stream_t stream) {
+  BMV_REQUIRE(xyz && src_ext && src_ixt && ndc, "bmv_ndc_coords: null pointer");
+  BMV_REQUIRE(B > 0 && P >= 0, "bmv_ndc_coords: bad shape");
+  if (P == 0) return BMV_OK;
+  hipLaunchKernelGGL(ndc_coords_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, as_stream(stream), xyz, src_ext, src_ixt,
+                     inv_w, inv_h, P, ndc);
+  BMV_LAUNCH_END("bmv_ndc_coords");
 }
 
 int bmv_composite_fwd(const float* raw, const float* z_vals, long nrays, int Ns, int white_bkgd, float* rgb,

@@ -210,6 +210,7 @@ class Network(enerf_network.Network):
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
         cc = cfg.enerf.cas_config
+        self.ensure_rays(batch)
         dev = batch["all_src_inps"].device
         B, N = batch["all_src_inps"].shape[:2]
         K = int(cc.k_best)

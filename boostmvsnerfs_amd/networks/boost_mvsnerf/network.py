@@ -53,6 +53,7 @@ class Network(mvsnerf_network.Network):
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
         cc = cfg.enerf.cas_config
+        self.ensure_rays(batch)
         dev = batch["all_src_inps"].device
         B, N = batch["all_src_inps"].shape[:2]
         trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)

@@ -196,8 +196,23 @@ class Network(nn.Module):
         return feats, st0
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def ensure_rays(batch):
+        """batch['rays_i'] for every rendered level that the batch does not carry: built on the device from the target
+        camera (ops.make_rays = the full-image branch of lib/datasets/enerf_utils.py:25-71), which removes the
+        10.5 MB host->device copy per level and frame a loader-built ray tensor costs.  Batches that do carry rays
+        (training: sampled rays / patches) are used as they are."""
+        cc = cfg.enerf.cas_config
+        src = batch["all_src_inps"] if "all_src_inps" in batch and "src_inps" not in batch else batch["src_inps"]
+        H, W = src.shape[-2:]
+        for i in range(cc.num):
+            if cc.render_if[i] and f"rays_{i}" not in batch:
+                batch[f"rays_{i}"] = ops.make_rays(batch["tar_ext"], batch["tar_ixt"], H, W, cc.render_scale[i])
+        return batch
+
     def forward(self, batch):
         cc = cfg.enerf.cas_config
+        self.ensure_rays(batch)
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         st0 = None
         if self.overlap_front and engine_ok(self.feature_net, batch["src_inps"]):

@@ -10,7 +10,7 @@ from ... import ops
 from ...config import cfg
 
 __all__ = ["get_proj_mats", "homo_warp", "get_depth_values", "build_feature_volume", "depth_regression",
-           "build_rays", "sample_along_depth", "get_vox_feat", "get_img_feat", "mask_viewport", "raw2outputs",
+           "build_rays", "sample_along_depth", "get_vox_feat", "get_img_feat", "get_ndc_coords", "mask_viewport", "raw2outputs",
            "raw2outputs_blend", "unpreprocess"]
 
 
@@ -80,6 +80,18 @@ def get_img_feat(xyz, img_feat_rgb, batch, training, level):
     """utils.py:753-786 -> (B, N*Ns, S, C+4)."""
     return ops.img_feat(xyz, img_feat_rgb, batch["src_exts"], batch["src_ixts"], batch["tar_ext"],
                         _cas().render_scale[level])
+
+
+def _inv_scale(inv_scale):
+    if torch.is_tensor(inv_scale):
+        return tuple(float(v) for v in inv_scale.reshape(-1, 2)[0].tolist())
+    return inv_scale
+
+
+def get_ndc_coords(world_xyz, src_ext, src_ixt, inv_scale):
+    """utils.py:490-508: world_xyz (B,N,Ns,3), ONE source view per item -> (B,N,Ns,3) = (u, v, z)."""
+    inv_w, inv_h = _inv_scale(inv_scale)
+    return ops.ndc_coords(world_xyz, src_ext, src_ixt, inv_w, inv_h)
 
 
 def mask_viewport(world_xyz, src_exts, src_ixts, inv_scale):

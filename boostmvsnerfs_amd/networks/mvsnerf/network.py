@@ -253,6 +253,16 @@ class Network(nn.Module):
             self.capture.update({"mlp_in": x86, "raw": raw, "cost_volume": st.cost_volume, "volume": st.volume})
         return raw, z, mask
 
+    @staticmethod
+    def ensure_rays(batch):
+        """batch['rays_0'] built on the device when the batch does not carry it (ops.make_rays = the full-image branch
+        of lib/datasets/enerf_utils.py:25-71; columns 6-7 hold the pixel x, y exactly as the shipped loaders leave
+        them -- quirk 9 of SURVEY.md: the reference marches from z = x_pix to z = y_pix)."""
+        if "rays_0" not in batch:
+            H, W = batch["all_src_inps"].shape[-2:]
+            batch["rays_0"] = ops.make_rays(batch["tar_ext"], batch["tar_ixt"], H, W, cfg.enerf.cas_config.render_scale[0])
+        return batch
+
     # reference names kept callable
     def get_proj_mats(self, batch):
         return ops.mvs_proj_mats(batch["src_exts"], batch["src_ixts"])
@@ -265,6 +275,7 @@ class Network(nn.Module):
         if torch.is_grad_enabled() and self.training:
             raise NotImplementedError("training (backward kernels) is not part of this build yet")
         dev = batch["all_src_inps"].device
+        self.ensure_rays(batch)
         feats = self.feature(batch["all_src_inps"])
         B = feats.shape[0]
         ids = torch.tensor([0, 1, 2], device=dev).view(1, 3).expand(B, -1)

@@ -29,12 +29,14 @@ def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):
 
 def make_rays(tar_ext, tar_ixt, H, W, scale=1.0):
     """batch['rays_i'] of the full-image branch of `build_rays` (lib/datasets/enerf_utils.py:25-31, 62-71), built on
-    the device from the target camera: (B, int(H*scale) * int(W*scale), 8) = [origin | direction | x, y]."""
+    the device from the target camera: (B, h * w, 8) = [origin | direction | x, y] with h x w the size cv2.resize
+    gives the scaled target image there (round(H*scale) x round(W*scale)); the size is computed HERE, once, and
+    handed to the kernel."""
     B = tar_ext.shape[0]
-    h, w = int(H * scale), int(W * scale)
+    h, w = (int(H), int(W)) if scale == 1.0 else (int(round(H * scale)), int(round(W * scale)))
     rays = torch.empty(B, h * w, 8, device=tar_ext.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.bmv_make_rays(dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), B, int(H), int(W),
+    _lib.check(lib.bmv_make_rays(dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), B, h, w,
                                  float(scale), dptr(rays), stream()), "make_rays")
     return rays
 
@@ -275,6 +277,18 @@ def mask_viewport(xyz, src_exts, src_ixts, inv_w, inv_h):
     _lib.check(lib.bmv_mask_viewport(dptr(pts, "xyz"), dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
                                      float(inv_w), float(inv_h), B, P, V, dptr(mask), stream()), "mask_viewport")
     return mask
+
+
+def ndc_coords(xyz, src_ext, src_ixt, inv_w, inv_h):
+    """get_ndc_coords (enerf/utils.py:490-508): xyz (B,N,Ns,3), one source view per item -> (B,N,Ns,3)."""
+    B = xyz.shape[0]
+    pts = _c(xyz).reshape(B, -1, 3)
+    out = torch.empty_like(pts)
+    lib = _lib.load()
+    _lib.check(lib.bmv_ndc_coords(dptr(pts, "xyz"), dptr(_c(src_ext).reshape(B, 16), "src_ext"),
+                                  dptr(_c(src_ixt).reshape(B, 9), "src_ixt"), float(inv_w), float(inv_h), B,
+                                  pts.shape[1], dptr(out), stream()), "ndc_coords")
+    return out.reshape(xyz.shape)
 
 
 def blend(raws, masks, z_vals, normalise):

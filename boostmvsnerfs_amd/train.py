@@ -11,9 +11,33 @@ from .config import cfg
 
 
 class NetworkWrapper(nn.Module):
-    def __init__(self, net):
+    """lib/train/losses/enerf.py:7-56: returns (output, loss, scalar_stats, image_stats) like the reference's wrapper,
+    with the reference's stat names (color_mse_i, psnr_i, perceptual_loss_i, loss).
+
+    `perceptual`: a callable (pred (n,3,h,w), target (n,3,h,w)) -> scalar standing in for the reference's
+    VGGPerceptualLoss (torchvision VGG16 weights, not available offline).  With `perceptual=None` the 0.01 *
+    perceptual term of the levels that ask for it (train_img / num_patchs > 0) is OFF; that is logged once and
+    reported in every step's stats as `perceptual_loss_i = nan` -- the loss then differs from the reference's by
+    exactly that term."""
+
+    def __init__(self, net, train_loader=None, perceptual=None):
         super().__init__()
         self.net = net
+        self.perceptual = perceptual
+        self._warned = False
+
+    def _perceptual_inputs(self, batch, out, i):
+        cc = cfg.enerf.cas_config
+        if cc.train_img[i]:
+            B, S, C, H, W = batch["src_inps"].shape
+            rs = cc.render_scale[i]
+            h, w = int(H * rs), int(W * rs)
+            return (out[f"rgb_level{i}"].reshape(B, h, w, 3).permute(0, 3, 1, 2),
+                    batch[f"rgb_{i}"].reshape(B, h, w, 3).permute(0, 3, 1, 2))
+        ps, nr, npatch = cc.patch_size[i], cc.num_rays[i], cc.num_patchs[i]
+        cut = slice(nr, nr + npatch * ps * ps)
+        return (out[f"rgb_level{i}"][:, cut].reshape(-1, ps, ps, 3).permute(0, 3, 1, 2),
+                batch[f"rgb_{i}"][:, cut].reshape(-1, ps, ps, 3).permute(0, 3, 1, 2))
 
     def forward(self, batch):
         out = self.net(batch)
@@ -25,11 +49,23 @@ class NetworkWrapper(nn.Module):
             if key not in out:
                 continue
             mse = ((out[key] - batch[f"rgb_{i}"]) ** 2).mean()
-            stats[f"mse_level{i}"] = mse.detach()
-            stats[f"psnr_level{i}"] = -10.0 * torch.log10(mse.detach())
+            stats[f"color_mse_{i}"] = mse.detach()
+            stats[f"psnr_{i}"] = -10.0 * torch.log10(mse.detach())
             loss = loss + cc.loss_weight[i] * mse
-        stats["loss"] = loss.detach()
-        return out, loss, stats
+            wants = bool(cc.get("train_img", [False] * cc.num)[i]) or cc.get("num_patchs", [0] * cc.num)[i] > 0
+            if wants and self.training:
+                if self.perceptual is not None:
+                    p = self.perceptual(*self._perceptual_inputs(batch, out, i))
+                    loss = loss + 0.01 * p * cc.loss_weight[i]
+                    stats[f"perceptual_loss_{i}"] = p.detach()
+                else:
+                    if not self._warned:
+                        print(f"[train] level {i}: the 0.01 * VGG perceptual term of lib/train/losses/enerf.py:33-52 is OFF "
+                              "(no VGG16 weights offline; pass NetworkWrapper(..., perceptual=fn) to enable it)")
+                        self._warned = True
+                    stats[f"perceptual_loss_{i}"] = torch.full((), float("nan"), device=mse.device)
+        stats["loss"] = loss.detach() if torch.is_tensor(loss) else loss
+        return out, loss, stats, {}
 
 
 def make_optimizer(net, lr=5e-4, weight_decay=0.0, eps=1e-8):
@@ -42,7 +78,7 @@ def make_lr_scheduler(optimizer, gamma=0.5, decay_epochs=50):
 
 
 def train_step(wrapper, optimizer, batch, clip=40.0):
-    out, loss, stats = wrapper(batch)
+    out, loss, stats, _ = wrapper(batch)
     loss = loss.mean()
     optimizer.zero_grad()
     loss.backward()

@@ -135,6 +135,10 @@ int bmv_composite_fwd(const float* raw, const float* z_vals, long nrays, int Ns,
  * xyz (B,P,3), src_exts (B,V,4,4), src_ixts (B,V,3,3), inv_scale (W-1,H-1) -> mask (B,P) */
 int bmv_mask_viewport(const float* xyz, const float* src_exts, const float* src_ixts, float inv_w, float inv_h,
                       int B, int P, int V, float* mask, bmv_stream_t stream);
+/* get_ndc_coords alone (utils.py:490-508): xyz (B,P,3), ONE source view per item src_ext (B,4,4), src_ixt (B,3,3)
+ * -> ndc (B,P,3) = (x/z/(W-1), y/z/(H-1), z) of K (R x + T) */
+int bmv_ndc_coords(const float* xyz, const float* src_ext, const float* src_ixt, float inv_w, float inv_h, int B,
+                   int P, float* ndc, bmv_stream_t stream);
 
 /* ---- a16 raw2outputs_blend + mask normalisation
  *          lib/networks/enerf/utils.py:639-667, lib/networks/boost_enerf/network.py:163-170
@@ -322,9 +326,11 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,
- * tar_ixt (B,3,3), render scale -> rays (B, h*w, 8) = [origin | direction | x, y], h = int(H*scale), w = int(W*scale):
- * the layout of batch['rays_i'].  float64 inside like the numpy original, rounded to float32 once. */
-int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int H, int W, float scale, float* rays,
+ * tar_ixt (B,3,3) at full resolution, render scale (rows 0-1 of the intrinsics are multiplied by it, :28-31) and the
+ * size h x w of the scaled image (the caller's: cv2.resize rounds, round(H*scale) x round(W*scale)) ->
+ * rays (B, h*w, 8) = [origin | direction | x, y]: the layout of batch['rays_i'].  float64 inside, rounded to
+ * float32 once. */
+int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int h, int w, double scale, float* rays,
                   bmv_stream_t stream);
 
 #ifdef __cplusplus

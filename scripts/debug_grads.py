@@ -21,7 +21,7 @@ loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - batch[f"rgb_{i}"]) ** 2)
 loss.backward()
 net = Network(); net.load_state_dict(sd); net = net.cuda().eval()
 bg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
-_, l2, _ = NetworkWrapper(net)(bg); l2.backward()
+_, l2, _, _ = NetworkWrapper(net)(bg); l2.backward()
 print("loss", float(loss), float(l2))
 for k, p in net.named_parameters():
     w = leaves[k].grad; gg = p.grad.cpu()
@@ -48,7 +48,7 @@ def lf(*a, **k):
     states.append(st)
     return st
 net.level_front = lf
-_, l3, _ = NetworkWrapper(net)(bg); l3.backward()
+_, l3, _, _ = NetworkWrapper(net)(bg); l3.backward()
 def cmp(name, g, w):
     g = g.cpu()
     print(f"{name:16s} |w|={float(w.norm()):.3e} rel_l2={float((g-w).norm()/(w.norm()+1e-30)):.2e}")

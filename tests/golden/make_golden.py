@@ -263,11 +263,142 @@ def gen_boost_mvsnerf():
          extra={"num_samples": [MVS_NS], "k_best": sel[key], "n_views": n_views, "hw": [TINY_H, TINY_W]})
 
 
+def gen_rays():
+    """batch['rays_i'] of the reference's dataset code (lib/datasets/enerf_utils.py:25-31, 62-71, full-image
+    branch) for two target cameras and both render scales.  cv2.resize only fixes the image SHAPE there: the stand-in
+    returns an array of the size cv2 documents for dsize=None, round(f * size)."""
+    from boostmvsnerfs_amd.synthetic import look_at_w2c, pinhole
+    cfg = load_reference("configs/exps/evaluate/enerf/free_eval.yaml")
+    import cv2
+
+    def resize(img, dsize, fx=None, fy=None, interpolation=None):
+        h, w = int(round(img.shape[0] * fy)), int(round(img.shape[1] * fx))
+        return np.zeros((h, w) + img.shape[2:], img.dtype)
+    cv2.resize, cv2.INTER_AREA, cv2.INTER_NEAREST = resize, 3, 0
+    from lib.datasets import enerf_utils
+    blob = {}
+    cams = [((0.0, 0.0, 0.0), (0.0, 0.0, 4.0), 64, 96), ((0.4, -0.2, 0.3), (0.1, 0.2, 3.0), 48, 80)]
+    for c, (pos, look, H, W) in enumerate(cams):
+        ext = look_at_w2c(pos, look).astype(np.float32)
+        ixt = pinhole(H, W).astype(np.float32)
+        ixt[0, 2] += 0.37 * c                                  # principal point off the pixel grid for the second camera
+        blob[f"in/tar_ext_{c}"], blob[f"in/tar_ixt_{c}"] = ext, ixt
+        blob[f"in/hw_{c}"] = np.array([H, W])
+        for level, scale in enumerate(cfg.enerf.cas_config.render_scale):
+            img, msk = np.zeros((H, W, 3), np.float32), np.ones((H, W), np.uint8)
+            rays, _, _ = enerf_utils.build_rays(img, ext, ixt, msk, level, "test")
+            blob[f"out/rays_{c}_{level}"] = rays
+            blob[f"extra/scale_{level}"] = np.asarray(scale, np.float64)
+    path = os.path.join(HERE, "rays_tiny.npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
+
+
+BASELINE_CFGS = {
+    # BASELINE.json configs[i] -> (yaml, CLI opts, how run.py is started)   SURVEY.md section 8
+    "config1_enerf_256x320_32planes": ("configs/exps/evaluate/enerf/free_eval.yaml", ["enerf.cas_config.volume_planes", "[32, 8]"]),
+    "config2_enerf_512x640_64planes": ("configs/exps/evaluate/enerf/free_eval.yaml", []),
+    "config3_enerf_ours_grass": ("configs/exps/finetune/enerf_ours/free/grass.yaml", []),
+    "config4_mvsnerf_ours_128": ("configs/exps/evaluate/mvsnerf_ours/scannet_plus_eval.yaml", ["enerf.cas_config.num_samples", "[128]"]),
+    "config5_enerf_ours_ft_grass": ("configs/exps/finetune/enerf_ours/free/grass.yaml", []),
+}
+
+
+def gen_cfg_dump(name):
+    """The attributes the network / trainer modules read, as the reference's lib.config resolves them through the
+    yaml parent_cfg chain + CLI opts (lib/config/config.py:170-188).  One process per config (argparse at import)."""
+    import json
+    yaml_file, opts = BASELINE_CFGS[name]
+    cfg = load_reference(yaml_file, opts)
+    cc = cfg.enerf.cas_config
+    keys = ["num", "depth_inv", "volume_scale", "volume_planes", "im_feat_scale", "im_ibr_scale", "render_scale",
+            "render_im_feat_level", "nerf_model_feat_ch", "num_samples", "render_if", "loss_weight", "num_rays",
+            "num_patchs", "train_img", "patch_size"]
+    dump = {"task": cfg.task, "network_module": cfg.network_module, "network_path": cfg.network_path,
+            "enerf": {k: getattr(cfg.enerf, k) for k in ("white_bkgd", "chunk_size", "viewdir_agg", "cost_volume_input_views")
+                      if k in cfg.enerf},
+            "cas_config": {k: (list(cc[k]) if isinstance(cc[k], (list, tuple)) else cc[k]) for k in keys if k in cc},
+            "train": {"lr": cfg.train.lr, "eps": cfg.train.eps, "weight_decay": cfg.train.weight_decay, "optim": cfg.train.optim,
+                      "epoch": cfg.train.epoch, "batch_size": cfg.train.batch_size,
+                      "scheduler": {"type": cfg.train.scheduler.type, "gamma": cfg.train.scheduler.gamma,
+                                    "decay_epochs": cfg.train.scheduler.decay_epochs}},
+            "ep_iter": cfg.ep_iter}
+    if "k_best" in cc:
+        dump["cas_config"]["k_best"] = cc.k_best
+    for side in ("train_dataset", "test_dataset"):
+        if side in cfg and "input_h_w" in cfg[side]:
+            dump[side + ".input_h_w"] = list(cfg[side].input_h_w)
+            dump[side + ".input_views_num"] = cfg[side].get("input_views_num", None)
+    path = os.path.join(HERE, "cfg_dumps.json")
+    allc = json.load(open(path)) if os.path.exists(path) else {}
+    allc[name] = dump
+    with open(path, "w") as f:
+        json.dump(allc, f, indent=1, sort_keys=True)
+    print("wrote", name, "->", path)
+
+
+def gen_adam_step():
+    """One optimiser step of the reference's trainer recipe (lib/train/trainers/trainer.py:44-63: loss.mean ->
+    zero_grad -> backward -> clip_grad_value_(40) -> step) with the reference's own make_optimizer /
+    make_lr_scheduler (lib/train/optimizer.py:12-28, lib/train/scheduler.py:5-16) on the enerf_tiny weights, batch and
+    targets of enerf_tiny_grads: parameter deltas + the learning rate along the epochs."""
+    from boostmvsnerfs_amd.synthetic import make_batch
+    cfg = load_reference("configs/exps/evaluate/enerf/free_eval.yaml")
+    from lib.networks.enerf import network
+    # lib/train/__init__.py pulls the trainer and the recorder (imgaug, plyfile, tensorboardX, ... are not in this image);
+    # make_optimizer / make_lr_scheduler do not need them: the two files are loaded as modules by path
+    import importlib.util
+
+    def by_path(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join("/root/reference", rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    make_optimizer = by_path("ref_train_optimizer", "lib/train/optimizer.py").make_optimizer
+    make_lr_scheduler = by_path("ref_train_scheduler", "lib/train/scheduler.py").make_lr_scheduler
+    cfg.enerf.cas_config.volume_planes = list(TINY_PLANES)
+    cfg.enerf.cas_config.render_if = [True, True]
+    torch.manual_seed(0)
+    net = perturb_(network.Network().eval())                 # eval-mode batch norm, as the gradient fixture
+    batch = make_batch(TINY_H, TINY_W, n_views=3, seed=0)
+    g = torch.Generator().manual_seed(0)
+    targets = {i: torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=g) for i in range(2)}
+    optimizer = make_optimizer(cfg, net)
+    scheduler = make_lr_scheduler(cfg, optimizer)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    w = list(cfg.enerf.cas_config.loss_weight)
+    out = net(batch)
+    loss = sum(w[i] * ((out[f"rgb_level{i}"] - targets[i]) ** 2).mean() for i in range(2))
+    loss = loss.mean()
+    optimizer.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+    optimizer.step()
+    blob = {"extra/loss": np.asarray(float(loss)), "extra/lr0": np.asarray(cfg.train.lr), "extra/eps": np.asarray(cfg.train.eps),
+            "extra/loss_weight": np.asarray(w)}
+    for k, p in net.named_parameters():
+        blob["delta/" + k] = (p.detach() - before[k]).numpy()
+    lrs = []
+    for epoch in range(101):
+        lrs.append(optimizer.param_groups[0]["lr"])
+        scheduler.step()
+    blob["extra/lr_by_epoch"] = np.asarray(lrs, np.float64)
+    path = os.path.join(HERE, "enerf_tiny_adam_step.npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "enerf"
-    if which != "enerf_grads":
+    if which == "cfg_dumps":
+        import subprocess
+        for name in BASELINE_CFGS:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "cfg_dump", name])
+    elif which == "cfg_dump":
+        gen_cfg_dump(sys.argv[2])
+    elif which != "enerf_grads":
         {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf, "mvsnerf": gen_mvsnerf,
-         "boost_mvsnerf": gen_boost_mvsnerf}[which]()
+         "boost_mvsnerf": gen_boost_mvsnerf, "rays": gen_rays, "adam_step": gen_adam_step}[which]()
 
 
 def gen_enerf_grads():

@@ -269,6 +269,61 @@ def test_sweep_windowed_ragged_shapes(ops, shape):
         assert_close(got, want, name=f"shape {shape} algo {algo}")
 
 
+def test_make_rays_matches_reference_rays():
+    """bmv_make_rays vs rays the REFERENCE's build_rays (lib/datasets/enerf_utils.py:25-71) produced
+    (tests/golden/rays_tiny.npz): two cameras (one with the principal point off the pixel grid), both render scales."""
+    import os
+    import numpy as np
+    from boostmvsnerfs_amd import ops
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rays_tiny.npz"))
+    for c in range(2):
+        H, W = (int(v) for v in fx[f"in/hw_{c}"])
+        ext = torch.from_numpy(fx[f"in/tar_ext_{c}"])[None].to(DEV)
+        ixt = torch.from_numpy(fx[f"in/tar_ixt_{c}"])[None].to(DEV)
+        for level in range(2):
+            want = torch.from_numpy(fx[f"out/rays_{c}_{level}"])[None]
+            got = ops.make_rays(ext, ixt, H, W, float(fx[f"extra/scale_{level}"])).cpu()
+            assert got.shape == want.shape
+            assert torch.equal(got[..., 6:], want[..., 6:])
+            # float64 inside vs the reference's float32 inverses: a few float32 ulp of the largest component
+            assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_forward_builds_missing_rays_on_the_device(enerf_fx):
+    """A batch without rays_i (Network.ensure_rays -> bmv_make_rays) renders what the batch with the loader's rays does."""
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    set_cfg(tiny_cfg(enerf_fx))
+    net = Network()
+    net.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net = net.to(DEV).eval()
+    b = enerf_fx.batch(DEV)
+    with torch.no_grad():
+        want = net(b)
+        b2 = {k: v for k, v in enerf_fx.batch(DEV).items() if not k.startswith("rays_")}
+        got = net(b2)
+    assert "rays_1" in b2 and torch.equal(b2["rays_1"][..., 6:], b["rays_1"][..., 6:])
+    for k in want:
+        assert_close(got[k], want[k], rtol=1e-4, atol_scale=1e-5, name=k)
+
+
+def test_get_ndc_coords():
+    from boostmvsnerfs_amd.networks.enerf import utils as U
+    from boostmvsnerfs_amd.synthetic import make_batch
+    from oracle import enerf as O
+    b = make_batch(48, 64, n_views=3, seed=2, B=2)
+    torch.manual_seed(0)
+    xyz = torch.randn(2, 37, 4, 3) * 0.5 + torch.tensor([0.0, 0.0, 4.0])
+    inv = torch.tensor([[63.0, 47.0]]).expand(2, -1)
+    want = O.ndc_coords(xyz, b["src_exts"][:, 1], b["src_ixts"][:, 1], inv)
+    got = U.get_ndc_coords(xyz.to(DEV), b["src_exts"][:, 1].to(DEV), b["src_ixts"][:, 1].to(DEV), inv.to(DEV))
+    assert_close(got, want, rtol=1e-5, atol_scale=1e-6, name="ndc")
+    # and mask_viewport is the viewport test on exactly these coordinates
+    m = U.mask_viewport(xyz.to(DEV), b["src_exts"][:, 1:2].to(DEV), b["src_ixts"][:, 1:2].to(DEV), inv.to(DEV)).cpu()
+    vis = ((want[..., 0] >= 0) & (want[..., 0] <= 1) & (want[..., 1] >= 0) & (want[..., 1] <= 1) & (want[..., 2] > 0))
+    assert float((m.reshape(vis.shape) - vis.float()).abs().mean()) < 1e-3
+
+
 def test_make_rays_matches_the_dataset_ray_builder():
     """bmv_make_rays vs the numpy restatement of `build_rays` (lib/datasets/enerf_utils.py:25-31, 62-71) the synthetic
     batches are built with: both render scales, two different target cameras in one batch."""

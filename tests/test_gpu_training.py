@@ -59,7 +59,7 @@ def test_enerf_finetune_gradients(enerf_fx):
     net.load_state_dict(sd, strict=True)
     net = net.to(DEV).eval()                                      # eval-mode batch norm on both sides
     bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
-    _, loss, _ = NetworkWrapper(net)(bg)
+    _, loss, _, _ = NetworkWrapper(net)(bg)
     loss.backward()
     assert len(want) == 115
     _check_grads(net, want, float(loss), loss_c)
@@ -70,9 +70,41 @@ def test_enerf_finetune_gradients(enerf_fx):
     for i in range(2):
         bg[f"rgb_{i}"] = gfx.t(f"in/rgb_{i}", DEV)
     net.zero_grad()
-    _, loss, _ = NetworkWrapper(net)(bg)
+    _, loss, _, _ = NetworkWrapper(net)(bg)
     loss.backward()
     _check_grads(net, ref, float(loss), float(gfx.raw["extra/loss"]))
+
+
+def test_one_optimiser_step_moves_parameters_like_the_reference(enerf_fx):
+    """trainer.py:44-63 with the reference's own make_optimizer (Adam, lr 5e-4, eps 1e-8): the parameter deltas of ONE
+    step on the reference (tests/golden/enerf_tiny_adam_step.npz: same weights, batch and targets as the gradient
+    fixture) vs train_step on the HIP path.  The first Adam step is -lr * g / (|g| + eps): entries whose gradient is
+    rounding noise (|g| ~ eps) may take either sign, every other entry must agree."""
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
+    from conftest import load_fixture
+    set_cfg(tiny_cfg(enerf_fx, "enerf_pretrain"))
+    afx, gfx = load_fixture("enerf_tiny_adam_step"), load_fixture("enerf_tiny_grads")
+    net = Network()
+    net.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net = net.to(DEV).eval()                                   # eval-mode batch norm, as the fixture
+    bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in enerf_fx.batch().items()}
+    for i in range(2):
+        bg[f"rgb_{i}"] = gfx.t(f"in/rgb_{i}", DEV)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    loss, _ = train_step(NetworkWrapper(net), make_optimizer(net), bg)
+    assert abs(float(loss) - float(afx.raw["extra/loss"])) <= 1e-4 * float(afx.raw["extra/loss"])
+    lr = float(afx.raw["extra/lr0"])
+    grads = {k[5:]: torch.from_numpy(v) for k, v in gfx.raw.items() if k.startswith("grad/")}
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for k, p in net.named_parameters():
+        want = torch.from_numpy(afx.raw["delta/" + k])
+        got = (p.detach() - before[k]).cpu()
+        solid = grads[k].abs() > 1e-5 * gmax                   # entries with a real gradient
+        err = (got - want).abs()
+        assert float(err[solid].max() if solid.any() else 0.0) <= 2e-2 * lr, f"{k}: step differs by {float(err[solid].max()):.2e}"
+        assert float((err > 2e-2 * lr).float().mean()) <= 0.02, k
 
 
 def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
@@ -95,7 +127,7 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     net = net.to(DEV).eval()
     bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
     wrapper = NetworkWrapper(net)
-    _, loss, _ = wrapper(bg)
+    _, loss, _, _ = wrapper(bg)
     loss.backward()
     _check_grads(net, want, float(loss), loss_c)
     # one optimiser step (trainer.py:44-63): parameters must move, loss must be finite
