@@ -76,7 +76,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
-    ap.add_argument("--shard", default="views", choices=["views", "rays"])
+    ap.add_argument("--shard", default="views", choices=["views", "rays", "volumes"],
+                    help="views: one target frame per rank (weak scaling); rays: ray ranges of ONE frame, front end replicated; "
+                         "volumes (K-volume boost networks): cost volumes x ray ranges of ONE frame (sharding.VolumeShard)")
     ap.add_argument("--sweep-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
@@ -225,7 +227,28 @@ def main():
     rgb_key, depth_key = f"rgb_level{level}", f"depth_level{level}"
     if args.shard == "rays" and world > 1:
         net.ray_range = sharding.ray_slice(N, world, rank)
-    gather = sharding.TileGather(world, N if args.shard == "views" else None, dev) if world > 1 else None
+    vshard = None
+    if args.shard == "volumes" and world > 1:
+        if wl["net"] != "boost_enerf" or wl.get("train"):
+            raise SystemExit("--shard volumes is the cost-volume parallelism of the boost_enerf inference workloads")
+        vshard = sharding.VolumeShard(world, rank, int(cc.k_best), N)
+        net.volume_ids, net.ray_range = vshard.volumes, vshard.ray_range
+    gather = sharding.TileGather(world, N if args.shard == "views" else None, dev) if (world > 1 and vshard is None) else None
+
+    def finish(out):
+        """The exchange step of the sharding mode on one rank's output."""
+        if vshard is not None:
+            raws, zs, ms = vshard.exchange(*out[f"stacks_level{level}"])
+            fused = net.merge_mlp_outputs(raws, ms, zs)
+            return vshard.gather_tiles(fused["rgb"], fused["depth"])
+        if gather is not None:
+            if args.shard == "views":
+                if args.sync_gather or not args.pipelined:
+                    return gather.all_gather_frames(out[rgb_key], out[depth_key])
+                # the exchange of frame i runs on RCCL's stream under the kernels of frame i+1
+                return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
+            return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
+        return out
 
     if wl.get("train"):
         # fine-tune step (trainer.py:44-63): every rank trains on its own target view, DDP averages the
@@ -248,15 +271,7 @@ def main():
     else:
         def step():
             with torch.no_grad():
-                out = net(batch)
-            if gather is not None:
-                if args.shard == "views":
-                    if args.sync_gather:
-                        return gather.all_gather_frames(out[rgb_key], out[depth_key])
-                    # the exchange of frame i runs on RCCL's stream under the kernels of frame i+1
-                    return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
-                return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
-            return out
+                return finish(net(batch))
 
     # MIOpen's solver search writes its per-user find-db: rank 0 searches first with a collective-free forward,
     # the other ranks then hit the finished db instead of N processes searching (and locking the db) at once.
@@ -292,14 +307,8 @@ def main():
             replay = fg.replay
 
             def step():   # noqa: F811
-                out = replay()
-                if gather is not None:
-                    if args.shard == "views":
-                        if args.sync_gather:
-                            return gather.all_gather_frames(out[rgb_key], out[depth_key])
-                        return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
-                    return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
-                return out
+                with torch.no_grad():
+                    return finish(replay())
             for _ in range(2):
                 step()
             graph_note = f"{len(fg.graphs)} graph(s)" + (f" + {len(fg.sweeps)} eager plane sweep(s)" if fg.sweeps else "")
@@ -465,7 +474,7 @@ def main():
             else f"rendered Mray/s per GPU ({args.workload})",
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.shard == "views" else "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak" if (args.shard == "views" or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "network": wl["net"], "H": H, "W": W, "src_views": wl["views"],
                        "volume_planes": list(cc.volume_planes) if "planes" in wl else None,

@@ -59,6 +59,9 @@ class Network(enerf_network.Network):
         self._sel_cache = {}
         self._streams = []
         self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
+        # multi-GPU, `--shard volumes` (boostmvsnerfs_amd/sharding.py VolumeShard): build and render only these cost
+        # volumes (indices into the K selected ones) and return their stacked (raw, z, mask) instead of the fused picture
+        self.volume_ids = None
         self.by_index = True        # inference: views picked by index inside the kernels (tests compare with gathered copies)
         if not preprocess:
             path = os.path.join(cfg.result_dir, "view_selection.json")
@@ -162,12 +165,13 @@ class Network(enerf_network.Network):
         main = torch.cuda.current_stream()
         while len(self._streams) < K:
             self._streams.append(torch.cuda.Stream())
+        ks = list(range(K)) if self.volume_ids is None else [int(k) for k in self.volume_ids]
         stacks = {}
         for i in range(cc.num):
             if cc.render_if[i]:
                 n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
-                stacks[i] = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
-                             torch.empty(1, K, n_i, ns_i, device=dev))
+                stacks[i] = (torch.empty(1, len(ks), n_i, ns_i, 4, device=dev), torch.empty(1, len(ks), n_i, ns_i, device=dev),
+                             torch.empty(1, len(ks), n_i, ns_i, device=dev))
         # the packed-weight caches (MLP blobs, folded convolution weights) are filled lazily by whichever chain touches
         # them first: fill them HERE, on the stream every chain forks from, or volumes 1..K-1 could read blobs that
         # volume 0's stream is still writing (first frame after load / .to() / an optimiser step)
@@ -176,8 +180,8 @@ class Network(enerf_network.Network):
             if cc.render_if[i]:
                 getattr(self, f"nerf_{i}").packed_weights()
         first = {}
-        for k in range(K):
-            s = self._streams[k]
+        for j, k in enumerate(ks):
+            s = self._streams[j]
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 vid = sel32[:, k]
@@ -187,21 +191,28 @@ class Network(enerf_network.Network):
                     st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid)
                     if cc.render_if[i]:
                         self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch, mode=1,
-                                          outs=tuple(t[:, k] for t in stacks[i]), view_ids=vid)
+                                          outs=tuple(t[:, j] for t in stacks[i]), view_ids=vid)
                         if k == 0:
                             first[i] = (st.depth, st.std)
-        for k in range(K):
-            main.wait_stream(self._streams[k])
+        for j in range(len(ks)):
+            main.wait_stream(self._streams[j])
         ret = {}
         for i, (raws, zs, ms) in stacks.items():
+            if self.ray_range is not None:   # the render launches wrote rays [begin, end) of the full-size buffers
+                b_, e_ = self.ray_range
+                raws, zs, ms = raws[:, :, b_:e_], zs[:, :, b_:e_], ms[:, :, b_:e_]
             if self.capture is not None:     # tests: per-volume raw outputs / depths / visibility masks
                 self.capture[f"level{i}"] = (raws, zs, ms)
-            out = self.merge_mlp_outputs(raws, ms, zs)
-            depth0, std0 = first[i]                                 # depth_mvs / std come from volume 0 only
-            if not torch.cuda.is_current_stream_capturing():
-                depth0.record_stream(main), std0.record_stream(main)
-            out["depth_mvs"] = torch.reciprocal(depth0) if cc.depth_inv[i] else depth0
-            out["std"] = std0
+            if self.volume_ids is not None:  # volume sharding: the fusion happens after the exchange between ranks
+                out = {"stacks": (raws, zs, ms)}
+            else:
+                out = self.merge_mlp_outputs(raws.contiguous(), ms.contiguous(), zs.contiguous())
+            if i in first:
+                depth0, std0 = first[i]                             # depth_mvs / std come from volume 0 only
+                if not torch.cuda.is_current_stream_capturing():
+                    depth0.record_stream(main), std0.record_stream(main)
+                out["depth_mvs"] = torch.reciprocal(depth0) if cc.depth_inv[i] else depth0
+                out["std"] = std0
             ret.update({f"{k_}_level{i}": v for k_, v in out.items()})
         batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
         return ret
@@ -241,8 +252,10 @@ class Network(enerf_network.Network):
         if by_index:
             sel32 = sel.to(torch.int32)
             cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
-            if self.parallel_volumes and B == 1 and self.ray_range is None:
+            if (self.parallel_volumes or self.volume_ids is not None) and B == 1:
                 return self._forward_parallel(batch, feats, sel, sel32, cams, K)
+        if self.volume_ids is not None:
+            raise NotImplementedError("volume_ids (multi-GPU volume sharding) needs the inference path with views by index, B = 1")
         for i in range(cc.num):
             raws, zs, ms = [], [], []
             stacks = None

@@ -8,6 +8,12 @@ inside the kernels:
   * rays:  one frame, contiguous row-major ray ranges per rank (the front end --
     features, sweep, regulariser -- is replicated: no halo logic, no traffic),
     then the same all-gather reassembles the frame.
+  * volumes (the K-volume boost networks): the K cost volumes of a frame are independent until the fusion
+    (boost_enerf/network.py:172-237), so rank (g, r) builds and renders volumes {k : k % G == g} for ray slice r
+    (G = min(world, K) volume groups x R = world / G ray groups; the 2-D feature net is replicated), the G ranks of a
+    ray group swap (raw, z, mask) with ONE all-to-all so that each ends up with ALL K volumes for 1/G of the slice,
+    fuses it (the blend kernel), and the usual tile all-gather reassembles the frame.  Unlike ray sharding this
+    divides the 3-D regularisers -- 3/4 of a boost frame -- by G instead of replicating them.
 Tiles are packed (rgb, depth) into one buffer so a step issues ONE collective;
 at 512x640 it moves 5.2 MB per rank, latency-bound on xGMI.
 """
@@ -107,3 +113,75 @@ class TileGather:
         if all(e - b == rows for b, e in slices):
             return parts.reshape(n_rays, 4)
         return torch.cat([parts[r, : e - b] for r, (b, e) in enumerate(slices)], 0)
+
+
+class VolumeShard:
+    """Cost-volume parallelism of the K-volume boost path (see the module docstring).
+
+    rank = r * G + g; `volumes` and `ray_range` are what this rank tells its network to compute
+    (`net.volume_ids`, `net.ray_range`); `exchange` turns its (1, K/G, n_r, Ns, .) stacks into the
+    (1, K, n_sub, Ns, .) stacks of its ray sub-slice; `gather_tiles` reassembles the fused frame."""
+
+    def __init__(self, world, rank, K, n_rays):
+        G = min(world, K)
+        if K % G or world % G:
+            raise ValueError(f"volume sharding needs K ({K}) and the world size ({world}) to be multiples of min(world, K)")
+        self.world, self.rank, self.K, self.G, self.R, self.n_rays = world, rank, K, G, world // G, n_rays
+        self.g, self.r = rank % G, rank // G
+        self.volumes = [k for k in range(K) if k % G == self.g]
+        self.ray_range = ray_slice(n_rays, self.R, self.r)
+        # every rank creates every group (torch.distributed requirement); mine is the one of my ray group
+        self.group = None
+        if self.R > 1:
+            for r in range(self.R):
+                grp = dist.new_group(ranks=[r * G + g for g in range(G)])
+                if r == self.r:
+                    self.group = grp
+        n_r = self.ray_range[1] - self.ray_range[0]
+        self.sub = -(-n_r // G)                                            # rays per rank after the exchange (padded)
+        self.sub_max = -(-max(e - b for b, e in all_slices(n_rays, self.R)) // G)
+        self._tile = None
+
+    def sub_range(self):
+        """Rays of the frame this rank fuses: [begin, end)."""
+        b, e = self.ray_range
+        return min(b + self.g * self.sub, e), min(b + (self.g + 1) * self.sub, e)
+
+    def exchange(self, raws, zs, ms):
+        """(1, K/G, n_r, Ns, 4), (1, K/G, n_r, Ns), (1, K/G, n_r, Ns) of MY volumes over the whole ray slice ->
+        the same three for ALL K volumes (in order) over my ray sub-slice."""
+        kl, n_r, Ns = raws.shape[1], raws.shape[2], raws.shape[3]
+        G, sub = self.G, self.sub
+        if G == 1:
+            return raws, zs, ms
+        pack = torch.zeros(kl, G * sub, Ns, 6, device=raws.device, dtype=torch.float32)
+        pack[:, :n_r, :, :4] = raws[0]
+        pack[:, :n_r, :, 4] = zs[0]
+        pack[:, :n_r, :, 5] = ms[0]
+        send = pack.view(kl, G, sub, Ns, 6).transpose(0, 1).contiguous()      # (G peers, kl, sub, Ns, 6)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        # recv[g'] = volumes {g', g' + G, ...} of peer g' for my sub-slice -> volume order k = j * G + g'
+        full = recv.permute(1, 0, 2, 3, 4).reshape(self.K, sub, Ns, 6)
+        b, e = self.sub_range()
+        full = full[:, : e - b]
+        return (full[None, ..., :4].contiguous(), full[None, ..., 4].contiguous(), full[None, ..., 5].contiguous())
+
+    def gather_tiles(self, rgb, depth):
+        """Fused (1, n_sub, 3), (1, n_sub) of every rank's sub-slice -> the frame (n_rays, 4)."""
+        n = rgb.shape[-2]
+        if self._tile is None or self._tile[0].device != rgb.device:
+            self._tile = (torch.zeros(self.sub_max, 4, device=rgb.device), torch.empty(self.world * self.sub_max, 4, device=rgb.device))
+        send, recv = self._tile
+        send[:n, :3] = rgb.reshape(n, 3)
+        send[:n, 3] = depth.reshape(n)
+        dist.all_gather_into_tensor(recv, send)
+        parts = recv.view(self.world, self.sub_max, 4)
+        out = []
+        for r in range(self.R):
+            b, e = ray_slice(self.n_rays, self.R, r)
+            sub = -(-(e - b) // self.G)
+            for g in range(self.G):
+                lo, hi = min(b + g * sub, e), min(b + (g + 1) * sub, e)
+                out.append(parts[r * self.G + g, : hi - lo])
+        return torch.cat(out, 0)

@@ -49,6 +49,13 @@ def _boost_enerf(tmp, sel, seed=0):
     return Network().eval().to(DEV)
 
 
+def _run_raw(net, batch):
+    from boostmvsnerfs_amd.synthetic import clone_batch
+    with torch.no_grad():
+        out = net(clone_batch(batch))
+    return {k: (tuple(t.clone() for t in v) if isinstance(v, tuple) else v.clone()) for k, v in out.items()}
+
+
 def _run(net, batch):
     from boostmvsnerfs_amd.synthetic import clone_batch
     with torch.no_grad():
@@ -69,6 +76,35 @@ def test_config3_execution_paths_agree_bit_for_bit(cfg3):
     for k in want:
         assert torch.equal(seq[k], want[k]), f"{k}: one stream vs K streams"
         assert torch.equal(gathered[k], want[k]), f"{k}: gathered views vs views by index"
+
+
+def test_config3_volume_subsets_and_ray_ranges_reassemble(cfg3):
+    """What `bench.py --shard volumes` (sharding.VolumeShard) asks of each rank: a subset of the K cost volumes over a
+    ray range, returned as stacked (raw, z, mask).  Two ranks' worth of subsets, interleaved back and fused, are the
+    full frame bit for bit; a ray range of the fused path equals that slice of the full frame."""
+    cfg, tmp, batch = cfg3
+    net = _boost_enerf(tmp, [0, 7, 13, 19])
+    want = _run(net, batch)
+    N = 480 * 736
+    rng = (N // 3 + 5, N // 3 + 5 + 100_003)
+    net.ray_range = rng
+    part = _run(net, batch)
+    for k in ("rgb_level1", "depth_level1", "weights_level1"):
+        assert torch.equal(part[k], want[k][:, rng[0]:rng[1]]), k
+    halves = []
+    for ids in ([0, 2], [1, 3]):
+        net.volume_ids = ids
+        out = _run_raw(net, batch)
+        assert ("depth_mvs_level1" in out) == (0 in ids)             # depth_mvs / std belong to volume 0's owner
+        halves.append(out["stacks_level1"])
+    net.volume_ids = None
+    net.ray_range = None
+    raws, zs, ms = (torch.stack([halves[0][j][:, 0], halves[1][j][:, 0], halves[0][j][:, 1], halves[1][j][:, 1]], 1)
+                    for j in range(3))
+    assert raws.shape == (1, 4, rng[1] - rng[0], 2, 4)
+    fused = net.merge_mlp_outputs(raws.contiguous(), ms.contiguous(), zs.contiguous())
+    assert torch.equal(fused["rgb"], want["rgb_level1"][:, rng[0]:rng[1]])
+    assert torch.equal(fused["depth"], want["depth_level1"][:, rng[0]:rng[1]])
 
 
 def test_config3_volume_order_does_not_change_the_fused_picture(cfg3):

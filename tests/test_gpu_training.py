@@ -29,7 +29,10 @@ def _oracle_grads(forward, sd, batch, cfg):
     return float(loss), {k: v.grad for k, v in leaves.items() if v.requires_grad}
 
 
-def _check_grads(net, want, loss_g, loss_c):
+def _check_grads(net, want, loss_g, loss_c, outliers=0.0):
+    """Every parameter gradient within 2e-3 relative (+ 2e-3 of the tensor's rms, + 2e-6 of the largest gradient of
+    the network for tensors that are rounding noise, e.g. a bias in front of a softmax over views).  Measured on the
+    reference's own gradients (scripts/grad_err_vs_reference.py): max |d| <= 1e-4 rms on every tensor, no outliers."""
     assert abs(loss_g - loss_c) <= 1e-4 * abs(loss_c), (loss_g, loss_c)
     named = dict(net.named_parameters())
     assert set(named) == set(want)                       # every parameter tensor of the reference gets a gradient
@@ -38,10 +41,10 @@ def _check_grads(net, want, loss_g, loss_c):
     for k, p in named.items():
         assert p.grad is not None, f"{k} received no gradient"
         err = (p.grad.cpu() - want[k]).abs()
-        tol = 1e-2 * want[k].abs() + 1e-2 * float(want[k].pow(2).mean().sqrt()) + 1e-5 * gmax
+        tol = 2e-3 * want[k].abs() + 2e-3 * float(want[k].pow(2).mean().sqrt()) + 2e-6 * gmax
         bad = float((err > tol).float().mean())
         worst[k] = bad
-        assert bad <= 0.02, f"{k}: {bad:.1%} of the gradient outside tolerance (max err {float(err.max()):.3e})"
+        assert bad <= outliers, f"{k}: {bad:.2%} of the gradient outside tolerance (max err {float(err.max()):.3e})"
     return worst
 
 
@@ -141,3 +144,39 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     for k, p in net.named_parameters():
         if float(want[k].abs().max()) > 1e-6 * gmax:
             assert bool((p.detach() != before[k]).any()), f"{k} did not move"
+
+
+def test_finetune_step_under_ddp_and_syncbn(enerf_fx):
+    """trainer.py:15-22 on the GPU: SyncBatchNorm conversion + DistributedDataParallel (RCCL backend, a world of one
+    process here) around the loss wrapper, network in train mode as the trainer sets it, one train_step on the HIP
+    forward / backward path: finite loss, every parameter that receives a gradient moves, state-dict keys unchanged."""
+    import os
+    import torch.distributed as dist
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
+    set_cfg(tiny_cfg(enerf_fx, "enerf_pretrain"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        net = Network()
+        net.load_state_dict(enerf_fx.group("sd"), strict=True)
+        keys = list(net.state_dict().keys())
+        net = net.to(DEV).train()
+        wrapper = torch.nn.SyncBatchNorm.convert_sync_batchnorm(NetworkWrapper(net))
+        assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in wrapper.modules())
+        ddp = torch.nn.parallel.DistributedDataParallel(wrapper, device_ids=[0], output_device=0, find_unused_parameters=True)
+        assert [k.replace("module.net.", "") for k in ddp.state_dict().keys()] == keys
+        bg = _targets(enerf_fx.batch())
+        bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in bg.items()}
+        before = {k: p.detach().clone() for k, p in ddp.module.net.named_parameters()}
+        loss, stats = train_step(ddp, make_optimizer(ddp.module.net), bg)
+        assert bool(torch.isfinite(loss)) and "color_mse_1" in stats and "psnr_0" in stats
+        moved = sum(bool((p.detach() != before[k]).any()) for k, p in ddp.module.net.named_parameters())
+        assert moved >= 110, moved          # (a few heads sit behind dead ReLUs / a softmax over views: zero gradients)
+    finally:
+        if created:
+            dist.destroy_process_group()
