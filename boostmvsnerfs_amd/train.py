@@ -4,6 +4,8 @@ rgb_{i}) [+ 0.01 * VGG perceptual loss when torchvision VGG16 weights are availa
 offline, so the perceptual term is off and reported as such], Adam(lr 5e-4, eps 1e-8), gradient value
 clipping at 40, exponential LR decay (gamma 0.5 every 50 epochs).  Works under torch DDP
 (gradient all-reduce over RCCL) unchanged: every op is a regular autograd Function."""
+import sys
+
 import torch
 import torch.nn as nn
 
@@ -61,7 +63,7 @@ class NetworkWrapper(nn.Module):
                 else:
                     if not self._warned:
                         print(f"[train] level {i}: the 0.01 * VGG perceptual term of lib/train/losses/enerf.py:33-52 is OFF "
-                              "(no VGG16 weights offline; pass NetworkWrapper(..., perceptual=fn) to enable it)")
+                              "(no VGG16 weights offline; pass NetworkWrapper(..., perceptual=fn) to enable it)", file=sys.stderr)
                         self._warned = True
                     stats[f"perceptual_loss_{i}"] = torch.full((), float("nan"), device=mse.device)
         stats["loss"] = loss.detach() if torch.is_tensor(loss) else loss

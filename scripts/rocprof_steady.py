@@ -16,11 +16,12 @@ ap.add_argument("trace")
 ap.add_argument("--marker", default="render_rays_kernel")
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--out", default=None)
+ap.add_argument("--markers-per-step", type=int, default=1, help="dispatches of the marker kernel in one step")
 a = ap.parse_args()
 
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]][a.markers_per_step - 1::a.markers_per_step]
 if len(marks) < a.steps + 1:
     raise SystemExit(f"only {len(marks)} marker dispatches")
 lo, hi = marks[-(a.steps + 1)] + 1, marks[-1] + 1          # a.steps whole steps, ending on a marker
