@@ -190,6 +190,7 @@ struct MvsMlp {
   static constexpr int TOTAL = A_TOTAL + S_TOTAL;
 };
 static_assert(MvsMlp::offset(MvsMlp::N_CHUNKS) == MvsMlp::A_TOTAL, "chunk table");
+static constexpr int kMvsSmall = ((MvsMlp::S_TOTAL + 255) / 256) * 256;   // floats of LDS in front of the chunk buffers
 
 __device__ __forceinline__ int hid_index(int u, int h) { return 32 * (u >> 4) + n16(u & 15, h); }  // k-step u of a 128-wide input
 
@@ -259,12 +260,25 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
   blob[idx] = v;
 }
 
-// stage chunk c of the blob into the LDS buffer (whole workgroup, 256 threads)
-__device__ __forceinline__ void stage_chunk(const float* __restrict__ blob, float* __restrict__ buf, int c) {
-  const float4* src = reinterpret_cast<const float4*>(blob + MvsMlp::offset(c));
-  float4* dst = reinterpret_cast<float4*>(buf);
-  const int n4 = MvsMlp::steps(c) * 32;
-  for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+// Weight streaming.  The chunks go through TWO LDS buffers by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
+// instruction, no VGPR round trip): chunk c + 1 is in flight while the MFMAs of chunk c run, so a chunk costs one
+// workgroup barrier and no exposed load latency (one buffer + a register-staged copy between two barriers per chunk
+// left the matrix pipe idle half of the time: 51 % of the fp32 MFMA peak at 1 wave per SIMD).  The buffer parity is a
+// running count over chunks AND tiles (17 chunks per tile is odd: chunk 0 of the next tile takes the other buffer and
+// is fetched under the last chunk of this one).
+struct ChunkPipe {
+  int count;   // chunks consumed so far by this workgroup (buffer = count & 1)
+  bool more;   // another tile follows this one: prefetch its chunk 0
+};
+
+__device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ buf2, int c, int parity) {
+  const char* src = reinterpret_cast<const char*>(blob + MvsMlp::offset(c));
+  char* dst = reinterpret_cast<char*>(buf2 + parity * MvsMlp::CHUNK_MAX);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int npieces = MvsMlp::steps(c) / 2;          // 128 floats per k-step = 512 B; a piece is 1 KB
+  for (int p = wave; p < npieces; p += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
 }
 
 // acc{0,1} += W_chunk[:, steps T0..T0+NT) * B, B given by `bval(t)` for the chunk-local step t
@@ -279,18 +293,24 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ blob, floa
 
 // e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
 // Must be called by all 4 waves of the workgroup together (chunk staging uses __syncthreads).
+// Chunk 0 of this tile must already be in flight (issue_chunk(blob, buf2, 0, pipe.count & 1) by every wave).
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
-                                                float* __restrict__ buf, int lane, const float (&e)[32],
-                                                const float (&f)[10], const float (&dv)[2], float (&out)[4]) {
+                                                float* __restrict__ buf2, ChunkPipe& pipe, int lane,
+                                                const float (&e)[32], const float (&f)[10], const float (&dv)[2],
+                                                float (&out)[4]) {
   const int h = lane >> 5;
   const float* __restrict__ Sv = small + h;
   f32x16 bias[4], hcur[4], hnew[4];
   int chunk = 0;
+  const float* buf = buf2;
   auto next_chunk = [&]() {
-    __syncthreads();  // everyone is done with the previous chunk
-    stage_chunk(blob, buf, chunk);
-    __syncthreads();
-    ++chunk;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this chunk have landed
+    __syncthreads();                                   // everyone's have; everyone is done with the previous chunk
+    const int par = pipe.count & 1;
+    buf = buf2 + par * MvsMlp::CHUNK_MAX;
+    if (chunk + 1 < MvsMlp::N_CHUNKS) issue_chunk(blob, buf2, chunk + 1, par ^ 1);
+    else if (pipe.more) issue_chunk(blob, buf2, 0, par ^ 1);
+    ++chunk, ++pipe.count;
   };
   // pts_bias (network.py:210): bias = W_b feat + b_b
 #pragma unroll
@@ -466,9 +486,9 @@ __device__ __forceinline__ void mvs_point_inputs(const bmv_mvs_render_args& a, c
 template <int S>
 __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 16 B)
-  float* buf = lds + ((MvsMlp::S_TOTAL + 3) / 4) * 4;   // one weight chunk
-  MvsCams* mc = reinterpret_cast<MvsCams*>(buf + MvsMlp::CHUNK_MAX);
+  float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 1 KB for the DMA buffers)
+  float* buf = lds + kMvsSmall;                         // two weight-chunk buffers
+  MvsCams* mc = reinterpret_cast<MvsCams*>(buf + 2 * MvsMlp::CHUNK_MAX);
   if (a.blob)
     for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = a.blob[MvsMlp::A_TOTAL + i];
   if ((int)threadIdx.x < S) load_cam(a.src_exts + threadIdx.x * 16, a.src_ixts + threadIdx.x * 9, 1.f, mc->cam[threadIdx.x]);
@@ -482,7 +502,10 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
   const long npts = (long)(a.ray_end - a.ray_begin) * a.Ns;
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
+  ChunkPipe pipe{0, false};
+  if (a.blob) issue_chunk(a.blob, buf, 0, 0);   // under the gathers / sincos of the first tile
   for (long round = 0; round * per_round < ntiles; ++round) {   // uniform trip count across the workgroup
+    pipe.more = (round + 1) * per_round < ntiles;
     long tile = round * per_round + (long)blockIdx.x * 4 + wave;
     long pt = tile * 32 + s;
     bool valid = pt < npts;
@@ -502,7 +525,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
       else row[84] = dv[0];
     }
     if (a.blob) {
-      mvs_mlp_forward(a.blob, small, buf, lane, e, f, dv, res);
+      mvs_mlp_forward(a.blob, small, buf, pipe, lane, e, f, dv, res);
       if (valid && h == 0) {
         float4 o4 = {res[0], res[1], res[2], res[3]};
         reinterpret_cast<float4*>(a.raw)[gi] = o4;
@@ -519,14 +542,17 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
                                                           long npts, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* small = lds;
-  float* buf = lds + ((MvsMlp::S_TOTAL + 3) / 4) * 4;
+  float* buf = lds + kMvsSmall;
   for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = blob[MvsMlp::A_TOTAL + i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 31, h = lane >> 5;
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
+  ChunkPipe pipe{0, false};
+  issue_chunk(blob, buf, 0, 0);
   for (long round = 0; round * per_round < ntiles; ++round) {
+    pipe.more = (round + 1) * per_round < ntiles;
     long pt = (round * per_round + (long)blockIdx.x * 4 + wave) * 32 + s;
     bool valid = pt < npts;
     const float* row = x + (valid ? pt : npts - 1) * 86;
@@ -537,7 +563,7 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
     for (int t = 0; t < 10; ++t) f[t] = row[63 + 2 * t + h];
     dv[0] = row[83 + h];
     dv[1] = h ? 0.f : row[85];
-    mvs_mlp_forward(blob, small, buf, lane, e, f, dv, res);
+    mvs_mlp_forward(blob, small, buf, pipe, lane, e, f, dv, res);
     if (valid && h == 0) {
       float4 o4 = {res[0], res[1], res[2], res[3]};
       reinterpret_cast<float4*>(out)[pt] = o4;
@@ -567,7 +593,7 @@ __global__ void mvs_march_mask_kernel(const float* __restrict__ rays, const floa
   mask[i] = acc / (float)V;
 }
 
-static constexpr size_t kMvsLds = (((MvsMlp::S_TOTAL + 3) / 4) * 4 + MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
+static constexpr size_t kMvsLds = (kMvsSmall + 2 * MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
 
 }  // namespace bmv
 
