@@ -138,6 +138,12 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
 }
 
 #define BMV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#ifndef BMV_MLP_G1
+#define BMV_MLP_G1 3   // k-steps per software-pipelined group, one-tile chains
+#endif
+#ifndef BMV_MLP_G2
+#define BMV_MLP_G2 2   // two-tile chains (2 MFMAs per k-step)
+#endif
 // The weight reads are LDS loads with compile-time offsets; left alone, the
 // scheduler hoists dozens of them ahead of the MFMA chain they feed and spills.
 // A scheduling fence every few k-steps keeps the live set to one chunk.
@@ -146,6 +152,57 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
   do {                         \
     if (((t) % (n)) == (n)-1) BMV_FENCE(); \
   } while (0)
+
+// MFMA chains with the A operands (weights, LDS) software-pipelined by one group of G k-steps: the ds_reads of
+// group g + 1 are issued BEFORE the MFMAs of group g, so no MFMA waits for an LDS round trip (with the reads issued
+// right behind a scheduling fence, as before, the first MFMA of every group stalled ~100-200 cycles: one s_waitcnt
+// per MFMA in the ISA, the matrix pipe 46-54 % busy).  `t` is the k-step visible to BEXPR.
+//   BMV_CHAIN1: one accumulator tile,  A of step t at Wa[AOFF + t * 64]
+//   BMV_CHAIN2: two accumulator tiles, A of (step t, tile tl) at Wa[AOFF + (t * 2 + tl) * 64]
+#define BMV_CHAIN1(AOFF, NT, G, BEXPR, ACC)                                                        \
+  {                                                                                                \
+    float a_[2][G];                                                                                \
+    _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_)                                             \
+      if (u_ < (NT)) a_[0][u_] = Wa[(AOFF) + u_ * 64];                                             \
+    _Pragma("unroll") for (int g_ = 0; g_ < ((NT) + (G)-1) / (G); ++g_) {                          \
+      _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_) {                                         \
+        const int tn_ = (g_ + 1) * (G) + u_;                                                       \
+        if (tn_ < (NT)) a_[(g_ + 1) & 1][u_] = Wa[(AOFF) + tn_ * 64];                              \
+      }                                                                                            \
+      BMV_FENCE();                                                                                 \
+      _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_) {                                         \
+        const int t = g_ * (G) + u_;                                                               \
+        if (t < (NT)) {                                                                            \
+          const float b_ = (BEXPR);                                                                \
+          ACC = BMV_MFMA(a_[g_ & 1][u_], b_, ACC);                                                 \
+        }                                                                                          \
+      }                                                                                            \
+      BMV_FENCE();                                                                                 \
+    }                                                                                              \
+  }
+#define BMV_CHAIN2(AOFF, NT, G, BEXPR, ACC0, ACC1)                                                 \
+  {                                                                                                \
+    float a_[2][G][2];                                                                             \
+    _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_)                                             \
+      if (u_ < (NT)) a_[0][u_][0] = Wa[(AOFF) + (u_ * 2) * 64], a_[0][u_][1] = Wa[(AOFF) + (u_ * 2 + 1) * 64]; \
+    _Pragma("unroll") for (int g_ = 0; g_ < ((NT) + (G)-1) / (G); ++g_) {                          \
+      _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_) {                                         \
+        const int tn_ = (g_ + 1) * (G) + u_;                                                       \
+        if (tn_ < (NT))                                                                            \
+          a_[(g_ + 1) & 1][u_][0] = Wa[(AOFF) + (tn_ * 2) * 64], a_[(g_ + 1) & 1][u_][1] = Wa[(AOFF) + (tn_ * 2 + 1) * 64]; \
+      }                                                                                            \
+      BMV_FENCE();                                                                                 \
+      _Pragma("unroll") for (int u_ = 0; u_ < (G); ++u_) {                                         \
+        const int t = g_ * (G) + u_;                                                               \
+        if (t < (NT)) {                                                                            \
+          const float b_ = (BEXPR);                                                                \
+          ACC0 = BMV_MFMA(a_[g_ & 1][u_][0], b_, ACC0);                                            \
+          ACC1 = BMV_MFMA(a_[g_ & 1][u_][1], b_, ACC1);                                            \
+        }                                                                                          \
+      }                                                                                            \
+      BMV_FENCE();                                                                                 \
+    }                                                                                              \
+  }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
@@ -191,27 +248,12 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   f32x16 gsh;
 #pragma unroll
   for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
-#pragma unroll
-  for (int t = 0; t < KFC; ++t) {
-    gsh = BMV_MFMA(Wa[L::A_GSH + t * 64], var[t], gsh);
-    BMV_FENCE_EVERY(t, 6);
-  }
-  BMV_FENCE();
-#pragma unroll
-  for (int t = 0; t < KFC; ++t) {
-    gsh = BMV_MFMA(Wa[L::A_GSH + (KFC + t) * 64], mean[t], gsh);
-    BMV_FENCE_EVERY(t, 6);
-  }
-  BMV_FENCE();
+  BMV_CHAIN1(L::A_GSH, 2 * KFC, BMV_MLP_G1, (t < KFC ? var[t < KFC ? t : 0] : mean[t >= KFC ? t - KFC : 0]), gsh)
   f32x16 g[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     g[i] = gsh;
-#pragma unroll
-    for (int t = 0; t < KFC; ++t) {
-      g[i] = BMV_MFMA(Wa[L::A_GV + t * 64], fval(i, t), g[i]);
-      BMV_FENCE_EVERY(t, 6);
-    }
+    BMV_CHAIN1(L::A_GV, KFC, BMV_MLP_G1, fval(i, t), g[i])
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[i][r] = fmaxf(g[i][r], 0.f);
     BMV_FENCE();
@@ -236,13 +278,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   f32x16 q;
 #pragma unroll
   for (int r = 0; r < 16; ++r) q[r] = Wv[L::V_BFC + r * 2];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    float im = aw[0] * g[0][t] + aw[1] * g[1][t] + aw[2] * g[2][t];
-    q = BMV_MFMA(Wa[L::A_FC + t * 64], im, q);
-    BMV_FENCE_EVERY(t, 8);
-  }
-  BMV_FENCE();
+  BMV_CHAIN1(L::A_FC, 16, BMV_MLP_G1, (aw[0] * g[0][t] + aw[1] * g[1][t] + aw[2] * g[2][t]), q)
   float im16[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) im16[r] = fmaxf(q[r], 0.f);
@@ -252,13 +288,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[tl][r] = Wv[L::V_B0 + (tl * 16 + r) * 2];
-#pragma unroll
-  for (int t = 0; t < 12; ++t) {
-    float b = t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) x[tl] = BMV_MFMA(Wa[L::A_L0 + (t * 2 + tl) * 64], b, x[tl]);
-    BMV_FENCE_EVERY(t, 4);
-  }
+  BMV_CHAIN2(L::A_L0, 12, BMV_MLP_G2, (t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0]), x[0], x[1])
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
@@ -279,32 +309,15 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) csh[tl][r] = Wv[L::V_BC + (tl * 16 + r) * 2];
-#pragma unroll
-  for (int t = 0; t < 44; ++t) {
-    float b;
-    if (t < 32)
-      b = x[t < 32 ? (t >> 4) : 0][t & 15];
-    else if (t < 36)
-      b = vox[t >= 32 && t < 36 ? t - 32 : 0];
-    else
-      b = im16[t >= 36 ? t - 36 : 0];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) csh[tl] = BMV_MFMA(Wa[L::A_CSH + (t * 2 + tl) * 64], b, csh[tl]);
-    BMV_FENCE_EVERY(t, 4);
-  }
-  BMV_FENCE();
+  BMV_CHAIN2(L::A_CSH, 44, BMV_MLP_G2,
+             (t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : im16[t >= 36 ? t - 36 : 0]),
+             csh[0], csh[1])
   // per-view part + color.2 + softmax over views (nerf.py:39-42)
   float cl[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     f32x16 hc[2] = {csh[0], csh[1]};
-#pragma unroll
-    for (int t = 0; t < KF; ++t) {
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) hc[tl] = BMV_MFMA(Wa[L::A_CV + (t * 2 + tl) * 64], fin[i][t], hc[tl]);
-      BMV_FENCE_EVERY(t, 4);
-    }
-    BMV_FENCE();
+    BMV_CHAIN2(L::A_CV, KF, BMV_MLP_G2, fin[i][t], hc[0], hc[1])
     float s = 0.f;
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)

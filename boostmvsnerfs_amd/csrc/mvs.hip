@@ -282,13 +282,32 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
 }
 
 // acc{0,1} += W_chunk[:, steps T0..T0+NT) * B, B given by `bval(t)` for the chunk-local step t
-#define MVS_GEMM(buf, T0, NT, BEXPR, ACC0, ACC1)                                   \
-  _Pragma("unroll") for (int t_ = 0; t_ < (NT); ++t_) {                            \
-    const int t = t_;                                                              \
-    float b_ = (BEXPR);                                                            \
-    ACC0 = BMV_MFMA((buf)[((T0) + t_) * 128 + lane], b_, ACC0);                    \
-    ACC1 = BMV_MFMA((buf)[((T0) + t_) * 128 + 64 + lane], b_, ACC1);               \
-    BMV_FENCE_EVERY(t_, 4);                                                        \
+// (A operands software-pipelined by one group of MVS_G k-steps, as BMV_CHAIN2 of mlp.hpp)
+#ifndef MVS_G
+#define MVS_G 2
+#endif
+#define MVS_GEMM(buf, T0, NT, BEXPR, ACC0, ACC1)                                                        \
+  {                                                                                                     \
+    float a_[2][MVS_G][2];                                                                              \
+    _Pragma("unroll") for (int u_ = 0; u_ < MVS_G; ++u_)                                                \
+      if (u_ < (NT)) a_[0][u_][0] = (buf)[((T0) + u_) * 128 + lane], a_[0][u_][1] = (buf)[((T0) + u_) * 128 + 64 + lane]; \
+    _Pragma("unroll") for (int g_ = 0; g_ < ((NT) + MVS_G - 1) / MVS_G; ++g_) {                         \
+      _Pragma("unroll") for (int u_ = 0; u_ < MVS_G; ++u_) {                                            \
+        const int tn_ = (g_ + 1) * MVS_G + u_;                                                          \
+        if (tn_ < (NT))                                                                                 \
+          a_[(g_ + 1) & 1][u_][0] = (buf)[((T0) + tn_) * 128 + lane], a_[(g_ + 1) & 1][u_][1] = (buf)[((T0) + tn_) * 128 + 64 + lane]; \
+      }                                                                                                 \
+      BMV_FENCE();                                                                                      \
+      _Pragma("unroll") for (int u_ = 0; u_ < MVS_G; ++u_) {                                            \
+        const int t = g_ * MVS_G + u_;                                                                  \
+        if (t < (NT)) {                                                                                 \
+          const float b_ = (BEXPR);                                                                     \
+          ACC0 = BMV_MFMA(a_[g_ & 1][u_][0], b_, ACC0);                                                 \
+          ACC1 = BMV_MFMA(a_[g_ & 1][u_][1], b_, ACC1);                                                 \
+        }                                                                                               \
+      }                                                                                                 \
+      BMV_FENCE();                                                                                      \
+    }                                                                                                   \
   }
 
 // e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.

@@ -9,6 +9,8 @@
 // is exactly the k-slot order the MLP wants (mlp.hpp).  The MLP weights sit in
 // LDS once per workgroup (4 waves) and the workgroup walks tiles grid-stride.
 #define BMV_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))   // see bmv_common.hpp
+#include <stdlib.h>
+
 #include "mlp.hpp"
 #include "render_geom.hpp"
 
@@ -265,7 +267,14 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
   BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
 }
 
+// workgroups of the fused renderer: 2 are resident per CU (launch bounds), tiles are walked grid-stride
+static unsigned render_grid() {
+  static const unsigned v = getenv("BMV_RENDER_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_GRID")) : 512u;   // = 2 per CU: every workgroup is resident from the start
+  return v;
+}
+
 int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
+  const unsigned kRenderGrid = render_grid();
   BMV_REQUIRE(a, "bmv_render_rays_fwd: null args");
   BMV_REQUIRE(a->rays && a->depth && a->std && a->near_far && a->volume && a->im_feat && a->rgb_src && a->src_exts &&
                   a->src_ixts && a->tar_ext && a->blob && a->out0 && a->out1 && a->out2,
@@ -284,7 +293,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
     BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");   \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
-    unsigned grid = (unsigned)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);                                  \
+    unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
     hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
