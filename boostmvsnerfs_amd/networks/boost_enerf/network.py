@@ -231,7 +231,11 @@ class Network(enerf_network.Network):
         sel = self._sel_cache.get(key)
         if sel is None:
             trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)
-            k_best = torch.tensor([self.view_selection_outputs[t] for t in key[0]], device=dev)
+            picks = [self.view_selection_outputs[t] for t in key[0]]
+            n_trip = trip.shape[0]
+            if any(not (0 <= int(v) < n_trip) for row in picks for v in row):      # host check: the kernels index with them
+                raise ValueError(f"view_selection.json holds a triplet index outside [0, {n_trip}) for {N} source views")
+            k_best = torch.tensor(picks, device=dev)
             if k_best.shape[1] < K:
                 raise ValueError(f"view_selection.json holds {k_best.shape[1]} volumes per target, cfg k_best={K}")
             sel = trip[k_best[:, :K]]                               # (B,K,3)

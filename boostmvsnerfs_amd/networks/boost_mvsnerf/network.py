@@ -57,8 +57,10 @@ class Network(mvsnerf_network.Network):
         dev = batch["all_src_inps"].device
         B, N = batch["all_src_inps"].shape[:2]
         trip = torch.tensor(view_triplets(N, cfg.enerf.cost_volume_input_views), device=dev)
-        k_best = torch.tensor([self.view_selection_outputs[f"{s}_{v}"]
-                               for s, v in zip(batch["meta"]["scene"], batch["meta"]["tar_view"])], device=dev)
+        picks = [self.view_selection_outputs[f"{s}_{v}"] for s, v in zip(batch["meta"]["scene"], batch["meta"]["tar_view"])]
+        if any(not (0 <= int(v) < trip.shape[0]) for row in picks for v in row):
+            raise ValueError(f"view_selection.json holds a triplet index outside [0, {trip.shape[0]}) for {N} source views")
+        k_best = torch.tensor(picks, device=dev)
         K = int(cc.k_best)
         if k_best.shape[1] < K:
             raise ValueError(f"view_selection.json holds {k_best.shape[1]} volumes per target, cfg k_best={K}")
