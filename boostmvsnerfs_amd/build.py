@@ -19,6 +19,8 @@ SOURCES = ["sweep.hip", "sweep_tiled.hip", "sweep_lds.hip", "sweep_split.hip", "
 HEADERS = ["bmv_common.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}    # per-file flags
+if os.environ.get("BMV_RENDER_DEFS"):   # e.g. "-DBMV_RENDER_STAMPS" for scripts/stamps_render.py
+    EXTRA_FLAGS["render.hip"] = os.environ["BMV_RENDER_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

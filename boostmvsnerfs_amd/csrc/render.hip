@@ -59,6 +59,10 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
   }
 }
 
+#ifdef BMV_RENDER_STAMPS
+__device__ float g_stamps[512 * 4 * 8];
+#endif
+
 template <int FEAT_CH, int NS, bool INV>
 __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) {
   using L = MlpLayout<FEAT_CH>;
@@ -98,7 +102,23 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
   }
   const int nrays = a.ray_end - a.ray_begin;
   const int ntiles = (nrays + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
+  // -DBMV_RENDER_STAMPS: shader-clock stamps of the phases of every wave's third tile (scripts/stamps_render.py reads
+  // them through bmv_debug_fetch_stamps); a tuning build, never the shipped library
+#ifdef BMV_RENDER_STAMPS
+  unsigned long long st[8];
+  int tile_no = 0;
+#define RSTAMP(i)                                                       \
+  {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
+    st[i] = __builtin_amdgcn_s_memtime();                               \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+  }
+#else
+#define RSTAMP(i)
+#endif
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    RSTAMP(0)
     int ray = a.ray_begin + tile * RAYS_PER_TILE + s / NS;
     bool valid = ray < a.ray_end;
     int rr = valid ? ray : a.ray_end - 1;
@@ -111,6 +131,7 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
     sample_point(o, d, rn, rf, vn, vf, k, NS, INV, z, xyz, dn);
 
     float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    RSTAMP(1)
     {  // a9: trilinear lookup, this half's 4 channels
       Taps3 t3 = taps3_zeros(BMV_DIV(px, inv_w), BMV_DIV(py, inv_h), dn, a.wv, a.hv, a.Dv);
       const size_t cs = (size_t)a.Dv * hwv;
@@ -123,6 +144,7 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
       for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch_buf(rs_vol, t3, (unsigned)(2 * j) * (unsigned)cs * 4u);
     }
     BMV_FENCE();
+    RSTAMP(2)
     float vis = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
@@ -153,7 +175,20 @@ __global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) 
       BMV_FENCE();
     }
 
+    RSTAMP(3)
     mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    RSTAMP(4)
+#ifdef BMV_RENDER_STAMPS
+    if (tile_no == 2 && lane == 0 && blockIdx.x < 512) {
+      float* o = g_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+      for (int i = 1; i < 5; ++i) o[i] = (float)(unsigned)(st[i] - st[0]);
+      o[0] = 1.f;
+    }
+    if (tile_no == 3 && lane == 0 && blockIdx.x < 512)
+      g_stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = (float)(unsigned)(st[0] - st[7]);
+    st[7] = st[0];
+    ++tile_no;
+#endif
 
     if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
       if (valid && h == 0) {
@@ -218,6 +253,12 @@ static int set_lds(K kernel, size_t bytes) {
 using namespace bmv;
 
 extern "C" {
+
+#ifdef BMV_RENDER_STAMPS
+int bmv_debug_fetch_stamps(float* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(float) * 512 * 4 * 8);
+}
+#endif
 
 int bmv_nerf_blob_size(int feat_ch) {
   if (feat_ch == 8) return MlpLayout<8>::TOTAL;
