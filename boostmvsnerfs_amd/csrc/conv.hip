@@ -394,19 +394,59 @@ __global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < CF; ++i) f[i] = fine[((size_t)b * CF + i) * hw + (size_t)y * W + x];
   const Lerp1 ly = upsample_axis(y, Hc, H), lx = upsample_axis(x, Wc, W);
-  for (int c = 0; c < C; ++c) {
-    float v = bias[c];
+  float* op = out + (size_t)b * C * hw + (size_t)y * W + x;
+  if constexpr (COARSE_CL) {
+    // coarse is (B, Hc, Wc, C), the channel-last map the plane sweep reads: a bilinear tap of FOUR channels is one
+    // 16-byte load (C % 4 == 0, checked by the launcher); two quads in flight
+    const float* cp = coarse + (size_t)b * hwc * C;
+    const size_t o00 = (size_t)(ly.i0 * Wc + lx.i0) * C, o01 = (size_t)(ly.i0 * Wc + lx.i1) * C;
+    const size_t o10 = (size_t)(ly.i1 * Wc + lx.i0) * C, o11 = (size_t)(ly.i1 * Wc + lx.i1) * C;
+    const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
+    for (int c = 0; c < C; c += 4) {
+      const float4 t00 = *reinterpret_cast<const float4*>(cp + o00 + c), t01 = *reinterpret_cast<const float4*>(cp + o01 + c);
+      const float4 t10 = *reinterpret_cast<const float4*>(cp + o10 + c), t11 = *reinterpret_cast<const float4*>(cp + o11 + c);
+      float v[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
 #pragma unroll
-    for (int i = 0; i < CF; ++i) v = fmaf(w[c * CF + i], f[i], v);
-    if constexpr (COARSE_CL) {   // coarse is (B, Hc, Wc, C): the channel-last map the plane sweep reads
-      const float* cp = coarse + (size_t)b * hwc * C + c;
-      const size_t sC = (size_t)C;
-      v += ly.l0 * (lx.l0 * cp[(ly.i0 * Wc + lx.i0) * sC] + lx.l1 * cp[(ly.i0 * Wc + lx.i1) * sC]) +
-           ly.l1 * (lx.l0 * cp[(ly.i1 * Wc + lx.i0) * sC] + lx.l1 * cp[(ly.i1 * Wc + lx.i1) * sC]);
-    } else {
-      v += upsample_fetch(coarse + ((size_t)b * C + c) * hwc, Wc, ly, lx);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < CF; ++i) v[j] = fmaf(w[(c + j) * CF + i], f[i], v[j]);
+      // same association as the planar path: l0y (l0x a + l1x b) + l1y (l0x c + l1x d)
+      v[0] += ly.l0 * (lx.l0 * t00.x + lx.l1 * t01.x) + ly.l1 * (lx.l0 * t10.x + lx.l1 * t11.x);
+      v[1] += ly.l0 * (lx.l0 * t00.y + lx.l1 * t01.y) + ly.l1 * (lx.l0 * t10.y + lx.l1 * t11.y);
+      v[2] += ly.l0 * (lx.l0 * t00.z + lx.l1 * t01.z) + ly.l1 * (lx.l0 * t10.z + lx.l1 * t11.z);
+      v[3] += ly.l0 * (lx.l0 * t00.w + lx.l1 * t01.w) + ly.l1 * (lx.l0 * t10.w + lx.l1 * t11.w);
+      (void)w00, (void)w01, (void)w10, (void)w11;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) op[(size_t)(c + j) * hw] = v[j];
     }
-    out[((size_t)b * C + c) * hw + (size_t)y * W + x] = v;
+  } else {
+    // planar coarse: four channels per iteration, their 16 taps issued before the first is consumed
+    const int i00 = ly.i0 * Wc + lx.i0, i01 = ly.i0 * Wc + lx.i1, i10 = ly.i1 * Wc + lx.i0, i11 = ly.i1 * Wc + lx.i1;
+    const float* cp = coarse + (size_t)b * C * hwc;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* q = cp + (size_t)(c + j) * hwc;
+        t[j][0] = q[i00], t[j][1] = q[i01], t[j][2] = q[i10], t[j][3] = q[i11];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = bias[c + j];
+#pragma unroll
+        for (int i = 0; i < CF; ++i) v = fmaf(w[(c + j) * CF + i], f[i], v);
+        v += ly.l0 * (lx.l0 * t[j][0] + lx.l1 * t[j][1]) + ly.l1 * (lx.l0 * t[j][2] + lx.l1 * t[j][3]);
+        op[(size_t)(c + j) * hw] = v;
+      }
+    }
+    for (; c < C; ++c) {
+      float v = bias[c];
+#pragma unroll
+      for (int i = 0; i < CF; ++i) v = fmaf(w[c * CF + i], f[i], v);
+      v += upsample_fetch(cp + (size_t)c * hwc, Wc, ly, lx);
+      op[(size_t)c * hw] = v;
+    }
   }
 }
 
@@ -778,6 +818,7 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   using namespace bmv;
   BMV_REQUIRE(fine && coarse && w && bias && out, "fpn_topdown: null pointer");
   BMV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_topdown: bad shape");
+  BMV_REQUIRE(!coarse_channels_last || C % 4 == 0, "fpn_topdown: a channel-last coarse map needs C %% 4 == 0 (C=%d)", C);
   dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
   hipStream_t st = as_stream(stream);
   if (Cf == 8 && !coarse_channels_last)
