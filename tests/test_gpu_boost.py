@@ -111,3 +111,22 @@ def test_missing_view_selection_is_loud(boost_fx, tmp_path):
     from boostmvsnerfs_amd.networks.boost_enerf.network import Network
     with pytest.raises(FileNotFoundError):
         Network()
+
+
+def test_evaluate_harness_bootstraps_view_selection_and_times_like_run_py(enerf_fx, boost_fx, tmp_path):
+    """boostmvsnerfs_amd/evaluate.py = run.py:71-129: a missing view_selection.json is built by the preprocess network
+    (and equals the reference's selection), then every batch is timed in the synchronize bracket and FPS drops the
+    first iteration."""
+    from boostmvsnerfs_amd import evaluate as E
+    cfg = _cfg(boost_fx, tmp_path / "result")
+    cfg.require_view_selection = True
+    batches = [boost_fx.batch() for _ in range(3)]                       # host batches, as a loader hands them over
+    path = E.ensure_view_selection(cfg, lambda: _net(enerf_fx, preprocess=True), batches[:1])
+    assert json.load(open(path)) == {"synthetic_0": [int(k) for k in boost_fx.raw["extra/k_best"]]}
+    assert E.ensure_view_selection(cfg, lambda: 1 / 0, batches[:1]) == path          # exists now: no preprocess
+    net = _net(enerf_fx, preprocess=False)
+    seen = []
+    res = E.evaluate(net, batches, on_output=lambda out, b: seen.append(out["rgb_level1"].shape))
+    assert len(res["net_time"]) == 3 and len(seen) == 3
+    mean = sum(res["net_time"][1:]) / 2
+    assert abs(res["FPS"] - 1.0 / mean) < 1e-9 and abs(res["Mray/s"] - seen[0][1] / mean / 1e6) < 1e-9
