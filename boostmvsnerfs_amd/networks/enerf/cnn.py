@@ -1,7 +1,9 @@
 """2-D feature pyramid and 3-D cost regularisers of ENeRF.
 
-These convolution stacks sit between the hot-path kernels (SURVEY.md section 8f:
-"next" rows, not hot-path kernels); they stay torch modules and run on MIOpen.
+These convolution stacks sit between the hot-path kernels.  The modules keep torch
+parameters (so checkpoints load and training works through autograd), but inference runs them on the package's own
+implicit-GEMM MFMA convolution engine (csrc/conv.hip via convnet.py) with eval-mode batch norm folded into the
+weights; only the training forward/backward uses torch's convolution kernels.
 Module/parameter names reproduce the reference's state-dict keys exactly
 (lib/networks/enerf/feature_net.py:4-36, cost_reg_net.py:4-86, utils.py:10-33)
 so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.

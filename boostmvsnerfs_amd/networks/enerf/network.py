@@ -7,7 +7,7 @@ Same module boundary as the reference's lib/networks/enerf/network.py:11-113:
 
 Inside, a cascade level is five launches instead of the reference's ~150 torch
 ops: projection matrices -> depth hypotheses -> fused plane-sweep variance ->
-[3-D regulariser, torch/MIOpen] -> depth regression -> ONE fused kernel from
+[3-D regulariser, csrc/conv.hip MFMA engine] -> depth regression -> ONE fused kernel from
 rays to composited pixels (per-ray bounds, samples, volume + image lookups,
 MFMA MLP, alpha compositing).  No warped volume, sample tensor or per-view
 feature tensor is ever materialised.
