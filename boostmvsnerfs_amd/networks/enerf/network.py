@@ -97,27 +97,29 @@ class Network(nn.Module):
             st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
         return st
 
-    # ------------------------------------------------------------------ training renderer (unfused, differentiable)
-    def render_level_train(self, i, st, im_feat, views, batch, mode=0):
-        """Same maths as render_level through the per-op autograd Functions: the per-sample tensors are
-        materialised between ops (as the reference does) so every op has a HIP backward
-        (backward contract)."""
+    # ------------------------------------------------------------------ unfused renderer (differentiable)
+    def _render_bounded(self, i, rays12, feature_volume, im_feat, views, tar_ext, nerf, mode=0):
+        """Bounded rays (B,n,12) -> composited pixels, one HIP kernel per reference op (network.py:24-44): the
+        per-sample tensors are materialised between ops as the reference does, so every op has a HIP backward
+        (backward contract).  Differentiable when grad mode is on."""
         cc = cfg.enerf.cas_config
         src_inps, src_exts, src_ixts = views
         B = src_inps.shape[0]
         H, W = src_inps.shape[-2:]
         rs = cc.render_scale[i]
         Hr, Wr = int(H * rs), int(W * rs)
-        if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
-            raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
+        up = cc.render_scale[i] / cc.im_ibr_scale[i]
+        if up != 1.0:      # network.py:29-32 (no shipped config takes this branch; torch's resize, as there)
+            b_, s_, c_, h_, w_ = im_feat.shape
+            im_feat = torch.nn.functional.interpolate(im_feat.reshape(b_ * s_, c_, h_, w_), None, scale_factor=up,
+                                                      align_corners=True, mode="bilinear")
+            im_feat = im_feat.view(b_, s_, c_, int(h_ * up), int(w_ * up))
         Ns, inv = cc.num_samples[i], cc.depth_inv[i]
-        nerf = getattr(self, f"nerf_{i}")
-        rays12 = A.BuildRays.apply(batch[f"rays_{i}"], st.depth, st.std, st.near_far, Hr, Wr, inv)
-        xyz, uvd, z = A.SampleAlongDepth.apply(rays12, Ns, inv)
+        xyz, uvd, z = A.SampleAlongDepth.apply(rays12.contiguous(), Ns, inv)
         uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(B, -1, 3)
-        vox = A.VoxFeat.apply(uvd01, st.feature_volume)
+        vox = A.VoxFeat.apply(uvd01, feature_volume)
         img = torch.cat([im_feat, ops.unpreprocess(src_inps, Hr, Wr)], 2)
-        feat = A.ImgFeat.apply(xyz, img, src_exts, src_ixts, batch["tar_ext"], rs)
+        feat = A.ImgFeat.apply(xyz, img, src_exts, src_ixts, tar_ext, rs)
         params = [t for lin in nerf._linears() for t in (lin.weight, lin.bias)]
         raw = A.NerfMLP.apply(vox, feat, nerf.feat_ch - 3, *params).reshape(B, -1, Ns, 4)
         if mode == 1:
@@ -125,6 +127,16 @@ class Network(nn.Module):
                 mask = ops.mask_viewport(xyz, src_exts, src_ixts, Wr - 1, Hr - 1).view(B, -1, Ns)
             return raw, z, mask
         return A.Composite.apply(raw, z, cfg.enerf.white_bkgd)
+
+    def render_level_train(self, i, st, im_feat, views, batch, mode=0):
+        """Training renderer of one level: build_rays (a6) + the unfused chain."""
+        cc = cfg.enerf.cas_config
+        H, W = views[0].shape[-2:]
+        rs = cc.render_scale[i]
+        if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
+            raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
+        rays12 = A.BuildRays.apply(batch[f"rays_{i}"], st.depth, st.std, st.near_far, int(H * rs), int(W * rs), cc.depth_inv[i])
+        return self._render_bounded(i, rays12, st.feature_volume, im_feat, views, batch["tar_ext"], getattr(self, f"nerf_{i}"), mode)
 
     # ------------------------------------------------------------------ fused renderer of one level
     def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None, view_ids=None):
@@ -160,11 +172,22 @@ class Network(nn.Module):
             outs = tuple(t[:, begin:end] for t in outs)
         return outs
 
-    # reference method names kept callable (network.py:24-55)
-    def render_rays(self, rays, **kw):
-        raise NotImplementedError("use render_level(): sampling, lookups, MLP and compositing are one fused kernel")
+    # ------------------------------------------------------------------ the reference's per-chunk entry points
+    def render_rays(self, rays, **kwargs):
+        """network.py:24-44, same keywords: `rays` are bounded rays (B,n,12) from build_rays, `level`, `batch`,
+        `im_feat`, `feature_volume`, `nerf_model`.  Returns raw2outputs' dict.  forward() does not come through here
+        (it uses the fused kernel of render_level); this is the op-by-op HIP chain, differentiable."""
+        level, batch = kwargs["level"], kwargs["batch"]
+        views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
+        rgb, depth, weights = self._render_bounded(level, rays, kwargs["feature_volume"], kwargs["im_feat"], views,
+                                                   batch["tar_ext"], kwargs["nerf_model"])
+        return {"rgb": rgb, "depth": depth, "weights": weights}
 
-    batchify_rays = render_rays
+    def batchify_rays(self, rays, **kwargs):
+        """network.py:46-56: render_rays over chunks of cfg.enerf.chunk_size rays, concatenated."""
+        chunk = int(cfg.enerf.chunk_size)
+        parts = [self.render_rays(rays[:, c0:c0 + chunk], **kwargs) for c0 in range(0, rays.shape[1], chunk)]
+        return {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
 
     # ------------------------------------------------------------------ overlapped front end (inference)
     def _front_overlapped(self, batch, views):

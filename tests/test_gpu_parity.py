@@ -172,6 +172,30 @@ def test_network_forward_matches_reference(ops, enerf_fx):
     assert mse < 1e-8, f"PSNR delta too large (mse between renders {mse:.3e})"
 
 
+def test_render_rays_and_batchify_keep_the_reference_signature(ops, enerf_fx):
+    """lib/networks/enerf/network.py:24-56: render_rays(rays12, level=, batch=, im_feat=, feature_volume=, nerf_model=)
+    and batchify_rays (chunks of cfg.enerf.chunk_size) on the reference's own captured inputs vs raw2outputs."""
+    from boostmvsnerfs_amd.config import get_cfg
+    net = _network(enerf_fx)
+    c = get_cfg().enerf.cas_config
+    b = enerf_fx.batch(DEV)
+    g = lambda k: enerf_fx.t(k).to(DEV)
+    feats = [g(f"cap/feature_net#0.{j}")[None] for j in range(3)]        # coarse -> fine
+    for lvl in range(2):
+        im_feat = feats[c.render_im_feat_level[lvl]]
+        kw = dict(level=lvl, batch=b, im_feat=im_feat, feature_volume=g(f"cap/cost_reg_{lvl}#0.0"),
+                  nerf_model=getattr(net, f"nerf_{lvl}"))
+        rays12 = g(f"cap/build_rays#{lvl}")
+        with torch.no_grad():
+            out = net.render_rays(rays12, **kw)
+            get_cfg().enerf.chunk_size = 100                             # ragged last chunk
+            outb = net.batchify_rays(rays12, **kw)
+        assert set(out) == {"rgb", "depth", "weights"}
+        for k in out:
+            assert_close(out[k], enerf_fx.t(f"cap/raw2outputs#{lvl}.{k}"), name=f"{k}{lvl}")
+            assert torch.equal(out[k], outb[k]), k
+
+
 def test_network_ray_sharding(ops, enerf_fx):
     net = _network(enerf_fx)
     from boostmvsnerfs_amd.config import get_cfg
