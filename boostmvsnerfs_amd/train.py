@@ -8,6 +8,7 @@ import sys
 
 import torch
 import torch.nn as nn
+from torch.optim._functional import adam as _adam_update
 
 from .config import cfg
 
@@ -70,9 +71,47 @@ class NetworkWrapper(nn.Module):
         return out, loss, stats, {}
 
 
+class GroupedAdam(torch.optim.Adam):
+    """torch.optim.Adam with the reference's one-param-group-per-parameter layout (lib/train/optimizer.py:18-21,
+    so optimizer state dicts stay interchangeable with its checkpoints), stepping all groups that share their
+    hyper-parameters in ONE multi-tensor update instead of one per group: 115 groups x ~9 foreach launches per step
+    (5 ms of 3 us kernels and 15 ms of host time at 512x640) become ~9 launches.  The arithmetic is torch's own
+    `torch.optim._functional.adam`, called once per bucket with the concatenated tensor lists: bit-identical results."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        buckets = {}
+        for group in self.param_groups:
+            key = (group["lr"], tuple(group["betas"]), group["eps"], group["weight_decay"], group["amsgrad"],
+                   group["maximize"], group["foreach"], group["capturable"], group["differentiable"], group["fused"],
+                   group["decoupled_weight_decay"])
+            if any(torch.is_tensor(k) for k in key[:4]):       # tensor hyper-parameters: leave to torch
+                return super().step()
+            b = buckets.setdefault(key, (group, [], [], [], [], [], [], [False]))
+            b[7][0] |= bool(self._init_group(group, *b[1:7]))
+        for group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, cplx in buckets.values():
+            if not params:
+                continue
+            beta1, beta2 = group["betas"]
+            _adam_update(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group["amsgrad"],
+                                  has_complex=cplx[0], beta1=beta1, beta2=beta2, lr=group["lr"],
+                                  weight_decay=group["weight_decay"], eps=group["eps"], maximize=group["maximize"],
+                                  foreach=group["foreach"], capturable=group["capturable"],
+                                  differentiable=group["differentiable"], fused=group["fused"],
+                                  grad_scale=getattr(self, "grad_scale", None), found_inf=getattr(self, "found_inf", None),
+                                  decoupled_weight_decay=group["decoupled_weight_decay"])
+        return loss
+
+
 def make_optimizer(net, lr=5e-4, weight_decay=0.0, eps=1e-8):
-    params = [{"params": [p], "lr": lr, "weight_decay": weight_decay} for _, p in net.named_parameters() if p.requires_grad]
-    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, eps=eps)
+    """lib/train/optimizer.py:12-28 with cfg.train.optim = 'adam' (every shipped config): one param group per
+    parameter, in named_parameters() order."""
+    params = [{"params": [p], "lr": lr, "weight_decay": weight_decay, "eps": eps} for _, p in net.named_parameters() if p.requires_grad]
+    return GroupedAdam(params, lr=lr, weight_decay=weight_decay, eps=eps)
 
 
 def make_lr_scheduler(optimizer, gamma=0.5, decay_epochs=50):
