@@ -166,9 +166,10 @@ class Blend(torch.autograd.Function):
 
 
 class NerfMLP(torch.autograd.Function):
-    """a11.  forward: MFMA kernel.  backward: MFMA kernel for the data path (input gradients,
-    pre-activation gradients written as [row][sample] matrices) + library GEMMs over the sample
-    dimension for the weight gradients (see csrc/mlp_bwd.hip)."""
+    """a11.  forward: MFMA kernel.  backward: three launches inside bmv_nerf_mlp_bwd (csrc/mlp_bwd.hip): the data
+    path (input gradients; pre-activation gradients and layer inputs parked as per-tile matrices), every weight and
+    bias gradient as MFMA products over the sample dimension, and a deterministic reduction into tensors of the
+    parameters' shapes."""
 
     @staticmethod
     def forward(ctx, vox_feat, img_feat_rgb_dir, feat_ch, *params):
@@ -184,43 +185,10 @@ class NerfMLP(torch.autograd.Function):
         feat_ch = ctx.feat_ch
         FC = feat_ch + 3
         FCP = 2 * ((FC + 1) // 2)
-        (wv, bv, wg, bg, wa, ba, wfc, bfc, w0, b0, ws, bs, wc, bc, wc2, bc2) = params
         blob_bwd = ops.nerf_pack_bwd_weights(list(params), feat_ch)
         lead = vox.shape[:-1]
         voxf, imgf = vox.reshape(-1, 8), img.reshape(-1, 3, FC + 4)
-        rows, d_vox, d_img, vecs = ops.nerf_mlp_bwd(voxf, imgf, d_out.reshape(-1, 4).contiguous(), blob, blob_bwd, feat_ch)
-        o = 0
-        D_h = rows[o:o + 192].view(3, 64, -1); o += 192
-        D_x = rows[o:o + 64]; o += 64
-        D_fc = rows[o:o + 16]; o += 16
-        D_g = rows[o:o + 96].view(3, 32, -1); o += 96
-        D_v = rows[o:o + 3 * FCP].view(3, FCP, -1)[:, :FC]; o += 3 * FCP
-        D_s = rows[o:o + 8]; o += 8
-        A_x = rows[o:o + 64]; o += 64
-        A_im16 = rows[o:o + 16]; o += 16
-        A_im = rows[o:o + 32]; o += 32
-        # ---- weight gradients: GEMMs over the sample dimension (rocBLAS)
-        in_all = imgf.permute(1, 0, 2)                                    # (3, P, FC+4)
-        xv = torch.cat([A_x, voxf.t(), A_im16], 0)                        # (88, P)
-        Dh_sum = D_h.sum(0)
-        g_wc = torch.cat([Dh_sum @ xv.t(), torch.bmm(D_h, in_all).sum(0)], 1)
-        g_bc = Dh_sum.sum(1)
-        g_w0 = D_x @ torch.cat([voxf.t(), A_im16], 0).t()
-        g_b0 = D_x.sum(1)
-        g_wfc = D_fc @ A_im.t()
-        g_bfc = D_fc.sum(1)
-        dirs = in_all[..., FC:]                                           # (3, P, 4)
-        f = in_all[..., :FC] + torch.relu(dirs @ wv.t() + bv)             # (3, P, FC): Agg residual, recomputed
-        mean = f.mean(0)
-        var = f.var(0)                                                    # unbiased over the 3 views
-        Dg_sum = D_g.sum(0)
-        g_wg = torch.cat([torch.bmm(D_g, f).sum(0), Dg_sum @ var, Dg_sum @ mean], 1)
-        g_bg = Dg_sum.sum(1)
-        g_wv = torch.bmm(D_v, dirs).sum(0)
-        g_bv = D_v.sum((0, 2))
-        g_wc2, g_ws, g_wa = vecs[:64][None], vecs[64:128][None], vecs[128:160][None]
-        g_ba, g_bs, g_bc2 = D_s[0:3].sum().view(1), D_s[3].sum().view(1), D_s[4:7].sum().view(1)
+        d_vox, d_img, grads = ops.nerf_mlp_bwd(voxf, imgf, d_out.reshape(-1, 4).contiguous(), blob, blob_bwd, feat_ch)
         d_vox_feat = d_vox.t().reshape(*lead, 8)
         d_img_feat = torch.cat([d_img[:, :FC], d_img[:, FCP:FCP + 4]], 1).permute(2, 0, 1).reshape(img.shape)
-        grads = (g_wv, g_bv, g_wg, g_bg, g_wa, g_ba, g_wfc, g_bfc, g_w0, g_b0, g_ws, g_bs, g_wc, g_bc, g_wc2, g_bc2)
-        return (d_vox_feat, d_img_feat, None) + grads
+        return (d_vox_feat, d_img_feat, None) + tuple(grads)

@@ -1,18 +1,26 @@
 // Backward of ENeRF's tiny MLP (a11: Agg + NeRF, lib/networks/enerf/nerf.py:29-43, 74-89) on
 // the fp32 matrix cores.
 //
-// Split.  One kernel (this file) recomputes the forward of a 32-sample tile in registers
-// and back-propagates the DATA path: every product W^T d_pre is again a transposed MFMA
-// product with the sample on the lane, using weight tables transposed once by a pack
-// kernel, laid out so that the gradient of every layer input comes out in exactly the
-// register slots the forward consumed it from (output register r == forward k-step r).
-// The pre-activation gradients (and the three hidden activations that cannot be rebuilt
-// from the inputs) are written to HBM as [row][sample] matrices; the WEIGHT gradients
-// are then plain library GEMMs over the sample dimension, dW = D_pre @ ACT^T (host side,
-// rocBLAS via torch.matmul) -- the reduction over 10^5..10^6 samples is the K dimension of
-// a tall-skinny GEMM, not something to do with atomics.  Only the three 1-wide heads
-// (agg_w_fc, sigma, color.2 weights) are reduced in-kernel (per-lane running sums, one
-// wave reduction and 160 atomics per wave at the very end).
+// Three kernels.
+//  1. nerf_mlp_bwd_kernel recomputes the forward of a 32-sample tile in registers and
+//     back-propagates the DATA path: every product W^T d_pre is again a transposed MFMA
+//     product with the sample on the lane, using weight tables transposed once by a pack
+//     kernel, laid out so that the gradient of every layer input comes out in exactly the
+//     register slots the forward consumed it from (output register r == forward k-step r).
+//     The pre-activation gradients and the layer inputs are written to HBM as per-tile
+//     matrices rows[tile][row][32 samples].  Phases are ordered so that little stays live
+//     across them (the aggregation forward and lr0 are recomputed where their backward
+//     needs them; 46 + 24 of ~700 MFMAs per tile).
+//  2. nerf_wgrad_kernel computes every WEIGHT gradient dW = D_pre ACT^T on the matrix cores
+//     with the SAMPLE index as the MFMA k dimension: lane (m, kk) holds row m of a 32-row
+//     block for the 32 samples of tile 2p + kk (one contiguous 128-byte read), so 32
+//     v_mfma_f32_32x32x2 steps reduce 64 samples into a 32x32 block of dW.  The four waves of
+//     a workgroup own disjoint blocks (no LDS, no barrier); each workgroup writes its partial
+//     blocks once.  Bias gradients are row sums of the same operands (VALU, free).
+//  3. nerf_wgrad_finish_kernel sums the partials in a fixed order (deterministic, no
+//     atomics) straight into tensors of the reference's parameter shapes.
+// Only the two 1-wide heads whose inputs are not stored (agg_w_fc, color.2 weights) are
+// reduced in kernel 1 (per-lane running sums, one wave reduction, 96 atomics per wave).
 #include "mlp.hpp"
 
 namespace bmv {
@@ -36,19 +44,36 @@ struct MlpBwdLayout {
   static constexpr int GV_TILES = (KFC + 15) / 16;
   static constexpr int V_WV = T_GV + 16 * GV_TILES * 64;       // view_fc^T for d_dir: [KFC][4][2]
   static constexpr int TOTAL = (V_WV + KFC * 4 * 2 + 3) / 4 * 4;
-  // rows of the per-sample matrices written for the weight-gradient GEMMs
+  // rows of the per-tile matrices rows[tile][row][32] read by the weight-gradient kernel
   static constexpr int FCP = 2 * KFC;                          // padded channel rows per view
+  static constexpr int INR = FCP + 4;                          // per-view input rows: channels (padded) + 4 dir
   static constexpr int R_DH = 0;                               // d_pre color.0        3 x 64
   static constexpr int R_DX = R_DH + 192;                      // d_pre lr0            64
   static constexpr int R_DFC = R_DX + 64;                      // d_pre agg.fc         16
   static constexpr int R_DG = R_DFC + 16;                      // d_pre global_fc      3 x 32
   static constexpr int R_DV = R_DG + 96;                       // d_pre view_fc        3 x FCP
-  static constexpr int R_DS = R_DV + 3 * FCP;                  // d_pre agg_w x3, sigma, color.2 x3  (7)
-  static constexpr int R_AX = R_DS + 8;                        // x                    64
-  static constexpr int R_AIM16 = R_AX + 64;                    // relu(agg.fc)         16
-  static constexpr int R_AIM = R_AIM16 + 16;                   // sum_i w_i g_i        32
-  static constexpr int R_TOTAL = R_AIM + 32;
-  static constexpr int IN_ROWS = FCP + 4;                      // d_img rows per view: channels (padded) + 4 dir
+  static constexpr int R_DS = R_DV + 3 * FCP;                  // d_pre agg_w x3, sigma, color.2 x3  (7 of 8)
+  static constexpr int R_AX = R_DS + 8;                        // x = relu(lr0)        64
+  static constexpr int R_AV24 = R_AX + 64;                     // vox 8 | relu(agg.fc) 16
+  static constexpr int R_AIM = R_AV24 + 24;                    // sum_i w_i g_i        32
+  static constexpr int R_IN = R_AIM + 32;                      // per-view inputs      3 x INR
+  static constexpr int R_F = R_IN + 3 * INR;                   // f_i (Agg residual)   3 x FCP
+  static constexpr int R_VAR = R_F + 3 * FCP;                  // var | mean           2 x FCP
+  static constexpr int R_TOTAL = R_VAR + 2 * FCP;
+  static constexpr int IN_ROWS = INR;                          // d_img rows per view
+  // 32x32 blocks of the weight-gradient partials (one workgroup writes NBLK blocks + NBB bias vectors of 64)
+  static constexpr int NB_IN = (INR + 31) / 32, NB_F = (FCP + 31) / 32, NB_VM = (2 * FCP + 31) / 32;
+  static constexpr int BLK_WC_SH = 0;                          // [tl 2][tb 3]  sum_i D_h x [x, vox|im16]
+  static constexpr int BLK_WC_V = BLK_WC_SH + 6;               // [tl 2][NB_IN] sum_i D_h_i x in_i
+  static constexpr int BLK_W0 = BLK_WC_V + 2 * NB_IN;          // [tl 2]        D_x x [vox|im16]
+  static constexpr int BLK_WS = BLK_W0 + 2;                    // [tb 2]        D_s x x      (row 3 = sigma weight)
+  static constexpr int BLK_WFC = BLK_WS + 2;                   //               D_fc x im
+  static constexpr int BLK_WV = BLK_WFC + 1;                   // [NB_F]        sum_i D_v_i x dir_i
+  static constexpr int BLK_WG_V = BLK_WV + NB_F;               // [NB_F]        sum_i D_g_i x f_i
+  static constexpr int BLK_WG_SH = BLK_WG_V + NB_F;            // [NB_VM]       sum_i D_g_i x [var|mean]
+  static constexpr int NBLK = BLK_WG_SH + NB_VM;
+  static constexpr int BB_DH = 0, BB_DX = 2, BB_DS = 4, BB_DFC = 5, BB_DG = 6, BB_DV = 7, NBB = 7 + NB_F;
+  static constexpr int PART = NBLK * 1024 + NBB * 64;          // floats per workgroup partial
 };
 
 template <int FEAT_CH>
@@ -111,12 +136,45 @@ __global__ void nerf_pack_bwd_kernel(bmv_nerf_params p, float* __restrict__ blob
   blob[idx] = v;
 }
 
+// MFMA chain over NT k-steps into TILES accumulator tiles; A of (step t, tile tt) at A[(t * TILES + tt) * 64] (LDS,
+// lane-offset pointer).  The A reads of group g + 1 are issued before the MFMAs of group g (see BMV_CHAIN1).
+template <int NT, int TILES, int G, class BF>
+__device__ __forceinline__ void mfma_chain(const float* __restrict__ A, BF&& b_of, f32x16* acc) {
+  float a[2][G][TILES];
+#pragma unroll
+  for (int u = 0; u < G; ++u)
+    if (u < NT)
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) a[0][u][tt] = A[(u * TILES + tt) * 64];
+#pragma unroll
+  for (int g = 0; g < (NT + G - 1) / G; ++g) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int tn = (g + 1) * G + u;
+      if (tn < NT)
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) a[(g + 1) & 1][u][tt] = A[(tn * TILES + tt) * 64];
+    }
+    BMV_FENCE();
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int t = g * G + u;
+      if (t < NT) {
+        const float b = b_of(t);
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = BMV_MFMA(a[g & 1][u][tt], b, acc[tt]);
+      }
+    }
+    BMV_FENCE();
+  }
+}
+
 template <int FEAT_CH>
 struct BwdOut {
-  float* rows;   // (R_TOTAL, P)
+  float* rows;   // (ntiles, R_TOTAL, 32)
   float* d_vox;  // (8, P)
   float* d_img;  // (3, IN_ROWS, P)
-  float* vecs;   // 64 color.2 weight grad | 64 sigma weight grad | 32 agg_w_fc weight grad  (atomics)
+  float* vecs;   // 64 color.2 weight grad | 32 agg_w_fc weight grad  (atomics)
 };
 
 template <int FEAT_CH>
@@ -145,20 +203,26 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
   const float ba = W[L::V_SC + 0], bs = W[L::V_SC + 1], bc2 = W[L::V_SC + 2];
   const long P = npts;
 
-  // running sums of the three 1-wide weight gradients (this lane's neurons, over its samples)
-  f32x16 acc_wc2[2], acc_ws[2], acc_wa;
+  // running sums of the two 1-wide weight gradients whose inputs are not stored (this lane's neurons, its samples)
+  f32x16 acc_wc2[2], acc_wa;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc_wc2[0][r] = acc_wc2[1][r] = acc_ws[0][r] = acc_ws[1][r] = acc_wa[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc_wc2[0][r] = acc_wc2[1][r] = acc_wa[r] = 0.f;
 
   const long ntiles = (npts + 31) / 32;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     const long pt = tile * 32 + s;
     const bool valid = pt < npts;
     const long pc = valid ? pt : npts - 1;
+    float* __restrict__ rows = o.rows + tile * (long)(LB::R_TOTAL * 32) + s;   // + row * 32
+    // rows past npts hold finite activations of the clamped sample and exactly-zero gradients (go = 0)
+    auto put = [&](int row, float v) { rows[row * 32] = v; };
     // ------------------------------------------------------------------ inputs
     float fin[3][KF], dir[3][4], vox[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vox[j] = vox_feat[pc * 8 + 2 * j + h];
+    for (int j = 0; j < 4; ++j) {
+      vox[j] = vox_feat[pc * 8 + 2 * j + h];
+      put(LB::R_AV24 + 2 * j + h, vox[j]);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float* q = img + (pc * 3 + i) * L::IN;
@@ -168,95 +232,97 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int k = 0; k < 2; ++k) fin[i][KFC + k] = q[L::FC + 2 * k + h];
 #pragma unroll
       for (int k = 0; k < 4; ++k) dir[i][k] = q[L::FC + k];
+#pragma unroll
+      for (int j = 0; j < KF; ++j) put(LB::R_IN + i * LB::INR + 2 * j + h, fin[i][j]);
     }
     float go[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) go[k] = valid ? d_out[pc * 4 + k] : 0.f;
+    BMV_FENCE();
 
-    // ------------------------------------------------------------------ forward recompute (mlp.hpp, intermediates kept)
     auto pre_v = [&](int i, int j) -> float {
       return Wv[L::V_VF + (j * 5 + 4) * 2] + Wv[L::V_VF + (j * 5 + 0) * 2] * dir[i][0] +
              Wv[L::V_VF + (j * 5 + 1) * 2] * dir[i][1] + Wv[L::V_VF + (j * 5 + 2) * 2] * dir[i][2] +
              Wv[L::V_VF + (j * 5 + 3) * 2] * dir[i][3];
     };
     auto fval = [&](int i, int j) -> float { return fin[i][j] + fmaxf(pre_v(i, j), 0.f); };
-    float var[KFC], mean[KFC];
-#pragma unroll
-    for (int j = 0; j < KFC; ++j) {
-      float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
-      float m = (f0 + f1 + f2) / 3.f;
-      mean[j] = m;
-      var[j] = ((f0 - m) * (f0 - m) + (f1 - m) * (f1 - m) + (f2 - m) * (f2 - m)) * 0.5f;
-      BMV_FENCE_EVERY(j, 6);
-    }
-    BMV_FENCE();
-    f32x16 gsh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
-#pragma unroll
-    for (int t = 0; t < KFC; ++t) {
-      gsh = BMV_MFMA(Wa[L::A_GSH + t * 64], var[t], gsh);
-      BMV_FENCE_EVERY(t, 6);
-    }
-#pragma unroll
-    for (int t = 0; t < KFC; ++t) {
-      gsh = BMV_MFMA(Wa[L::A_GSH + (KFC + t) * 64], mean[t], gsh);
-      BMV_FENCE_EVERY(t, 6);
-    }
-    BMV_FENCE();
+
+    // ------------------------------------------------------------------ aggregation forward (mlp.hpp); run twice:
+    // first for im16 (and the stored activations), again right before its own backward
+    float mean[KFC];
     f32x16 g[3];
     float aw[3], apre[3];
+    auto agg_forward = [&](bool store) {
+      float var[KFC];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      g[i] = gsh;
-#pragma unroll
-      for (int t = 0; t < KFC; ++t) {
-        g[i] = BMV_MFMA(Wa[L::A_GV + t * 64], fval(i, t), g[i]);
-        BMV_FENCE_EVERY(t, 6);
+      for (int j = 0; j < KFC; ++j) {
+        float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
+        float m = (f0 + f1 + f2) / 3.f;
+        mean[j] = m;
+        var[j] = ((f0 - m) * (f0 - m) + (f1 - m) * (f1 - m) + (f2 - m) * (f2 - m)) * 0.5f;
+        if (store) {
+          put(LB::R_F + 0 * LB::FCP + 2 * j + h, f0), put(LB::R_F + 1 * LB::FCP + 2 * j + h, f1);
+          put(LB::R_F + 2 * LB::FCP + 2 * j + h, f2);
+          put(LB::R_VAR + 2 * j + h, var[j]), put(LB::R_VAR + LB::FCP + 2 * j + h, m);
+        }
+        BMV_FENCE_EVERY(j, 6);
       }
-      float sdot = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        g[i][r] = fmaxf(g[i][r], 0.f);
-        sdot += Wv[L::V_WA + r * 2] * g[i][r];
-      }
-      apre[i] = xhalf_sum(sdot) + ba;
-      aw[i] = fmaxf(apre[i], 0.f);
       BMV_FENCE();
-    }
-    {
+      f32x16 gsh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
+      mfma_chain<2 * KFC, 1, BMV_MLP_G1>(Wa + L::A_GSH, [&](int t) { return t < KFC ? var[t < KFC ? t : 0] : mean[t >= KFC ? t - KFC : 0]; }, &gsh);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        g[i] = gsh;
+        mfma_chain<KFC, 1, BMV_MLP_G1>(Wa + L::A_GV, [&](int t) { return fval(i, t); }, &g[i]);
+        float sdot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          g[i][r] = fmaxf(g[i][r], 0.f);
+          sdot += Wv[L::V_WA + r * 2] * g[i][r];
+        }
+        apre[i] = xhalf_sum(sdot) + ba;
+        aw[i] = fmaxf(apre[i], 0.f);
+        BMV_FENCE();
+      }
       float m = fmaxf(aw[0], fmaxf(aw[1], aw[2]));
       float e0 = __expf(aw[0] - m), e1 = __expf(aw[1] - m), e2 = __expf(aw[2] - m);
       float inv = 1.f / (e0 + e1 + e2);
       aw[0] = e0 * inv, aw[1] = e1 * inv, aw[2] = e2 * inv;
-    }
-    f32x16 im, q16;
+    };
+    float im16[8];
+    {
+      agg_forward(true);
+      f32x16 im, q16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      im[r] = aw[0] * g[0][r] + aw[1] * g[1][r] + aw[2] * g[2][r];
-      q16[r] = Wv[L::V_BFC + r * 2];
-    }
+      for (int r = 0; r < 16; ++r) {
+        im[r] = aw[0] * g[0][r] + aw[1] * g[1][r] + aw[2] * g[2][r];
+        q16[r] = Wv[L::V_BFC + r * 2];
+        put(LB::R_AIM + n16(r, h), im[r]);
+      }
+      mfma_chain<16, 1, BMV_MLP_G1>(Wa + L::A_FC, [&](int t) { return im[t]; }, &q16);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      q16 = BMV_MFMA(Wa[L::A_FC + t * 64], im[t], q16);
-      BMV_FENCE_EVERY(t, 8);
+      for (int r = 0; r < 8; ++r) {
+        im16[r] = fmaxf(q16[r], 0.f);
+        put(LB::R_AV24 + 8 + n16(r, h), im16[r]);
+      }
     }
     BMV_FENCE();
-    float im16[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) im16[r] = fmaxf(q16[r], 0.f);
+    // ------------------------------------------------------------------ lr0 forward (again before its backward)
     f32x16 x[2];
+    auto lr0_forward = [&]() {
 #pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
+      for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[tl][r] = Wv[L::V_B0 + (tl * 16 + r) * 2];
+        for (int r = 0; r < 16; ++r) x[tl][r] = Wv[L::V_B0 + (tl * 16 + r) * 2];
+      mfma_chain<12, 2, BMV_MLP_G2>(Wa + L::A_L0, [&](int t) { return t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0]; }, x);
 #pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      float b = t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0];
+      for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-      for (int tl = 0; tl < 2; ++tl) x[tl] = BMV_MFMA(Wa[L::A_L0 + (t * 2 + tl) * 64], b, x[tl]);
-      BMV_FENCE_EVERY(t, 4);
-    }
+        for (int r = 0; r < 16; ++r) x[tl][r] = fmaxf(x[tl][r], 0.f);
+    };
+    lr0_forward();
     float spre;
     {
       float sdot = 0.f;
@@ -264,41 +330,27 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          x[tl][r] = fmaxf(x[tl][r], 0.f);
           sdot += Wv[L::V_WS + (tl * 16 + r) * 2] * x[tl][r];
+          put(LB::R_AX + 32 * tl + n16(r, h), x[tl][r]);
         }
       spre = xhalf_sum(sdot) + bs;
     }
+    // ------------------------------------------------------------------ colour forward
     f32x16 csh[2];
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
       for (int r = 0; r < 16; ++r) csh[tl][r] = Wv[L::V_BC + (tl * 16 + r) * 2];
-#pragma unroll
-    for (int t = 0; t < 44; ++t) {
-      float b;
-      if (t < 32)
-        b = x[t < 32 ? (t >> 4) : 0][t & 15];
-      else if (t < 36)
-        b = vox[t >= 32 && t < 36 ? t - 32 : 0];
-      else
-        b = im16[t >= 36 ? t - 36 : 0];
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) csh[tl] = BMV_MFMA(Wa[L::A_CSH + (t * 2 + tl) * 64], b, csh[tl]);
-      BMV_FENCE_EVERY(t, 4);
-    }
+    mfma_chain<44, 2, BMV_MLP_G2>(Wa + L::A_CSH, [&](int t) {
+      return t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : im16[t >= 36 ? t - 36 : 0];
+    }, csh);
     BMV_FENCE();
     // colour logits need all three views before the softmax backward: first pass keeps only c_i
     float cl[3], cpre[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       f32x16 hc[2] = {csh[0], csh[1]};
-#pragma unroll
-      for (int t = 0; t < KF; ++t) {
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) hc[tl] = BMV_MFMA(Wa[L::A_CV + (t * 2 + tl) * 64], fin[i][t], hc[tl]);
-        BMV_FENCE_EVERY(t, 4);
-      }
+      mfma_chain<KF, 2, BMV_MLP_G2>(Wa + L::A_CV, [&](int t) { return fin[i][t]; }, hc);
       float sdot = 0.f;
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl)
@@ -315,28 +367,27 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       cl[0] = e0 * inv, cl[1] = e1 * inv, cl[2] = e2 * inv;
     }
 
-    // ------------------------------------------------------------------ backward
-    float* rows = o.rows + pt;  // + row * P
-    auto put = [&](int row, float v) {
-      if (valid) rows[(long)row * P] = v;
-    };
+    // ------------------------------------------------------------------ colour backward
     // rgb = sum_i cw_i rgb_i : the colour channels FEAT_CH+{0,1,2} sit at (half0, slot J), (half1, J), (half0, J+1)
     constexpr int J = FEAT_CH / 2;
     const float g_mine0 = h == 0 ? go[0] : go[1];  // gradient of the channel in slot J of this half
     const float g_mine1 = h == 0 ? go[2] : 0.f;    // slot J+1: blue (half 0) or padding (half 1)
-    float d_cw[3], dotc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      d_cw[i] = xhalf_sum(g_mine0 * fin[i][J] + g_mine1 * fin[i][J + 1]);
-      dotc += cl[i] * d_cw[i];
-    }
     float d_cpre[3];
+    {
+      float d_cw[3], dotc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      d_cpre[i] = cpre[i] > 0.f ? cl[i] * (d_cw[i] - dotc) : 0.f;
-      if (h == 0) put(LB::R_DS + 4 + i, d_cpre[i]);
+      for (int i = 0; i < 3; ++i) {
+        d_cw[i] = xhalf_sum(g_mine0 * fin[i][J] + g_mine1 * fin[i][J + 1]);
+        dotc += cl[i] * d_cw[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        d_cpre[i] = cpre[i] > 0.f ? cl[i] * (d_cw[i] - dotc) : 0.f;
+        if (h == 0) put(LB::R_DS + 4 + i, d_cpre[i]);
+      }
+      if (h == 1) put(LB::R_DS + 7, 0.f);
     }
-    // per view: recompute hc_i, d_pre_h_i, its weight-gradient rows, input gradient, and the running sum over views
+    // per view: recompute hc_i, d_pre_h_i, its rows, the input gradient, and the running sum over views
     f32x16 dhs[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dhs[0][r] = dhs[1][r] = 0.f;
@@ -344,12 +395,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       f32x16 hc[2] = {csh[0], csh[1]};
-#pragma unroll
-      for (int t = 0; t < KF; ++t) {
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) hc[tl] = BMV_MFMA(Wa[L::A_CV + (t * 2 + tl) * 64], fin[i][t], hc[tl]);
-        BMV_FENCE_EVERY(t, 4);
-      }
+      mfma_chain<KF, 2, BMV_MLP_G2>(Wa + L::A_CV, [&](int t) { return fin[i][t]; }, hc);
       f32x16 dh[2];
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl)
@@ -369,14 +415,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int tt = 0; tt < LB::CV_TILES; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) di[tt][r] = 0.f;
-#pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        float b = dh[u >> 4][u & 15];
-#pragma unroll
-        for (int tt = 0; tt < LB::CV_TILES; ++tt)
-          di[tt] = BMV_MFMA(Ta[LB::T_CV + (u * LB::CV_TILES + tt) * 64], b, di[tt]);
-        BMV_FENCE_EVERY(u, 4);
-      }
+      mfma_chain<32, LB::CV_TILES, BMV_MLP_G2>(Ta + LB::T_CV, [&](int u) { return dh[u >> 4][u & 15]; }, di);
 #pragma unroll
       for (int t = 0; t < KF; ++t) d_in[i][t] = di[t >> 4][t & 15];
       // the blended colour reads the sampled source colour directly
@@ -390,37 +429,27 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dxv[tt][r] = 0.f;
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      float b = dhs[u >> 4][u & 15];
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) dxv[tt] = BMV_MFMA(Ta[LB::T_CSH + (u * 3 + tt) * 64], b, dxv[tt]);
-      BMV_FENCE_EVERY(u, 4);
-    }
+    mfma_chain<32, 3, BMV_MLP_G2>(Ta + LB::T_CSH, [&](int u) { return dhs[u >> 4][u & 15]; }, dxv);
     BMV_FENCE();
-    // sigma head and lr0
-    const float d_spre = go[3] * (1.f / (1.f + __expf(-spre)));  // softplus' = sigmoid (threshold branch: 1)
-    if (h == 0) put(LB::R_DS + 3, spre > 20.f ? go[3] : d_spre);
-    const float d_sp = spre > 20.f ? go[3] : d_spre;
-    f32x16 dx[2];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc_ws[tl][r] += d_sp * x[tl][r];
-        float d = dxv[tl][r] + d_sp * Wv[L::V_WS + (tl * 16 + r) * 2];
-        d = x[tl][r] > 0.f ? d : 0.f;
-        dx[tl][r] = d;
-        put(LB::R_DX + 32 * tl + n16(r, h), d);
-        put(LB::R_AX + 32 * tl + n16(r, h), x[tl][r]);
-      }
+    // ------------------------------------------------------------------ sigma head and lr0 backward (x recomputed)
+    const float d_sp = spre > 20.f ? go[3] : go[3] * (1.f / (1.f + __expf(-spre)));  // softplus' = sigmoid
+    if (h == 0) put(LB::R_DS + 3, d_sp);
     f32x16 dv24;  // slots 0..3 vox, 4..11 im16
+    {
+      lr0_forward();
+      f32x16 dx[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dv24[r] = 0.f;
+      for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      dv24 = BMV_MFMA(Ta[LB::T_L0 + u * 64], dx[u >> 4][u & 15], dv24);
-      BMV_FENCE_EVERY(u, 8);
+        for (int r = 0; r < 16; ++r) {
+          float d = dxv[tl][r] + d_sp * Wv[L::V_WS + (tl * 16 + r) * 2];
+          d = x[tl][r] > 0.f ? d : 0.f;
+          dx[tl][r] = d;
+          put(LB::R_DX + 32 * tl + n16(r, h), d);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dv24[r] = 0.f;
+      mfma_chain<32, 1, BMV_MLP_G1>(Ta + LB::T_L0, [&](int u) { return dx[u >> 4][u & 15]; }, &dv24);
     }
     BMV_FENCE();
     // vox gradient: slots 32..35 of the colour input + slots 0..3 of lr0
@@ -428,49 +457,51 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     for (int j = 0; j < 4; ++j)
       if (valid) o.d_vox[(long)(2 * j + h) * P + pt] = dxv[2][j] + dv24[j];
     // agg.fc
-    float dfc[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      float d = dxv[2][4 + r] + dv24[4 + r];
-      d = im16[r] > 0.f ? d : 0.f;
-      dfc[r] = d;
-      put(LB::R_DFC + n16(r, h), d);
-      put(LB::R_AIM16 + n16(r, h), im16[r]);
-    }
     f32x16 dim;
+    {
+      float dfc[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dim[r] = 0.f;
+      for (int r = 0; r < 8; ++r) {
+        float d = dxv[2][4 + r] + dv24[4 + r];
+        d = im16[r] > 0.f ? d : 0.f;
+        dfc[r] = d;
+        put(LB::R_DFC + n16(r, h), d);
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dim = BMV_MFMA(Ta[LB::T_FC + u * 64], dfc[u], dim);
-    BMV_FENCE();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) put(LB::R_AIM + n16(r, h), im[r]);
-    // softmax over views of the aggregation weights, agg_w_fc, global_fc
-    float d_w[3], dotw = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float sdot = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sdot += dim[r] * g[i][r];
-      d_w[i] = xhalf_sum(sdot);
-      dotw += aw[i] * d_w[i];
+      for (int r = 0; r < 16; ++r) dim[r] = 0.f;
+      mfma_chain<8, 1, BMV_MLP_G1>(Ta + LB::T_FC, [&](int u) { return dfc[u]; }, &dim);
     }
+    BMV_FENCE();
+    // ------------------------------------------------------------------ aggregation backward (forward recomputed)
+    agg_forward(false);
+    // softmax over views of the aggregation weights, agg_w_fc, global_fc
     f32x16 dgs;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dgs[r] = 0.f;
     f32x16 dg[3];
+    {
+      float d_w[3], dotw = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float d_apre = apre[i] > 0.f ? aw[i] * (d_w[i] - dotw) : 0.f;
-      if (h == 0) put(LB::R_DS + i, d_apre);
+      for (int i = 0; i < 3; ++i) {
+        float sdot = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc_wa[r] += d_apre * g[i][r];
-        float d = aw[i] * dim[r] + d_apre * Wv[L::V_WA + r * 2];
-        d = g[i][r] > 0.f ? d : 0.f;
-        dg[i][r] = d;
-        dgs[r] += d;
-        put(LB::R_DG + i * 32 + n16(r, h), d);
+        for (int r = 0; r < 16; ++r) sdot += dim[r] * g[i][r];
+        d_w[i] = xhalf_sum(sdot);
+        dotw += aw[i] * d_w[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dgs[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float d_apre = apre[i] > 0.f ? aw[i] * (d_w[i] - dotw) : 0.f;
+        if (h == 0) put(LB::R_DS + i, d_apre);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc_wa[r] += d_apre * g[i][r];
+          float d = aw[i] * dim[r] + d_apre * Wv[L::V_WA + r * 2];
+          d = g[i][r] > 0.f ? d : 0.f;
+          dg[i][r] = d;
+          dgs[r] += d;
+          put(LB::R_DG + i * 32 + n16(r, h), d);
+        }
       }
     }
     BMV_FENCE();
@@ -480,13 +511,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     for (int tt = 0; tt < LB::GSH_TILES; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dvm[tt][r] = 0.f;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-#pragma unroll
-      for (int tt = 0; tt < LB::GSH_TILES; ++tt)
-        dvm[tt] = BMV_MFMA(Ta[LB::T_GSH + (u * LB::GSH_TILES + tt) * 64], dgs[u], dvm[tt]);
-      BMV_FENCE_EVERY(u, 8);
-    }
+    mfma_chain<16, LB::GSH_TILES, BMV_MLP_G2>(Ta + LB::T_GSH, [&](int u) { return dgs[u]; }, dvm);
     BMV_FENCE();
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -495,23 +520,19 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int tt = 0; tt < LB::GV_TILES; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dfv[tt][r] = 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-#pragma unroll
-        for (int tt = 0; tt < LB::GV_TILES; ++tt)
-          dfv[tt] = BMV_MFMA(Ta[LB::T_GV + (u * LB::GV_TILES + tt) * 64], dg[i][u], dfv[tt]);
-        BMV_FENCE_EVERY(u, 8);
-      }
+      mfma_chain<16, LB::GV_TILES, BMV_MLP_G2>(Ta + LB::T_GV, [&](int u) { return dg[i][u]; }, dfv);
       float d_dir[4] = {0.f, 0.f, 0.f, 0.f};
+      float* dimg = o.d_img + (long)i * LB::IN_ROWS * P + pt;
 #pragma unroll
       for (int j = 0; j < KFC; ++j) {
-        float fj = fval(i, j);
+        float pv = pre_v(i, j);
+        float fj = fin[i][j] + fmaxf(pv, 0.f);
         // var = sum (f - m)^2 / 2, mean = sum f / 3
         float d_f = dfv[j >> 4][j & 15] + dvm[j >> 4][j & 15] * (fj - mean[j]) +
                     dvm[(KFC + j) >> 4][(KFC + j) & 15] * (1.f / 3.f);
-        d_in[i][j] += d_f;
-        float d_pv = pre_v(i, j) > 0.f ? d_f : 0.f;
-        if (valid) o.rows[(long)(LB::R_DV + i * LB::FCP + 2 * j + h) * P + pt] = d_pv;
+        if (valid) dimg[(long)(2 * j + h) * P] = d_in[i][j] + d_f;
+        float d_pv = pv > 0.f ? d_f : 0.f;
+        put(LB::R_DV + i * LB::FCP + 2 * j + h, d_pv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) d_dir[q] += d_pv * WB[LB::V_WV + ((j * 4 + q) << 1) + h];
         BMV_FENCE_EVERY(j, 6);
@@ -519,15 +540,9 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       // the 4 direction inputs: this half's slots from color.0, plus view_fc^T summed over BOTH halves' channels
 #pragma unroll
       for (int q = 0; q < 4; ++q) d_dir[q] = xhalf_sum(d_dir[q]);
-      d_in[i][KFC] += h ? d_dir[1] : d_dir[0];
-      d_in[i][KFC + 1] += h ? d_dir[3] : d_dir[2];
-      // store the per-view input gradient rows: channel 2j+h, then dir 2k+h
-      float* dimg = o.d_img + (long)i * LB::IN_ROWS * P + pt;
       if (valid) {
-#pragma unroll
-        for (int j = 0; j < KFC; ++j) dimg[(long)(2 * j + h) * P] = d_in[i][j];
-        dimg[(long)(LB::FCP + h) * P] = d_in[i][KFC];
-        dimg[(long)(LB::FCP + 2 + h) * P] = d_in[i][KFC + 1];
+        dimg[(long)(LB::FCP + h) * P] = d_in[i][KFC] + (h ? d_dir[1] : d_dir[0]);
+        dimg[(long)(LB::FCP + 2 + h) * P] = d_in[i][KFC + 1] + (h ? d_dir[3] : d_dir[2]);
       }
       BMV_FENCE();
     }
@@ -542,22 +557,303 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float a = reduce32(acc_wc2[tl][r]), b = reduce32(acc_ws[tl][r]);
-      if (s == 0) {
-        atomicAdd(o.vecs + 32 * tl + n16(r, h), a);
-        atomicAdd(o.vecs + 64 + 32 * tl + n16(r, h), b);
-      }
+      float a = reduce32(acc_wc2[tl][r]);
+      if (s == 0) atomicAdd(o.vecs + 32 * tl + n16(r, h), a);
     }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float a = reduce32(acc_wa[r]);
-    if (s == 0) atomicAdd(o.vecs + 128 + n16(r, h), a);
+    if (s == 0) atomicAdd(o.vecs + 64 + n16(r, h), a);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients: dW block (32 x 32) += A (32 rows x 64 samples) B^T (32 rows x 64 samples), samples = MFMA k.
+// ---------------------------------------------------------------------------------------------------------------
+template <int FEAT_CH>
+__global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restrict__ rows, long ntiles,
+                                                             float* __restrict__ partials) {
+  using LB = MlpBwdLayout<FEAT_CH>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, kk = lane >> 5;
+  const long npairs = (ntiles + 1) / 2;
+  float* __restrict__ part = partials + (long)blockIdx.x * LB::PART;
+
+  // operand: row (row_base + m) of tile, 32 consecutive samples (128 B per lane); rows past nrows / tiles past the end: 0
+  auto load = [&](long tile, int row_base, int nrows, float (&v)[32]) {
+    if (m < nrows && tile < ntiles) {
+      const float4* p = reinterpret_cast<const float4*>(rows + (tile * LB::R_TOTAL + row_base + m) * 32);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 t = p[q];
+        v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = 0.f;
+    }
+  };
+  auto mm = [&](const float (&a)[32], const float (&b)[32], f32x16& acc) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc = BMV_MFMA(a[j], b[j], acc);
+  };
+  auto rowsum = [&](const float (&a)[32]) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += a[j];
+    return t;
+  };
+  auto zero = [&](f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  };
+  // accumulator register r, lane (n, hh) holds D[m = n16(r, hh)][n]
+  auto store_block = [&](int blk, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[blk * 1024 + n16(r, kk) * 32 + m] = acc[r];
+  };
+  auto store_bias = [&](int bb, float v) { part[LB::NBLK * 1024 + bb * 64 + lane] = v; };
+
+  if (wave < 2) {
+    // colour layer, output neurons 32 * wave ..: sum_i D_h_i x in_i, then (sum_i D_h_i) x [x | vox, im16]
+    const int tl = wave;
+    f32x16 acc_sh[3], acc_v[LB::NB_IN];
+    float bias = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) zero(acc_sh[q]);
+#pragma unroll
+    for (int q = 0; q < LB::NB_IN; ++q) zero(acc_v[q]);
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+      const long tile = 2 * pair + kk;
+      float asum[32], a[32], b[32];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        load(tile, LB::R_DH + i * 64 + tl * 32, 32, a);
+#pragma unroll
+        for (int bb = 0; bb < LB::NB_IN; ++bb) {
+          load(tile, LB::R_IN + i * LB::INR + bb * 32, LB::INR - bb * 32, b);
+          mm(a, b, acc_v[bb]);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) asum[j] = i == 0 ? a[j] : asum[j] + a[j];
+      }
+      bias += rowsum(asum);
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        load(tile, tb < 2 ? LB::R_AX + tb * 32 : LB::R_AV24, tb < 2 ? 32 : 24, b);
+        mm(asum, b, acc_sh[tb]);
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) store_block(LB::BLK_WC_SH + tl * 3 + tb, acc_sh[tb]);
+#pragma unroll
+    for (int bb = 0; bb < LB::NB_IN; ++bb) store_block(LB::BLK_WC_V + tl * LB::NB_IN + bb, acc_v[bb]);
+    store_bias(LB::BB_DH + tl, bias);
+  } else if (wave == 2) {
+    // lr0, sigma head, agg.fc, view_fc
+    f32x16 acc_w0[2], acc_ws[2], acc_fc, acc_wv[LB::NB_F];
+    float bias_dx[2] = {0.f, 0.f}, bias_ds = 0.f, bias_fc = 0.f, bias_dv[LB::NB_F];
+    zero(acc_w0[0]), zero(acc_w0[1]), zero(acc_ws[0]), zero(acc_ws[1]), zero(acc_fc);
+#pragma unroll
+    for (int q = 0; q < LB::NB_F; ++q) zero(acc_wv[q]), bias_dv[q] = 0.f;
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+      const long tile = 2 * pair + kk;
+      float a[32], b[32];
+      load(tile, LB::R_AV24, 24, b);
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        load(tile, LB::R_DX + tl * 32, 32, a);
+        mm(a, b, acc_w0[tl]);
+        bias_dx[tl] += rowsum(a);
+      }
+      load(tile, LB::R_DS, 8, a);
+      bias_ds += rowsum(a);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        load(tile, LB::R_AX + tb * 32, 32, b);
+        mm(a, b, acc_ws[tb]);
+      }
+      load(tile, LB::R_DFC, 16, a);
+      load(tile, LB::R_AIM, 32, b);
+      mm(a, b, acc_fc);
+      bias_fc += rowsum(a);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        load(tile, LB::R_IN + i * LB::INR + LB::FCP, 4, b);
+#pragma unroll
+        for (int ab = 0; ab < LB::NB_F; ++ab) {
+          load(tile, LB::R_DV + i * LB::FCP + ab * 32, LB::FCP - ab * 32, a);
+          mm(a, b, acc_wv[ab]);
+          bias_dv[ab] += rowsum(a);
+        }
+      }
+    }
+    store_block(LB::BLK_W0, acc_w0[0]), store_block(LB::BLK_W0 + 1, acc_w0[1]);
+    store_block(LB::BLK_WS, acc_ws[0]), store_block(LB::BLK_WS + 1, acc_ws[1]);
+    store_block(LB::BLK_WFC, acc_fc);
+    store_bias(LB::BB_DX, bias_dx[0]), store_bias(LB::BB_DX + 1, bias_dx[1]);
+    store_bias(LB::BB_DS, bias_ds), store_bias(LB::BB_DFC, bias_fc);
+#pragma unroll
+    for (int ab = 0; ab < LB::NB_F; ++ab) store_block(LB::BLK_WV + ab, acc_wv[ab]), store_bias(LB::BB_DV + ab, bias_dv[ab]);
+  } else {
+    // global_fc: sum_i D_g_i x f_i, then (sum_i D_g_i) x [var | mean]
+    f32x16 acc_gv[LB::NB_F], acc_gs[LB::NB_VM];
+    float bias = 0.f;
+#pragma unroll
+    for (int q = 0; q < LB::NB_F; ++q) zero(acc_gv[q]);
+#pragma unroll
+    for (int q = 0; q < LB::NB_VM; ++q) zero(acc_gs[q]);
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+      const long tile = 2 * pair + kk;
+      float asum[32], a[32], b[32];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        load(tile, LB::R_DG + i * 32, 32, a);
+#pragma unroll
+        for (int bb = 0; bb < LB::NB_F; ++bb) {
+          load(tile, LB::R_F + i * LB::FCP + bb * 32, LB::FCP - bb * 32, b);
+          mm(a, b, acc_gv[bb]);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) asum[j] = i == 0 ? a[j] : asum[j] + a[j];
+      }
+      bias += rowsum(asum);
+#pragma unroll
+      for (int bb = 0; bb < LB::NB_VM; ++bb) {
+        load(tile, LB::R_VAR + bb * 32, 2 * LB::FCP - bb * 32, b);
+        mm(asum, b, acc_gs[bb]);
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < LB::NB_F; ++bb) store_block(LB::BLK_WG_V + bb, acc_gv[bb]);
+#pragma unroll
+    for (int bb = 0; bb < LB::NB_VM; ++bb) store_block(LB::BLK_WG_SH + bb, acc_gs[bb]);
+    store_bias(LB::BB_DG, bias);
+  }
+}
+
+// One thread per parameter-gradient element: where it sits in a partial (up to 3 places for the summed 1-wide
+// biases), summed over the workgroups' partials in a fixed order.
+template <int FEAT_CH>
+__global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ vecs,
+                                         bmv_nerf_grads g) {
+  using LB = MlpBwdLayout<FEAT_CH>;
+  constexpr int FC = LB::FC, FCP = LB::FCP, CW = 88 + FC + 4;
+  constexpr int N_VW = FC * 4, N_VB = FC, N_GW = 32 * 3 * FC, N_GB = 32, N_AW = 32, N_AB = 1, N_FW = 16 * 32, N_FB = 16,
+                N_0W = 64 * 24, N_0B = 64, N_SW = 64, N_SB = 1, N_CW = 64 * CW, N_CB = 64, N_2W = 64, N_2B = 1;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  auto blk = [](int b, int mm, int nn) { return b * 1024 + mm * 32 + nn; };
+  auto bias = [](int bb, int mm) { return LB::NBLK * 1024 + bb * 64 + mm; };   // + 32 for the other sample half
+  float* dst = nullptr;
+  int src[3] = {-1, -1, -1};
+  bool is_bias = false;
+  int vec = -1;
+  int e = idx;
+  if (e < N_VW) {
+    int c = e / 4, q = e % 4;
+    dst = g.view_fc_w + e, src[0] = blk(LB::BLK_WV + c / 32, c % 32, q);
+  } else if ((e -= N_VW) < N_VB) {
+    dst = g.view_fc_b + e, src[0] = bias(LB::BB_DV + e / 32, e % 32), is_bias = true;
+  } else if ((e -= N_VB) < N_GW) {
+    int n = e / (3 * FC), k = e % (3 * FC);
+    dst = g.global_fc_w + e;
+    if (k < FC) {
+      src[0] = blk(LB::BLK_WG_V + k / 32, n, k % 32);
+    } else {
+      int row = k < 2 * FC ? k - FC : FCP + (k - 2 * FC);
+      src[0] = blk(LB::BLK_WG_SH + row / 32, n, row % 32);
+    }
+  } else if ((e -= N_GW) < N_GB) {
+    dst = g.global_fc_b + e, src[0] = bias(LB::BB_DG, e), is_bias = true;
+  } else if ((e -= N_GB) < N_AW) {
+    dst = g.agg_w_w + e, vec = 64 + e;
+  } else if ((e -= N_AW) < N_AB) {
+    dst = g.agg_w_b, src[0] = bias(LB::BB_DS, 0), src[1] = bias(LB::BB_DS, 1), src[2] = bias(LB::BB_DS, 2), is_bias = true;
+  } else if ((e -= N_AB) < N_FW) {
+    dst = g.fc_w + e, src[0] = blk(LB::BLK_WFC, e / 32, e % 32);
+  } else if ((e -= N_FW) < N_FB) {
+    dst = g.fc_b + e, src[0] = bias(LB::BB_DFC, e), is_bias = true;
+  } else if ((e -= N_FB) < N_0W) {
+    int n = e / 24, k = e % 24;
+    dst = g.lr0_w + e, src[0] = blk(LB::BLK_W0 + n / 32, n % 32, k);
+  } else if ((e -= N_0W) < N_0B) {
+    dst = g.lr0_b + e, src[0] = bias(LB::BB_DX + e / 32, e % 32), is_bias = true;
+  } else if ((e -= N_0B) < N_SW) {
+    dst = g.sigma_w + e, src[0] = blk(LB::BLK_WS + e / 32, 3, e % 32);
+  } else if ((e -= N_SW) < N_SB) {
+    dst = g.sigma_b, src[0] = bias(LB::BB_DS, 3), is_bias = true;
+  } else if ((e -= N_SB) < N_CW) {
+    int n = e / CW, k = e % CW, tl = n / 32;
+    dst = g.color0_w + e;
+    if (k < 88) {
+      src[0] = blk(LB::BLK_WC_SH + tl * 3 + (k < 64 ? k / 32 : 2), n % 32, k < 64 ? k % 32 : k - 64);
+    } else {
+      int c = k - 88, row = c < FC ? c : FCP + (c - FC);
+      src[0] = blk(LB::BLK_WC_V + tl * LB::NB_IN + row / 32, n % 32, row % 32);
+    }
+  } else if ((e -= N_CW) < N_CB) {
+    dst = g.color0_b + e, src[0] = bias(LB::BB_DH + e / 32, e % 32), is_bias = true;
+  } else if ((e -= N_CB) < N_2W) {
+    dst = g.color2_w + e, vec = e;
+  } else if ((e -= N_2W) < N_2B) {
+    dst = g.color2_b, src[0] = bias(LB::BB_DS, 4), src[1] = bias(LB::BB_DS, 5), src[2] = bias(LB::BB_DS, 6), is_bias = true;
+  } else {
+    return;
+  }
+  float acc = 0.f;
+  if (vec >= 0) {
+    acc = vecs[vec];
+  } else {
+    for (int w = 0; w < nparts; ++w) {
+      const float* p = partials + (long)w * LB::PART;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (src[q] >= 0) acc += p[src[q]] + (is_bias ? p[src[q] + 32] : 0.f);
+    }
+  }
+  *dst = acc;
 }
 
 }  // namespace bmv
 
 using namespace bmv;
+
+namespace {
+constexpr int kWgradGrid = 256;   // one workgroup per CU (the kernel takes > 256 registers)
+
+template <int FC>
+long workspace_floats(long npts) {
+  using LB = MlpBwdLayout<FC>;
+  long ntiles = (npts + 31) / 32;
+  return ntiles * (long)LB::R_TOTAL * 32 + (long)kWgradGrid * LB::PART + 128;
+}
+
+template <int FC>
+int run_bwd(const float* vox_feat, const float* img, const float* d_out, const float* blob_fwd, const float* blob_bwd,
+            long npts, float* ws, float* d_vox, float* d_img, const bmv_nerf_grads* grads, hipStream_t st) {
+  using LB = MlpBwdLayout<FC>;
+  const long ntiles = (npts + 31) / 32;
+  float* rows = ws;
+  float* partials = rows + ntiles * (long)LB::R_TOTAL * 32;
+  float* vecs = partials + (long)kWgradGrid * LB::PART;
+  BMV_REQUIRE(hipMemsetAsync(vecs, 0, 128 * sizeof(float), st) == hipSuccess, "bmv_nerf_mlp_bwd: memset failed");
+  const unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
+  const size_t lds = (size_t)(MlpLayout<FC>::TOTAL + LB::TOTAL) * 4;
+  BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+              "bmv_nerf_mlp_bwd: cannot reserve %zu B of LDS", lds);
+  BwdOut<FC> o{rows, d_vox, d_img, vecs};
+  hipLaunchKernelGGL(nerf_mlp_bwd_kernel<FC>, dim3(grid), dim3(256), lds, st, vox_feat, img, d_out, blob_fwd, blob_bwd,
+                     npts, o);
+  const long npairs = (ntiles + 1) / 2;
+  const int nparts = (int)(npairs < kWgradGrid ? npairs : kWgradGrid);
+  hipLaunchKernelGGL(nerf_wgrad_kernel<FC>, dim3(nparts), dim3(256), 0, st, rows, ntiles, partials);
+  constexpr int F = FC + 3;
+  constexpr int total = F * 4 + F + 32 * 3 * F + 32 + 32 + 1 + 16 * 32 + 16 + 64 * 24 + 64 + 64 + 1 + 64 * (88 + F + 4) + 64 + 64 + 1;
+  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nparts, vecs, *grads);
+  BMV_LAUNCH_END("bmv_nerf_mlp_bwd");
+}
+}  // namespace
 
 extern "C" {
 
@@ -581,6 +877,17 @@ int bmv_nerf_bwd_rows(int feat_ch, int* d_img_rows) {
   return BMV_ERR_UNSUPPORTED;
 }
 
+long bmv_nerf_bwd_workspace(int feat_ch, long npts) {
+  if (npts < 0) {
+    set_error("bmv_nerf_bwd_workspace: npts=%ld", npts);
+    return BMV_ERR_INVALID;
+  }
+  if (feat_ch == 8) return workspace_floats<8>(npts);
+  if (feat_ch == 32) return workspace_floats<32>(npts);
+  set_error("bmv_nerf_bwd_workspace: feat_ch=%d unsupported (8 or 32)", feat_ch);
+  return BMV_ERR_UNSUPPORTED;
+}
+
 int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* p, int feat_ch, float* blob, bmv_stream_t stream) {
   BMV_REQUIRE(p && blob, "bmv_nerf_pack_bwd_weights: null pointer");
   if (feat_ch == 8)
@@ -597,28 +904,19 @@ int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* p, int feat_ch, float* blob
 }
 
 int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img, const float* d_out, const float* blob_fwd,
-                     const float* blob_bwd, int feat_ch, long npts, float* rows, float* d_vox, float* d_img, float* vecs,
-                     bmv_stream_t stream) {
-  BMV_REQUIRE(vox_feat && img && d_out && blob_fwd && blob_bwd && rows && d_vox && d_img && vecs,
+                     const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
+                     const bmv_nerf_grads* grads, bmv_stream_t stream) {
+  BMV_REQUIRE(vox_feat && img && d_out && blob_fwd && blob_bwd && workspace && d_vox && d_img && grads,
               "bmv_nerf_mlp_bwd: null pointer");
-  BMV_REQUIRE(npts >= 0, "bmv_nerf_mlp_bwd: npts=%ld", npts);
-  if (npts == 0) return BMV_OK;
-  long ntiles = (npts + 31) / 32;
-  unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
-#define BWD_CASE(FC)                                                                                               \
-  if (feat_ch == FC) {                                                                                             \
-    size_t lds = (size_t)(MlpLayout<FC>::TOTAL + MlpBwdLayout<FC>::TOTAL) * 4;                                     \
-    BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,           \
-                "bmv_nerf_mlp_bwd: cannot reserve %zu B of LDS", lds);                                             \
-    BwdOut<FC> o{rows, d_vox, d_img, vecs};                                                                        \
-    hipLaunchKernelGGL(nerf_mlp_bwd_kernel<FC>, dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, d_out, \
-                       blob_fwd, blob_bwd, npts, o);                                                               \
-    BMV_LAUNCH_END("bmv_nerf_mlp_bwd");                                                                            \
-  }
-  BWD_CASE(8)
-  BWD_CASE(32)
-#undef BWD_CASE
+  BMV_REQUIRE(grads->view_fc_w && grads->view_fc_b && grads->global_fc_w && grads->global_fc_b && grads->agg_w_w &&
+                  grads->agg_w_b && grads->fc_w && grads->fc_b && grads->lr0_w && grads->lr0_b && grads->sigma_w &&
+                  grads->sigma_b && grads->color0_w && grads->color0_b && grads->color2_w && grads->color2_b,
+              "bmv_nerf_mlp_bwd: null gradient pointer");
+  BMV_REQUIRE(npts > 0, "bmv_nerf_mlp_bwd: npts=%ld", npts);
+  if (feat_ch == 8)
+    return run_bwd<8>(vox_feat, img, d_out, blob_fwd, blob_bwd, npts, workspace, d_vox, d_img, grads, as_stream(stream));
+  if (feat_ch == 32)
+    return run_bwd<32>(vox_feat, img, d_out, blob_fwd, blob_bwd, npts, workspace, d_vox, d_img, grads, as_stream(stream));
   set_error("bmv_nerf_mlp_bwd: feat_ch=%d unsupported (8 or 32)", feat_ch);
   return BMV_ERR_UNSUPPORTED;
 }

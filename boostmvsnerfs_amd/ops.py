@@ -596,19 +596,32 @@ def nerf_bwd_rows(feat_ch):
     return r, ir.value
 
 
+def nerf_param_shapes(feat_ch):
+    """Shapes of the 16 parameter tensors in NERF_PARAM_ORDER (weight, bias)."""
+    F = int(feat_ch) + 3
+    return [(F, 4), (F,), (32, 3 * F), (32,), (1, 32), (1,), (16, 32), (16,), (64, 24), (64,), (1, 64), (1,),
+            (64, 88 + F + 4), (64,), (1, 64), (1,)]
+
+
 def nerf_mlp_bwd(vox_feat_t, img_feat_rgb_dir, d_out, blob_fwd, blob_bwd, feat_ch):
-    """-> rows (R,P), d_vox (8,P), d_img (3,IR,P), vecs (160)."""
+    """-> d_vox (8,P), d_img (3,IR,P), grads: the 16 parameter gradients in NERF_PARAM_ORDER (weight, bias).
+    Data path, weight gradients (MFMA over the sample dimension) and their reduction are three launches inside
+    bmv_nerf_mlp_bwd; the per-tile matrices between them live in a workspace sized by bmv_nerf_bwd_workspace."""
     npts = vox_feat_t.numel() // 8
-    R, IR = nerf_bwd_rows(feat_ch)
+    _, IR = nerf_bwd_rows(feat_ch)
     dev = vox_feat_t.device
-    rows = torch.empty(R, npts, device=dev, dtype=torch.float32)
+    lib = _lib.load()
+    n_ws = lib.bmv_nerf_bwd_workspace(int(feat_ch), npts)
+    if n_ws < 0:
+        _lib.check(int(n_ws), "nerf_bwd_workspace")
+    ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
     d_vox = torch.empty(8, npts, device=dev, dtype=torch.float32)
     d_img = torch.zeros(3, IR, npts, device=dev, dtype=torch.float32)
-    vecs = torch.zeros(160, device=dev, dtype=torch.float32)
-    lib = _lib.load()
+    grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in nerf_param_shapes(feat_ch)]
+    gp = _lib.NerfParams(*[dptr(t, f"nerf grad {i}") for i, t in enumerate(grads)])
     with ktimer.region(f"nerf_mlp_bwd[feat={feat_ch}]"):
         rc = lib.bmv_nerf_mlp_bwd(dptr(_c(vox_feat_t), "vox_feat"), dptr(_c(img_feat_rgb_dir), "img"),
                                   dptr(_c(d_out), "d_out"), dptr(blob_fwd, "blob_fwd"), dptr(blob_bwd, "blob_bwd"),
-                                  int(feat_ch), npts, dptr(rows), dptr(d_vox), dptr(d_img), dptr(vecs), stream())
+                                  int(feat_ch), npts, dptr(ws), dptr(d_vox), dptr(d_img), C.byref(gp), stream())
     _lib.check(rc, "nerf_mlp_bwd")
-    return rows, d_vox, d_img, vecs
+    return d_vox, d_img, grads

@@ -208,19 +208,27 @@ int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* d
                            int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
                            float* d_depth_values, bmv_stream_t stream);
 
-/* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89).  The kernel recomputes the forward of every
- * 32-sample tile and back-propagates the data path on the matrix cores; it writes
- *   rows  (R, P)           pre-activation gradients + the hidden activations the weight gradients need,
- *   d_vox (8, P), d_img (3, IR, P)   input gradients, [row][sample] layout,
- *   vecs  (160)            weight gradients of color.2 (64) | sigma (64) | agg_w_fc (32), accumulated (zero it first).
- * Weight gradients of the wide layers are library GEMMs over the sample dimension on the host side
- * (boostmvsnerfs_amd/autograd.py: dW = rows_block @ activations^T).  R / IR: bmv_nerf_bwd_rows(). */
+/* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89), three launches on `stream`:
+ *   1. the data path: the forward of every 32-sample tile is recomputed and back-propagated on the matrix cores;
+ *      d_vox (8, P) and d_img (3, IR, P) come out in [row][sample] layout (IR rows per view: the F channels padded
+ *      to an even count, then the 4 direction components), and the pre-activation gradients + layer inputs go to
+ *      `workspace` as per-tile matrices;
+ *   2. every weight / bias gradient, dW = D_pre ACT^T, with the sample index as the MFMA k dimension;
+ *   3. a deterministic reduction of the per-workgroup partials into `grads` (tensors of the reference's parameter
+ *      shapes, overwritten).
+ * workspace: bmv_nerf_bwd_workspace(feat_ch, npts) floats (about 80 KB per 32 samples for feat_ch 8).
+ * npts = 0 is rejected (nothing to write the gradients from).  IR: bmv_nerf_bwd_rows(). */
+typedef struct {
+  float *view_fc_w, *view_fc_b, *global_fc_w, *global_fc_b, *agg_w_w, *agg_w_b, *fc_w, *fc_b;
+  float *lr0_w, *lr0_b, *sigma_w, *sigma_b, *color0_w, *color0_b, *color2_w, *color2_b;
+} bmv_nerf_grads;   /* same order and shapes as bmv_nerf_params */
 int bmv_nerf_bwd_blob_size(int feat_ch);
 int bmv_nerf_bwd_rows(int feat_ch, int* d_img_rows);
+long bmv_nerf_bwd_workspace(int feat_ch, long npts);
 int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* params, int feat_ch, float* blob, bmv_stream_t stream);
 int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* d_out, const float* blob_fwd,
-                     const float* blob_bwd, int feat_ch, long npts, float* rows, float* d_vox, float* d_img,
-                     float* vecs, bmv_stream_t stream);
+                     const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
+                     const bmv_nerf_grads* grads, bmv_stream_t stream);
 
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
 
