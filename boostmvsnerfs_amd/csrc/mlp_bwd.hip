@@ -732,8 +732,9 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
   }
 }
 
-// One thread per parameter-gradient element: where it sits in a partial (up to 3 places for the summed 1-wide
-// biases), summed over the workgroups' partials in a fixed order.
+// Eight consecutive lanes per parameter-gradient element: where it sits in a partial (up to 3 places for the summed
+// 1-wide biases), the workgroups' partials summed in a fixed order (lane q takes partials q, q + 8, ...; then a
+// 3-step butterfly), so the result does not depend on scheduling.
 template <int FEAT_CH>
 __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ vecs,
                                          bmv_nerf_grads g) {
@@ -741,7 +742,7 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   constexpr int FC = LB::FC, FCP = LB::FCP, CW = 88 + FC + 4;
   constexpr int N_VW = FC * 4, N_VB = FC, N_GW = 32 * 3 * FC, N_GB = 32, N_AW = 32, N_AB = 1, N_FW = 16 * 32, N_FB = 16,
                 N_0W = 64 * 24, N_0B = 64, N_SW = 64, N_SB = 1, N_CW = 64 * CW, N_CB = 64, N_2W = 64, N_2B = 1;
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
   auto blk = [](int b, int mm, int nn) { return b * 1024 + mm * 32 + nn; };
   auto bias = [](int bb, int mm) { return LB::NBLK * 1024 + bb * 64 + mm; };   // + 32 for the other sample half
   float* dst = nullptr;
@@ -804,14 +805,17 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   if (vec >= 0) {
     acc = vecs[vec];
   } else {
-    for (int w = 0; w < nparts; ++w) {
+    for (int w = sub; w < nparts; w += 8) {
       const float* p = partials + (long)w * LB::PART;
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         if (src[q] >= 0) acc += p[src[q]] + (is_bias ? p[src[q] + 32] : 0.f);
     }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
   }
-  *dst = acc;
+  if (sub == 0)   *dst = acc;
 }
 
 }  // namespace bmv
@@ -850,7 +854,7 @@ int run_bwd(const float* vox_feat, const float* img, const float* d_out, const f
   hipLaunchKernelGGL(nerf_wgrad_kernel<FC>, dim3(nparts), dim3(256), 0, st, rows, ntiles, partials);
   constexpr int F = FC + 3;
   constexpr int total = F * 4 + F + 32 * 3 * F + 32 + 32 + 1 + 16 * 32 + 16 + 64 * 24 + 64 + 64 + 1 + 64 * (88 + F + 4) + 64 + 64 + 1;
-  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nparts, vecs, *grads);
+  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv((long)total * 8, 256)), dim3(256), 0, st, partials, nparts, vecs, *grads);
   BMV_LAUNCH_END("bmv_nerf_mlp_bwd");
 }
 }  // namespace
