@@ -1,0 +1,172 @@
+// Weight gradient of the 3x3x3 convolutions of the cost regularisers (lib/networks/enerf/cost_reg_net.py:4-86,
+// training leg of SURVEY.md section 8 row f1) on the fp32 matrix cores.
+//
+//   G[s, b, kd, kh, kw] = sum_p small[s, p] * big[b, stride * p + (kd, kh, kw)]
+//
+// `small` (Cs, Ds, Hs, Ws) is the output-side tensor (dY of a convolution, X of a transposed convolution) and `big`
+// (Cb, Db, Hb, Wb) the zero-padded input-side tensor (X padded by one voxel, resp. dY padded), so the 27 taps are 27
+// shifted views of `big` and no tap needs a boundary test.  The voxel index is the MFMA k dimension: lane (m, kk) of a
+// wave holds channel m of a 32-channel block for the 32 consecutive voxels  w0 + 32 kk ..  of one (d, h) row (one
+// contiguous 128-byte read; every other element of 256 bytes for stride 2), and 32 v_mfma_f32_32x32x2 steps reduce 64
+// voxels into a 32 x 32 block of one tap.  The four waves of a workgroup split the 27 taps (7, 7, 7, 6 accumulator
+// blocks); a workgroup walks (row, 64-voxel chunk) items grid-stride and writes its partial blocks once; a second
+// kernel sums the partials in a fixed order (deterministic, no atomics).
+// MIOpen's fp32 3-D backward-weights solvers take 40-300 ms for these layers on gfx950 (scripts/probe_conv3d.py) and
+// the slice-GEMM formulation this replaces needed 27 strided copies + a tall-skinny rocBLAS GEMM per layer.
+#include "mlp.hpp"
+
+namespace bmv {
+
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct WgradArgs {
+  const float* big;
+  const float* small;
+  float* partials;
+  int Cb, Db, Hb, Wb, Cs, Ds, Hs, Ws;
+  int nchunk, nitems, cb_blocks;
+};
+
+template <int STRIDE>
+__global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, kk = lane >> 5;
+  const int cs0 = (blockIdx.y / a.cb_blocks) * 32, cb0 = (blockIdx.y % a.cb_blocks) * 32;
+  const bool s_ok = cs0 + m < a.Cs, b_ok = cb0 + m < a.Cb;
+  const size_t s_plane = (size_t)a.Ds * a.Hs * a.Ws, b_plane = (size_t)a.Db * a.Hb * a.Wb;
+  const float* __restrict__ sm = a.small + (size_t)(s_ok ? cs0 + m : 0) * s_plane;
+  const float* __restrict__ bg = a.big + (size_t)(b_ok ? cb0 + m : 0) * b_plane;
+  constexpr int NT = 7;                       // taps per wave: wave, wave + 4, ...
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    const int row = item / a.nchunk, chunk = item - row * a.nchunk;
+    const int d = row / a.Hs, h = row - d * a.Hs;
+    const int w0 = chunk * 64 + kk * 32;
+    const int nv = min(max(a.Ws - w0, 0), 32);          // voxels of this lane's half that exist
+    float av[32];
+    {
+      const float* p = sm + ((size_t)d * a.Hs + h) * a.Ws + w0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (s_ok && 4 * q + 4 <= nv) {
+          float4u t = *reinterpret_cast<const float4u*>(p + 4 * q);
+          av[4 * q] = t.x, av[4 * q + 1] = t.y, av[4 * q + 2] = t.z, av[4 * q + 3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[4 * q + e] = (s_ok && 4 * q + e < nv) ? p[4 * q + e] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tap = wave + 4 * t;
+      if (tap < 27) {
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const float* p = bg + ((size_t)(STRIDE * d + kd) * a.Hb + (STRIDE * h + kh)) * a.Wb + STRIDE * w0 + kw;
+        float bv[32];
+        if (STRIDE == 1) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (b_ok && 4 * q + 4 <= nv) {
+              float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);
+              bv[4 * q] = v.x, bv[4 * q + 1] = v.y, bv[4 * q + 2] = v.z, bv[4 * q + 3] = v.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bv[4 * q + e] = (b_ok && 4 * q + e < nv) ? p[4 * q + e] : 0.f;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {        // 4 consecutive floats = voxels 2q, 2q + 1 (elements 0 and 2)
+            if (b_ok && 2 * q + 2 <= nv) {
+              float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);   // the padded row keeps p + 4q + 3 in bounds
+              bv[2 * q] = v.x, bv[2 * q + 1] = v.z;
+            } else {
+              bv[2 * q] = (b_ok && 2 * q < nv) ? p[4 * q] : 0.f;
+              bv[2 * q + 1] = 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[t] = BMV_MFMA(av[j], bv[j], acc[t]);
+      }
+    }
+  }
+  // accumulator register r, lane (n, hh): D[m = n16(r, hh)][n]
+  float* __restrict__ part = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < 27)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[tap * 1024 + n16(r, kk) * 32 + m] = acc[t][r];
+  }
+}
+
+// G (Cs, Cb, 27): eight consecutive lanes per element, partials summed in a fixed order.
+__global__ void conv3d_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, int nblk, int cb_blocks,
+                                           int Cs, int Cb, float* __restrict__ G) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+  if (idx >= Cs * Cb * 27) return;
+  const int tap = idx % 27, b = (idx / 27) % Cb, s = idx / (27 * Cb);
+  const int y = (s / 32) * cb_blocks + b / 32;
+  const size_t off = (size_t)y * (27 * 1024) + tap * 1024 + (s % 32) * 32 + (b % 32);
+  float acc = 0.f;
+  for (int w = sub; w < nparts; w += 8) acc += partials[(size_t)w * nblk * (27 * 1024) + off];
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (sub == 0) G[idx] = acc;
+}
+
+static int wgrad_grid(int nitems, int nblk) {
+  int g = 512 / nblk;                    // ~2 workgroups per CU in total
+  if (g < 1) g = 1;
+  return nitems < g ? nitems : g;
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+extern "C" {
+
+long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws) {
+  if (Cs <= 0 || Cb <= 0 || Ds <= 0 || Hs <= 0 || Ws <= 0) {
+    set_error("bmv_conv3d_wgrad_workspace: bad shape");
+    return BMV_ERR_INVALID;
+  }
+  const int nblk = ((Cs + 31) / 32) * ((Cb + 31) / 32);
+  const int nitems = Ds * Hs * ((Ws + 63) / 64);
+  return (long)wgrad_grid(nitems, nblk) * nblk * 27 * 1024;
+}
+
+int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
+                     int Ws, int stride, float* workspace, float* G, bmv_stream_t stream) {
+  BMV_REQUIRE(big && small && workspace && G, "bmv_conv3d_wgrad: null pointer");
+  BMV_REQUIRE(stride == 1 || stride == 2, "bmv_conv3d_wgrad: stride=%d unsupported (1 or 2)", stride);
+  BMV_REQUIRE(Cs > 0 && Cb > 0 && Ds > 0 && Hs > 0 && Ws > 0, "bmv_conv3d_wgrad: bad shape");
+  // every tap of every voxel must lie inside `big` (the caller pads); stride 2 reads one float past the last tap
+  BMV_REQUIRE(Db >= stride * (Ds - 1) + 3 && Hb >= stride * (Hs - 1) + 3 && Wb >= stride * (Ws - 1) + 3 + (stride == 2 ? 1 : 0),
+              "bmv_conv3d_wgrad: big (%d,%d,%d) too small for small (%d,%d,%d) at stride %d", Db, Hb, Wb, Ds, Hs, Ws, stride);
+  WgradArgs a;
+  a.big = big, a.small = small, a.partials = workspace;
+  a.Cb = Cb, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.Cs = Cs, a.Ds = Ds, a.Hs = Hs, a.Ws = Ws;
+  a.nchunk = (Ws + 63) / 64, a.nitems = Ds * Hs * a.nchunk, a.cb_blocks = (Cb + 31) / 32;
+  const int nblk = ((Cs + 31) / 32) * a.cb_blocks;
+  const int gx = wgrad_grid(a.nitems, nblk);
+  if (stride == 1)
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(conv3d_wgrad_finish_kernel, dim3(cdiv((long)Cs * Cb * 27 * 8, 256)), dim3(256), 0, as_stream(stream),
+                     workspace, gx, nblk, a.cb_blocks, Cs, Cb, G);
+  BMV_LAUNCH_END("bmv_conv3d_wgrad");
+}
+
+}  // extern "C"

@@ -1,39 +1,27 @@
-"""3-D convolutions whose WEIGHT gradient is 27 slice-GEMMs instead of MIOpen's conv3d
-backward-weights solvers.
+"""3-D convolutions whose WEIGHT gradient runs on the package's own MFMA kernel (csrc/conv_wgrad.hip) instead of
+MIOpen's conv3d backward-weights solvers.
 
-Measured on MI355X / ROCm 7.2 (scripts/probe_conv3d.py): MIOpen picks `naive_conv_*_wrw_ncdhw`
-or a 40 ms CK batched-GEMM for every 3x3x3 fp32 layer of the cost regularisers (308 ms per
-CostRegNet backward, >90 % of a fine-tune step; its exhaustive find mode takes >15 min).  The weight
-gradient of a k^3 convolution is k^3 small GEMMs over the voxel dimension,
+Measured on MI355X / ROCm 7.2 (scripts/probe_conv3d.py): MIOpen picks `naive_conv_*_wrw_ncdhw` or a 40 ms CK
+batched-GEMM for every 3x3x3 fp32 layer of the cost regularisers (308 ms per CostRegNet backward, >90 % of a fine-tune
+step; its exhaustive find mode takes >15 min).  The weight gradient of a k^3 convolution is k^3 products over the voxel
+dimension,
     dW[:, :, kd, kh, kw] = dY (Co x P) @ X_shift(kd,kh,kw)^T (P x Ci),
-which rocBLAS does in microseconds.  Forward and the data gradient stay on MIOpen.
-SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter
-names are unchanged (subclasses of nn.Conv3d / nn.ConvTranspose3d).
+which bmv_conv3d_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per workgroup, no
+im2col copies; the first version of this file made 27 strided copies and one tall-skinny rocBLAS GEMM per layer:
+4 ms of copies + ~5 ms of GEMMs per 512x640 step).  Forward and the data gradient stay on MIOpen.
+SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter names are unchanged
+(subclasses of nn.Conv3d / nn.ConvTranspose3d).
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
-def _slice_gemm_wgrad(big, small, stride, k=3):
+def _wgrad(big, small, stride, k=3):
     """big: (Cb, Db, Hb, Wb) already zero-padded; small: (Cs, Ds, Hs, Ws).
     Returns G (Cs, Cb, k, k, k) with G[s, b, kd, kh, kw] = sum_p small[s, p] * big[b, stride*p + (kd,kh,kw)]."""
-    Cs, Ds, Hs, Ws = small.shape
-    Cb = big.shape[0]
-    sm = small.reshape(Cs, -1)
-    P = sm.shape[1]
-    # gather the k^3 shifted views into one (k^3 * Cb, P) matrix (k^3 strided copies), then ONE GEMM with the
-    # voxel dimension as its K: (k^3 Cb x P) @ (P x Cs).  27 separate (Cs x P)(P x Cb) GEMMs ran at < 0.4 TB/s.
-    cols = torch.empty(k * k * k, Cb, P, device=small.device, dtype=small.dtype)
-    i = 0
-    for kd in range(k):
-        for kh in range(k):
-            for kw in range(k):
-                sl = big[:, kd:kd + stride * Ds:stride, kh:kh + stride * Hs:stride, kw:kw + stride * Ws:stride]
-                cols[i].view(Cb, Ds, Hs, Ws).copy_(sl)
-                i += 1
-    g = cols.view(k * k * k * Cb, P) @ sm.t()                       # (k^3 * Cb, Cs)
-    return g.view(k, k, k, Cb, Cs).permute(4, 3, 0, 1, 2).contiguous()
+    from ... import ops
+    return ops.conv3d_wgrad(big, small, stride)
 
 
 class _Conv3dFn(torch.autograd.Function):
@@ -54,8 +42,8 @@ class _Conv3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = 0
             for b in range(x.shape[0]):
-                xp = F.pad(x[b], (1, 1, 1, 1, 1, 1))
-                gw = gw + _slice_gemm_wgrad(xp, gy[b], s)          # (Co, Ci, 3,3,3)
+                xp = F.pad(x[b], (1, 2 if s == 2 else 1, 1, 1, 1, 1))
+                gw = gw + _wgrad(xp, gy[b], s)          # (Co, Ci, 3,3,3)
         return gx, gw, None
 
 
@@ -78,7 +66,7 @@ class _ConvT3dFn(torch.autograd.Function):
             for b in range(x.shape[0]):
                 # y[o] += x[i] * w[k] with o = 2 i - 1 + k  ->  dW[ci, co, k] = sum_i x[ci, i] * dY[co, 2 i - 1 + k]
                 gp = F.pad(gy[b], (1, 1, 1, 1, 1, 1))
-                gw = gw + _slice_gemm_wgrad(gp, x[b], 2)            # (Ci, Co, 3,3,3)
+                gw = gw + _wgrad(gp, x[b], 2)            # (Ci, Co, 3,3,3)
         return gx, gw
 
 

@@ -625,3 +625,21 @@ def nerf_mlp_bwd(vox_feat_t, img_feat_rgb_dir, d_out, blob_fwd, blob_bwd, feat_c
                                   int(feat_ch), npts, dptr(ws), dptr(d_vox), dptr(d_img), C.byref(gp), stream())
     _lib.check(rc, "nerf_mlp_bwd")
     return d_vox, d_img, grads
+
+
+def conv3d_wgrad(big, small, stride):
+    """big (Cb,Db,Hb,Wb) zero-padded input side, small (Cs,Ds,Hs,Ws) output side -> G (Cs,Cb,3,3,3) with
+    G[s,b,kd,kh,kw] = sum_p small[s,p] * big[b, stride*p + (kd,kh,kw)] (see include/bmv.h: bmv_conv3d_wgrad)."""
+    lib = _lib.load()
+    Cb, Db, Hb, Wb = big.shape
+    Cs, Ds, Hs, Ws = small.shape
+    n_ws = lib.bmv_conv3d_wgrad_workspace(Cs, Cb, Ds, Hs, Ws)
+    if n_ws < 0:
+        _lib.check(int(n_ws), "conv3d_wgrad_workspace")
+    ws = torch.empty(n_ws, device=small.device, dtype=torch.float32)
+    G = torch.empty(Cs, Cb, 3, 3, 3, device=small.device, dtype=torch.float32)
+    with ktimer.region("conv3d_wgrad"):
+        rc = lib.bmv_conv3d_wgrad(dptr(_c(big), "big"), dptr(_c(small), "small"), Cb, Db, Hb, Wb, Cs, Ds, Hs, Ws, int(stride),
+                                  dptr(ws), dptr(G), stream())
+    _lib.check(rc, "conv3d_wgrad")
+    return G

@@ -230,6 +230,18 @@ int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img_feat_rgb_dir, const
                      const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
                      const bmv_nerf_grads* grads, bmv_stream_t stream);
 
+/* ---- f1 (training leg): weight gradient of the cost regularisers' 3x3x3 convolutions
+ *          lib/networks/enerf/cost_reg_net.py:4-86 (Conv3d / ConvTranspose3d, k = 3, stride 1 or 2)
+ * G (Cs, Cb, 3,3,3): G[s,b,kd,kh,kw] = sum_p small[s,p] * big[b, stride*p + (kd,kh,kw)], the voxel index as the MFMA
+ * k dimension.  small (Cs,Ds,Hs,Ws) is the output-side tensor (dY of a convolution, X of a transposed one), big
+ * (Cb,Db,Hb,Wb) the input-side tensor ALREADY zero-padded by the caller so that every tap is in range:
+ * Db >= stride*(Ds-1)+3 (same for H), Wb >= stride*(Ws-1)+3 (+1 for stride 2).  Conv3d: dW = G(big = pad(X), small
+ * = dY); ConvTranspose3d (stride 2, padding 1, output_padding 1): dW = G(big = pad(dY), small = X, stride 2).
+ * workspace: bmv_conv3d_wgrad_workspace() floats. */
+long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws);
+int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
+                     int Ws, int stride, float* workspace, float* G, bmv_stream_t stream);
+
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
 
 /* ---- a18 Network.get_proj_mats            lib/networks/mvsnerf/network.py:1070-1090

@@ -203,3 +203,48 @@ def test_unsupported_shape_is_loud():
     wp, bp = convnet.pack_conv(torch.zeros(4, 4, 7, 7, device=DEV), None)
     with pytest.raises(RuntimeError, match="not one of the shapes"):
         convnet.conv_fwd(x, wp, bp, 4, 1, 7, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training leg: weight gradient of the 3x3x3 (transposed) convolutions on the MFMA kernel (csrc/conv_wgrad.hip)
+# vs torch autograd in float64 (lib/networks/enerf/cost_reg_net.py:4-86)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,stride,dhw", [
+    (16, 8, 1, (3, 9, 70)),       # level-1 conv0 shape class: tail chunk of 6 voxels
+    (8, 16, 2, (4, 10, 20)),      # strided, one partial chunk
+    (8, 16, 2, (5, 7, 9)),        # odd sizes
+    (32, 64, 2, (4, 6, 10)),      # two output blocks
+    (64, 64, 1, (2, 4, 5)),       # four block pairs, row shorter than a float4 pair
+    (8, 1, 1, (2, 5, 130)),       # depth head: one output channel, three chunks
+])
+def test_conv3d_weight_gradient(cin, cout, stride, dhw):
+    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import Conv3d
+    torch.manual_seed(0)
+    m = Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False).to(DEV)
+    x = torch.randn(2, cin, *dhw, device=DEV, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = m.weight.detach().double().requires_grad_(True)
+    torch.nn.functional.conv3d(xd, wd, None, stride, 1).backward(gy.double())
+    scale = float(wd.grad.abs().max())
+    assert float((m.weight.grad.double() - wd.grad).abs().max()) <= 2e-5 * scale
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-4 * float(xd.grad.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,dhw", [(64, 32, (2, 4, 5)), (16, 8, (4, 9, 40)), (32, 16, (3, 5, 33))])
+def test_conv_transpose3d_weight_gradient(cin, cout, dhw):
+    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import ConvTranspose3d
+    torch.manual_seed(1)
+    m = ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False).to(DEV)
+    x = torch.randn(1, cin, *dhw, device=DEV, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = m.weight.detach().double().requires_grad_(True)
+    torch.nn.functional.conv_transpose3d(xd, wd, None, stride=2, padding=1, output_padding=1).backward(gy.double())
+    scale = float(wd.grad.abs().max())
+    assert float((m.weight.grad.double() - wd.grad).abs().max()) <= 2e-5 * scale
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-4 * float(xd.grad.abs().max())
