@@ -5,12 +5,14 @@
 //
 // `small` (Cs, Ds, Hs, Ws) is the output-side tensor (dY of a convolution, X of a transposed convolution) and `big`
 // (Cb, Db, Hb, Wb) the zero-padded input-side tensor (X padded by one voxel, resp. dY padded), so the 27 taps are 27
-// shifted views of `big` and no tap needs a boundary test.  The voxel index is the MFMA k dimension: lane (m, kk) of a
-// wave holds channel m of a 32-channel block for the 32 consecutive voxels  w0 + 32 kk ..  of one (d, h) row (one
-// contiguous 128-byte read; every other element of 256 bytes for stride 2), and 32 v_mfma_f32_32x32x2 steps reduce 64
-// voxels into a 32 x 32 block of one tap.  The four waves of a workgroup split the 27 taps (7, 7, 7, 6 accumulator
-// blocks); a workgroup walks (row, 64-voxel chunk) items grid-stride and writes its partial blocks once; a second
-// kernel sums the partials in a fixed order (deterministic, no atomics).
+// shifted views of `big` and no tap needs a boundary test.  The voxel index is the MFMA k dimension of
+// v_mfma_f32_16x16x4_f32 (the layers that matter have 1-16 channels on either side; a 32 x 32 tile would idle 3/4 of
+// the matrix core): lane (m, kq) of a wave holds channel m of a 16-channel block for 16 consecutive voxels of one
+// (d, h) row -- the four lane groups kq take four consecutive 16-voxel groups of the flattened (row, group) list, so
+// rows whose length is not a multiple of 64 waste nothing -- and 16 MFMA steps reduce 64 voxels into a 16 x 16 block
+// of one tap.  A wave keeps all 27 tap blocks (108 accumulator registers), fetches tap t + 1 while the matrix core
+// works on tap t, walks its items grid-stride and writes its partial blocks once; a second kernel sums the partials
+// in a fixed order (deterministic, no atomics).
 // MIOpen's fp32 3-D backward-weights solvers take 40-300 ms for these layers on gfx950 (scripts/probe_conv3d.py) and
 // the slice-GEMM formulation this replaces needed 27 strided copies + a tall-skinny rocBLAS GEMM per layer.
 #include "mlp.hpp"
@@ -18,41 +20,41 @@
 namespace bmv {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct WgradArgs {
   const float* big;
   const float* small;
   float* partials;
   int Cb, Db, Hb, Wb, Cs, Ds, Hs, Ws;
-  int nchunk, nitems, cb_blocks;
+  int gpr, ngroups, nitems, cb_blocks;     // 16-voxel groups per row, in total; items of 4 groups
 };
 
 template <int STRIDE>
-__global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(WgradArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, kk = lane >> 5;
-  const int cs0 = (blockIdx.y / a.cb_blocks) * 32, cb0 = (blockIdx.y % a.cb_blocks) * 32;
+  const int m = lane & 15, kq = lane >> 4;
+  const int cs0 = (blockIdx.y / a.cb_blocks) * 16, cb0 = (blockIdx.y % a.cb_blocks) * 16;
   const bool s_ok = cs0 + m < a.Cs, b_ok = cb0 + m < a.Cb;
   const size_t s_plane = (size_t)a.Ds * a.Hs * a.Ws, b_plane = (size_t)a.Db * a.Hb * a.Wb;
   const float* __restrict__ sm = a.small + (size_t)(s_ok ? cs0 + m : 0) * s_plane;
   const float* __restrict__ bg = a.big + (size_t)(b_ok ? cb0 + m : 0) * b_plane;
-  constexpr int NT = 7;                       // taps per wave: wave, wave + 4, ...
-  f32x16 acc[NT];
+  f32x4 acc[27];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
-    const int row = item / a.nchunk, chunk = item - row * a.nchunk;
+  for (int item = blockIdx.x * 4 + wave; item < a.nitems; item += gridDim.x * 4) {
+    const int g = item * 4 + kq;                          // this lane group's 16-voxel group
+    const bool g_ok = g < a.ngroups;
+    const int gc = g_ok ? g : 0;
+    const int row = gc / a.gpr, w0 = (gc - row * a.gpr) * 16;
     const int d = row / a.Hs, h = row - d * a.Hs;
-    const int w0 = chunk * 64 + kk * 32;
-    const int nv = min(max(a.Ws - w0, 0), 32);          // voxels of this lane's half that exist
-    float av[32];
+    const int nv = g_ok ? min(a.Ws - w0, 16) : 0;         // voxels of the group that exist
+    float av[16];
     {
       const float* p = sm + ((size_t)d * a.Hs + h) * a.Ws + w0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 4; ++q) {
         if (s_ok && 4 * q + 4 <= nv) {
           float4u t = *reinterpret_cast<const float4u*>(p + 4 * q);
           av[4 * q] = t.x, av[4 * q + 1] = t.y, av[4 * q + 2] = t.z, av[4 * q + 3] = t.w;
@@ -62,72 +64,76 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(WgradArgs a) {
         }
       }
     }
+    const float* brow = bg + ((size_t)(STRIDE * d) * a.Hb + STRIDE * h) * a.Wb + STRIDE * w0;
+    auto fetch = [&](int tap, float (&bv)[16]) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const float* p = brow + ((size_t)kd * a.Hb + kh) * a.Wb + kw;
+      if (STRIDE == 1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int tap = wave + 4 * t;
-      if (tap < 27) {
-        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const float* p = bg + ((size_t)(STRIDE * d + kd) * a.Hb + (STRIDE * h + kh)) * a.Wb + STRIDE * w0 + kw;
-        float bv[32];
-        if (STRIDE == 1) {
+        for (int q = 0; q < 4; ++q) {
+          if (b_ok && 4 * q + 4 <= nv) {
+            float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);
+            bv[4 * q] = v.x, bv[4 * q + 1] = v.y, bv[4 * q + 2] = v.z, bv[4 * q + 3] = v.w;
+          } else {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (b_ok && 4 * q + 4 <= nv) {
-              float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);
-              bv[4 * q] = v.x, bv[4 * q + 1] = v.y, bv[4 * q + 2] = v.z, bv[4 * q + 3] = v.w;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) bv[4 * q + e] = (b_ok && 4 * q + e < nv) ? p[4 * q + e] : 0.f;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {        // 4 consecutive floats = voxels 2q, 2q + 1 (elements 0 and 2)
-            if (b_ok && 2 * q + 2 <= nv) {
-              float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);   // the padded row keeps p + 4q + 3 in bounds
-              bv[2 * q] = v.x, bv[2 * q + 1] = v.z;
-            } else {
-              bv[2 * q] = (b_ok && 2 * q < nv) ? p[4 * q] : 0.f;
-              bv[2 * q + 1] = 0.f;
-            }
+            for (int e = 0; e < 4; ++e) bv[4 * q + e] = (b_ok && 4 * q + e < nv) ? p[4 * q + e] : 0.f;
           }
         }
+      } else {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[t] = BMV_MFMA(av[j], bv[j], acc[t]);
+        for (int q = 0; q < 8; ++q) {         // 4 consecutive floats = voxels 2q, 2q + 1 (elements 0 and 2)
+          if (b_ok && 2 * q + 2 <= nv) {
+            float4u v = *reinterpret_cast<const float4u*>(p + 4 * q);   // the padded row keeps p + 4q + 3 in bounds
+            bv[2 * q] = v.x, bv[2 * q + 1] = v.z;
+          } else {
+            bv[2 * q] = (b_ok && 2 * q < nv) ? p[4 * q] : 0.f;
+            bv[2 * q + 1] = 0.f;
+          }
+        }
       }
+    };
+    float bv[2][16];
+    fetch(0, bv[0]);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      if (t + 1 < 27) fetch(t + 1, bv[(t + 1) & 1]);
+      BMV_FENCE();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[t & 1][j], acc[t], 0, 0, 0);
+      BMV_FENCE();
     }
   }
-  // accumulator register r, lane (n, hh): D[m = n16(r, hh)][n]
-  float* __restrict__ part = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
+  // accumulator register r, lane (n, kq): D[m = 4 kq + r][n]
+  float* __restrict__ part = a.partials + (((size_t)blockIdx.x * 4 + wave) * gridDim.y + blockIdx.y) * (27 * 256);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int tap = wave + 4 * t;
-    if (tap < 27)
+  for (int t = 0; t < 27; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[tap * 1024 + n16(r, kk) * 32 + m] = acc[t][r];
-  }
+    for (int r = 0; r < 4; ++r) part[t * 256 + (4 * kq + r) * 16 + m] = acc[t][r];
 }
 
-// G (Cs, Cb, 27): eight consecutive lanes per element, partials summed in a fixed order.
+// G (Cs, Cb, 27): sixteen consecutive lanes per element, partials summed in a fixed order.
 __global__ void conv3d_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, int nblk, int cb_blocks,
                                            int Cs, int Cb, float* __restrict__ G) {
-  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
   if (idx >= Cs * Cb * 27) return;
   const int tap = idx % 27, b = (idx / 27) % Cb, s = idx / (27 * Cb);
-  const int y = (s / 32) * cb_blocks + b / 32;
-  const size_t off = (size_t)y * (27 * 1024) + tap * 1024 + (s % 32) * 32 + (b % 32);
+  const int y = (s / 16) * cb_blocks + b / 16;
+  const size_t off = (size_t)y * (27 * 256) + tap * 256 + (s % 16) * 16 + (b % 16);
   float acc = 0.f;
-  for (int w = sub; w < nparts; w += 8) acc += partials[(size_t)w * nblk * (27 * 1024) + off];
+#pragma unroll 8
+  for (int w = sub; w < nparts; w += 16) acc += partials[(size_t)w * nblk * (27 * 256) + off];
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 8, 64);
   if (sub == 0) G[idx] = acc;
 }
 
 static int wgrad_grid(int nitems, int nblk) {
-  int g = 512 / nblk;                    // ~2 workgroups per CU in total
+  int g = 512 / nblk;                    // 2 workgroups per CU in total
   if (g < 1) g = 1;
-  return nitems < g ? nitems : g;
+  const int need = (nitems + 3) / 4;
+  return need < g ? need : g;
 }
 
 }  // namespace bmv
@@ -141,9 +147,9 @@ long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws) {
     set_error("bmv_conv3d_wgrad_workspace: bad shape");
     return BMV_ERR_INVALID;
   }
-  const int nblk = ((Cs + 31) / 32) * ((Cb + 31) / 32);
-  const int nitems = Ds * Hs * ((Ws + 63) / 64);
-  return (long)wgrad_grid(nitems, nblk) * nblk * 27 * 1024;
+  const int nblk = ((Cs + 15) / 16) * ((Cb + 15) / 16);
+  const int ngroups = Ds * Hs * ((Ws + 15) / 16);
+  return (long)wgrad_grid((ngroups + 3) / 4, nblk) * 4 * nblk * 27 * 256;
 }
 
 int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
@@ -157,15 +163,15 @@ int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int H
   WgradArgs a;
   a.big = big, a.small = small, a.partials = workspace;
   a.Cb = Cb, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.Cs = Cs, a.Ds = Ds, a.Hs = Hs, a.Ws = Ws;
-  a.nchunk = (Ws + 63) / 64, a.nitems = Ds * Hs * a.nchunk, a.cb_blocks = (Cb + 31) / 32;
-  const int nblk = ((Cs + 31) / 32) * a.cb_blocks;
+  a.gpr = (Ws + 15) / 16, a.ngroups = Ds * Hs * a.gpr, a.nitems = (a.ngroups + 3) / 4, a.cb_blocks = (Cb + 15) / 16;
+  const int nblk = ((Cs + 15) / 16) * a.cb_blocks;
   const int gx = wgrad_grid(a.nitems, nblk);
   if (stride == 1)
     hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
-  hipLaunchKernelGGL(conv3d_wgrad_finish_kernel, dim3(cdiv((long)Cs * Cb * 27 * 8, 256)), dim3(256), 0, as_stream(stream),
-                     workspace, gx, nblk, a.cb_blocks, Cs, Cb, G);
+  hipLaunchKernelGGL(conv3d_wgrad_finish_kernel, dim3(cdiv((long)Cs * Cb * 27 * 16, 256)), dim3(256), 0, as_stream(stream),
+                     workspace, gx * 4, nblk, a.cb_blocks, Cs, Cb, G);
   BMV_LAUNCH_END("bmv_conv3d_wgrad");
 }
 

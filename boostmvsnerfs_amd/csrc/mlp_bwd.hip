@@ -805,6 +805,7 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   if (vec >= 0) {
     acc = vecs[vec];
   } else {
+#pragma unroll 4
     for (int w = sub; w < nparts; w += 8) {
       const float* p = partials + (long)w * LB::PART;
 #pragma unroll

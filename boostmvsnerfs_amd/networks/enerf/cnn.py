@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import convnet
-from .conv3d_wgrad import Conv3d, ConvTranspose3d   # MIOpen forward / data grad, slice-GEMM weight grad
+from .conv3d_wgrad import Conv3d, ConvTranspose3d, _Conv3dFn   # MIOpen forward / data grad, MFMA weight grad
 
 
 def engine_ok(module, x):
@@ -221,6 +221,12 @@ class _CostReg(nn.Module):
             y = s2 + self.conv7(self.conv6(self.conv5(s2)))
         y = s1 + self.conv9(y)
         y = s0 + self.conv11(y)
+        fw, dw = self.feat_conv[0].weight, self.depth_conv[0].weight
+        if torch.is_grad_enabled() and fw.requires_grad and dw.requires_grad:
+            # both heads read the same tensor: one 9-channel convolution (one forward, one data gradient and one
+            # weight-gradient pass over the full-resolution volume instead of two); autograd splits the gradient
+            heads = _Conv3dFn.apply(y, torch.cat([fw, dw], 0), 1)
+            return heads[:, :8], heads[:, 8]
         return self.feat_conv(y), self.depth_conv(y).squeeze(1)
 
 
