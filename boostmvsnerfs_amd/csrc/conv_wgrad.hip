@@ -11,8 +11,8 @@
 // (d, h) row -- the four lane groups kq take four consecutive 16-voxel groups of the flattened (row, group) list, so
 // rows whose length is not a multiple of 64 waste nothing -- and 16 MFMA steps reduce 64 voxels into a 16 x 16 block
 // of one tap.  A wave keeps all 27 tap blocks (108 accumulator registers), fetches tap t + 1 while the matrix core
-// works on tap t, walks its items grid-stride and writes its partial blocks once; a second kernel sums the partials
-// in a fixed order (deterministic, no atomics).
+// works on tap t and walks its items grid-stride; the four waves of a workgroup add their blocks up in LDS and write one
+// partial; a second kernel sums the partials in a fixed order (deterministic, no atomics).
 // MIOpen's fp32 3-D backward-weights solvers take 40-300 ms for these layers on gfx950 (scripts/probe_conv3d.py) and
 // the slice-GEMM formulation this replaces needed 27 strided copies + a tall-skinny rocBLAS GEMM per layer.
 #include "mlp.hpp"
@@ -103,29 +103,40 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(WgradArgs a) {
       BMV_FENCE();
     }
   }
-  // accumulator register r, lane (n, kq): D[m = 4 kq + r][n]
-  float* __restrict__ part = a.partials + (((size_t)blockIdx.x * 4 + wave) * gridDim.y + blockIdx.y) * (27 * 256);
+  // accumulator register r, lane (n, kq): D[m = 4 kq + r][n].  The four waves add their blocks up in LDS one after
+  // the other (fixed order), then the workgroup writes one partial.
+  __shared__ float red[27 * 256];
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int t = 0; t < 27; ++t)
+      for (int t = 0; t < 27; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[t * 256 + (4 * kq + r) * 16 + m] = acc[t][r];
+        for (int r = 0; r < 4; ++r) {
+          const int o = t * 256 + (4 * kq + r) * 16 + m;
+          red[o] = w == 0 ? acc[t][r] : red[o] + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ part = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 256);
+  for (int i = threadIdx.x; i < 27 * 256 / 4; i += 256)
+    reinterpret_cast<float4*>(part)[i] = reinterpret_cast<const float4*>(red)[i];
 }
 
-// G (Cs, Cb, 27): sixteen consecutive lanes per element, partials summed in a fixed order.
+// G (Cs, Cb, 27): one wave per element, the workgroups' partials summed in a fixed order.
 __global__ void conv3d_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, int nblk, int cb_blocks,
                                            int Cs, int Cb, float* __restrict__ G) {
-  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, sub = threadIdx.x & 63;
   if (idx >= Cs * Cb * 27) return;
   const int tap = idx % 27, b = (idx / 27) % Cb, s = idx / (27 * Cb);
   const int y = (s / 16) * cb_blocks + b / 16;
   const size_t off = (size_t)y * (27 * 256) + tap * 256 + (s % 16) * 16 + (b % 16);
   float acc = 0.f;
 #pragma unroll 8
-  for (int w = sub; w < nparts; w += 16) acc += partials[(size_t)w * nblk * (27 * 256) + off];
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  acc += __shfl_xor(acc, 8, 64);
+  for (int w = sub; w < nparts; w += 64) acc += partials[(size_t)w * nblk * (27 * 256) + off];
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) acc += __shfl_xor(acc, k, 64);
   if (sub == 0) G[idx] = acc;
 }
 
@@ -149,7 +160,7 @@ long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws) {
   }
   const int nblk = ((Cs + 15) / 16) * ((Cb + 15) / 16);
   const int ngroups = Ds * Hs * ((Ws + 15) / 16);
-  return (long)wgrad_grid((ngroups + 3) / 4, nblk) * 4 * nblk * 27 * 256;
+  return (long)wgrad_grid((ngroups + 3) / 4, nblk) * nblk * 27 * 256;
 }
 
 int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
@@ -170,8 +181,8 @@ int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int H
     hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(gx, nblk), dim3(256), 0, as_stream(stream), a);
-  hipLaunchKernelGGL(conv3d_wgrad_finish_kernel, dim3(cdiv((long)Cs * Cb * 27 * 16, 256)), dim3(256), 0, as_stream(stream),
-                     workspace, gx * 4, nblk, a.cb_blocks, Cs, Cb, G);
+  hipLaunchKernelGGL(conv3d_wgrad_finish_kernel, dim3(cdiv((long)Cs * Cb * 27 * 64, 256)), dim3(256), 0, as_stream(stream),
+                     workspace, gx, nblk, a.cb_blocks, Cs, Cb, G);
   BMV_LAUNCH_END("bmv_conv3d_wgrad");
 }
 
