@@ -118,16 +118,21 @@ class ImgFeat(torch.autograd.Function):
     """a10: gradient to the image features (scatter) and to the sample positions."""
 
     @staticmethod
-    def forward(ctx, xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale):
+    def forward(ctx, xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, n_grad=None, ray_w=0):
+        """n_grad: leading channels of img_feat_rgb that need a gradient (the colour channels appended to the
+        features are data); ray_w: the rays of xyz (B, rays, Ns, 3) are row-major over an image this wide (a hint
+        for the backward kernel's tiling, 0 = unknown)."""
         ctx.save_for_backward(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext)
         ctx.rs = float(render_scale)
+        ctx.hints = (n_grad, int(ray_w or 0))
         return ops.img_feat(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale)
 
     @staticmethod
     def backward(ctx, d_out):
         xyz, img, exts, ixts, tar = ctx.saved_tensors
-        d_img, d_xyz = ops.img_feat_bwd(xyz, img, exts, ixts, tar, ctx.rs, d_out.contiguous())
-        return d_xyz, d_img, None, None, None, None
+        n_grad, ray_w = ctx.hints
+        d_img, d_xyz = ops.img_feat_bwd(xyz, img, exts, ixts, tar, ctx.rs, d_out.contiguous(), n_grad, ray_w)
+        return d_xyz, d_img, None, None, None, None, None, None
 
 
 class Composite(torch.autograd.Function):

@@ -116,6 +116,85 @@ __global__ void blend_bwd_kernel(const float* __restrict__ raws, const float* __
 }
 
 // ---------------------------------------------------------------------------
+// Scatter-add of bilinear taps through an LDS window.  The threads of a workgroup handle a compact 2-D tile of
+// voxels / rays, so the taps of one source view land in a small box of its feature map: the box is found with an
+// LDS min/max, the taps are accumulated there with ds_add_f32, and the box is added to the gradient image once, row
+// by row (coalesced, ~1 global atomic per touched texel instead of 4 per sample: neighbouring samples share texels).
+// A box that does not fit (steep parallax) falls back to one global atomic per tap.
+// ---------------------------------------------------------------------------
+constexpr int kWinCap = 1536;   // texels per channel of the LDS window
+constexpr int kWinCh = 8;       // channels per pass
+
+struct WinBox {
+  int minx, miny, maxx, maxy;
+};
+
+struct TapSet {                 // the 4 taps of one sample in one view; weight 0 = not written
+  int x0, y0, x1, y1;
+  float w00, w01, w10, w11;
+};
+
+// returns true if the window path is taken (uniform over the workgroup); box = inclusive texel bounds
+__device__ __forceinline__ bool win_begin(WinBox* box, const TapSet& t, bool active) {
+  if (threadIdx.x == 0) *box = WinBox{0x7fffffff, 0x7fffffff, -1, -1};
+  __syncthreads();
+  if (active) {
+    const bool l = t.w00 != 0.f || t.w10 != 0.f, r = t.w01 != 0.f || t.w11 != 0.f;
+    const bool u = t.w00 != 0.f || t.w01 != 0.f, d = t.w10 != 0.f || t.w11 != 0.f;
+    if (l || r) {
+      atomicMin(&box->minx, l ? t.x0 : t.x1), atomicMax(&box->maxx, r ? t.x1 : t.x0);
+      atomicMin(&box->miny, u ? t.y0 : t.y1), atomicMax(&box->maxy, d ? t.y1 : t.y0);
+    }
+  }
+  __syncthreads();
+  const int wx = box->maxx - box->minx + 1, wy = box->maxy - box->miny + 1;
+  return box->maxx >= 0 && wx * wy <= kWinCap;
+}
+
+// one pass of `nc` (<= kWinCh) channels: g[c] = gradient of this thread's sample for channel c of the pass;
+// dst = gradient image plane of the pass's first channel, planes `plane` apart, rows `W` apart
+__device__ __forceinline__ void win_scatter(float* win, const WinBox* box, const TapSet& t, bool active, const float* g,
+                                            int nc, float* __restrict__ dst, size_t plane, int W) {
+  const int minx = box->minx, miny = box->miny, wx = box->maxx - minx + 1, wy = box->maxy - miny + 1;
+  const int n = wx * wy;
+  for (int i = threadIdx.x; i < nc * n; i += blockDim.x) win[i] = 0.f;
+  __syncthreads();
+  if (active) {
+    const int o00 = (t.y0 - miny) * wx + (t.x0 - minx), o01 = (t.y0 - miny) * wx + (t.x1 - minx);
+    const int o10 = (t.y1 - miny) * wx + (t.x0 - minx), o11 = (t.y1 - miny) * wx + (t.x1 - minx);
+    for (int c = 0; c < nc; ++c) {
+      float* wc = win + c * n;
+      if (t.w00 != 0.f) atomicAdd(wc + o00, t.w00 * g[c]);
+      if (t.w01 != 0.f) atomicAdd(wc + o01, t.w01 * g[c]);
+      if (t.w10 != 0.f) atomicAdd(wc + o10, t.w10 * g[c]);
+      if (t.w11 != 0.f) atomicAdd(wc + o11, t.w11 * g[c]);
+    }
+  }
+  __syncthreads();
+  // flush: 32 lanes along x, 8 (channel, row) pairs per sweep of the workgroup
+  const int lx = threadIdx.x & 31, lr = threadIdx.x >> 5, nrows = nc * wy, rstep = blockDim.x >> 5;
+  for (int r0 = lr; r0 < nrows; r0 += rstep) {
+    const int c = r0 / wy, yy = r0 - c * wy;
+    for (int xx = lx; xx < wx; xx += 32) {
+      const float v = win[c * n + yy * wx + xx];
+      if (v != 0.f) atomicAdd(dst + c * plane + (size_t)(miny + yy) * W + (minx + xx), v);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void direct_scatter(const TapSet& t, const float* g, int nc, float* __restrict__ dst,
+                                               size_t plane, int W) {
+  for (int c = 0; c < nc; ++c) {
+    float* d = dst + c * plane;
+    if (t.w00 != 0.f) atomicAdd(d + (size_t)t.y0 * W + t.x0, t.w00 * g[c]);
+    if (t.w01 != 0.f) atomicAdd(d + (size_t)t.y0 * W + t.x1, t.w01 * g[c]);
+    if (t.w10 != 0.f) atomicAdd(d + (size_t)t.y1 * W + t.x0, t.w10 * g[c]);
+    if (t.w11 != 0.f) atomicAdd(d + (size_t)t.y1 * W + t.x1, t.w11 * g[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // a9 get_vox_feat backward: d_out (B,P,C) -> d_volume (atomics), d_d01 (B,P) (only the depth
 // coordinate of uvd carries gradient: u, v are pixel constants).
 // ---------------------------------------------------------------------------
@@ -169,25 +248,40 @@ __device__ __forceinline__ void unit_eps_bwd(const float* x, float eps, const fl
   for (int j = 0; j < 3; ++j) dx[j] = dy[j] / s - x[j] * k;
 }
 
-__global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ img,
-                                    const float* __restrict__ src_exts, const float* __restrict__ src_ixts,
-                                    const float* __restrict__ tar_ext, float render_scale,
-                                    const float* __restrict__ d_out, int P, int S, int C, int H, int W,
-                                    float* __restrict__ d_img, float* __restrict__ d_xyz) {
-  extern __shared__ float smem[];
-  Cam* cams = reinterpret_cast<Cam*>(smem);
-  float* tar_c = smem + (sizeof(Cam) / 4) * S;
-  int b = blockIdx.y;
+// Thread -> sample.  With the layout hint (rays row-major over an image `ray_w` wide, Ns samples per ray, Ns a power
+// of two <= 64) a workgroup takes a compact tw x th tile of rays and all their samples, so that the taps of a view
+// land in a small box (see win_begin); without it, 256 consecutive samples.
+__global__ void __launch_bounds__(256) img_feat_bwd_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ img, const float* __restrict__ src_exts,
+    const float* __restrict__ src_ixts, const float* __restrict__ tar_ext, float render_scale,
+    const float* __restrict__ d_out, int P, int S, int C, int c_grad, int H, int W, int ray_w, int Ns, int tw, int th,
+    int tiles_x, float* __restrict__ d_img, float* __restrict__ d_xyz) {
+  __shared__ float win[kWinCh * kWinCap];
+  __shared__ WinBox box;
+  __shared__ Cam cams[16];
+  __shared__ float tar_c[4];
+  const int b = blockIdx.y;
   if ((int)threadIdx.x < S)
     load_cam(src_exts + ((size_t)b * S + threadIdx.x) * 16, src_ixts + ((size_t)b * S + threadIdx.x) * 9, render_scale,
              cams[threadIdx.x]);
   if ((int)threadIdx.x == S) camera_centre(tar_ext + (size_t)b * 16, tar_c);
   __syncthreads();
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+  int i;
+  bool valid;
+  if (ray_w > 0) {
+    const int smp = threadIdx.x % Ns, r = threadIdx.x / Ns;
+    const int rx = (blockIdx.x % tiles_x) * tw + r % tw, ry = (blockIdx.x / tiles_x) * th + r / tw;
+    const int ray_h = P / (ray_w * Ns);
+    valid = rx < ray_w && ry < ray_h;
+    i = valid ? (ry * ray_w + rx) * Ns + smp : 0;
+  } else {
+    i = blockIdx.x * blockDim.x + threadIdx.x;
+    valid = i < P;
+    i = valid ? i : 0;
+  }
   const float p[3] = {xyz[((size_t)b * P + i) * 3], xyz[((size_t)b * P + i) * 3 + 1], xyz[((size_t)b * P + i) * 3 + 2]};
   float gp[3] = {0.f, 0.f, 0.f};
-  size_t plane = (size_t)H * W;
+  const size_t plane = (size_t)H * W;
   for (int s = 0; s < S; ++s) {
     const Cam& cam = cams[s];
     const float* go = d_out + (((size_t)b * P + i) * S + s) * (C + 4);
@@ -203,6 +297,8 @@ __global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* 
     // border clip: gradient passes only strictly inside [0, size-1] (aten clip_coordinates_set_grad)
     float mx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f, my = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
     float cix = fminf(fmaxf(ix, 0.f), (float)(W - 1)), ciy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    if (!(cix == cix)) cix = 0.f;      // NaN coordinates sample texel 0 (taps_border), no gradient
+    if (!(ciy == ciy)) ciy = 0.f;
     float fx = floorf(cix), fy = floorf(ciy);
     int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
     bool vx1 = x1 <= W - 1, vy1 = y1 <= H - 1;
@@ -211,16 +307,25 @@ __global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* 
     float* df = d_img + ((size_t)b * S + s) * C * plane;
     float gix = 0.f, giy = 0.f;
     size_t o00 = (size_t)y0 * W + x0, o01 = o00 + (vx1 ? 1 : 0), o10 = o00 + (vy1 ? W : 0), o11 = o10 + (vx1 ? 1 : 0);
-    for (int c = 0; c < C; ++c) {
-      float g = go[c];
-      const float* fc = f + c * plane;
-      float v00 = fc[o00], v01 = vx1 ? fc[o01] : 0.f, v10 = vy1 ? fc[o10] : 0.f, v11 = (vx1 && vy1) ? fc[o11] : 0.f;
-      atomicAdd(df + c * plane + o00, ex * ey * g);
-      if (vx1) atomicAdd(df + c * plane + o01, ax * ey * g);
-      if (vy1) atomicAdd(df + c * plane + o10, ex * ay * g);
-      if (vx1 && vy1) atomicAdd(df + c * plane + o11, ax * ay * g);
-      gix += g * ((v01 - v00) * ey + (v11 - v10) * ay);
-      giy += g * ((v10 - v00) * ex + (v11 - v01) * ax);
+    TapSet ts{x0, y0, vx1 ? x1 : x0, vy1 ? y1 : y0, ex * ey, vx1 ? ax * ey : 0.f, vy1 ? ex * ay : 0.f,
+              (vx1 && vy1) ? ax * ay : 0.f};
+    const bool use_win = win_begin(&box, ts, valid);
+    for (int cg = 0; cg < C; cg += kWinCh) {
+      const int nc = min(kWinCh, C - cg), ng = max(0, min(nc, c_grad - cg));   // channels of the pass / that need d_img
+      float g[kWinCh];
+      for (int c = 0; c < nc; ++c) {
+        g[c] = valid ? go[cg + c] : 0.f;
+        const float* fc = f + (cg + c) * plane;
+        float v00 = fc[o00], v01 = vx1 ? fc[o01] : 0.f, v10 = vy1 ? fc[o10] : 0.f, v11 = (vx1 && vy1) ? fc[o11] : 0.f;
+        gix += g[c] * ((v01 - v00) * ey + (v11 - v10) * ay);
+        giy += g[c] * ((v10 - v00) * ex + (v11 - v01) * ax);
+      }
+      if (ng > 0) {
+        if (use_win)
+          win_scatter(win, &box, ts, valid, g, ng, df + (size_t)cg * plane, plane, W);
+        else if (valid)
+          direct_scatter(ts, g, ng, df + (size_t)cg * plane, plane, W);
+      }
     }
     gix *= mx, giy *= my;
     // ix = (qx / z): the normalise / unnormalise pair cancels exactly in the derivative
@@ -247,7 +352,7 @@ __global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* 
       nd += dfv[j] * dfv[j];
     }
     nd = sqrtf(nd);
-    const float* gd = go + C;  // gradients of the 4 direction components
+    const float gd[4] = {valid ? go[C] : 0.f, valid ? go[C + 1] : 0.f, valid ? go[C + 2] : 0.f, valid ? go[C + 3] : 0.f};
     float g_df[3];
     if (nd > 1e-6f) {  // dirn = df / |df|
       float dot = dfv[0] * gd[0] + dfv[1] * gd[1] + dfv[2] * gd[2];
@@ -264,8 +369,10 @@ __global__ void img_feat_bwd_kernel(const float* __restrict__ xyz, const float* 
     unit_eps_bwd(xb, 1e-6f, gb, gxb);
     for (int j = 0; j < 3; ++j) gp[j] += gxa[j] + gxb[j];
   }
-  float* o = d_xyz + ((size_t)b * P + i) * 3;
-  o[0] = gp[0], o[1] = gp[1], o[2] = gp[2];
+  if (valid) {
+    float* o = d_xyz + ((size_t)b * P + i) * 3;
+    o[0] = gp[0], o[1] = gp[1], o[2] = gp[2];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -426,24 +533,30 @@ __global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth,
 
 // ---------------------------------------------------------------------------
 // a3+a4 sweep backward: d_var (B,C,D,h,w) -> d_feats (B,S,C,Hs,Ws) (atomics), d_depth_values (B,D,h,w) or null.
-// One thread per voxel: the S warped values per channel are recomputed (never stored by the forward).
+// One thread per voxel, one workgroup per 16 x 16 tile of one plane and 8 channels: the S warped values per channel
+// are recomputed (never stored by the forward), then the feature gradient of each view goes through the LDS window.
 // ---------------------------------------------------------------------------
 template <int CB, int S>
 __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict__ feats,
                                                          const float* __restrict__ proj,
                                                          const float* __restrict__ dv,
                                                          const float* __restrict__ g_var, int C, int Hs, int Ws, int D,
-                                                         int h, int w, float* __restrict__ d_feats,
-                                                         float* __restrict__ d_dv) {
-  int b = blockIdx.z;
-  int c0 = blockIdx.y * CB;
-  size_t nvox = (size_t)D * h * w;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nvox) return;
-  int x = (int)(i % w), y = (int)((i / w) % h);
-  float depth = dv[(size_t)b * nvox + i];
-  size_t plane = (size_t)Hs * Ws;
+                                                         int h, int w, int tiles_x, int tiles_y,
+                                                         float* __restrict__ d_feats, float* __restrict__ d_dv) {
+  static_assert(CB <= kWinCh, "one window pass per channel block");
+  __shared__ float win[kWinCh * kWinCap];
+  __shared__ WinBox box;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CB;
+  const size_t nvox = (size_t)D * h * w;
+  const int tile = blockIdx.x, d = tile / (tiles_x * tiles_y), tr = tile - d * (tiles_x * tiles_y);
+  const int x = (tr % tiles_x) * 16 + (threadIdx.x & 15), y = (tr / tiles_x) * 16 + (threadIdx.x >> 4);
+  const bool valid = x < w && y < h;
+  const size_t i = ((size_t)d * h + (valid ? y : 0)) * w + (valid ? x : 0);
+  const float depth = dv[(size_t)b * nvox + i];
+  const size_t plane = (size_t)Hs * Ws;
   Taps2 tp[S];
+  TapSet ts[S];
   float ex[S], ey[S], ax[S], ay[S], pxs[S], pys[S], pzs[S];
   bool vx0[S], vx1[S], vy0[S], vy1[S];
   for (int s = 0; s < S; ++s) {
@@ -460,8 +573,9 @@ __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict_
     int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Ws), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hs);
     vx0[s] = x0 >= 0 && x0 <= Ws - 1, vx1[s] = x0 + 1 >= 0 && x0 + 1 <= Ws - 1;
     vy0[s] = y0 >= 0 && y0 <= Hs - 1, vy1[s] = y0 + 1 >= 0 && y0 + 1 <= Hs - 1;
+    ts[s] = TapSet{x0, y0, x0 + 1, y0 + 1, tp[s].w00, tp[s].w01, tp[s].w10, tp[s].w11};   // weight 0 where out of range
   }
-  float gix[S], giy[S];
+  float gix[S], giy[S], gw[S][CB];
   for (int s = 0; s < S; ++s) gix[s] = giy[s] = 0.f;
   for (int c = 0; c < CB; ++c) {
     float v[S][4], wv[S], mean = 0.f;
@@ -472,23 +586,26 @@ __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict_
       mean += wv[s];
     }
     mean /= (float)S;
-    float g = g_var[((size_t)b * C + c0 + c) * nvox + i];
+    const float g = valid ? g_var[((size_t)b * C + c0 + c) * nvox + i] : 0.f;
     for (int s = 0; s < S; ++s) {
-      float gw = (2.f / (float)S) * g * (wv[s] - mean);  // d var / d warped_s
-      float* df = d_feats + (((size_t)b * S + s) * C + c0 + c) * plane;
-      if (tp[s].w00 != 0.f) atomicAdd(df + tp[s].o00, tp[s].w00 * gw);
-      if (tp[s].w01 != 0.f) atomicAdd(df + tp[s].o01, tp[s].w01 * gw);
-      if (tp[s].w10 != 0.f) atomicAdd(df + tp[s].o10, tp[s].w10 * gw);
-      if (tp[s].w11 != 0.f) atomicAdd(df + tp[s].o11, tp[s].w11 * gw);
+      const float gws = (2.f / (float)S) * g * (wv[s] - mean);  // d var / d warped_s
+      gw[s][c] = gws;
       if (d_dv) {  // d warped / d (ix, iy): only in-bounds taps contribute (zeros padding)
         float a00 = (vx0[s] && vy0[s]) ? v[s][0] : 0.f, a01 = (vx1[s] && vy0[s]) ? v[s][1] : 0.f;
         float a10 = (vx0[s] && vy1[s]) ? v[s][2] : 0.f, a11 = (vx1[s] && vy1[s]) ? v[s][3] : 0.f;
-        gix[s] += gw * ((a01 - a00) * ey[s] + (a11 - a10) * ay[s]);
-        giy[s] += gw * ((a10 - a00) * ex[s] + (a11 - a01) * ax[s]);
+        gix[s] += gws * ((a01 - a00) * ey[s] + (a11 - a10) * ay[s]);
+        giy[s] += gws * ((a10 - a00) * ex[s] + (a11 - a01) * ax[s]);
       }
     }
   }
-  if (d_dv) {
+  for (int s = 0; s < S; ++s) {
+    float* df = d_feats + (((size_t)b * S + s) * C + c0) * plane;
+    if (win_begin(&box, ts[s], valid))
+      win_scatter(win, &box, ts[s], valid, gw[s], CB, df, plane, Ws);
+    else if (valid)
+      direct_scatter(ts[s], gw[s], CB, df, plane, Ws);
+  }
+  if (d_dv && valid) {
     float gdepth = 0.f;
     for (int s = 0; s < S; ++s) {
       const float* P = proj + ((size_t)b * S + s) * 12;
@@ -539,14 +656,28 @@ int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out
 }
 
 int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
-                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C, int H,
-                     int W, float* d_img, float* d_xyz, bmv_stream_t stream) {
+                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
+                     int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, bmv_stream_t stream) {
   BMV_REQUIRE(xyz && img_feat_rgb && src_exts && src_ixts && tar_ext && d_out && d_img && d_xyz,
               "bmv_img_feat_bwd: null pointer");
   BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "bmv_img_feat_bwd: bad shape");
+  BMV_REQUIRE(c_grad >= 0 && c_grad <= C, "bmv_img_feat_bwd: c_grad=%d outside [0, %d]", c_grad, C);
   if (P == 0) return BMV_OK;
-  hipLaunchKernelGGL(img_feat_bwd_kernel, dim3(cdiv(P, 256), B), dim3(256), sizeof(Cam) * S + 16, as_stream(stream),
-                     xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, P, S, C, H, W, d_img, d_xyz);
+  int tw = 0, th = 0, tiles_x = 0, nblocks = (int)cdiv(P, 256);
+  // layout hint usable: whole rows of rays, Ns a power of two dividing 256
+  if (ray_w > 0 && Ns > 0 && Ns <= 64 && (Ns & (Ns - 1)) == 0 && P % (ray_w * Ns) == 0) {
+    const int nr = 256 / Ns, ray_h = P / (ray_w * Ns);
+    th = 1;
+    while (th * th * 4 <= nr) th *= 2;       // th = largest power of two with th^2 <= nr ... tw >= th
+    tw = nr / th;
+    tiles_x = (ray_w + tw - 1) / tw;
+    nblocks = tiles_x * ((ray_h + th - 1) / th);
+  } else {
+    ray_w = 0;
+  }
+  hipLaunchKernelGGL(img_feat_bwd_kernel, dim3(nblocks, B), dim3(256), 0, as_stream(stream), xyz, img_feat_rgb, src_exts,
+                     src_ixts, tar_ext, render_scale, d_out, P, S, C, c_grad, H, W, ray_w, Ns, tw, th, tiles_x, d_img,
+                     d_xyz);
   BMV_LAUNCH_END("bmv_img_feat_bwd");
 }
 
@@ -601,9 +732,10 @@ int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* d
     set_error("bmv_sweep_variance_bwd: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
     return BMV_ERR_UNSUPPORTED;
   }
-  size_t nvox = (size_t)D * h * w;
-  hipLaunchKernelGGL((sweep_bwd_kernel<8, 3>), dim3(cdiv(nvox, 256), C / 8, B), dim3(256), 0, as_stream(stream), feats,
-                     proj, depth_values, d_variance, C, Hs, Ws, D, h, w, d_feats, d_depth_values);
+  const int tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
+  hipLaunchKernelGGL((sweep_bwd_kernel<8, 3>), dim3(tiles_x * tiles_y * D, C / 8, B), dim3(256), 0, as_stream(stream),
+                     feats, proj, depth_values, d_variance, C, Hs, Ws, D, h, w, tiles_x, tiles_y, d_feats,
+                     d_depth_values);
   BMV_LAUNCH_END("bmv_sweep_variance_bwd");
 }
 

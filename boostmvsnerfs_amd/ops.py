@@ -502,8 +502,11 @@ def vox_feat_bwd(uvd01, volume, d_out):
     return d_vol, d_d
 
 
-def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out):
+def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, n_grad=None, ray_w=0):
+    """n_grad: leading channels of img_feat_rgb that need a gradient (default all); ray_w: layout hint -- xyz is
+    (B, rays, Ns, 3) with the rays row-major over an image ray_w wide (0 = unknown).  See include/bmv.h."""
     B, S, C_, H, W = img_feat_rgb.shape
+    Ns = xyz.shape[-2] if (ray_w and xyz.dim() == 4) else 0
     pts = _c(xyz).reshape(B, -1, 3)
     P = pts.shape[1]
     d_img = torch.zeros_like(img_feat_rgb, memory_format=torch.contiguous_format)
@@ -511,7 +514,8 @@ def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d
     lib = _lib.load()
     _lib.check(lib.bmv_img_feat_bwd(dptr(pts, "xyz"), dptr(_c(img_feat_rgb), "img"), dptr(_c(src_exts), "src_exts"),
                                     dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"), float(render_scale),
-                                    dptr(_c(d_out), "d_out"), B, P, S, C_, H, W, dptr(d_img), dptr(d_xyz), stream()),
+                                    dptr(_c(d_out), "d_out"), B, P, S, C_, C_ if n_grad is None else int(n_grad), H, W,
+                                    int(ray_w) if Ns else 0, int(Ns), dptr(d_img), dptr(d_xyz), stream()),
                "img_feat_bwd")
     return d_img, d_xyz.reshape(xyz.shape)
 

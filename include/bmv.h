@@ -189,9 +189,13 @@ int bmv_blend_bwd(const float* raws, const float* masks /*normalised*/, const fl
                   float* d_raws, bmv_stream_t stream);
 int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
                      int w, float* d_volume, float* d_d01, bmv_stream_t stream);
+/* c_grad: only the first c_grad of the C channels receive d_img (the trailing colour channels of [features, rgb] are
+ * data); ray_w / Ns: optional layout hint (0 = none) -- the P samples are Ns per ray, rays row-major over an image
+ * ray_w wide -- that lets a workgroup take a compact tile of rays and pre-reduce its scatter-adds in LDS; the result
+ * does not depend on it. */
 int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
-                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C, int H,
-                     int W, float* d_img, float* d_xyz, bmv_stream_t stream);
+                     const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
+                     int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, bmv_stream_t stream);
 int bmv_sample_along_depth_bwd(const float* rays, const float* d_xyz, const float* d_dn, int B, int N, int Ns,
                                int depth_inv, float* d_near_far /*(B,N,2)*/, bmv_stream_t stream);
 int bmv_build_rays_bwd(const float* rays, const float* depth, const float* std, const float* near_far,

@@ -40,6 +40,10 @@ def test_composite_and_blend_bwd():
     assert_close(rg.grad, r.grad, name="d_raws", **GTOL)
 
 
+def rays_are_full_frame(rays, Hr, Wr):
+    return rays.shape[1] == Hr * Wr
+
+
 def test_lookup_and_sampler_bwd(enerf_fx):
     from boostmvsnerfs_amd import autograd as A
     from oracle import enerf as O
@@ -56,7 +60,7 @@ def test_lookup_and_sampler_bwd(enerf_fx):
         img = torch.cat([enerf_fx.t(f"cap/feature_net#0.{0 if lvl == 0 else 2}")[None], enerf_fx.t(f"cap/unpreprocess#{lvl}")], 2)
         Ns = c.num_samples[lvl]
 
-        def run(dev, mods):
+        def run(dev, mods, hinted=False):
             d, s, v, im = (leaf(t.to(dev)) for t in (depth, std, vol, img))
             bb = {k: (t.to(dev) if torch.is_tensor(t) else t) for k, t in b.items()}
             if mods is O:
@@ -70,7 +74,10 @@ def test_lookup_and_sampler_bwd(enerf_fx):
                 xyz, uvd, z = mods.SampleAlongDepth.apply(rays, Ns, inv)
                 uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3)
                 vox = mods.VoxFeat.apply(uvd01, v)
-                feat = mods.ImgFeat.apply(xyz, im, bb["src_exts"], bb["src_ixts"], bb["tar_ext"], rs)
+                # hinted: tell the backward that only the feature channels need d_img and that the rays are a
+                # full Hr x Wr frame (2-D tiles + LDS pre-reduction instead of 256 consecutive samples)
+                hints = (im.shape[2] - 3, Wr) if hinted else ()
+                feat = mods.ImgFeat.apply(xyz, im, bb["src_exts"], bb["src_ixts"], bb["tar_ext"], rs, *hints)
             torch.manual_seed(7)
             gv, gf = torch.randn(vox.shape), torch.randn(feat.shape)
             ((vox * gv.to(dev)).sum() + (feat * gf.to(dev)).sum()).backward()
@@ -80,6 +87,12 @@ def test_lookup_and_sampler_bwd(enerf_fx):
         got = run(DEV, A)
         for name, g, w_ in zip(("d_depth", "d_std", "d_volume", "d_img"), got, want):
             assert_close(g, w_, name=f"{name} level {lvl}", **GTOL)
+        got = run(DEV, A, hinted=True)
+        assert rays_are_full_frame(b[f"rays_{lvl}"], Hr, Wr)
+        for name, g, w_ in zip(("d_depth", "d_std", "d_volume"), got, want):
+            assert_close(g, w_, name=f"{name} level {lvl} (hinted)", **GTOL)
+        assert_close(got[3][:, :, :-3], want[3][:, :, :-3], name=f"d_img level {lvl} (hinted)", **GTOL)
+        assert float(got[3][:, :, -3:].abs().max()) == 0.0          # the colour channels were declared data
 
 
 def test_depth_bwd(enerf_fx):
