@@ -166,7 +166,38 @@ def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
             fn()
         return time.perf_counter() - t0
 
-    if wl["net"] == "enerf":
+    if wl.get("train"):
+        # fine-tune step on the CPU port: forward + MSE loss + torch.autograd backward to every parameter (no optimiser:
+        # Adam on 115 small tensors is noise next to it).  ENeRF: one full frame; the K-volume network: the front end in
+        # full and two strided ray subsets, extrapolated linearly in the ray count like the inference leg.
+        from oracle import enerf as O   # checker / baseline only
+        cc = cfg.enerf.cas_config
+        k_best = list(sel)[: wl.get("k_best", 1)] if sel is not None else None
+
+        def step(stride):
+            b = clone_batch(batch_cpu)
+            g = torch.Generator().manual_seed(0)
+            for i in range(cc.num):
+                b[f"rays_{i}"] = b[f"rays_{i}"][:, ::stride].contiguous()
+                b[f"rgb_{i}"] = torch.rand(1, b[f"rays_{i}"].shape[1], 3, generator=g)
+            leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in state_dict.items()}
+            t0 = time.perf_counter()
+            out = (O.enerf_forward(leaves, b, cfg) if wl["net"] == "enerf" else O.boost_enerf_forward(leaves, b, cfg, k_best))
+            loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - b[f"rgb_{i}"]) ** 2).mean()
+                       for i in range(cc.num) if f"rgb_level{i}" in out)
+            loss.backward()
+            return time.perf_counter() - t0, b[f"rays_{cc.num - 1}"].shape[1]
+        if wl["net"] == "enerf":
+            timed(lambda: O.enerf_forward(state_dict, make_batch(64, 96), cfg))      # page-in / thread-pool warm-up
+            dt, _ = step(1)
+            sample = f"1 step at {H}x{W} (whole workload: forward + loss + backward), oracle/enerf.py torch-CPU fp32 autograd, {dt:.2f} s"
+        else:
+            (t1, n1), (t2, n2) = step(8), step(4)
+            per_ray = max((t2 - t1) / (n2 - n1), 0.0)
+            dt = t1 + per_ray * (N - n1)
+            sample = (f"forward + loss + backward; front end in full + rays ::8 ({n1} rays, {t1:.2f} s) and ::4 ({n2} rays, "
+                      f"{t2:.2f} s), step time extrapolated linearly in the ray count to {N} rays = {dt:.1f} s; oracle torch-CPU fp32 autograd")
+    elif wl["net"] == "enerf":
         from oracle import enerf as O   # checker / baseline only
         timed(lambda: O.enerf_forward(state_dict, make_batch(64, 96), cfg))          # page-in / thread-pool warm-up
         dt = timed(lambda: O.enerf_forward(state_dict, clone_batch(batch_cpu), cfg))
@@ -490,7 +521,7 @@ def main():
             "value_per_gpu": value / world, "value_extra": extra,
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline and (headline or args.cpu_baseline) and not wl.get("train"):
+        if world == 1 and not args.no_cpu_baseline and (headline or args.cpu_baseline):
             cb = cpu_baseline(args, cfg, wl, sd_cpu, batch_cpu, _SELECTION)
             if cb is not None:
                 line["cpu_baseline"] = cb
