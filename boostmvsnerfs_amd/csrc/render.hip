@@ -64,7 +64,10 @@ __device__ float g_stamps[512 * 4 * 8];
 #endif
 
 template <int FEAT_CH, int NS, bool INV>
-__global__ void __launch_bounds__(256, 2) render_rays_kernel(bmv_render_args a) {
+#ifndef BMV_RENDER_WPS
+#define BMV_RENDER_WPS 2   // workgroups (= waves per SIMD) resident per CU
+#endif
+__global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_render_args a) {
   using L = MlpLayout<FEAT_CH>;
   static_assert(32 % NS == 0, "samples per ray must divide 32");
   constexpr int RAYS_PER_TILE = 32 / NS;
@@ -310,7 +313,7 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
 
 // workgroups of the fused renderer: 2 are resident per CU (launch bounds), tiles are walked grid-stride
 static unsigned render_grid() {
-  static const unsigned v = getenv("BMV_RENDER_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_GRID")) : 512u;   // = 2 per CU: every workgroup is resident from the start
+  static const unsigned v = getenv("BMV_RENDER_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_GRID")) : 256u * BMV_RENDER_WPS;   // every workgroup is resident from the start
   return v;
 }
 
