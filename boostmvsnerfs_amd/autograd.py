@@ -197,3 +197,22 @@ class NerfMLP(torch.autograd.Function):
         d_vox_feat = d_vox.t().reshape(*lead, 8)
         d_img_feat = torch.cat([d_img[:, :FC], d_img[:, FCP:FCP + 4]], 1).permute(2, 0, 1).reshape(img.shape)
         return (d_vox_feat, d_img_feat, None) + tuple(grads)
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm{2,3}d in training mode, optionally with the ReLU that follows it in ConvBnReLU(3D)
+    (lib/networks/enerf/utils.py:10-33), on the HBM-bound kernels of csrc/bn.hip.  Running statistics are updated in
+    place exactly as torch does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        y, mean, invstd = ops.bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu)
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        dx, dw, db = ops.bn_train_bwd(x, y, dy.contiguous(), weight, mean, invstd, ctx.relu)
+        return dx, dw, db, None, None, None, None, None

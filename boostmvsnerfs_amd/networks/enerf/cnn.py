@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import autograd as A
 from ... import convnet
 from .conv3d_wgrad import Conv3d, ConvTranspose3d, _Conv3dFn   # MIOpen forward / data grad, MFMA weight grad
 
@@ -62,6 +63,19 @@ def _pack_cbr(m):
     return convnet.pack_conv(*convnet.fold_bn(m.conv.weight, m.bn), stride=m.conv.stride[0])
 
 
+def _bn_forward(bn, x, relu):
+    """bn(x) [+ ReLU].  A plain nn.BatchNorm{2,3}d in training mode on the GPU runs on csrc/bn.hip (statistics pass +
+    apply pass, ReLU fused; MIOpen's spatial batch norm costs ~73 us per call whatever the size); everything else --
+    eval mode, SyncBatchNorm under DDP, BMV_BN=torch -- stays on torch."""
+    if (type(bn) in (nn.BatchNorm2d, nn.BatchNorm3d) and bn.training and bn.track_running_stats and bn.affine
+            and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32
+            and os.environ.get("BMV_BN", "hip") != "torch"):
+        bn.num_batches_tracked.add_(1)
+        return A.BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+    y = bn(x)
+    return F.relu(y, inplace=True) if relu else y
+
+
 class _ConvBN(nn.Module):
     """conv (no bias) -> batch norm -> ReLU; children named `conv` and `bn`."""
 
@@ -71,7 +85,7 @@ class _ConvBN(nn.Module):
         self.bn = bn_cls(cout)
 
     def forward(self, x):
-        return F.relu(self.bn(self.conv(x)), inplace=True)
+        return _bn_forward(self.bn, self.conv(x), True)
 
 
 def cbr2(cin, cout, k=3, stride=1, pad=1):
@@ -82,9 +96,15 @@ def cbr3(cin, cout, stride=1):
     return _ConvBN(Conv3d, nn.BatchNorm3d, cin, cout, 3, stride, 1)
 
 
+class _Up3(nn.Sequential):
+    """transposed conv -> batch norm (no ReLU); a Sequential so that the state-dict keys stay `convN.0.*`, `convN.1.*`"""
+
+    def forward(self, x):
+        return _bn_forward(self[1], self[0](x), False)
+
+
 def up3(cin, cout):
-    return nn.Sequential(ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
-                         nn.BatchNorm3d(cout))
+    return _Up3(ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(cout))
 
 
 class FeatureNet(nn.Module):

@@ -647,3 +647,42 @@ def conv3d_wgrad(big, small, stride):
                                   dptr(ws), dptr(G), stream())
     _lib.check(rc, "conv3d_wgrad")
     return G
+
+
+def bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu):
+    """Training-mode batch norm (+ ReLU) of x (N,C,*spatial); updates the running statistics in place.
+    -> y, save_mean (C), save_invstd (C)."""
+    lib = _lib.load()
+    x = _c(x)
+    N, C_ = x.shape[:2]
+    S = x.numel() // (N * C_)
+    chunks = lib.bmv_bn_chunks(N, S)
+    ws = torch.empty(C_ * chunks * 3, device=x.device, dtype=torch.float32)
+    mean = torch.empty(C_, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C_, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x)
+    with ktimer.region("bn_train_fwd"):
+        rc = lib.bmv_bn_train_fwd(dptr(x, "x"), dptr(weight, "weight"), dptr(bias, "bias"), dptr(running_mean, "running_mean"),
+                                  dptr(running_var, "running_var"), N, C_, S, float(eps), float(momentum), int(bool(relu)),
+                                  dptr(ws), dptr(mean), dptr(invstd), dptr(y), stream())
+    _lib.check(rc, "bn_train_fwd")
+    return y, mean, invstd
+
+
+def bn_train_bwd(x, y, dy, weight, mean, invstd, relu):
+    """-> dx, dweight (C), dbias (C)."""
+    lib = _lib.load()
+    x, dy = _c(x), _c(dy)
+    N, C_ = x.shape[:2]
+    S = x.numel() // (N * C_)
+    chunks = lib.bmv_bn_chunks(N, S)
+    ws = torch.empty(C_ * chunks * 2 + 2 * C_, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    dw = torch.empty(C_, device=x.device, dtype=torch.float32)
+    db = torch.empty(C_, device=x.device, dtype=torch.float32)
+    with ktimer.region("bn_train_bwd"):
+        rc = lib.bmv_bn_train_bwd(dptr(x, "x"), dptr(_c(y), "y") if relu else None, dptr(dy, "dy"), dptr(weight, "weight"),
+                                  dptr(mean), dptr(invstd), N, C_, S, int(bool(relu)), dptr(ws), dptr(dx), dptr(dw), dptr(db),
+                                  stream())
+    _lib.check(rc, "bn_train_bwd")
+    return dx, dw, db

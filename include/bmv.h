@@ -246,6 +246,21 @@ long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws);
 int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
                      int Ws, int stride, float* workspace, float* G, bmv_stream_t stream);
 
+/* ---- f1 / f2 (training leg): batch normalisation in training mode (+ ReLU) of ConvBnReLU / ConvBnReLU3D
+ *          lib/networks/enerf/utils.py:10-33 (nn.BatchNorm2d / nn.BatchNorm3d under net.train())
+ * x, y, dy, dx: (N, C, S) planar, S = H*W or D*H*W.  Forward: batch statistics (biased variance normalises, the
+ * unbiased one updates running_var; momentum as torch: new = (1 - m) old + m batch), y = relu?(xhat * w + b);
+ * save_mean / save_invstd (C) feed the backward.  Backward: the ReLU mask is taken from y (y > 0).
+ * workspace: C * bmv_bn_chunks(N, S) * 3 floats (forward), C * bmv_bn_chunks(N, S) * 2 + 2 C (backward).
+ * weight / bias / running_* / dweight / dbias may be NULL. */
+int bmv_bn_chunks(int N, long S);
+int bmv_bn_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                     int N, int C, long S, float eps, float momentum, int relu, float* workspace, float* save_mean,
+                     float* save_invstd, float* y, bmv_stream_t stream);
+int bmv_bn_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
+                     const float* save_invstd, int N, int C, long S, int relu, float* workspace, float* dx,
+                     float* dweight, float* dbias, bmv_stream_t stream);
+
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */
 
 /* ---- a18 Network.get_proj_mats            lib/networks/mvsnerf/network.py:1070-1090

@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="enerf_ft_512x640_3src")
     ap.add_argument("--rows", type=int, default=40)
+    ap.add_argument("--sort", default="self_cuda_time_total")
     a = ap.parse_args()
     sys.argv = [sys.argv[0], "--workload", a.workload]
     args = bench.parse()
@@ -34,7 +35,7 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         train_step(wrapper, opt, batch)
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=a.rows, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by=a.sort, row_limit=a.rows, max_name_column_width=60))
     ev = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::clone", "aten::contiguous")]
     ev.sort(key=lambda e: -e.count)
     for e in ev[:25]:

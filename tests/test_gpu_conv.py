@@ -248,3 +248,52 @@ def test_conv_transpose3d_weight_gradient(cin, cout, dhw):
     scale = float(wd.grad.abs().max())
     assert float((m.weight.grad.double() - wd.grad).abs().max()) <= 2e-5 * scale
     assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-4 * float(xd.grad.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training-mode batch norm (+ ReLU) on csrc/bn.hip vs torch in float64 (lib/networks/enerf/utils.py:10-33)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,relu", [((3, 8, 37, 53), True), ((1, 16, 4, 32, 48), True), ((1, 32, 2, 4, 5), False),
+                                         ((2, 8, 3, 17, 33), False), ((2, 64, 1, 2, 3), True), ((1, 8, 8, 256, 320), True)])
+def test_batch_norm_training(shape, relu):
+    from boostmvsnerfs_amd import autograd as A
+    torch.manual_seed(0)
+    C = shape[1]
+    x = (torch.randn(shape, device=DEV) * 3 + 50.0)                     # a mean far from zero: nothing may cancel against it
+    x.requires_grad_(True)
+    w = torch.rand(C, device=DEV, requires_grad=True)
+    b = torch.randn(C, device=DEV, requires_grad=True)
+    rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+    rm_d, rv_d = rm.double().clone(), rv.double().clone()
+    y = A.BatchNormTrain.apply(x, w, b, rm, rv, 1e-5, 0.1, relu)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = F.batch_norm(xd, rm_d, rv_d, wd, bd, True, 0.1, 1e-5)
+    if relu:
+        # the mask of the fp32 output: values within rounding of zero may fall on either side, and every flip moves
+        # the channel sums by a whole term -- both sides must differentiate the same function
+        assert float((torch.relu(yd) - y.double()).abs().max()) <= 2e-5 * float(yd.abs().max())
+        yd = yd * (y.detach() > 0).double()
+    yd.backward(gy.double())
+    _close(y.double(), yd.detach(), 2e-5)
+    _close(rm.double(), rm_d, 1e-5), _close(rv.double(), rv_d, 1e-4)
+    _close(x.grad.double(), xd.grad, 2e-4)
+    _close(w.grad.double(), wd.grad, 2e-4), _close(b.grad.double(), bd.grad, 2e-4)
+
+
+def test_cost_reg_training_forward_matches_torch_modules(monkeypatch):
+    """The whole training-mode regulariser (our batch norm, merged heads) == the same modules on torch's batch norm."""
+    from boostmvsnerfs_amd.networks.enerf.cnn import MinCostRegNet
+    torch.manual_seed(0)
+    net = MinCostRegNet(16).to(DEV).train()
+    ref = MinCostRegNet(16).to(DEV).train()
+    ref.load_state_dict(net.state_dict())
+    x = torch.randn(1, 16, 8, 32, 48, device=DEV)
+    f1, d1 = net(x)
+    monkeypatch.setenv("BMV_BN", "torch")
+    f2, d2 = ref(x)
+    _close(f1, f2, 2e-4), _close(d1, d2, 2e-4)
+    for (k, a), (_, bb) in zip(net.state_dict().items(), ref.state_dict().items()):
+        _close(a.float(), bb.float(), 2e-4) if a.dtype.is_floating_point else None
+        assert a.dtype.is_floating_point or torch.equal(a, bb), k

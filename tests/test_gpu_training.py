@@ -45,6 +45,7 @@ def _check_grads(net, want, loss_g, loss_c, outliers=0.0):
         bad = float((err > tol).float().mean())
         worst[k] = bad
         assert bad <= outliers, f"{k}: {bad:.2%} of the gradient outside tolerance (max err {float(err.max()):.3e})"
+        assert bool((err <= 3 * tol).all()), f"{k}: an entry more than 3x outside tolerance (max err {float(err.max()):.3e})"
     return worst
 
 
@@ -132,7 +133,12 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     wrapper = NetworkWrapper(net)
     _, loss, _, _ = wrapper(bg)
     loss.backward()
-    _check_grads(net, want, float(loss), loss_c)
+    # K-volume path: a sample whose viewport test lands on the other side of the mask threshold than the oracle's
+    # (the forward tests budget 0.2 % such flips, test_gpu_boost.py) shifts the weight-gradient SUMS it feeds; measured
+    # (scripts/grad_flake_probe.py): worst entry 0.96 x tolerance, identical run to run, on nerf_1.color.0.weight --
+    # so a change of MIOpen's convolution algorithm on a fresh box can tip single entries over.  Budget: 0.2 % of the
+    # entries of a tensor, none beyond 3 x the tolerance.
+    _check_grads(net, want, float(loss), loss_c, outliers=2e-3)
     # one optimiser step (trainer.py:44-63): parameters must move, loss must be finite
     opt = make_optimizer(net)
     before = {k: p.detach().clone() for k, p in net.named_parameters()}
