@@ -41,3 +41,35 @@ def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch):
         err = (p.grad.cpu() - want).abs()
         tol = 2e-3 * want.abs() + 2e-3 * float(want.pow(2).mean().sqrt()) + 1e-6 * gmax
         assert bool((err <= tol).all()), f"grad {n}: worst {float(err.max()):.3e} (scale {gmax:.3e})"
+
+
+def test_nerf_mlp_backward_many_tiles(enerf_fx):
+    """70 001 samples (2188 tiles): every workgroup of the data-path kernel and of the weight-gradient kernel walks
+    its grid-stride loop several times, the last tile is ragged and the tile count is even + the pair count odd-ish;
+    gradients vs torch.autograd on the CPU oracle."""
+    from boostmvsnerfs_amd import autograd as A, ops
+    from oracle import enerf as O
+    sd = enerf_fx.group("sd")
+    lvl, feat_ch, prefix = 1, 8, "nerf_1."
+    names = [f"{prefix}{n}.{k}" for n in ops.NERF_PARAM_ORDER for k in ("weight", "bias")]
+    P = 70001
+    torch.manual_seed(11)
+    base_v, base_i = enerf_fx.t(f"cap/get_vox_feat#{lvl}"), enerf_fx.t(f"cap/get_img_feat#{lvl}")
+    idx = torch.randint(0, base_v.shape[1], (P,))
+    vox = (base_v[:, idx] + 0.05 * torch.randn(1, P, 8)).contiguous()
+    img = (base_i[:, idx] + 0.05 * torch.randn(1, P, *base_i.shape[2:])).contiguous()
+    g = torch.randn(1, P, 4)
+    sd_cpu = {k: v.detach().clone().requires_grad_(k in names) for k, v in sd.items()}
+    v_c, i_c = vox.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    (O.nerf_mlp(sd_cpu, prefix, v_c, i_c) * g).sum().backward()
+    params = [sd[n].to(DEV).clone().requires_grad_(True) for n in names]
+    v_g, i_g = vox.to(DEV).requires_grad_(True), img.to(DEV).requires_grad_(True)
+    (A.NerfMLP.apply(v_g, i_g, feat_ch, *params) * g.to(DEV)).sum().backward()
+    assert_close(v_g.grad, v_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_vox_feat")
+    assert_close(i_g.grad, i_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_img_feat")
+    gmax = max(float(sd_cpu[n].grad.abs().max()) for n in names)
+    for n, p in zip(names, params):
+        want = sd_cpu[n].grad
+        err = (p.grad.cpu() - want).abs()
+        tol = 2e-3 * want.abs() + 2e-3 * float(want.pow(2).mean().sqrt()) + 1e-6 * gmax
+        assert bool((err <= tol).all()), f"grad {n}: worst {float(err.max()):.3e} (scale {gmax:.3e})"
