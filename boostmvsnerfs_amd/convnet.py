@@ -51,6 +51,38 @@ def pack_conv(weight, bias, stride=1, allow_pair=True):
     return wpack, b
 
 
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, device):
+    key = (n, str(device))
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return _ZERO_BIAS[key]
+
+
+def pack_conv_dev(weight, bias, stride=1, transposed=False):
+    """pack_conv / pack_convT in ONE launch (bmv_conv_pack_weights), for weights that change every step.
+    Returns (wpack, bias16); without a bias the (cached) zero vector is returned."""
+    lib = _lib.load()
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    Cout, Cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    k = w.shape[-1]
+    kd = w.shape[2] if w.dim() == 5 else 1
+    n = ((Cout + 15) // 16) * ((Cin + 3) // 4) * kd * k * k * 64 if transposed else lib.bmv_conv_wpack_floats(Cin, Cout, kd, k, stride)
+    wpack = torch.empty(n, device=w.device, dtype=torch.float32)
+    _lib.check(lib.bmv_conv_pack_weights(dptr(w, "weight"), Cin, Cout, kd, k, stride, int(transposed), dptr(wpack), stream()),
+               "conv_pack_weights")
+    nt16 = (Cout + 15) // 16 * 16
+    if bias is None:
+        b = _zero_bias(nt16, w.device)
+    else:
+        b = torch.zeros(nt16, device=w.device, dtype=torch.float32)
+        b[:Cout] = bias.detach()
+    return wpack, b
+
+
 def pack_convT(weight, bias):
     """ConvTranspose3d weight (Cin,Cout,3,3,3) -> the same blob layout with the roles of dims 0/1 swapped."""
     return pack_conv(weight.detach().transpose(0, 1), bias, allow_pair=False)

@@ -758,6 +758,49 @@ int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride) {
   return ((Cout + 15) / 16) * ((Cin + 3) / 4) * taps * 64;
 }
 
+// One thread per wpack element: the layouts documented in include/bmv.h, straight from torch's weight tensor
+// ((Cout,Cin,taps), or (Cin,Cout,taps) for a transposed convolution) -- the training forward repacks every step.
+namespace bmv {
+__global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int kd, int k, int pair, int transposed,
+                                 int total, float* __restrict__ wpack) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int nc = (Cin + 3) / 4;
+  const int o = idx & 15, kk = (idx >> 4) & 3;
+  int r = idx >> 6;
+  float v = 0.f;
+  if (pair) {
+    const int taps = kd * (k + 1) * k;
+    const int tap = r % taps, c = r / taps;
+    const int kx = tap % k, j = (tap / k) % (k + 1), kz = tap / (k * (k + 1));
+    const int ci = 4 * c + kk, co = o & 7, ky = o < 8 ? j : j - 1;
+    if (co < Cout && ci < Cin && ky >= 0 && ky < k) v = w[((size_t)co * Cin + ci) * (kd * k * k) + (kz * k + ky) * k + kx];
+  } else {
+    const int taps = kd * k * k;
+    const int tap = r % taps;
+    r /= taps;
+    const int c = r % nc, t = r / nc;
+    const int co = 16 * t + o, ci = 4 * c + kk;
+    if (co < Cout && ci < Cin)
+      v = transposed ? w[((size_t)ci * Cout + co) * taps + tap] : w[((size_t)co * Cin + ci) * taps + tap];
+  }
+  wpack[idx] = v;
+}
+}  // namespace bmv
+
+int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed,
+                          float* wpack, bmv_stream_t stream) {
+  using namespace bmv;
+  BMV_REQUIRE(weight && wpack, "conv_pack: null pointer");
+  BMV_REQUIRE(Cin > 0 && Cout > 0 && kd > 0 && k > 0, "conv_pack: bad shape");
+  const int pair = transposed ? 0 : bmv_conv_pairs_rows(Cout, kd, k, stride);
+  const int total = transposed ? ((Cout + 15) / 16) * ((Cin + 3) / 4) * kd * k * k * 64
+                               : bmv_conv_wpack_floats(Cin, Cout, kd, k, stride);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), weight, Cout, Cin, kd, k,
+                     pair, transposed, total, wpack);
+  BMV_LAUNCH_END("bmv_conv_pack_weights");
+}
+
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                  int D, int H, int W, int Cout, int kd, int k, int stride, float act_slope, int out_channels_last,
                  bmv_stream_t stream) {

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from ... import autograd as A
 from ... import convnet
-from .conv3d_wgrad import Conv3d, ConvTranspose3d, _Conv3dFn   # MIOpen forward / data grad, MFMA weight grad
+from .conv3d_wgrad import Conv2d, Conv3d, ConvTranspose3d, _Conv3dFn   # engine forward, MIOpen data grad, MFMA weight grad
 
 
 def engine_ok(module, x):
@@ -89,7 +89,7 @@ class _ConvBN(nn.Module):
 
 
 def cbr2(cin, cout, k=3, stride=1, pad=1):
-    return _ConvBN(nn.Conv2d, nn.BatchNorm2d, cin, cout, k, stride, pad)
+    return _ConvBN(Conv2d, nn.BatchNorm2d, cin, cout, k, stride, pad)
 
 
 def cbr3(cin, cout, stride=1):
@@ -116,11 +116,11 @@ class FeatureNet(nn.Module):
         self.conv0 = nn.Sequential(cbr2(3, widths[0]), cbr2(widths[0], widths[0]))
         self.conv1 = nn.Sequential(cbr2(widths[0], widths[1], 5, 2, 2), cbr2(widths[1], widths[1]))
         self.conv2 = nn.Sequential(cbr2(widths[1], widths[2], 5, 2, 2), cbr2(widths[2], widths[2]))
-        self.toplayer = nn.Conv2d(32, 32, 1)
-        self.lat1 = nn.Conv2d(16, 32, 1)
-        self.lat0 = nn.Conv2d(8, 32, 1)
-        self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
-        self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
+        self.toplayer = Conv2d(32, 32, 1)
+        self.lat1 = Conv2d(16, 32, 1)
+        self.lat0 = Conv2d(8, 32, 1)
+        self.smooth1 = Conv2d(32, 16, 3, padding=1)
+        self.smooth0 = Conv2d(32, 8, 3, padding=1)
         self._packed = _Packed()
 
     @staticmethod

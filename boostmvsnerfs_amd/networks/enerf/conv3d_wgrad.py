@@ -12,9 +12,20 @@ im2col copies; the first version of this file made 27 strided copies and one tal
 SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter names are unchanged
 (subclasses of nn.Conv3d / nn.ConvTranspose3d).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ... import convnet
+
+
+def _engine_forward(x):
+    """The training FORWARD of a convolution runs on the package's engine (csrc/conv.hip, weights repacked on the
+    device every step: one launch) unless BMV_TRAIN_CONV=torch; the backward never does (MIOpen data gradients, own
+    weight-gradient kernel for 3-D)."""
+    return x.is_cuda and x.dtype == torch.float32 and os.environ.get("BMV_TRAIN_CONV", "engine") != "torch"
 
 
 def _wgrad(big, small, stride, k=3):
@@ -29,6 +40,8 @@ class _Conv3dFn(torch.autograd.Function):
     def forward(ctx, x, w, stride):
         ctx.save_for_backward(x, w)
         ctx.stride = stride
+        if _engine_forward(x):
+            return convnet.conv_fwd(x, *convnet.pack_conv_dev(w, None, stride), w.shape[0], 3, 3, stride)
         return F.conv3d(x, w, None, stride, 1)
 
     @staticmethod
@@ -53,6 +66,8 @@ class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        if _engine_forward(x):
+            return convnet.convT3d_fwd(x, *convnet.pack_conv_dev(w, None, transposed=True), w.shape[1])
         return F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
 
     @staticmethod
@@ -68,6 +83,36 @@ class _ConvT3dFn(torch.autograd.Function):
                 gp = F.pad(gy[b], (1, 1, 1, 1, 1, 1))
                 gw = gw + _wgrad(gp, x[b], 2)            # (Ci, Co, 3,3,3)
         return gx, gw
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (k in {1, 3, 5}, zero padding k // 2): forward on the engine, both gradients on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, b is not None)
+        return convnet.conv_fwd(x, *convnet.pack_conv_dev(w, b, stride), w.shape[0], 1, w.shape[-1], stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        s, has_b = ctx.cfg
+        p = w.shape[-1] // 2
+        gx, gw, gb = torch.ops.aten.convolution_backward(gy.contiguous(), x, w, [w.shape[0]] if has_b else None, [s, s], [p, p],
+                                                         [1, 1], False, [0, 0], 1,
+                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b])
+        return gx, gw, (gb if has_b else None), None
+
+
+class Conv2d(nn.Conv2d):
+    def forward(self, x):
+        k = self.kernel_size[0]
+        if (torch.is_grad_enabled() and _engine_forward(x) and self.kernel_size == (k, k) and (k, self.stride) in
+                ((1, (1, 1)), (3, (1, 1)), (5, (2, 2))) and self.padding == (k // 2, k // 2) and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding_mode == "zeros"):
+            return _Conv2dFn.apply(x, self.weight, self.bias, self.stride[0])
+        return super().forward(x)
 
 
 class Conv3d(nn.Conv3d):

@@ -232,6 +232,8 @@ def test_conv3d_weight_gradient(cin, cout, stride, dhw):
     wd = m.weight.detach().double().to(ref_dev).requires_grad_(True)
     torch.nn.functional.conv3d(xd, wd, None, stride, 1).backward(gy.double().to(ref_dev))
     gw, gx = wd.grad.to(DEV), xd.grad.to(DEV)
+    yd = torch.nn.functional.conv3d(xd.detach(), wd.detach(), None, stride, 1).to(DEV)
+    assert float((y.double() - yd).abs().max()) <= 2e-5 * float(yd.abs().max())        # engine forward (repacked weights)
     assert float((m.weight.grad.double() - gw).abs().max()) <= 2e-5 * float(gw.abs().max())
     assert float((x.grad.double() - gx).abs().max()) <= 1e-4 * float(gx.abs().max())
 
@@ -300,3 +302,27 @@ def test_cost_reg_training_forward_matches_torch_modules(monkeypatch):
     for (k, a), (_, bb) in zip(net.state_dict().items(), ref.state_dict().items()):
         _close(a.float(), bb.float(), 2e-4) if a.dtype.is_floating_point else None
         assert a.dtype.is_floating_point or torch.equal(a, bb), k
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,bias,hw", [(3, 8, 3, 1, False, (37, 53)), (8, 16, 5, 2, False, (64, 96)),
+                                                        (32, 32, 1, 1, True, (16, 24)), (32, 8, 3, 1, True, (40, 72)),
+                                                        (16, 32, 1, 1, True, (19, 21))])
+def test_conv2d_training_module(cin, cout, k, stride, bias, hw):
+    """FeatureNet's convolutions under autograd: forward on the engine (weights repacked on the device), gradients
+    on MIOpen, vs float64."""
+    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import Conv2d
+    torch.manual_seed(2)
+    m = Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias).to(DEV)
+    x = torch.randn(3, cin, *hw, device=DEV, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = m.weight.detach().double().requires_grad_(True)
+    bd = m.bias.detach().double().requires_grad_(True) if bias else None
+    yd = F.conv2d(xd, wd, bd, stride, k // 2)
+    yd.backward(gy.double())
+    _close(y.double(), yd.detach(), 2e-5)
+    _close(x.grad.double(), xd.grad, 1e-4), _close(m.weight.grad.double(), wd.grad, 1e-4)
+    if bias:
+        _close(m.bias.grad.double(), bd.grad, 1e-4)
