@@ -61,19 +61,22 @@ def _zero_bias(n, device):
     return _ZERO_BIAS[key]
 
 
-def pack_conv_dev(weight, bias, stride=1, transposed=False):
+def pack_conv_dev(weight, bias, stride=1, transposed=False, flip=False, for_convT=False):
     """pack_conv / pack_convT in ONE launch (bmv_conv_pack_weights), for weights that change every step.
-    Returns (wpack, bias16); without a bias the (cached) zero vector is returned."""
+    `weight` is torch's tensor as stored; the blob is for a convolution whose (Cout, Cin) are weight.shape[:2], or
+    shape[1::-1] when `transposed`; `flip` reverses the taps (transposed + flip: the data gradient of a stride-1
+    convolution as a convolution); `for_convT`: the blob feeds convT3d_fwd.  Returns (wpack, bias16); without a bias
+    the (cached) zero vector."""
     lib = _lib.load()
     w = weight.detach()
     w = w if w.is_contiguous() else w.contiguous()
     Cout, Cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     k = w.shape[-1]
     kd = w.shape[2] if w.dim() == 5 else 1
-    n = ((Cout + 15) // 16) * ((Cin + 3) // 4) * kd * k * k * 64 if transposed else lib.bmv_conv_wpack_floats(Cin, Cout, kd, k, stride)
+    n = ((Cout + 15) // 16) * ((Cin + 3) // 4) * kd * k * k * 64 if for_convT else lib.bmv_conv_wpack_floats(Cin, Cout, kd, k, stride)
     wpack = torch.empty(n, device=w.device, dtype=torch.float32)
-    _lib.check(lib.bmv_conv_pack_weights(dptr(w, "weight"), Cin, Cout, kd, k, stride, int(transposed), dptr(wpack), stream()),
-               "conv_pack_weights")
+    _lib.check(lib.bmv_conv_pack_weights(dptr(w, "weight"), Cin, Cout, kd, k, stride, int(transposed), int(flip), int(for_convT),
+                                         dptr(wpack), stream()), "conv_pack_weights")
     nt16 = (Cout + 15) // 16 * 16
     if bias is None:
         b = _zero_bias(nt16, w.device)

@@ -762,10 +762,15 @@ int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride) {
 // ((Cout,Cin,taps), or (Cin,Cout,taps) for a transposed convolution) -- the training forward repacks every step.
 namespace bmv {
 __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int kd, int k, int pair, int transposed,
-                                 int total, float* __restrict__ wpack) {
+                                 int flip, int total, float* __restrict__ wpack) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int nc = (Cin + 3) / 4;
+  const int nc = (Cin + 3) / 4, ntap = kd * k * k;
+  // weight of the convolution being packed at (output channel, input channel, tap), from the source tensor
+  auto src = [&](int co, int ci, int tap) {
+    const int t = flip ? ntap - 1 - tap : tap;
+    return transposed ? w[((size_t)ci * Cout + co) * ntap + t] : w[((size_t)co * Cin + ci) * ntap + t];
+  };
   const int o = idx & 15, kk = (idx >> 4) & 3;
   int r = idx >> 6;
   float v = 0.f;
@@ -774,30 +779,28 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
     const int tap = r % taps, c = r / taps;
     const int kx = tap % k, j = (tap / k) % (k + 1), kz = tap / (k * (k + 1));
     const int ci = 4 * c + kk, co = o & 7, ky = o < 8 ? j : j - 1;
-    if (co < Cout && ci < Cin && ky >= 0 && ky < k) v = w[((size_t)co * Cin + ci) * (kd * k * k) + (kz * k + ky) * k + kx];
+    if (co < Cout && ci < Cin && ky >= 0 && ky < k) v = src(co, ci, (kz * k + ky) * k + kx);
   } else {
-    const int taps = kd * k * k;
-    const int tap = r % taps;
-    r /= taps;
+    const int tap = r % ntap;
+    r /= ntap;
     const int c = r % nc, t = r / nc;
     const int co = 16 * t + o, ci = 4 * c + kk;
-    if (co < Cout && ci < Cin)
-      v = transposed ? w[((size_t)ci * Cout + co) * taps + tap] : w[((size_t)co * Cin + ci) * taps + tap];
+    if (co < Cout && ci < Cin) v = src(co, ci, tap);
   }
   wpack[idx] = v;
 }
 }  // namespace bmv
 
-int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed,
-                          float* wpack, bmv_stream_t stream) {
+int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed, int flip,
+                          int for_transpose_kernel, float* wpack, bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(weight && wpack, "conv_pack: null pointer");
   BMV_REQUIRE(Cin > 0 && Cout > 0 && kd > 0 && k > 0, "conv_pack: bad shape");
-  const int pair = transposed ? 0 : bmv_conv_pairs_rows(Cout, kd, k, stride);
-  const int total = transposed ? ((Cout + 15) / 16) * ((Cin + 3) / 4) * kd * k * k * 64
-                               : bmv_conv_wpack_floats(Cin, Cout, kd, k, stride);
+  const int pair = for_transpose_kernel ? 0 : bmv_conv_pairs_rows(Cout, kd, k, stride);
+  const int total = for_transpose_kernel ? ((Cout + 15) / 16) * ((Cin + 3) / 4) * kd * k * k * 64
+                                         : bmv_conv_wpack_floats(Cin, Cout, kd, k, stride);
   hipLaunchKernelGGL(conv_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), weight, Cout, Cin, kd, k,
-                     pair, transposed, total, wpack);
+                     pair, transposed, flip, total, wpack);
   BMV_LAUNCH_END("bmv_conv_pack_weights");
 }
 

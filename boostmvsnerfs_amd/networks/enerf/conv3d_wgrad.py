@@ -50,8 +50,16 @@ class _Conv3dFn(torch.autograd.Function):
         s = ctx.stride
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [s] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
-                                                     [True, False, False])[0]
+            even = all(v % 2 == 0 for v in x.shape[2:])
+            if _engine_forward(gy) and s == 1:
+                # the adjoint of a stride-1 convolution is the convolution with the flipped, transposed filter
+                gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 1, transposed=True, flip=True), w.shape[1], 3, 3, 1)
+            elif _engine_forward(gy) and s == 2 and even:
+                # ... of a stride-2 one (even input sizes) the transposed convolution with the same filter
+                gx = convnet.convT3d_fwd(gy, *convnet.pack_conv_dev(w, None, transposed=True, for_convT=True), w.shape[1])
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, [s] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             gw = 0
             for b in range(x.shape[0]):
@@ -67,15 +75,18 @@ class _ConvT3dFn(torch.autograd.Function):
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
         if _engine_forward(x):
-            return convnet.convT3d_fwd(x, *convnet.pack_conv_dev(w, None, transposed=True), w.shape[1])
+            return convnet.convT3d_fwd(x, *convnet.pack_conv_dev(w, None, transposed=True, for_convT=True), w.shape[1])
         return F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = F.conv3d(gy, w, None, 2, 1)                        # adjoint of the transposed conv
+        if ctx.needs_input_grad[0]:                                 # adjoint of the transposed conv: the stride-2 conv
+            if _engine_forward(gy):
+                gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 2), w.shape[0], 3, 3, 2)
+            else:
+                gx = F.conv3d(gy, w, None, 2, 1)
         if ctx.needs_input_grad[1]:
             gw = 0
             for b in range(x.shape[0]):

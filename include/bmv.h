@@ -346,10 +346,12 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
  *   wpack[0][c][tap][kk][8 + o] = weight[o][4 c + kk][kz][j - 1][kx]  (j >= 1, o < 8), zero elsewhere. */
 int bmv_conv_pairs_rows(int Cout, int kd, int k, int stride);
 int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride);
-/* wpack from torch's weight tensor on the device, one launch (the training forward repacks every step): weight
- * (Cout,Cin,[kd,]k,k), or (Cin,Cout,3,3,3) with transposed != 0 (the blob of bmv_conv3d_transpose_fwd, never paired). */
-int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed,
-                          float* wpack, bmv_stream_t stream);
+/* wpack on the device, one launch (training repacks every step).  The blob is for a convolution with Cin inputs and
+ * Cout outputs; its weight at (co, ci, tap) is read from `weight` laid out (Cout,Cin,taps), or (Cin,Cout,taps) when
+ * transposed != 0, at tap index taps-1-tap when flip != 0 (transposed + flip = the data gradient of a stride-1
+ * convolution run as a convolution).  for_transpose_kernel != 0: the blob of bmv_conv3d_transpose_fwd (never paired). */
+int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed, int flip,
+                          int for_transpose_kernel, float* wpack, bmv_stream_t stream);
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                  int D, int H, int W, int Cout, int kd, int k, int stride, float act_slope, int out_channels_last,
                  bmv_stream_t stream);
