@@ -110,9 +110,14 @@ class _Conv2dFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         s, has_b = ctx.cfg
         p = w.shape[-1] // 2
-        gx, gw, gb = torch.ops.aten.convolution_backward(gy.contiguous(), x, w, [w.shape[0]] if has_b else None, [s, s], [p, p],
+        gy = gy.contiguous()
+        want_x = ctx.needs_input_grad[0]
+        gx_engine = want_x and s == 1 and _engine_forward(gy)      # stride 1: the convolution with the flipped, transposed filter
+        gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, [s, s], [p, p],
                                                          [1, 1], False, [0, 0], 1,
-                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b])
+                                                         [want_x and not gx_engine, ctx.needs_input_grad[1], has_b])
+        if gx_engine:
+            gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 1, transposed=True, flip=True), w.shape[1], 1, w.shape[-1], 1)
         return gx, gw, (gb if has_b else None), None
 
 
