@@ -23,8 +23,8 @@ for w in $WL; do
     c1) run r2_config1_enerf256x320 enerf_256x320_3src_32planes "render_rays_kernel" 1 10 3 ;;
     c3) run r2_config3_enerf_ours480x736_k4 enerf_ours_480x736_6src_k4 "blend_kernel" 1 8 3 ;;
     c4) run r2_config4_mvsnerf_ours_128planes_k4 mvsnerf_ours_224x352_128planes_k4 "blend_kernel" 1 4 2 ;;
-    c5) run r2_config5_enerf_ours_ft480x736_k4 enerf_ours_ft_480x736_6src_k4 "blend_bwd_kernel" 2 4 2 ;;
-    ft) run r2_enerf_ft512x640 enerf_ft_512x640_3src "nerf_mlp_bwd_kernel<8>" 1 6 3 ;;
+    c5) run r2_config5_enerf_ours_ft480x736_k4 enerf_ours_ft_480x736_6src_k4 "blend_bwd_kernel" 2 6 4 ;;
+    ft) run r2_enerf_ft512x640 enerf_ft_512x640_3src "nerf_mlp_bwd_kernel<8>" 1 16 6 ;;
   esac
 done
 ls -la $R/$OUT
