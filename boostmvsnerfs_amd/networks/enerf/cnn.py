@@ -3,7 +3,9 @@
 These convolution stacks sit between the hot-path kernels.  The modules keep torch
 parameters (so checkpoints load and training works through autograd), but inference runs them on the package's own
 implicit-GEMM MFMA convolution engine (csrc/conv.hip via convnet.py) with eval-mode batch norm folded into the
-weights; only the training forward/backward uses torch's convolution kernels.
+weights.  Under autograd the same engine does the convolution forward and the 3-D data gradients (weights repacked on
+the device every step), csrc/conv_wgrad.hip the 3-D weight gradients and csrc/bn.hip the training-mode batch norm;
+MIOpen is left with the 2-D weight gradients (conv3d_wgrad.py).
 Module/parameter names reproduce the reference's state-dict keys exactly
 (lib/networks/enerf/feature_net.py:4-36, cost_reg_net.py:4-86, utils.py:10-33)
 so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.
