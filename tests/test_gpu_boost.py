@@ -130,3 +130,58 @@ def test_evaluate_harness_bootstraps_view_selection_and_times_like_run_py(enerf_
     assert len(res["net_time"]) == 3 and len(seen) == 3
     mean = sum(res["net_time"][1:]) / 2
     assert abs(res["FPS"] - 1.0 / mean) < 1e-9 and abs(res["Mray/s"] - seen[0][1] / mean / 1e6) < 1e-9
+
+
+def test_evaluate_harness_graph_mode_equals_eager(enerf_fx, boost_fx, tmp_path):
+    """evaluate(graph=True): frames 2.. are HIP-graph replays on static copies of the batch; the outputs must be the
+    eager ones for batches whose VALUES differ (other source images and cameras), for ENeRF and for the K-volume
+    network (graph keyed by the selected triplets)."""
+    import copy
+    from boostmvsnerfs_amd import evaluate as E
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network as ENeRF
+
+    def variants(b0, n=4):
+        out = []
+        for i in range(n):
+            b = copy.deepcopy(b0)
+            g = torch.Generator().manual_seed(100 + i)
+            for k in ("src_inps", "all_src_inps"):
+                if k in b:
+                    b[k] = (b[k] + 0.1 * torch.randn(b[k].shape, generator=g)).clamp(-1, 1)
+            b["tar_ext"] = b["tar_ext"].clone()
+            b["tar_ext"][..., 0, 3] += 0.01 * i
+            for k in [k for k in b if k.startswith("rays_")]:
+                del b[k]                                                   # rebuilt on the device from the moved camera
+            out.append(b)
+        return out
+
+    def run(net, batches, graph):
+        outs = []
+        res = E.evaluate(net, batches, on_output=lambda o, b: outs.append({k: v.clone() for k, v in o.items()}), graph=graph)
+        return res, outs
+
+    set_cfg(tiny_cfg(enerf_fx, "enerf_eval"))
+    net = ENeRF()
+    net.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net = net.to(DEV).eval()
+    batches = variants(enerf_fx.batch())
+    _, eager = run(net, batches, False)
+    res, graphed = run(net, batches, True)
+    assert len(res["net_time"]) == len(batches)
+    for a, b in zip(eager, graphed):
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(eager[1]["rgb_level1"], eager[2]["rgb_level1"])      # the batches really differ
+
+    _cfg(boost_fx, tmp_path)
+    with open(tmp_path / "view_selection.json", "w") as f:
+        json.dump({"synthetic_0": [int(k) for k in boost_fx.raw["extra/k_best"]]}, f)
+    bnet = _net(enerf_fx, preprocess=False)
+    bb = variants(boost_fx.batch(), 3)
+    _, eager = run(bnet, bb, False)
+    _, graphed = run(bnet, bb, True)
+    for a, b in zip(eager, graphed):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
