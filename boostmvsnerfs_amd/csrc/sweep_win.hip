@@ -88,8 +88,15 @@ struct WinArgs {
   int nh;      // channel halves per workgroup (host side: 2 only where the kernel is instantiated)
 };
 
+// waves per SIMD the register allocator must leave room for: 256-thread workgroups (4 waves, 29 KB of LDS) fit 5 per
+// CU = 5 waves per SIMD at 96 VGPRs (13 spilled: level 1 22.9 -> 21.9 us, scripts/ab_sweep_wpe.sh); the 512-thread
+// ones are 2 per CU whatever the register count, so they keep 128 registers
 #ifndef BMV_WIN_WPE
-#define BMV_WIN_WPE 4
+#define BMV_WIN_WPE(threads) ((threads) <= 256 ? 5 : 4)
+#else
+#define BMV_WIN_WPE_FIXED BMV_WIN_WPE
+#undef BMV_WIN_WPE
+#define BMV_WIN_WPE(threads) BMV_WIN_WPE_FIXED
 #endif
 #ifndef BMV_WIN_TAPBUF
 #define BMV_WIN_TAPBUF 2
@@ -99,7 +106,7 @@ struct WinArgs {
 // boxes -- and the per-view tap geometry are computed once and reused for the second 16 channels; with NH = 1 the two
 // halves are two workgroups that each redo them)
 template <int TXW, int TYH, int DP, int S, int NB, int NH>
-__global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(BMV_WIN_WPE, 8)))
+__global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(BMV_WIN_WPE(TXW* TYH* DP), 8)))
 sweep_win_kernel(const WinArgs a) {
   constexpr int NT = TXW * TYH * DP, NW = NT / 64;
   static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
