@@ -21,6 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 EXTRA_FLAGS = {}    # per-file flags
 if os.environ.get("BMV_RENDER_DEFS"):   # e.g. "-DBMV_RENDER_STAMPS" for scripts/stamps_render.py
     EXTRA_FLAGS["render.hip"] = os.environ["BMV_RENDER_DEFS"].split()
+if os.environ.get("BMV_CONV_DEFS"):   # e.g. "-DBMV_CONV_WPE_TUNED=0": the convolution kernels at the allocator's own occupancy
+    EXTRA_FLAGS["conv.hip"] = os.environ["BMV_CONV_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

@@ -67,8 +67,25 @@ struct ConvTile {
   static_assert(!PAIR || (S == 1 && NCT == 1 && R % 2 == 0), "row pairing: stride 1, one cout tile, even rows");
 };
 
+// Occupancy the register allocator must leave room for (workgroups per CU = waves per SIMD).  The default allocation
+// of the full-resolution layers lands a few registers above a step of the occupancy table, and their grids are small
+// multiples of the resident-workgroup count, so one more resident workgroup removes a mostly idle second round:
+//   3-D row-paired 16|32 -> 8 (conv0, 112 VGPRs, 1280 workgroups at level 1): 5 per CU = one round instead of 1.25
+//   3-D 8 -> 9 heads (112 VGPRs, 2560 / 1280 workgroups): 5 per CU = 2 / 1 rounds instead of 2.5 / 1.25
+//   2-D row-paired 32 -> 8 (smooth0, 68 VGPRs, 1920 workgroups): 8 per CU = one round instead of 1.07
+#ifndef BMV_CONV_WPE_TUNED
+#define BMV_CONV_WPE_TUNED 1
+#endif
+constexpr int conv_wpe(int KD, int K, int S, int NCT, int R, int MAP, bool PAIR) {
+  if (!BMV_CONV_WPE_TUNED) return 1;
+  if (KD == 3 && K == 3 && S == 1 && NCT == 1 && MAP == 1 && ((PAIR && R == 8) || (!PAIR && R == 4))) return 5;
+  if (KD == 1 && K == 3 && S == 1 && NCT == 1 && MAP == 0 && PAIR && R == 8) return 8;
+  return 1;
+}
+
 template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_wpe(KD, K, S, NCT, R, MAP, PAIR), 8)))
+void conv_mfma_kernel(ConvArgs a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   __shared__ float lds[4 * T::PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
