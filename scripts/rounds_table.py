@@ -14,7 +14,8 @@ def main(path, skip_first=0.3):
         name = r["Kernel_Name"]
         wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
         grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        vg = int(r.get("Arch_VGPR_Count", r.get("VGPR_Count", 0)) or 0) + int(r.get("Accum_VGPR_Count", 0) or 0)
+        # rocprofv3 (ROCm 7.2) reports half the allocated VGPRs here (96 for a 191-register kernel)
+        vg = 2 * (int(r.get("Arch_VGPR_Count", r.get("VGPR_Count", 0)) or 0) + int(r.get("Accum_VGPR_Count", 0) or 0))
         lds = int(r.get("LDS_Block_Size", 0) or 0)
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
         agg[(name, grid, wg, vg, lds)].append(dur)
