@@ -262,8 +262,11 @@ struct ConvTTile {
   static constexpr int ROWBASE = (MAP == 1) ? TYH * RS : R * RS;
 };
 
+// R <= 2: the allocator takes 184 registers (2 workgroups per CU; conv11 at level 1 is 640 workgroups = 1.25 rounds)
+// but is as happy with 140 (3 per CU, one round, no spills) when asked
 template <int NCT, int R, int MAP>
-__global__ __launch_bounds__(256) void convT3d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BMV_CONV_WPE_TUNED && R <= 2) ? 3 : 1, 8)))
+void convT3d_mfma_kernel(ConvArgs a) {
   using T = ConvTTile<NCT, R, MAP>;
   __shared__ float lds[4 * T::PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
