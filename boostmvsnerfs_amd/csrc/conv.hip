@@ -488,7 +488,9 @@ struct SplitKTile {
 };
 
 template <int KD, int K, int S, bool IS3D>
-__global__ __launch_bounds__(256) void conv_splitk_kernel(ConvArgs a) {
+// stride 1: 4 workgroups per CU fit the LDS (38 KB each); the allocator needs 121 instead of 160 registers for that
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BMV_CONV_WPE_TUNED && S == 1) ? 4 : 1, 8)))
+void conv_splitk_kernel(ConvArgs a) {
   using T = SplitKTile<KD, K, S, IS3D>;
   __shared__ float lds[16 * T::PS];
   __shared__ f32x4 red[4][4][64];
@@ -604,7 +606,9 @@ static void launch_splitk(const ConvArgs& a, hipStream_t st) {
 // Split-K form of the transposed convolution for the deep levels: one input row x 16 input x per workgroup, wave w takes
 // every 4th k-step of a 16-channel stage with all 8 parity accumulators, the partial sums meet in LDS and wave w
 // finishes output row pair (pz, py) = (w >> 1, w & 1).
-__global__ __launch_bounds__(256) void convT3d_splitk_kernel(ConvArgs a) {
+// 4 workgroups per CU (LDS 38 KB each): 90 instead of 144 registers, no spills; conv9 at level 1 is 3072 workgroups
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_CONV_WPE_TUNED ? 4 : 1, 8)))
+void convT3d_splitk_kernel(ConvArgs a) {
   constexpr int RS = 17, SLOTS = 2 * 2 * RS, PS = (SLOTS + 15) / 32 * 32 + 16;
   __shared__ float lds[16 * PS];
   __shared__ f32x4 red[4][8][64];
