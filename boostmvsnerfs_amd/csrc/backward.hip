@@ -449,50 +449,97 @@ __global__ void build_rays_bwd_kernel(const float* __restrict__ rays, const floa
 // ---------------------------------------------------------------------------
 // a5 depth_regression backward: d_depth, d_std (B,h,w) -> d_prob, d_values (B,D,h,w)
 // ---------------------------------------------------------------------------
-__global__ void depth_regress_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ dvals,
-                                         const float* __restrict__ g_depth, const float* __restrict__ g_std, int D,
-                                         int hw, int depth_inv, float* __restrict__ d_prob,
-                                         float* __restrict__ d_values) {
+// DT > 0: D == DT, the DT hypotheses of a pixel are loaded once (all loads in flight together) and the passes run out
+// of registers, like the forward; DT == 0: generic multi-pass form for any D.
+template <int DT>
+__global__ void __launch_bounds__(64) depth_regress_bwd_kernel(const float* __restrict__ prob,
+                                                                const float* __restrict__ dvals,
+                                                                const float* __restrict__ g_depth,
+                                                                const float* __restrict__ g_std, int D, int hw,
+                                                                int depth_inv, float* __restrict__ d_prob,
+                                                                float* __restrict__ d_values) {
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
   const float* p = prob + (size_t)b * D * hw + i;
   const float* v = dvals + (size_t)b * D * hw + i;
-  float mx = -INFINITY;
-  for (int d = 0; d < D; ++d) mx = fmaxf(mx, p[(size_t)d * hw]);
-  float den = 0.f;
-  for (int d = 0; d < D; ++d) den += expf(p[(size_t)d * hw] - mx);
-  float mean = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float val = v[(size_t)d * hw];
-    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
-    mean += expf(p[(size_t)d * hw] - mx) / den * val;
-  }
-  float var = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float val = v[(size_t)d * hw];
-    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
-    var += expf(p[(size_t)d * hw] - mx) / den * (val - mean) * (val - mean);
-  }
-  float gd = g_depth[(size_t)b * hw + i], gs = g_std[(size_t)b * hw + i];
-  float gvar = var > 1e-10f ? gs / (2.f * sqrtf(var)) : 0.f;
-  // sum_d p_d (v_d - mean) = 0, so the variance does not feed back into d_mean
-  float dotp = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float val = v[(size_t)d * hw];
-    if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
-    float pd = expf(p[(size_t)d * hw] - mx) / den;
-    dotp += pd * (gd * val + gvar * (val - mean) * (val - mean));
-  }
-  for (int d = 0; d < D; ++d) {
-    float raw = v[(size_t)d * hw];
-    float val = depth_inv ? 1.f / fmaxf(raw, 1e-6f) : raw;
-    float pd = expf(p[(size_t)d * hw] - mx) / den;
-    float gp = gd * val + gvar * (val - mean) * (val - mean);
-    d_prob[(size_t)b * D * hw + (size_t)d * hw + i] = pd * (gp - dotp);
-    float gv = pd * (gd + 2.f * gvar * (val - mean));
-    if (depth_inv) gv = raw > 1e-6f ? -gv / (raw * raw) : 0.f;
-    d_values[(size_t)b * D * hw + (size_t)d * hw + i] = gv;
+  const float gd = g_depth[(size_t)b * hw + i], gs = g_std[(size_t)b * hw + i];
+  float* dp = d_prob + (size_t)b * D * hw + i;
+  float* dvv = d_values + (size_t)b * D * hw + i;
+  if constexpr (DT > 0) {
+    float e[DT], raw[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) e[d] = p[(size_t)d * hw], raw[d] = v[(size_t)d * hw];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) mx = fmaxf(mx, e[d]);
+    float den = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) e[d] = expf(e[d] - mx), den += e[d];
+    float mean = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      e[d] = e[d] / den;
+      mean += e[d] * (depth_inv ? 1.f / fmaxf(raw[d], 1e-6f) : raw[d]);
+    }
+    float var = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float val = depth_inv ? 1.f / fmaxf(raw[d], 1e-6f) : raw[d];
+      var += e[d] * (val - mean) * (val - mean);
+    }
+    const float gvar = var > 1e-10f ? gs / (2.f * sqrtf(var)) : 0.f;
+    float dotp = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float val = depth_inv ? 1.f / fmaxf(raw[d], 1e-6f) : raw[d];
+      dotp += e[d] * (gd * val + gvar * (val - mean) * (val - mean));
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float val = depth_inv ? 1.f / fmaxf(raw[d], 1e-6f) : raw[d];
+      const float gp = gd * val + gvar * (val - mean) * (val - mean);
+      dp[(size_t)d * hw] = e[d] * (gp - dotp);
+      float gv = e[d] * (gd + 2.f * gvar * (val - mean));
+      if (depth_inv) gv = raw[d] > 1e-6f ? -gv / (raw[d] * raw[d]) : 0.f;
+      dvv[(size_t)d * hw] = gv;
+    }
+  } else {
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, p[(size_t)d * hw]);
+    float den = 0.f;
+    for (int d = 0; d < D; ++d) den += expf(p[(size_t)d * hw] - mx);
+    float mean = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float val = v[(size_t)d * hw];
+      if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+      mean += expf(p[(size_t)d * hw] - mx) / den * val;
+    }
+    float var = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float val = v[(size_t)d * hw];
+      if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+      var += expf(p[(size_t)d * hw] - mx) / den * (val - mean) * (val - mean);
+    }
+    float gvar = var > 1e-10f ? gs / (2.f * sqrtf(var)) : 0.f;
+    // sum_d p_d (v_d - mean) = 0, so the variance does not feed back into d_mean
+    float dotp = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float val = v[(size_t)d * hw];
+      if (depth_inv) val = 1.f / fmaxf(val, 1e-6f);
+      float pd = expf(p[(size_t)d * hw] - mx) / den;
+      dotp += pd * (gd * val + gvar * (val - mean) * (val - mean));
+    }
+    for (int d = 0; d < D; ++d) {
+      float raw = v[(size_t)d * hw];
+      float val = depth_inv ? 1.f / fmaxf(raw, 1e-6f) : raw;
+      float pd = expf(p[(size_t)d * hw] - mx) / den;
+      float gp = gd * val + gvar * (val - mean) * (val - mean);
+      dp[(size_t)d * hw] = pd * (gp - dotp);
+      float gv = pd * (gd + 2.f * gvar * (val - mean));
+      if (depth_inv) gv = raw > 1e-6f ? -gv / (raw * raw) : 0.f;
+      dvv[(size_t)d * hw] = gv;
+    }
   }
 }
 
@@ -708,8 +755,17 @@ int bmv_depth_regress_bwd(const float* depth_prob, const float* depth_values, co
                           float* d_values, bmv_stream_t stream) {
   BMV_REQUIRE(depth_prob && depth_values && d_depth && d_std && d_prob && d_values, "bmv_depth_regress_bwd: null pointer");
   BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bmv_depth_regress_bwd: bad shape");
-  hipLaunchKernelGGL(depth_regress_bwd_kernel, dim3(cdiv(h * w, 128), B), dim3(128), 0, as_stream(stream), depth_prob,
-                     depth_values, d_depth, d_std, D, h * w, depth_inv, d_prob, d_values);
+#define DRB(DT)                                                                                                  \
+  hipLaunchKernelGGL(depth_regress_bwd_kernel<DT>, dim3(cdiv(h * w, 64), B), dim3(64), 0, as_stream(stream), depth_prob, \
+                     depth_values, d_depth, d_std, D, h * w, depth_inv, d_prob, d_values)
+  switch (D) {
+    case 8: DRB(8); break;
+    case 16: DRB(16); break;
+    case 32: DRB(32); break;
+    case 64: DRB(64); break;
+    default: DRB(0); break;
+  }
+#undef DRB
   BMV_LAUNCH_END("bmv_depth_regress_bwd");
 }
 
