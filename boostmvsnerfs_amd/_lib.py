@@ -89,7 +89,7 @@ SIGNATURES = {
     "bmv_make_rays": [c_f, c_f, c_i, c_i, c_i, C.c_double, c_f, c_f],
     "bmv_composite_bwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f],
     "bmv_blend_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
-    "bmv_vox_feat_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_vox_feat_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_img_feat_bwd": [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sample_along_depth_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_build_rays_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],

@@ -101,17 +101,20 @@ class VoxFeat(torch.autograd.Function):
     """a9: gradient to the feature volume (scatter) and to the depth coordinate of uvd."""
 
     @staticmethod
-    def forward(ctx, uvd01, volume):
+    def forward(ctx, uvd01, volume, ray_w=0, Ns=0):
+        """ray_w / Ns: the samples of uvd01 (B, rays * Ns, 3) are Ns per ray, rays row-major over an image ray_w wide
+        (a hint for the backward kernel's tiling, 0 = unknown)."""
         ctx.save_for_backward(uvd01, volume)
+        ctx.hints = (int(ray_w or 0), int(Ns or 0))
         return ops.vox_feat(uvd01, volume)
 
     @staticmethod
     def backward(ctx, d_out):
         uvd01, volume = ctx.saved_tensors
-        d_vol, d_d = ops.vox_feat_bwd(uvd01, volume, d_out.contiguous())
+        d_vol, d_d = ops.vox_feat_bwd(uvd01, volume, d_out.contiguous(), *ctx.hints)
         d_uvd = torch.zeros_like(uvd01)
         d_uvd[..., 2] = d_d
-        return d_uvd, d_vol
+        return d_uvd, d_vol, None, None
 
 
 class ImgFeat(torch.autograd.Function):

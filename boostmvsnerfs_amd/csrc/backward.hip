@@ -198,42 +198,96 @@ __device__ __forceinline__ void direct_scatter(const TapSet& t, const float* g, 
 // a9 get_vox_feat backward: d_out (B,P,C) -> d_volume (atomics), d_d01 (B,P) (only the depth
 // coordinate of uvd carries gradient: u, v are pixel constants).
 // ---------------------------------------------------------------------------
-__global__ void vox_feat_bwd_kernel(const float* __restrict__ uvd01, const float* __restrict__ vol,
-                                    const float* __restrict__ d_out, int P, int C, int D, int h, int w,
-                                    float* __restrict__ d_vol, float* __restrict__ d_d01) {
-  int b = blockIdx.y;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+// Thread -> sample as in img_feat_bwd_kernel (2-D tiles of rays with the layout hint).  The 8 taps of the workgroup's
+// samples land in a small box of the volume: found with an LDS min/max, accumulated with ds_add_f32 (C <= 8 channels x
+// kWinCap voxels), added to d_volume once per touched voxel, x-contiguous; a box that does not fit falls back to one
+// global atomic per tap.
+__global__ void __launch_bounds__(256) vox_feat_bwd_kernel(const float* __restrict__ uvd01, const float* __restrict__ vol,
+                                                           const float* __restrict__ d_out, int P, int C, int D, int h,
+                                                           int w, int ray_w, int Ns, int tw, int th, int tiles_x,
+                                                           float* __restrict__ d_vol, float* __restrict__ d_d01) {
+  __shared__ float win[kWinCh * kWinCap];
+  __shared__ int box[6];   // min x, y, z, max x, y, z
+  const int b = blockIdx.y;
+  int i;
+  bool valid;
+  if (ray_w > 0) {
+    const int smp = threadIdx.x % Ns, r = threadIdx.x / Ns;
+    const int rx = (blockIdx.x % tiles_x) * tw + r % tw, ry = (blockIdx.x / tiles_x) * th + r / tw;
+    const int ray_h = P / (ray_w * Ns);
+    valid = rx < ray_w && ry < ray_h;
+    i = valid ? (ry * ray_w + rx) * Ns + smp : 0;
+  } else {
+    i = blockIdx.x * blockDim.x + threadIdx.x;
+    valid = i < P;
+    i = valid ? i : 0;
+  }
   const float* q = uvd01 + ((size_t)b * P + i) * 3;
   float ix = unnorm(q[0] * 2.f - 1.f, w), iy = unnorm(q[1] * 2.f - 1.f, h), iz = unnorm(q[2] * 2.f - 1.f, D);
   float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-  bool ok = (fx >= -1.f) && (fx <= (float)(w - 1)) && (fy >= -1.f) && (fy <= (float)(h - 1)) && (fz >= -1.f) &&
-            (fz <= (float)(D - 1));
+  const bool ok = valid && (fx >= -1.f) && (fx <= (float)(w - 1)) && (fy >= -1.f) && (fy <= (float)(h - 1)) &&
+                  (fz >= -1.f) && (fz <= (float)(D - 1));
+  const int x0 = ok ? (int)fx : 0, y0 = ok ? (int)fy : 0, z0 = ok ? (int)fz : 0;
+  const float ax = ix - fx, ay = iy - fy, az = iz - fz, ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy, ez = (fz + 1.f) - iz;
+  // per axis: which of the two taps exist (zeros padding)
+  const bool vx0 = ok && x0 >= 0, vx1 = ok && x0 + 1 <= w - 1, vy0 = ok && y0 >= 0, vy1 = ok && y0 + 1 <= h - 1;
+  const bool vz0 = ok && z0 >= 0, vz1 = ok && z0 + 1 <= D - 1;
+  const bool any = (vx0 || vx1) && (vy0 || vy1) && (vz0 || vz1);
+  if (threadIdx.x == 0) box[0] = box[1] = box[2] = 0x7fffffff, box[3] = box[4] = box[5] = -1;
+  __syncthreads();
+  if (any) {
+    atomicMin(&box[0], vx0 ? x0 : x0 + 1), atomicMax(&box[3], vx1 ? x0 + 1 : x0);
+    atomicMin(&box[1], vy0 ? y0 : y0 + 1), atomicMax(&box[4], vy1 ? y0 + 1 : y0);
+    atomicMin(&box[2], vz0 ? z0 : z0 + 1), atomicMax(&box[5], vz1 ? z0 + 1 : z0);
+  }
+  __syncthreads();
+  const int bx = box[0], by = box[1], bz = box[2];
+  const int wx = box[3] - bx + 1, wy = box[4] - by + 1, wz = box[5] - bz + 1;
+  const bool use_win = box[3] >= 0 && wx * wy * wz <= kWinCap && C <= kWinCh;
+  const int n = wx * wy * wz;
+  if (use_win) {
+    for (int k = threadIdx.x; k < C * n; k += blockDim.x) win[k] = 0.f;
+    __syncthreads();
+  }
+  const size_t cs = (size_t)D * h * w;
+  const float* v = vol + (size_t)b * C * cs;
+  float* dv = d_vol + (size_t)b * C * cs;
+  const float* go = d_out + ((size_t)b * P + i) * C;
   float gz = 0.f;
-  if (ok) {
-    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    float ax = ix - fx, ay = iy - fy, az = iz - fz, ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy, ez = (fz + 1.f) - iz;
-    size_t cs = (size_t)D * h * w;
-    const float* v = vol + (size_t)b * C * cs;
-    float* dv = d_vol + (size_t)b * C * cs;
-    const float* go = d_out + ((size_t)b * P + i) * C;
+  if (any) {
     for (int k = 0; k < 8; ++k) {
-      int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-      int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-      if (!(x >= 0 && x <= w - 1 && y >= 0 && y <= h - 1 && z >= 0 && z <= D - 1)) continue;
-      float wxy = (dx ? ax : ex) * (dy ? ay : ey), wgt = wxy * (dz ? az : ez);
-      size_t o = ((size_t)z * h + y) * w + x;
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      if (!((dx ? vx1 : vx0) && (dy ? vy1 : vy0) && (dz ? vz1 : vz0))) continue;
+      const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+      const float wxy = (dx ? ax : ex) * (dy ? ay : ey), wgt = wxy * (dz ? az : ez);
+      const size_t o = ((size_t)z * h + y) * w + x;
+      const int lo = ((z - bz) * wy + (y - by)) * wx + (x - bx);
       float acc = 0.f;
       for (int c = 0; c < C; ++c) {
-        float g = go[c];
-        atomicAdd(dv + c * cs + o, wgt * g);
+        const float g = go[c];
+        if (use_win)
+          atomicAdd(win + c * n + lo, wgt * g);
+        else
+          atomicAdd(dv + c * cs + o, wgt * g);
         acc += g * v[c * cs + o];
       }
       gz += (dz ? 1.f : -1.f) * wxy * acc;
     }
   }
   // iz = ((2 d - 1) + 1) / 2 * (D - 1)  ->  d iz / d d01 = D - 1
-  d_d01[(size_t)b * P + i] = gz * (float)(D - 1);
+  if (valid) d_d01[(size_t)b * P + i] = gz * (float)(D - 1);
+  if (use_win) {
+    __syncthreads();
+    // flush: 32 lanes along x, 8 (channel, z, y) rows per sweep of the workgroup
+    const int lx = threadIdx.x & 31, lr = threadIdx.x >> 5, nrows = C * wz * wy, rstep = blockDim.x >> 5;
+    for (int r0 = lr; r0 < nrows; r0 += rstep) {
+      const int c = r0 / (wz * wy), rem = r0 - c * (wz * wy), zz = rem / wy, yy = rem - zz * wy;
+      for (int xx = lx; xx < wx; xx += 32) {
+        const float val = win[c * n + (zz * wy + yy) * wx + xx];
+        if (val != 0.f) atomicAdd(dv + c * cs + ((size_t)(bz + zz) * h + (by + yy)) * w + (bx + xx), val);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -692,13 +746,32 @@ int bmv_blend_bwd(const float* raws, const float* masks, const float* d_rgb, int
   BMV_LAUNCH_END("bmv_blend_bwd");
 }
 
+// tile of rays a 256-thread workgroup takes when the layout hint is usable (whole rows of rays, Ns a power of two <= 64)
+static bool ray_tiles(int P, int& ray_w, int Ns, int& tw, int& th, int& tiles_x, int& nblocks) {
+  tw = th = tiles_x = 0;
+  nblocks = (int)cdiv(P, 256);
+  if (ray_w > 0 && Ns > 0 && Ns <= 64 && (Ns & (Ns - 1)) == 0 && P % (ray_w * Ns) == 0) {
+    const int nr = 256 / Ns, ray_h = P / (ray_w * Ns);
+    th = 1;
+    while (th * th * 4 <= nr) th *= 2;       // largest power of two with th^2 <= nr, so tw >= th
+    tw = nr / th;
+    tiles_x = (ray_w + tw - 1) / tw;
+    nblocks = tiles_x * ((ray_h + th - 1) / th);
+    return true;
+  }
+  ray_w = 0;
+  return false;
+}
+
 int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
-                     int w, float* d_volume, float* d_d01, bmv_stream_t stream) {
+                     int w, int ray_w, int Ns, float* d_volume, float* d_d01, bmv_stream_t stream) {
   BMV_REQUIRE(uvd01 && volume && d_out && d_volume && d_d01, "bmv_vox_feat_bwd: null pointer");
   BMV_REQUIRE(B > 0 && P >= 0 && C > 0 && D > 0 && h > 0 && w > 0, "bmv_vox_feat_bwd: bad shape");
   if (P == 0) return BMV_OK;
-  hipLaunchKernelGGL(vox_feat_bwd_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, as_stream(stream), uvd01, volume, d_out,
-                     P, C, D, h, w, d_volume, d_d01);
+  int tw, th, tiles_x, nblocks;
+  ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
+  hipLaunchKernelGGL(vox_feat_bwd_kernel, dim3(nblocks, B), dim3(256), 0, as_stream(stream), uvd01, volume, d_out, P, C, D,
+                     h, w, ray_w, Ns, tw, th, tiles_x, d_volume, d_d01);
   BMV_LAUNCH_END("bmv_vox_feat_bwd");
 }
 
@@ -710,18 +783,8 @@ int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* s
   BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "bmv_img_feat_bwd: bad shape");
   BMV_REQUIRE(c_grad >= 0 && c_grad <= C, "bmv_img_feat_bwd: c_grad=%d outside [0, %d]", c_grad, C);
   if (P == 0) return BMV_OK;
-  int tw = 0, th = 0, tiles_x = 0, nblocks = (int)cdiv(P, 256);
-  // layout hint usable: whole rows of rays, Ns a power of two dividing 256
-  if (ray_w > 0 && Ns > 0 && Ns <= 64 && (Ns & (Ns - 1)) == 0 && P % (ray_w * Ns) == 0) {
-    const int nr = 256 / Ns, ray_h = P / (ray_w * Ns);
-    th = 1;
-    while (th * th * 4 <= nr) th *= 2;       // th = largest power of two with th^2 <= nr ... tw >= th
-    tw = nr / th;
-    tiles_x = (ray_w + tw - 1) / tw;
-    nblocks = tiles_x * ((ray_h + th - 1) / th);
-  } else {
-    ray_w = 0;
-  }
+  int tw, th, tiles_x, nblocks;
+  ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
   hipLaunchKernelGGL(img_feat_bwd_kernel, dim3(nblocks, B), dim3(256), 0, as_stream(stream), xyz, img_feat_rgb, src_exts,
                      src_ixts, tar_ext, render_scale, d_out, P, S, C, c_grad, H, W, ray_w, Ns, tw, th, tiles_x, d_img,
                      d_xyz);

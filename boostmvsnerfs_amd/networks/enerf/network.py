@@ -117,11 +117,12 @@ class Network(nn.Module):
         Ns, inv = cc.num_samples[i], cc.depth_inv[i]
         xyz, uvd, z = A.SampleAlongDepth.apply(rays12.contiguous(), Ns, inv)
         uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(B, -1, 3)
-        vox = A.VoxFeat.apply(uvd01, feature_volume)
+        full = xyz.shape[1] == Hr * Wr          # a whole frame of rays (train_img): the scatter kernels tile it in 2-D
+        vox = A.VoxFeat.apply(uvd01, feature_volume, Wr if full else 0, Ns)
         img = torch.cat([im_feat, ops.unpreprocess(src_inps, Hr, Wr)], 2)
         # the colour channels are data; a full frame of rays (train_img) lets the backward tile them in 2-D
         feat = A.ImgFeat.apply(xyz, img, src_exts, src_ixts, tar_ext, rs,
-                               None if src_inps.requires_grad else im_feat.shape[2], Wr if xyz.shape[1] == Hr * Wr else 0)
+                               None if src_inps.requires_grad else im_feat.shape[2], Wr if full else 0)
         params = [t for lin in nerf._linears() for t in (lin.weight, lin.bias)]
         raw = A.NerfMLP.apply(vox, feat, nerf.feat_ch - 3, *params).reshape(B, -1, Ns, 4)
         if mode == 1:

@@ -491,14 +491,16 @@ def blend_bwd(raws, masks, d_rgb):
     return d_raws
 
 
-def vox_feat_bwd(uvd01, volume, d_out):
+def vox_feat_bwd(uvd01, volume, d_out, ray_w=0, Ns=0):
+    """ray_w / Ns: layout hint -- the P samples are Ns per ray, rays row-major over an image ray_w wide (0 = unknown)."""
     B, P = uvd01.shape[:2]
     _, C_, D, h, w = volume.shape
     d_vol = torch.zeros_like(volume, memory_format=torch.contiguous_format)
     d_d = torch.empty(B, P, device=volume.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.bmv_vox_feat_bwd(dptr(_c(uvd01), "uvd"), dptr(_c(volume), "volume"), dptr(_c(d_out), "d_out"), B, P,
-                                    C_, D, h, w, dptr(d_vol), dptr(d_d), stream()), "vox_feat_bwd")
+                                    C_, D, h, w, int(ray_w) if Ns else 0, int(Ns), dptr(d_vol), dptr(d_d), stream()),
+               "vox_feat_bwd")
     return d_vol, d_d
 
 

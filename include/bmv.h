@@ -187,8 +187,9 @@ int bmv_composite_bwd(const float* raw, const float* z_vals, const float* d_rgb,
                       long nrays, int Ns, float* d_raw, bmv_stream_t stream);
 int bmv_blend_bwd(const float* raws, const float* masks /*normalised*/, const float* d_rgb, int B, int K, int N, int Ns,
                   float* d_raws, bmv_stream_t stream);
+/* ray_w / Ns: the optional layout hint of bmv_img_feat_bwd (0 = none) */
 int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
-                     int w, float* d_volume, float* d_d01, bmv_stream_t stream);
+                     int w, int ray_w, int Ns, float* d_volume, float* d_d01, bmv_stream_t stream);
 /* c_grad: only the first c_grad of the C channels receive d_img (the trailing colour channels of [features, rgb] are
  * data); ray_w / Ns: optional layout hint (0 = none) -- the P samples are Ns per ray, rays row-major over an image
  * ray_w wide -- that lets a workgroup take a compact tile of rays and pre-reduce its scatter-adds in LDS; the result

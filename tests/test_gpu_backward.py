@@ -73,7 +73,7 @@ def test_lookup_and_sampler_bwd(enerf_fx):
                 rays = mods.BuildRays.apply(bb[f"rays_{lvl}"], d, s, nf.to(dev), Hr, Wr, inv)
                 xyz, uvd, z = mods.SampleAlongDepth.apply(rays, Ns, inv)
                 uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(1, -1, 3)
-                vox = mods.VoxFeat.apply(uvd01, v)
+                vox = mods.VoxFeat.apply(uvd01, v, *((Wr, Ns) if hinted else ()))
                 # hinted: tell the backward that only the feature channels need d_img and that the rays are a
                 # full Hr x Wr frame (2-D tiles + LDS pre-reduction instead of 256 consecutive samples)
                 hints = (im.shape[2] - 3, Wr) if hinted else ()
