@@ -101,8 +101,8 @@ SIGNATURES = {
     "bmv_nerf_pack_bwd_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],
     "bmv_nerf_bwd_workspace": [c_i, c_l],
     "bmv_nerf_mlp_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, C.POINTER(NerfParams), c_f],
-    "bmv_conv3d_wgrad_workspace": [c_i, c_i, c_i, c_i, c_i],
-    "bmv_conv3d_wgrad": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_conv_wgrad_workspace": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i],
+    "bmv_conv_wgrad": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_conv_pack_weights": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_bn_chunks": [c_i, c_l],
     "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_f],
@@ -131,7 +131,7 @@ def load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.bmv_nerf_bwd_workspace.restype = C.c_long
-    lib.bmv_conv3d_wgrad_workspace.restype = C.c_long
+    lib.bmv_conv_wgrad_workspace.restype = C.c_long
     lib.bmv_last_error.argtypes = []
     lib.bmv_last_error.restype = C.c_char_p
     _lib = lib

@@ -6,7 +6,7 @@ batched-GEMM for every 3x3x3 fp32 layer of the cost regularisers (308 ms per Cos
 step; its exhaustive find mode takes >15 min).  The weight gradient of a k^3 convolution is k^3 products over the voxel
 dimension,
     dW[:, :, kd, kh, kw] = dY (Co x P) @ X_shift(kd,kh,kw)^T (P x Ci),
-which bmv_conv3d_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per workgroup, no
+which bmv_conv_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per workgroup, no
 im2col copies; the first version of this file made 27 strided copies and one tall-skinny rocBLAS GEMM per layer:
 4 ms of copies + ~5 ms of GEMMs per 512x640 step).  Forward and the data gradient stay on MIOpen.
 SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter names are unchanged
@@ -28,11 +28,11 @@ def _engine_forward(x):
     return x.is_cuda and x.dtype == torch.float32 and os.environ.get("BMV_TRAIN_CONV", "engine") != "torch"
 
 
-def _wgrad(big, small, stride, k=3):
-    """big: (Cb, Db, Hb, Wb) already zero-padded; small: (Cs, Ds, Hs, Ws).
-    Returns G (Cs, Cb, k, k, k) with G[s, b, kd, kh, kw] = sum_p small[s, p] * big[b, stride*p + (kd,kh,kw)]."""
+def _wgrad(big, small, stride, kd=3, k=3):
+    """big: (B, Cb, [Db,] Hb, Wb) already zero-padded; small: (B, Cs, [Ds,] Hs, Ws).
+    Returns G (Cs, Cb, [kd,] k, k) with G[s, b, tap] = sum_n sum_p small[n, s, p] * big[n, b, stride*p + tap]."""
     from ... import ops
-    return ops.conv3d_wgrad(big, small, stride)
+    return ops.conv_wgrad(big, small, stride, kd, k)
 
 
 class _Conv3dFn(torch.autograd.Function):
@@ -61,10 +61,7 @@ class _Conv3dFn(torch.autograd.Function):
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, [s] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = 0
-            for b in range(x.shape[0]):
-                xp = F.pad(x[b], (1, 2 if s == 2 else 1, 1, 1, 1, 1))
-                gw = gw + _wgrad(xp, gy[b], s)          # (Co, Ci, 3,3,3)
+            gw = _wgrad(F.pad(x, (1, 2 if s == 2 else 1, 1, 1, 1, 1)), gy, s)          # (Co, Ci, 3,3,3)
         return gx, gw, None
 
 
@@ -88,11 +85,8 @@ class _ConvT3dFn(torch.autograd.Function):
             else:
                 gx = F.conv3d(gy, w, None, 2, 1)
         if ctx.needs_input_grad[1]:
-            gw = 0
-            for b in range(x.shape[0]):
-                # y[o] += x[i] * w[k] with o = 2 i - 1 + k  ->  dW[ci, co, k] = sum_i x[ci, i] * dY[co, 2 i - 1 + k]
-                gp = F.pad(gy[b], (1, 1, 1, 1, 1, 1))
-                gw = gw + _wgrad(gp, x[b], 2)            # (Ci, Co, 3,3,3)
+            # y[o] += x[i] * w[k] with o = 2 i - 1 + k  ->  dW[ci, co, k] = sum_i x[ci, i] * dY[co, 2 i - 1 + k]
+            gw = _wgrad(F.pad(gy, (1, 1, 1, 1, 1, 1)), x, 2)                           # (Ci, Co, 3,3,3)
         return gx, gw
 
 
@@ -111,14 +105,21 @@ class _Conv2dFn(torch.autograd.Function):
         s, has_b = ctx.cfg
         p = w.shape[-1] // 2
         gy = gy.contiguous()
-        want_x = ctx.needs_input_grad[0]
-        gx_engine = want_x and s == 1 and _engine_forward(gy)      # stride 1: the convolution with the flipped, transposed filter
-        gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, [s, s], [p, p],
-                                                         [1, 1], False, [0, 0], 1,
-                                                         [want_x and not gx_engine, ctx.needs_input_grad[1], has_b])
+        k = w.shape[-1]
+        want_x, eng = ctx.needs_input_grad[0], _engine_forward(gy)
+        gx_engine = want_x and s == 1 and eng                      # stride 1: the convolution with the flipped, transposed filter
+        gw_engine = ctx.needs_input_grad[1] and eng                # weight gradient: own MFMA kernel over (batch, pixel)
+        gx = gw = gb = None
+        if (want_x and not gx_engine) or (ctx.needs_input_grad[1] and not gw_engine):
+            gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [s, s], [p, p], [1, 1], False, [0, 0], 1,
+                                                            [want_x and not gx_engine, ctx.needs_input_grad[1] and not gw_engine, False])
         if gx_engine:
-            gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 1, transposed=True, flip=True), w.shape[1], 1, w.shape[-1], 1)
-        return gx, gw, (gb if has_b else None), None
+            gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 1, transposed=True, flip=True), w.shape[1], 1, k, 1)
+        if gw_engine:
+            gw = _wgrad(F.pad(x, (p, p + (1 if s == 2 else 0), p, p)) if p else x, gy, s, 1, k)
+        if has_b:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
 
 
 class Conv2d(nn.Conv2d):

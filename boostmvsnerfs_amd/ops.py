@@ -633,21 +633,26 @@ def nerf_mlp_bwd(vox_feat_t, img_feat_rgb_dir, d_out, blob_fwd, blob_bwd, feat_c
     return d_vox, d_img, grads
 
 
-def conv3d_wgrad(big, small, stride):
-    """big (Cb,Db,Hb,Wb) zero-padded input side, small (Cs,Ds,Hs,Ws) output side -> G (Cs,Cb,3,3,3) with
-    G[s,b,kd,kh,kw] = sum_p small[s,p] * big[b, stride*p + (kd,kh,kw)] (see include/bmv.h: bmv_conv3d_wgrad)."""
+def conv_wgrad(big, small, stride, kd, k):
+    """big (B,Cb,[Db,]Hb,Wb) zero-padded input side, small (B,Cs,[Ds,]Hs,Ws) output side -> G (Cs,Cb,[kd,]k,k) with
+    G[s,b,taps] = sum_n sum_p small[n,s,p] * big[n,b, stride*p + tap] (include/bmv.h: bmv_conv_wgrad)."""
     lib = _lib.load()
-    Cb, Db, Hb, Wb = big.shape
-    Cs, Ds, Hs, Ws = small.shape
-    n_ws = lib.bmv_conv3d_wgrad_workspace(Cs, Cb, Ds, Hs, Ws)
+    is3d = small.dim() == 5
+    B, Cb = big.shape[:2]
+    Cs = small.shape[1]
+    Db = big.shape[2] if is3d else 1
+    Ds = small.shape[2] if is3d else 1
+    Hb, Wb = big.shape[-2:]
+    Hs, Ws = small.shape[-2:]
+    n_ws = lib.bmv_conv_wgrad_workspace(B, Cs, Cb, Ds, Hs, Ws, kd, k)
     if n_ws < 0:
-        _lib.check(int(n_ws), "conv3d_wgrad_workspace")
+        _lib.check(int(n_ws), "conv_wgrad_workspace")
     ws = torch.empty(n_ws, device=small.device, dtype=torch.float32)
-    G = torch.empty(Cs, Cb, 3, 3, 3, device=small.device, dtype=torch.float32)
-    with ktimer.region("conv3d_wgrad"):
-        rc = lib.bmv_conv3d_wgrad(dptr(_c(big), "big"), dptr(_c(small), "small"), Cb, Db, Hb, Wb, Cs, Ds, Hs, Ws, int(stride),
-                                  dptr(ws), dptr(G), stream())
-    _lib.check(rc, "conv3d_wgrad")
+    G = torch.empty((Cs, Cb, kd, k, k) if is3d else (Cs, Cb, k, k), device=small.device, dtype=torch.float32)
+    with ktimer.region("conv_wgrad"):
+        rc = lib.bmv_conv_wgrad(dptr(_c(big), "big"), dptr(_c(small), "small"), B, Cb, Db, Hb, Wb, Cs, Ds, Hs, Ws, int(kd), int(k),
+                                int(stride), dptr(ws), dptr(G), stream())
+    _lib.check(rc, "conv_wgrad")
     return G
 
 

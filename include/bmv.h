@@ -235,17 +235,19 @@ int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img_feat_rgb_dir, const
                      const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
                      const bmv_nerf_grads* grads, bmv_stream_t stream);
 
-/* ---- f1 (training leg): weight gradient of the cost regularisers' 3x3x3 convolutions
- *          lib/networks/enerf/cost_reg_net.py:4-86 (Conv3d / ConvTranspose3d, k = 3, stride 1 or 2)
- * G (Cs, Cb, 3,3,3): G[s,b,kd,kh,kw] = sum_p small[s,p] * big[b, stride*p + (kd,kh,kw)], the voxel index as the MFMA
- * k dimension.  small (Cs,Ds,Hs,Ws) is the output-side tensor (dY of a convolution, X of a transposed one), big
- * (Cb,Db,Hb,Wb) the input-side tensor ALREADY zero-padded by the caller so that every tap is in range:
- * Db >= stride*(Ds-1)+3 (same for H), Wb >= stride*(Ws-1)+3 (+1 for stride 2).  Conv3d: dW = G(big = pad(X), small
- * = dY); ConvTranspose3d (stride 2, padding 1, output_padding 1): dW = G(big = pad(dY), small = X, stride 2).
- * workspace: bmv_conv3d_wgrad_workspace() floats. */
-long bmv_conv3d_wgrad_workspace(int Cs, int Cb, int Ds, int Hs, int Ws);
-int bmv_conv3d_wgrad(const float* big, const float* small, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
-                     int Ws, int stride, float* workspace, float* G, bmv_stream_t stream);
+/* ---- f1 / f2 (training leg): weight gradient of the convolutions
+ *          lib/networks/enerf/cost_reg_net.py:4-86 (Conv3d / ConvTranspose3d, 3x3x3, stride 1 or 2),
+ *          lib/networks/enerf/feature_net.py:4-36 (Conv2d: 1x1, 3x3 stride 1; 5x5 stride 2)
+ * G (Cs, Cb, kd,k,k): G[s,b,kz,ky,kx] = sum_n sum_p small[n,s,p] * big[n,b, stride*p + (kz,ky,kx)], the voxel index as
+ * the MFMA k dimension.  small (B,Cs,Ds,Hs,Ws) is the output-side tensor (dY of a convolution, X of a transposed
+ * one), big (B,Cb,Db,Hb,Wb) the input-side tensor ALREADY zero-padded by the caller so that every tap is in range:
+ * Db >= stride*(Ds-1)+kd, Hb >= stride*(Hs-1)+k, Wb >= stride*(Ws-1)+k (+1 for stride 2); 2-D: Ds = Db = kd = 1.
+ * Conv: dW = G(big = pad(X), small = dY); ConvTranspose3d (stride 2, padding 1, output_padding 1): dW = G(big =
+ * pad(dY), small = X, stride 2).  Built: (kd,k,stride) in {(3,3,1|2), (1,3,1), (1,1,1), (1,5,2)}.
+ * workspace: bmv_conv_wgrad_workspace() floats. */
+long bmv_conv_wgrad_workspace(int B, int Cs, int Cb, int Ds, int Hs, int Ws, int kd, int k);
+int bmv_conv_wgrad(const float* big, const float* small, int B, int Cb, int Db, int Hb, int Wb, int Cs, int Ds, int Hs,
+                   int Ws, int kd, int k, int stride, float* workspace, float* G, bmv_stream_t stream);
 
 /* ---- f1 / f2 (training leg): batch normalisation in training mode (+ ReLU) of ConvBnReLU / ConvBnReLU3D
  *          lib/networks/enerf/utils.py:10-33 (nn.BatchNorm2d / nn.BatchNorm3d under net.train())

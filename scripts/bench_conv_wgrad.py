@@ -1,4 +1,4 @@
-"""Time bmv_conv3d_wgrad on the cost regularisers' layer shapes of the 512x640 fine-tune workload
+"""Time bmv_conv_wgrad on the cost regularisers' layer shapes of the 512x640 fine-tune workload
 (level 1: 16 -> 8 volume of 8 x 256 x 320, MinCostRegNet; level 0: 32 -> 8 volume of 64 x 64 x 80, CostRegNet)."""
 import os
 import sys
@@ -38,12 +38,12 @@ def main():
                 big = F.pad(torch.randn(co, 2 * d, 2 * h, 2 * w, device=dev), (1, 1, 1, 1, 1, 1))
                 s = 2
             for _ in range(2):
-                ops.conv3d_wgrad(big, small, s)
+                ops.conv_wgrad(big[None], small[None], s, 3, 3)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.conv3d_wgrad(big, small, s)
+                ops.conv_wgrad(big[None], small[None], s, 3, 3)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
