@@ -403,7 +403,10 @@ void convT3d_mfma_kernel(ConvArgs a) {
 // 1x1 weights are wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------------------
 template <int CF, bool COARSE_CL>
-__global__ __launch_bounds__(256) void fpn_topdown_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
+#ifndef BMV_FPN_WPE
+#define BMV_FPN_WPE 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE, 8))) void fpn_topdown_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int C, int H, int W) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
