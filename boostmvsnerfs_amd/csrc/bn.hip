@@ -175,6 +175,7 @@ int bmv_bn_train_fwd(const float* x, const float* weight, const float* bias, flo
   BMV_REQUIRE(x && workspace && save_mean && save_invstd && y, "bmv_bn_train_fwd: null pointer");
   BMV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bmv_bn_train_fwd: running stats come in pairs");
   BMV_REQUIRE(N > 0 && C > 0 && S > 0 && (long)N * S > 1, "bmv_bn_train_fwd: bad shape (needs more than one value per channel)");
+  BMV_REQUIRE((long)N * C <= 65535 && C <= 65535, "bmv_bn_train_fwd: N * C = %ld planes exceed the launch grid", (long)N * C);
   const int cpp = bn_cpp(N, S), chunks = N * cpp;
   const long per_chunk = (S + cpp - 1) / cpp;
   hipStream_t st = as_stream(stream);
@@ -195,6 +196,7 @@ int bmv_bn_train_bwd(const float* x, const float* y, const float* dy, const floa
   BMV_REQUIRE(x && dy && save_mean && save_invstd && workspace && dx, "bmv_bn_train_bwd: null pointer");
   BMV_REQUIRE(!relu || y, "bmv_bn_train_bwd: the fused ReLU needs the forward output");
   BMV_REQUIRE(N > 0 && C > 0 && S > 0, "bmv_bn_train_bwd: bad shape");
+  BMV_REQUIRE((long)N * C <= 65535 && C <= 65535, "bmv_bn_train_bwd: N * C = %ld planes exceed the launch grid", (long)N * C);
   const long total = (long)N * S;
   const int cpp = bn_cpp(N, S), chunks = N * cpp;
   const long per_chunk = (S + cpp - 1) / cpp;
