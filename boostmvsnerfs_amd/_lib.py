@@ -103,6 +103,8 @@ SIGNATURES = {
     "bmv_nerf_mlp_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, C.POINTER(NerfParams), c_f],
     "bmv_conv_wgrad_workspace": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i],
     "bmv_conv_wgrad": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_mvs_sweep_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_mvs_vol_feat_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_conv_pack_weights": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_bn_chunks": [c_i, c_l],
     "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_f],

@@ -219,3 +219,36 @@ class BatchNormTrain(torch.autograd.Function):
         x, y, weight, mean, invstd = ctx.saved_tensors
         dx, dw, db = ops.bn_train_bwd(x, y, dy.contiguous(), weight, mean, invstd, ctx.relu)
         return dx, dw, db, None, None, None, None, None
+
+
+class MvsSweep(torch.autograd.Function):
+    """a19 + a20 (MVSNeRF's padded sweep): gradient to the source features through the masked-variance channels."""
+
+    @staticmethod
+    def forward(ctx, imgs_small, feats, proj, depth_values, pad):
+        ctx.save_for_backward(feats, proj, depth_values)
+        ctx.pad = int(pad)
+        return ops.mvs_sweep(imgs_small, feats, proj, depth_values, pad)
+
+    @staticmethod
+    def backward(ctx, d_vol):
+        feats, proj, dv = ctx.saved_tensors
+        return None, ops.mvs_sweep_bwd(feats, proj, dv, d_vol.contiguous(), ctx.pad), None, None, None
+
+
+class MvsVolFeat(torch.autograd.Function):
+    """a22 + a23: the 8 volume channels of the MLP input (values already produced by the render kernel's input
+    builder) with their gradient to the regularised volume."""
+
+    @staticmethod
+    def forward(ctx, volume, values, rays, src_ext0, src_ixt0, near_far, H, W, pad):
+        ctx.save_for_backward(rays, src_ext0, src_ixt0, near_far)
+        ctx.cfg = (int(H), int(W), tuple(volume.shape), int(pad))
+        return values.clone()
+
+    @staticmethod
+    def backward(ctx, d_values):
+        rays, e0, k0, nf = ctx.saved_tensors
+        H, W, vshape, pad = ctx.cfg
+        d_vol = ops.mvs_vol_feat_bwd(rays, e0, k0, nf, d_values.contiguous(), H, W, vshape, pad)
+        return d_vol, None, None, None, None, None, None, None, None

@@ -614,6 +614,122 @@ __global__ void mvs_march_mask_kernel(const float* __restrict__ rays, const floa
 
 static constexpr size_t kMvsLds = (kMvsSmall + 2 * MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
 
+// ---------------------------------------------------------------------------
+// Backward of the MVSNeRF path (training).  Gradient reaches the network only through the masked variance channels of
+// the padded sweep (-> source features) and through the trilinear lookup of the regularised volume (-> volume); the
+// colour channels, the positional encoding and the view directions are data.
+// ---------------------------------------------------------------------------
+// a19 + a20 backward: d_out (B, 3S+C, D, hp, wp) -> d_feats (B,S,C,h,w) (atomics); one thread per padded voxel and CB
+// channels.  var = sum(v^2) inv - (sum(v) inv)^2 with inv = 1 / count (a constant of the mask): d var / d v_s =
+// 2 inv (v_s - m) for every view that contributes (the reference view inside the un-padded window, a source view
+// through its 4 zero-padded taps).
+template <int CB, int S>
+__global__ void __launch_bounds__(256) mvs_sweep_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ proj,
+                                                             const float* __restrict__ depth_values,
+                                                             const float* __restrict__ d_out, int C, int h, int w, int D,
+                                                             int pad, float* __restrict__ d_feats) {
+  const int b = blockIdx.z, c0 = blockIdx.y * CB;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
+  const size_t nvox = (size_t)D * hp * wp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  const int xp = (int)(i % wp), yp = (int)((i / wp) % hp), d = (int)(i / ((size_t)hp * wp));
+  const int x = xp - pad, y = yp - pad;
+  const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+  const size_t plane = (size_t)h * w;
+  const float depth = depth_values[b * D + d];
+  Taps2 tp[S];
+  float count = 1.f;
+#pragma unroll
+  for (int s = 1; s < S; ++s) {
+    const float* P = proj + ((size_t)b * S + s) * 12;
+    float px = P[0] * x + P[1] * y + P[2] + P[3] / depth;
+    float py = P[4] * x + P[5] * y + P[6] + P[7] / depth;
+    float pz = P[8] * x + P[9] * y + P[10] + P[11] / depth;
+    float gx = (px / pz) / ((float)(w - 1) * 0.5f) - 1.f;
+    float gy = (py / pz) / ((float)(h - 1) * 0.5f) - 1.f;
+    count += (gx > -1.f && gx < 1.f && gy > -1.f && gy < 1.f) ? 1.f : 0.f;
+    tp[s] = taps_zeros(unnorm(gx, w), unnorm(gy, h), w, h);
+  }
+  const float inv = 1.f / count;
+  const float* g_var = d_out + ((size_t)b * (3 * S + C) + 3 * S + c0) * nvox + i;
+  const size_t ref_off = inside ? (size_t)y * w + x : 0;
+  for (int c = 0; c < CB; ++c) {
+    float v[S], sum = 0.f;
+    v[0] = inside ? feats[(((size_t)b * S) * C + c0 + c) * plane + ref_off] : 0.f;
+    sum = v[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+      v[s] = tap_fetch(feats + (((size_t)b * S + s) * C + c0 + c) * plane, tp[s]);
+      sum += v[s];
+    }
+    const float m = sum * inv, g = g_var[(size_t)c * nvox];
+    if (g == 0.f) continue;
+    if (inside) atomicAdd(d_feats + (((size_t)b * S) * C + c0 + c) * plane + ref_off, 2.f * inv * g * (v[0] - m));
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+      const float gw = 2.f * inv * g * (v[s] - m);
+      float* df = d_feats + (((size_t)b * S + s) * C + c0 + c) * plane;
+      if (tp[s].w00 != 0.f) atomicAdd(df + tp[s].o00, tp[s].w00 * gw);
+      if (tp[s].w01 != 0.f) atomicAdd(df + tp[s].o01, tp[s].w01 * gw);
+      if (tp[s].w10 != 0.f) atomicAdd(df + tp[s].o10, tp[s].w10 * gw);
+      if (tp[s].w11 != 0.f) atomicAdd(df + tp[s].o11, tp[s].w11 * gw);
+    }
+  }
+}
+
+// a22 + a23 backward: d_feat (N, Ns, 8) = gradient of the 8 volume channels of the MLP input -> d_volume (8,D,hp,wp)
+// (atomics, trilinear, zeros padding); the NDC point of every sample is recomputed from its ray exactly as the forward
+// does (mvs_point_inputs).
+__global__ void __launch_bounds__(256) mvs_vol_feat_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ ext0,
+                                                                const float* __restrict__ ixt0,
+                                                                const float* __restrict__ near_far,
+                                                                const float* __restrict__ d_feat, long npts, int Ns, int H,
+                                                                int W, int D, int hp, int wp, int pad,
+                                                                float* __restrict__ d_volume) {
+  __shared__ Cam cam;
+  __shared__ float nf[2];
+  if (threadIdx.x == 0) load_cam(ext0, ixt0, 1.f, cam);
+  if (threadIdx.x == 32) {
+    float n0 = near_far[0], n1 = near_far[1];
+    nf[0] = fminf(n0, n1), nf[1] = fmaxf(n0, n1);
+  }
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npts) return;
+  const long ray = idx / Ns;
+  const int k = (int)(idx - ray * Ns);
+  const float* r = rays + ray * 8;
+  const float t = linspace01(k, Ns);
+  const float z = r[6] * (1.f - t) + r[7] * t;
+  const float xyz[3] = {r[0] + r[3] * z, r[1] + r[4] * z, r[2] + r[5] * z};
+  const float inv_w = (float)(W - 1), inv_h = (float)(H - 1);
+  const Cam& c = cam;
+  float cx = xyz[0] * c.E[0] + xyz[1] * c.E[1] + xyz[2] * c.E[2] + c.E[3];
+  float cy = xyz[0] * c.E[4] + xyz[1] * c.E[5] + xyz[2] * c.E[6] + c.E[7];
+  float cz = xyz[0] * c.E[8] + xyz[1] * c.E[9] + xyz[2] * c.E[10] + c.E[11];
+  float qx = cx * c.Kf[0] + cy * c.Kf[1] + cz * c.Kf[2];
+  float qy = cx * c.Kf[3] + cy * c.Kf[4] + cz * c.Kf[5];
+  float qz = cx * c.Kf[6] + cy * c.Kf[7] + cz * c.Kf[8];
+  float u = (qx / qz + 0.f) / inv_w, v = (qy / qz + 0.f) / inv_h;
+  float wf = (inv_w + 1.f) / 4.f, hf = (inv_h + 1.f) / 4.f;
+  float p2 = (float)(pad * 2);
+  const float n1 = v * hf / (hf + p2) + (float)pad / (hf + p2);
+  const float n0 = u * wf / (wf + p2) + (float)pad / (wf + p2);
+  const float n2 = (qz - nf[0]) / (nf[1] - nf[0]);
+  const Taps3 t3 = taps3_zeros(n0, n1, n2, wp, hp, D);
+  const size_t cs = (size_t)D * hp * wp;
+  const float* g = d_feat + idx * 8;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    const float gc = g[ch];
+    if (gc == 0.f) continue;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t3.w[q] != 0.f) atomicAdd(d_volume + (size_t)ch * cs + t3.o[q], t3.w[q] * gc);
+  }
+}
+
 }  // namespace bmv
 
 using namespace bmv;
@@ -702,6 +818,32 @@ int bmv_mvs_render_fwd(const bmv_mvs_render_args* a, bmv_stream_t stream) {
   unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
   hipLaunchKernelGGL(mvs_render_kernel<3>, dim3(grid), dim3(256), kMvsLds, as_stream(stream), *a);
   BMV_LAUNCH_END("bmv_mvs_render_fwd");
+}
+
+int bmv_mvs_sweep_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
+                      int S, int C, int h, int w, int D, int pad, float* d_feats, bmv_stream_t stream) {
+  BMV_REQUIRE(feats && proj && depth_values && d_volume && d_feats, "bmv_mvs_sweep_bwd: null pointer");
+  BMV_REQUIRE(B > 0 && h > 1 && w > 1 && D > 0 && pad >= 0, "bmv_mvs_sweep_bwd: bad shape");
+  if (S != 3 || C % 8 != 0) {
+    set_error("bmv_mvs_sweep_bwd: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  const size_t nvox = (size_t)D * (h + 2 * pad) * (w + 2 * pad);
+  hipLaunchKernelGGL((mvs_sweep_bwd_kernel<8, 3>), dim3(cdiv(nvox, 256), C / 8, B), dim3(256), 0, as_stream(stream), feats,
+                     proj, depth_values, d_volume, C, h, w, D, pad, d_feats);
+  BMV_LAUNCH_END("bmv_mvs_sweep_bwd");
+}
+
+int bmv_mvs_vol_feat_bwd(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
+                         const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
+                         float* d_volume, bmv_stream_t stream) {
+  BMV_REQUIRE(rays && src_ext0 && src_ixt0 && near_far && d_feat && d_volume, "bmv_mvs_vol_feat_bwd: null pointer");
+  BMV_REQUIRE(N >= 0 && Ns > 0 && H > 1 && W > 1 && D > 0 && hp > 0 && wp > 0, "bmv_mvs_vol_feat_bwd: bad shape");
+  if (N == 0) return BMV_OK;
+  const long npts = N * Ns;
+  hipLaunchKernelGGL(mvs_vol_feat_bwd_kernel, dim3(cdiv(npts, 256)), dim3(256), 0, as_stream(stream), rays, src_ext0,
+                     src_ixt0, near_far, d_feat, npts, Ns, H, W, D, hp, wp, pad, d_volume);
+  BMV_LAUNCH_END("bmv_mvs_vol_feat_bwd");
 }
 
 }  // extern "C"

@@ -48,8 +48,6 @@ class Network(mvsnerf_network.Network):
 
     # ------------------------------------------------------------------ fused forward
     def forward(self, batch):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training (backward kernels) is not part of this build yet")
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
         cc = cfg.enerf.cas_config
@@ -67,12 +65,22 @@ class Network(mvsnerf_network.Network):
         sel = trip[k_best[:, :K]]                                   # (B,K,3)
         feats = self.feature(batch["all_src_inps"])
         n_rays, Ns = batch["rays_0"].shape[1], cc.num_samples[0]
-        raws = torch.empty(1, K, n_rays, Ns, 4, device=dev)
-        zs = torch.empty(1, K, n_rays, Ns, device=dev)
-        ms = torch.empty(1, K, n_rays, Ns, device=dev)
-        for k in range(K):
-            st = self.build_volume(batch, feats, sel[:, k])
-            self.render_volume(batch, st, want_mask=True, outs=(raws[0, k], zs[0, k], ms[0, k]))
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if train:      # differentiable path: per-volume tensors are stacked, nothing is written in place
+            parts = []
+            for k in range(K):
+                st = self.build_volume(batch, feats, sel[:, k])
+                parts.append(self.render_volume(batch, st, want_mask=True))
+            raws = torch.stack([p[0] for p in parts])[None]
+            zs = torch.stack([p[1] for p in parts])[None]
+            ms = torch.stack([p[2] for p in parts])[None]
+        else:
+            raws = torch.empty(1, K, n_rays, Ns, 4, device=dev)
+            zs = torch.empty(1, K, n_rays, Ns, device=dev)
+            ms = torch.empty(1, K, n_rays, Ns, device=dev)
+            for k in range(K):
+                st = self.build_volume(batch, feats, sel[:, k])
+                self.render_volume(batch, st, want_mask=True, outs=(raws[0, k], zs[0, k], ms[0, k]))
         if self.ray_range is not None:
             b, e = self.ray_range
             raws, zs, ms = raws[:, :, b:e].contiguous(), zs[:, :, b:e].contiguous(), ms[:, :, b:e].contiguous()
@@ -80,5 +88,12 @@ class Network(mvsnerf_network.Network):
             self.capture.update({"raws": raws, "zs": zs, "masks": ms})
         if cfg.enerf.white_bkgd:
             raise NotImplementedError
-        rgb, depth, weights = ops.blend(raws, ms, zs, normalise=True)
+        if train:      # masks are constants of the geometry (boost_mvsnerf/network.py:97-135): normalise, then blend
+            from ...autograd import Blend
+            with torch.no_grad():
+                tot = ms.sum(1, keepdim=True)
+                ms = torch.where(tot > 0, ms / tot, torch.full_like(ms, 1.0 / ms.shape[1]))
+            rgb, depth, weights = Blend.apply(raws, ms, zs)
+        else:
+            rgb, depth, weights = ops.blend(raws, ms, zs, normalise=True)
         return {"rgb_level0": rgb, "depth_level0": depth, "weights_level0": weights}

@@ -7,19 +7,23 @@ the three source views (padded by 24 feature pixels), not the target's.
 
 Per cost volume: reference-view projection matrices -> image resize -> fused padded
 sweep (reference rgb | warped source rgb | masked variance) -> [3-D regulariser,
-torch/MIOpen] -> ONE fused kernel that marches the rays, projects every sample into
+csrc/conv.hip engine] -> ONE fused kernel that marches the rays, projects every sample into
 the volume and the three images, builds the 86-wide input and runs the 6x128 MLP on
 the matrix cores -> compositing kernel.  The reference's 10-chunk Python loop
-(network.py:1010-1033) and its per-sample intermediates disappear.
+(network.py:1010-1033) and its per-sample intermediates disappear.  Under autograd (training) the same
+kernels build the MLP inputs, the sweep and the volume lookup have HIP backward kernels (csrc/mvs.hip) and the
+6 x 128 MLP runs in torch ops.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import autograd as A
 from ... import ops
 from ... import convnet
 from ...config import cfg
 from ..enerf.cnn import _Packed, _engine_ok
+from ..enerf.conv3d_wgrad import Conv2d, Conv3d, ConvTranspose3d   # under autograd: engine forward, own weight gradients
 
 PAD = 24   # network.py:1016, 1106
 
@@ -54,15 +58,15 @@ class _ConvABN(nn.Module):
 
 
 def _c2(cin, cout, k=3, stride=1, pad=1):
-    return _ConvABN(nn.Conv2d, cin, cout, k, stride, pad)
+    return _ConvABN(Conv2d, cin, cout, k, stride, pad)
 
 
 def _c3(cin, cout, stride=1):
-    return _ConvABN(nn.Conv3d, cin, cout, 3, stride, 1)
+    return _ConvABN(Conv3d, cin, cout, 3, stride, 1)
 
 
 def _up3(cin, cout):
-    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False), ABN(cout))
+    return nn.Sequential(ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False), ABN(cout))
 
 
 class FeatureNet(nn.Module):
@@ -73,7 +77,7 @@ class FeatureNet(nn.Module):
         self.conv0 = nn.Sequential(_c2(3, 8), _c2(8, 8))
         self.conv1 = nn.Sequential(_c2(8, 16, 5, 2, 2), _c2(16, 16), _c2(16, 16))
         self.conv2 = nn.Sequential(_c2(16, 32, 5, 2, 2), _c2(32, 32), _c2(32, 32))
-        self.toplayer = nn.Conv2d(32, 32, 1)
+        self.toplayer = Conv2d(32, 32, 1)
         self._packed = _Packed()
 
     def _forward_engine(self, x):
@@ -179,10 +183,25 @@ class RendererMLP(nn.Module):
             self._key = key
         return self._blob
 
+    def forward_torch(self, x):
+        """Renderer_ours.forward (network.py:201-229) in torch ops, for training: the 6 x 128 MLP's backward is
+        autograd's (the MFMA kernel is forward-only); pts_bias multiplies, layer 4's output is concatenated behind
+        the embedded point."""
+        pts, feat, views = x[..., :63], x[..., 63:83], x[..., 83:86]
+        bias = self.pts_bias(feat)
+        h = pts
+        for i in range(6):
+            h = F.relu(self.pts_linears[i](h) * bias)
+            if i == 4:
+                h = torch.cat([pts, h], -1)
+        alpha = F.relu(self.alpha_linear(h))
+        h = F.relu(self.views_linears[0](torch.cat([self.feature_linear(h), views], -1)))
+        return torch.cat([torch.sigmoid(self.rgb_linear(h)), alpha], -1)
+
     def forward(self, x):
         """x (..., 86) = [embedded ndc 63 | feature 20 | view dir 3] -> (..., 4) = [rgb, alpha]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward of the HIP MLP is not implemented yet; call under torch.no_grad()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_torch(x)
         return ops.mvs_mlp(x, self.packed_weights())
 
 
@@ -232,7 +251,8 @@ class Network(nn.Module):
         h, w = f.shape[-2:]
         proj = ops.mvs_proj_mats(batch["src_exts"], batch["src_ixts"])
         small = ops.resize_bilinear(batch["src_inps"], h, w)
-        vol = ops.mvs_sweep(small, f, proj, depth_values, PAD)
+        vol = (A.MvsSweep.apply(small, f, proj, depth_values, PAD) if torch.is_grad_enabled() and f.requires_grad
+               else ops.mvs_sweep(small, f, proj, depth_values, PAD))
         st = VolumeState()
         st.cost_volume = vol if self.capture is not None else None
         st.volume = self.cost_reg_2(vol)[0]
@@ -246,9 +266,28 @@ class Network(nn.Module):
         if cc.render_scale[0] != 1.0:
             raise NotImplementedError("MVSNeRF renders at full resolution in every shipped config")
         rays = batch["rays_0"][0]
+        if torch.is_grad_enabled() and (st.volume.requires_grad or any(p.requires_grad for p in self.nerf.parameters())):
+            return self._render_volume_train(rays, st, want_mask, outs)
         raw, z, mask, x86 = ops.mvs_render(rays, st.volume, *st.views, st.near_far, self.nerf.nerf.packed_weights(),
                                            Ns=cc.num_samples[0], pad=PAD, want_mask=want_mask,
                                            want_inputs=self.capture is not None, ray_range=self.ray_range, outs=outs)
+        if self.capture is not None:
+            self.capture.update({"mlp_in": x86, "raw": raw, "cost_volume": st.cost_volume, "volume": st.volume})
+        return raw, z, mask
+
+    def _render_volume_train(self, rays, st, want_mask, outs):
+        """Differentiable form of render_volume: the render kernel only builds the MLP inputs (marching, NDC point,
+        positional encoding, volume / colour lookups, visibility), the 8 volume channels get their gradient to the
+        regularised volume (autograd.MvsVolFeat), the MLP runs in torch ops."""
+        if self.ray_range is not None or outs is not None:
+            raise NotImplementedError("training renders every ray of batch['rays_0'] (no ray_range / preallocated outputs)")
+        cc = cfg.enerf.cas_config
+        src_inps, src_exts, src_ixts = st.views
+        H, W = src_inps.shape[-2:]
+        _, z, mask, x86 = ops.mvs_render(rays, st.volume.detach(), src_inps, src_exts, src_ixts, st.near_far, None,
+                                         Ns=cc.num_samples[0], pad=PAD, want_mask=want_mask, want_inputs=True)
+        vf = A.MvsVolFeat.apply(st.volume, x86[..., 63:71], rays, src_exts[0], src_ixts[0], st.near_far, H, W, PAD)
+        raw = self.nerf.nerf.forward_torch(torch.cat([x86[..., :63], vf, x86[..., 71:]], -1))
         if self.capture is not None:
             self.capture.update({"mlp_in": x86, "raw": raw, "cost_volume": st.cost_volume, "volume": st.volume})
         return raw, z, mask
@@ -272,8 +311,6 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch):
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training (backward kernels) is not part of this build yet")
         dev = batch["all_src_inps"].device
         self.ensure_rays(batch)
         feats = self.feature(batch["all_src_inps"])
@@ -283,5 +320,8 @@ class Network(nn.Module):
         raw, z, _ = self.render_volume(batch, st, want_mask=False)
         if self.ray_range is not None:
             raw, z = raw[self.ray_range[0]:self.ray_range[1]], z[self.ray_range[0]:self.ray_range[1]]
-        rgb, depth, weights = ops.composite(raw[None], z[None], cfg.enerf.white_bkgd)
+        if torch.is_grad_enabled() and raw.requires_grad:
+            rgb, depth, weights = A.Composite.apply(raw[None], z[None], cfg.enerf.white_bkgd)
+        else:
+            rgb, depth, weights = ops.composite(raw[None], z[None], cfg.enerf.white_bkgd)
         return {"rgb_level0": rgb, "depth_level0": depth, "weights_level0": weights}

@@ -693,3 +693,27 @@ def bn_train_bwd(x, y, dy, weight, mean, invstd, relu):
                                   stream())
     _lib.check(rc, "bn_train_bwd")
     return dx, dw, db
+
+
+def mvs_sweep_bwd(feats, proj, depth_values, d_volume, pad):
+    """d_volume (B, 3S+C, D, hp, wp) -> d_feats (B,S,C,h,w)."""
+    B, S, C_, h, w = feats.shape
+    D = depth_values.shape[1]
+    d_feats = torch.zeros_like(feats, memory_format=torch.contiguous_format)
+    lib = _lib.load()
+    _lib.check(lib.bmv_mvs_sweep_bwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
+                                     dptr(_c(d_volume), "d_volume"), B, S, C_, h, w, D, int(pad), dptr(d_feats), stream()),
+               "mvs_sweep_bwd")
+    return d_feats
+
+
+def mvs_vol_feat_bwd(rays, src_ext0, src_ixt0, near_far, d_feat, H, W, vol_shape, pad):
+    """d_feat (N,Ns,8) -> d_volume (8,D,hp,wp)."""
+    N, Ns = d_feat.shape[:2]
+    _, D, hp, wp = vol_shape
+    d_vol = torch.zeros(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.bmv_mvs_vol_feat_bwd(dptr(_c(rays), "rays"), dptr(_c(src_ext0), "src_ext0"), dptr(_c(src_ixt0), "src_ixt0"),
+                                        dptr(_c(near_far), "near_far"), dptr(_c(d_feat), "d_feat"), N, int(Ns), int(H), int(W), D,
+                                        hp, wp, int(pad), dptr(d_vol), stream()), "mvs_vol_feat_bwd")
+    return d_vol

@@ -324,6 +324,17 @@ typedef struct {
 } bmv_mvs_render_args;
 int bmv_mvs_render_fwd(const bmv_mvs_render_args* args, bmv_stream_t stream);
 
+/* ---- MVSNeRF backward (training): gradient reaches the network through the masked-variance channels of the padded
+ * sweep (a19 + a20 -> the source FEATURES; d_volume is the gradient of bmv_mvs_sweep_fwd's whole output, only its last
+ * C channels are read) and through the trilinear lookup of the regularised volume (a22 + a23: d_feat (N,Ns,8) = the
+ * gradient of columns 63..70 of the MLP input; rays (N,8), the reference view's camera, near_far as the forward).
+ * d_feats / d_volume receive scatter-adds: zero them first. */
+int bmv_mvs_sweep_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
+                      int S, int C, int h, int w, int D, int pad, float* d_feats, bmv_stream_t stream);
+int bmv_mvs_vol_feat_bwd(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
+                         const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
+                         float* d_volume, bmv_stream_t stream);
+
 /* ---- boost_mvsnerf calc_mask               lib/networks/boost_mvsnerf/network.py:23-45
  * rays (N,8) marched with Ns samples between columns 6 and 7; src_exts (V,4,4), src_ixts (V,3,3)
  * -> z_vals (N,Ns), mask (N,Ns) = fraction of the V views whose viewport holds the sample */
