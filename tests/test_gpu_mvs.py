@@ -204,3 +204,19 @@ def test_boost_mvsnerf_training_gradients(fx, bfx, tmp_path):
     loss.backward()
     # viewport-mask flips (budgeted 0.3 % in the forward test above) shift the gradient sums they feed
     _check(net, want, float(loss), loss_c, outliers=2e-3)
+
+
+def test_mvsnerf_train_step_with_the_reference_loss_wrapper(fx):
+    """configs/exps/pretrain/mvsnerf/dtu_pretrain.yaml inherits ENeRF's loss module and optimiser: one
+    trainer.py:44-63 step (train mode: batch statistics in the ABN blocks) on the HIP path."""
+    cfg = _cfg(fx, "mvsnerf_eval")
+    from boostmvsnerfs_amd.networks.mvsnerf.network import Network
+    from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
+    net = _net(fx, Network).train()
+    bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in fx.batch().items()}
+    bg["rgb_0"] = torch.rand(1, bg["rays_0"].shape[1], 3, device=DEV)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    loss, stats = train_step(NetworkWrapper(net), make_optimizer(net), bg)
+    assert torch.isfinite(loss) and "psnr_0" in stats
+    moved = sum(bool((p.detach() != before[k]).any()) for k, p in net.named_parameters())
+    assert moved >= 0.9 * len(before), f"only {moved} of {len(before)} parameter tensors moved"
