@@ -5,7 +5,7 @@ parameters (so checkpoints load and training works through autograd), but infere
 implicit-GEMM MFMA convolution engine (csrc/conv.hip via convnet.py) with eval-mode batch norm folded into the
 weights.  Under autograd the same engine does the convolution forward and the 3-D data gradients (weights repacked on
 the device every step), csrc/conv_wgrad.hip the weight gradients and csrc/bn.hip the training-mode batch norm;
-MIOpen is left with the data gradients of the two stride-2 5x5 layers (conv3d_wgrad.py).
+MIOpen is left with the data gradients of the two stride-2 5x5 layers (conv_train.py).
 Module/parameter names reproduce the reference's state-dict keys exactly
 (lib/networks/enerf/feature_net.py:4-36, cost_reg_net.py:4-86, utils.py:10-33)
 so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.
@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from ... import autograd as A
 from ... import convnet
-from .conv3d_wgrad import Conv2d, Conv3d, ConvTranspose3d, _Conv3dFn   # engine forward, MIOpen data grad, MFMA weight grad
+from .conv_train import Conv2d, Conv3d, ConvTranspose3d, _Conv3dFn   # engine forward / data gradients, MFMA weight gradients
 
 
 def engine_ok(module, x):

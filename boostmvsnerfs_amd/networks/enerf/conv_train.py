@@ -1,16 +1,18 @@
-"""3-D convolutions whose WEIGHT gradient runs on the package's own MFMA kernel (csrc/conv_wgrad.hip) instead of
-MIOpen's conv3d backward-weights solvers.
+"""The convolution modules of the CNN stacks under autograd: nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d subclasses whose
+forward, data gradients and WEIGHT gradients run on the package's own kernels (csrc/conv.hip, csrc/conv_wgrad.hip)
+instead of MIOpen's solvers.
 
 Measured on MI355X / ROCm 7.2 (scripts/probe_conv3d.py): MIOpen picks `naive_conv_*_wrw_ncdhw` or a 40 ms CK
 batched-GEMM for every 3x3x3 fp32 layer of the cost regularisers (308 ms per CostRegNet backward, >90 % of a fine-tune
 step; its exhaustive find mode takes >15 min).  The weight gradient of a k^3 convolution is k^3 products over the voxel
 dimension,
     dW[:, :, kd, kh, kw] = dY (Co x P) @ X_shift(kd,kh,kw)^T (P x Ci),
-which bmv_conv_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per workgroup, no
-im2col copies; the first version of this file made 27 strided copies and one tall-skinny rocBLAS GEMM per layer:
-4 ms of copies + ~5 ms of GEMMs per 512x640 step).  Forward and the data gradient stay on MIOpen.
-SURVEY.md section 8(f) rank 1 (the regularisers between sweep and sampler); module and parameter names are unchanged
-(subclasses of nn.Conv3d / nn.ConvTranspose3d).
+which bmv_conv_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per wave, no im2col
+copies; the first version of this file made 27 strided copies and one tall-skinny rocBLAS GEMM per layer: 4 ms of
+copies + ~5 ms of GEMMs per 512x640 step).  The forward runs on the inference engine with the weights repacked on the
+device, the data gradients are convolutions with transformed filters on the same engine (stride-2 5x5: MIOpen).
+SURVEY.md section 8(f) ranks 1-2; module and parameter names are unchanged (subclasses of nn.Conv2d / nn.Conv3d /
+nn.ConvTranspose3d).
 """
 import os
 

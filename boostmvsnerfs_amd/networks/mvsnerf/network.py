@@ -23,7 +23,7 @@ from ... import ops
 from ... import convnet
 from ...config import cfg
 from ..enerf.cnn import _Packed, _engine_ok
-from ..enerf.conv3d_wgrad import Conv2d, Conv3d, ConvTranspose3d   # under autograd: engine forward, own weight gradients
+from ..enerf.conv_train import Conv2d, Conv3d, ConvTranspose3d   # under autograd: engine forward, own weight gradients
 
 PAD = 24   # network.py:1016, 1106
 

@@ -219,7 +219,7 @@ def test_unsupported_shape_is_loud():
     (16, 8, 1, (8, 128, 160)),    # 10 240 voxel groups: every wave walks its grid-stride loop more than once
 ])
 def test_conv3d_weight_gradient(cin, cout, stride, dhw):
-    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import Conv3d
+    from boostmvsnerfs_amd.networks.enerf.conv_train import Conv3d
     torch.manual_seed(0)
     m = Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False).to(DEV)
     big = dhw[0] * dhw[1] * dhw[2] > 100000
@@ -240,7 +240,7 @@ def test_conv3d_weight_gradient(cin, cout, stride, dhw):
 
 @pytest.mark.parametrize("cin,cout,dhw", [(64, 32, (2, 4, 5)), (16, 8, (4, 9, 40)), (32, 16, (3, 5, 33))])
 def test_conv_transpose3d_weight_gradient(cin, cout, dhw):
-    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import ConvTranspose3d
+    from boostmvsnerfs_amd.networks.enerf.conv_train import ConvTranspose3d
     torch.manual_seed(1)
     m = ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False).to(DEV)
     x = torch.randn(1, cin, *dhw, device=DEV, requires_grad=True)
@@ -310,7 +310,7 @@ def test_cost_reg_training_forward_matches_torch_modules(monkeypatch):
 def test_conv2d_training_module(cin, cout, k, stride, bias, hw):
     """FeatureNet's convolutions under autograd: forward on the engine (weights repacked on the device), gradients
     on MIOpen, vs float64."""
-    from boostmvsnerfs_amd.networks.enerf.conv3d_wgrad import Conv2d
+    from boostmvsnerfs_amd.networks.enerf.conv_train import Conv2d
     torch.manual_seed(2)
     m = Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias).to(DEV)
     x = torch.randn(3, cin, *hw, device=DEV, requires_grad=True)
