@@ -107,8 +107,8 @@ SIGNATURES = {
     "bmv_mvs_vol_feat_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_conv_pack_weights": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_bn_chunks": [c_i, c_l],
-    "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_i, c_f, c_f, c_f, c_f, c_f],
-    "bmv_bn_train_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_f, c_f],
+    "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f],
+    "bmv_bn_train_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_f, c_f, c_f, c_f, c_f],
     "bmv_version": [],
 }
 

@@ -210,8 +210,8 @@ class BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
         y, mean, invstd = ops.bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu)
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
-        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, y if relu is not False else None, weight, mean, invstd)
+        ctx.relu = relu            # False: none, True: ReLU, a float: leaky slope
         return y
 
     @staticmethod

@@ -74,11 +74,12 @@ __global__ void bn_stats_finish_kernel(const float* __restrict__ partial, int C,
   }
 }
 
-// y = relu?((x - mean) * invstd * w + b); 4 elements per thread where the plane allows it
+// y = act((x - mean) * invstd * w + b), act(v) = v > 0 ? v : slope * v (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky
+// ReLU); 4 elements per thread where the plane allows it
 __global__ void __launch_bounds__(kBnThreads) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ w, const float* __restrict__ b,
-                                                              int C, long S, int relu, float* __restrict__ y) {
+                                                              int C, long S, float slope, float* __restrict__ y) {
   const long plane = blockIdx.y;                         // n * C + c
   const int c = (int)(plane % C);
   const float sc = invstd[c] * (w ? w[c] : 1.f), sh = (b ? b[c] : 0.f) - mean[c] * sc;
@@ -88,23 +89,24 @@ __global__ void __launch_bounds__(kBnThreads) bn_apply_kernel(const float* __res
     for (long i = (long)blockIdx.x * kBnThreads + threadIdx.x; i < S / 4; i += (long)gridDim.x * kBnThreads) {
       float4 v = reinterpret_cast<const float4*>(xp)[i];
       v.x = v.x * sc + sh, v.y = v.y * sc + sh, v.z = v.z * sc + sh, v.w = v.w * sc + sh;
-      if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+      v.x = v.x > 0.f ? v.x : slope * v.x, v.y = v.y > 0.f ? v.y : slope * v.y;
+      v.z = v.z > 0.f ? v.z : slope * v.z, v.w = v.w > 0.f ? v.w : slope * v.w;
       reinterpret_cast<float4*>(yp)[i] = v;
     }
   } else {
     for (long i = (long)blockIdx.x * kBnThreads + threadIdx.x; i < S; i += (long)gridDim.x * kBnThreads) {
       float v = xp[i] * sc + sh;
-      yp[i] = relu ? fmaxf(v, 0.f) : v;
+      yp[i] = v > 0.f ? v : slope * v;
     }
   }
 }
 
-// backward reductions per channel: sum(g), sum(g * xhat) with g = dy masked by the ReLU (y > 0); grid as bn_stats_kernel
+// backward reductions per channel: sum(g), sum(g * xhat) with g = dy * act'(y) (y > 0 ? 1 : slope); grid as bn_stats_kernel
 __global__ void __launch_bounds__(kBnThreads) bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                    const float* __restrict__ dy,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, int C, long S, int cpp,
-                                                                   long per_chunk, int relu, float* __restrict__ partial) {
+                                                                   long per_chunk, float slope, float* __restrict__ partial) {
   __shared__ float sh[4];
   const int c = blockIdx.y, chunks = gridDim.x, n = blockIdx.x / cpp, k = blockIdx.x - n * cpp;
   const long begin = (long)k * per_chunk, end = min(begin + per_chunk, S), base = ((long)n * C + c) * S;
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(kBnThreads) bn_bwd_reduce_kernel(const float* 
   float sg = 0.f, sgx = 0.f;
   for (long i = begin + threadIdx.x; i < end; i += kBnThreads) {
     float g = dy[base + i];
-    if (relu && !(y[base + i] > 0.f)) g = 0.f;
+    if (slope != 1.f && !(y[base + i] > 0.f)) g *= slope;
     sg += g, sgx += g * (x[base + i] - mu) * is;
   }
   sg = block_sum(sg, sh), sgx = block_sum(sgx, sh);
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(kBnThreads) bn_bwd_apply_kernel(const float* _
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ sums, int C, long S,
-                                                                  float inv_n, int relu, float* __restrict__ dx) {
+                                                                  float inv_n, float slope, float* __restrict__ dx) {
   const long plane = blockIdx.y;
   const int c = (int)(plane % C);
   const float mu = mean[c], is = invstd[c], k = is * (w ? w[c] : 1.f);
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(kBnThreads) bn_bwd_apply_kernel(const float* _
   const long base = plane * S;
   for (long i = (long)blockIdx.x * kBnThreads + threadIdx.x; i < S; i += (long)gridDim.x * kBnThreads) {
     float g = dy[base + i];
-    if (relu && !(y[base + i] > 0.f)) g = 0.f;
+    if (slope != 1.f && !(y[base + i] > 0.f)) g *= slope;
     const float xh = (x[base + i] - mu) * is;
     dx[base + i] = k * (g - a - xh * bq);
   }
@@ -170,7 +172,7 @@ extern "C" {
 int bmv_bn_chunks(int N, long S) { return N * bn_cpp(N, S); }
 
 int bmv_bn_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
-                     int N, int C, long S, float eps, float momentum, int relu, float* workspace, float* save_mean,
+                     int N, int C, long S, float eps, float momentum, float act_slope, float* workspace, float* save_mean,
                      float* save_invstd, float* y, bmv_stream_t stream) {
   BMV_REQUIRE(x && workspace && save_mean && save_invstd && y, "bmv_bn_train_fwd: null pointer");
   BMV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bmv_bn_train_fwd: running stats come in pairs");
@@ -186,15 +188,16 @@ int bmv_bn_train_fwd(const float* x, const float* weight, const float* bias, flo
   unsigned gx = (unsigned)((per_plane + kBnThreads - 1) / kBnThreads);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(kBnThreads), 0, st, x, save_mean, save_invstd, weight, bias, C,
-                     S, relu, y);
+                     S, act_slope, y);
   BMV_LAUNCH_END("bmv_bn_train_fwd");
 }
 
 int bmv_bn_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
-                     const float* save_invstd, int N, int C, long S, int relu, float* workspace, float* dx, float* dweight,
+                     const float* save_invstd, int N, int C, long S, float act_slope, float* workspace, float* dx, float* dweight,
                      float* dbias, bmv_stream_t stream) {
   BMV_REQUIRE(x && dy && save_mean && save_invstd && workspace && dx, "bmv_bn_train_bwd: null pointer");
-  BMV_REQUIRE(!relu || y, "bmv_bn_train_bwd: the fused ReLU needs the forward output");
+  BMV_REQUIRE(act_slope == 1.f || y, "bmv_bn_train_bwd: the fused activation needs the forward output");
+  BMV_REQUIRE(act_slope >= 0.f, "bmv_bn_train_bwd: the activation's mask is read off the sign of y: slope must be >= 0");
   BMV_REQUIRE(N > 0 && C > 0 && S > 0, "bmv_bn_train_bwd: bad shape");
   BMV_REQUIRE((long)N * C <= 65535 && C <= 65535, "bmv_bn_train_bwd: N * C = %ld planes exceed the launch grid", (long)N * C);
   const long total = (long)N * S;
@@ -203,12 +206,12 @@ int bmv_bn_train_bwd(const float* x, const float* y, const float* dy, const floa
   hipStream_t st = as_stream(stream);
   float* sums = workspace + (long)C * chunks * 2;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, C), dim3(kBnThreads), 0, st, x, y, dy, save_mean, save_invstd, C,
-                     S, cpp, per_chunk, relu, workspace);
+                     S, cpp, per_chunk, act_slope, workspace);
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, C, chunks, sums, dweight, dbias);
   unsigned gx = (unsigned)((S + kBnThreads - 1) / kBnThreads);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(kBnThreads), 0, st, x, y, dy, save_mean, save_invstd,
-                     weight, sums, C, S, 1.f / (float)total, relu, dx);
+                     weight, sums, C, S, 1.f / (float)total, act_slope, dx);
   BMV_LAUNCH_END("bmv_bn_train_bwd");
 }
 

@@ -14,6 +14,8 @@ the matrix cores -> compositing kernel.  The reference's 10-chunk Python loop
 kernels build the MLP inputs, the sweep and the volume lookup have HIP backward kernels (csrc/mvs.hip) and the
 6 x 128 MLP runs in torch ops.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,6 +44,10 @@ class ABN(nn.Module):
         self.eps, self.momentum, self.slope = eps, momentum, slope
 
     def forward(self, x):
+        if self.training and x.is_cuda and x.dtype == torch.float32 and os.environ.get("BMV_BN", "hip") != "torch":
+            # batch statistics + leaky ReLU on csrc/bn.hip (as ConvBnReLU's training path, enerf/cnn.py)
+            return A.BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                          self.momentum, float(self.slope))
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum,
                          self.eps)
         return F.leaky_relu(y, self.slope, inplace=True)

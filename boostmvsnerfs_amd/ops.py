@@ -656,9 +656,14 @@ def conv_wgrad(big, small, stride, kd, k):
     return G
 
 
+def _act_slope(relu):
+    """relu: False -> 1 (no activation), True -> 0 (ReLU), a float -> that leaky slope."""
+    return 1.0 if relu is False else 0.0 if relu is True else float(relu)
+
+
 def bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu):
-    """Training-mode batch norm (+ ReLU) of x (N,C,*spatial); updates the running statistics in place.
-    -> y, save_mean (C), save_invstd (C)."""
+    """Training-mode batch norm (+ ReLU / leaky ReLU: `relu` = True / a slope) of x (N,C,*spatial); updates the running
+    statistics in place.  -> y, save_mean (C), save_invstd (C)."""
     lib = _lib.load()
     x = _c(x)
     N, C_ = x.shape[:2]
@@ -670,7 +675,7 @@ def bn_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu
     y = torch.empty_like(x)
     with ktimer.region("bn_train_fwd"):
         rc = lib.bmv_bn_train_fwd(dptr(x, "x"), dptr(weight, "weight"), dptr(bias, "bias"), dptr(running_mean, "running_mean"),
-                                  dptr(running_var, "running_var"), N, C_, S, float(eps), float(momentum), int(bool(relu)),
+                                  dptr(running_var, "running_var"), N, C_, S, float(eps), float(momentum), _act_slope(relu),
                                   dptr(ws), dptr(mean), dptr(invstd), dptr(y), stream())
     _lib.check(rc, "bn_train_fwd")
     return y, mean, invstd
@@ -688,8 +693,8 @@ def bn_train_bwd(x, y, dy, weight, mean, invstd, relu):
     dw = torch.empty(C_, device=x.device, dtype=torch.float32)
     db = torch.empty(C_, device=x.device, dtype=torch.float32)
     with ktimer.region("bn_train_bwd"):
-        rc = lib.bmv_bn_train_bwd(dptr(x, "x"), dptr(_c(y), "y") if relu else None, dptr(dy, "dy"), dptr(weight, "weight"),
-                                  dptr(mean), dptr(invstd), N, C_, S, int(bool(relu)), dptr(ws), dptr(dx), dptr(dw), dptr(db),
+        rc = lib.bmv_bn_train_bwd(dptr(x, "x"), dptr(_c(y), "y") if relu is not False else None, dptr(dy, "dy"), dptr(weight, "weight"),
+                                  dptr(mean), dptr(invstd), N, C_, S, _act_slope(relu), dptr(ws), dptr(dx), dptr(dw), dptr(db),
                                   stream())
     _lib.check(rc, "bn_train_bwd")
     return dx, dw, db

@@ -252,16 +252,17 @@ int bmv_conv_wgrad(const float* big, const float* small, int B, int Cb, int Db, 
 /* ---- f1 / f2 (training leg): batch normalisation in training mode (+ ReLU) of ConvBnReLU / ConvBnReLU3D
  *          lib/networks/enerf/utils.py:10-33 (nn.BatchNorm2d / nn.BatchNorm3d under net.train())
  * x, y, dy, dx: (N, C, S) planar, S = H*W or D*H*W.  Forward: batch statistics (biased variance normalises, the
- * unbiased one updates running_var; momentum as torch: new = (1 - m) old + m batch), y = relu?(xhat * w + b);
- * save_mean / save_invstd (C) feed the backward.  Backward: the ReLU mask is taken from y (y > 0).
+ * unbiased one updates running_var; momentum as torch: new = (1 - m) old + m batch), y = act(xhat * w + b) with
+ * act(v) = v > 0 ? v : act_slope * v (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky ReLU, mvsnerf/network.py:699-779);
+ * save_mean / save_invstd (C) feed the backward.  Backward: act' is read off y (y > 0 ? 1 : act_slope).
  * workspace: C * bmv_bn_chunks(N, S) * 3 floats (forward), C * bmv_bn_chunks(N, S) * 2 + 2 C (backward).
  * weight / bias / running_* / dweight / dbias may be NULL. */
 int bmv_bn_chunks(int N, long S);
 int bmv_bn_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
-                     int N, int C, long S, float eps, float momentum, int relu, float* workspace, float* save_mean,
+                     int N, int C, long S, float eps, float momentum, float act_slope, float* workspace, float* save_mean,
                      float* save_invstd, float* y, bmv_stream_t stream);
 int bmv_bn_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
-                     const float* save_invstd, int N, int C, long S, int relu, float* workspace, float* dx,
+                     const float* save_invstd, int N, int C, long S, float act_slope, float* workspace, float* dx,
                      float* dweight, float* dbias, bmv_stream_t stream);
 
 /* ======================= MVSNeRF backbone (lib/networks/mvsnerf) ======================= */

@@ -259,7 +259,8 @@ def test_conv_transpose3d_weight_gradient(cin, cout, dhw):
 # training-mode batch norm (+ ReLU) on csrc/bn.hip vs torch in float64 (lib/networks/enerf/utils.py:10-33)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,relu", [((3, 8, 37, 53), True), ((1, 16, 4, 32, 48), True), ((1, 32, 2, 4, 5), False),
-                                         ((2, 8, 3, 17, 33), False), ((2, 64, 1, 2, 3), True), ((1, 8, 8, 256, 320), True)])
+                                         ((2, 8, 3, 17, 33), False), ((2, 64, 1, 2, 3), True), ((1, 8, 8, 256, 320), True),
+                                         ((2, 16, 3, 9, 20), 0.01)])       # InPlaceABN's leaky ReLU (MVSNeRF stacks)
 def test_batch_norm_training(shape, relu):
     from boostmvsnerfs_amd import autograd as A
     torch.manual_seed(0)
@@ -275,11 +276,12 @@ def test_batch_norm_training(shape, relu):
     y.backward(gy)
     xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
     yd = F.batch_norm(xd, rm_d, rv_d, wd, bd, True, 0.1, 1e-5)
-    if relu:
+    if relu is not False:
         # the mask of the fp32 output: values within rounding of zero may fall on either side, and every flip moves
         # the channel sums by a whole term -- both sides must differentiate the same function
-        assert float((torch.relu(yd) - y.double()).abs().max()) <= 2e-5 * float(yd.abs().max())
-        yd = yd * (y.detach() > 0).double()
+        slope = 0.0 if relu is True else float(relu)
+        assert float((F.leaky_relu(yd, slope) - y.double()).abs().max()) <= 2e-5 * float(yd.abs().max())
+        yd = yd * torch.where(y.detach() > 0, 1.0, slope).double()
     yd.backward(gy.double())
     _close(y.double(), yd.detach(), 2e-5)
     _close(rm.double(), rm_d, 1e-5), _close(rv.double(), rv_d, 1e-4)
