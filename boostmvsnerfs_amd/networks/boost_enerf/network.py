@@ -146,7 +146,7 @@ class Network(enerf_network.Network):
         utils.py:639-667); mask normalisation over K happens inside the kernel."""
         if cfg.enerf.white_bkgd:
             raise NotImplementedError          # as the reference (utils.py:660-661)
-        if torch.is_grad_enabled():             # fine-tuning: masks are constants (built under no_grad)
+        if raws.requires_grad:                  # fine-tuning: masks are constants (built under no_grad)
             from ...autograd import Blend
             with torch.no_grad():
                 tot = masks.sum(1, keepdim=True)
@@ -246,7 +246,7 @@ class Network(enerf_network.Network):
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K
         ret = {}
-        train = torch.is_grad_enabled()
+        train = self.wants_grad()
         # Inference with the engine's channel-last feature maps: the sweep and render kernels pick each volume's three
         # views out of the all-views tensors by index -- no gathered copies of images / feature maps per volume
         # (those copies were 15 % of a K = 4 frame); only the 4x4 / 3x3 camera matrices are gathered, once per volume.

@@ -72,7 +72,7 @@ class Network(nn.Module):
         h, w = int(H * cc.volume_scale[i]), int(W * cc.volume_scale[i])
         D = cc.volume_planes[i]
         st = LevelState()
-        train = torch.is_grad_enabled()       # fine-tuning: autograd Functions (HIP forward + HIP backward)
+        train = self.wants_grad()             # fine-tuning: autograd Functions (HIP forward + HIP backward)
         if prev is None or prev.depth is None:
             st.depth_values, st.near_far = ops.depth_values_uniform(batch["near_far"], D, h, w, cc.depth_inv[i])
         else:
@@ -96,6 +96,12 @@ class Network(nn.Module):
         else:
             st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
         return st
+
+    def wants_grad(self):
+        """The differentiable (op-by-op) path is taken only when something can receive a gradient: grad mode on AND a
+        parameter that requires it.  An eval-mode call that merely forgot torch.no_grad() on a frozen network keeps
+        the fused kernels (and with them chunking and ray sharding)."""
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     # ------------------------------------------------------------------ unfused renderer (differentiable)
     def _render_bounded(self, i, rays12, feature_volume, im_feat, views, tar_ext, nerf, mode=0):
@@ -138,7 +144,10 @@ class Network(nn.Module):
         rs = cc.render_scale[i]
         if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
             raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
-        rays12 = A.BuildRays.apply(batch[f"rays_{i}"], st.depth, st.std, st.near_far, int(H * rs), int(W * rs), cc.depth_inv[i])
+        rays = batch[f"rays_{i}"]
+        if self.ray_range is not None:          # the rays of this rank (sharding.ray_slice), as the fused path
+            rays = rays[:, self.ray_range[0]:self.ray_range[1]].contiguous()
+        rays12 = A.BuildRays.apply(rays, st.depth, st.std, st.near_far, int(H * rs), int(W * rs), cc.depth_inv[i])
         return self._render_bounded(i, rays12, st.feature_volume, im_feat, views, batch["tar_ext"], getattr(self, f"nerf_{i}"), mode)
 
     # ------------------------------------------------------------------ fused renderer of one level
@@ -245,7 +254,7 @@ class Network(nn.Module):
             feats, st0 = self._front_overlapped(batch, views)
         else:
             feats = self.forward_feat(batch["src_inps"])
-        render = self.render_level_train if torch.is_grad_enabled() else self.render_level
+        render = self.render_level_train if self.wants_grad() else self.render_level
         ret = {}
         st = None
         for i in range(cc.num):

@@ -366,3 +366,28 @@ def test_make_rays_matches_the_dataset_ray_builder():
         # and they are what the batch carries
         key = "rays_1" if scale == 1.0 else "rays_0"
         assert float((got - b[key]).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+def test_path_selection_follows_what_can_receive_a_gradient(ops, enerf_fx):
+    """Grad mode alone does not switch to the op-by-op path: a frozen network called without torch.no_grad() keeps the
+    fused kernels (so chunking and ray sharding keep working); the differentiable path honours ray_range too."""
+    from boostmvsnerfs_amd.config import get_cfg
+    net = _network(enerf_fx)
+    get_cfg().enerf.cas_config.render_if = [False, True]
+    b = enerf_fx.batch(DEV)
+    with torch.no_grad():
+        want = net(b)["rgb_level1"]
+    N = b["rays_1"].shape[1]
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert not net.wants_grad()
+    net.ray_range = (N // 3, N)
+    frozen = net(enerf_fx.batch(DEV))["rgb_level1"]              # grad mode on, nothing to differentiate: fused path
+    assert not frozen.requires_grad and frozen.shape[1] == N - N // 3
+    assert_close(frozen, want[:, N // 3:], rtol=1e-5, atol_scale=1e-6, name="frozen")
+    for p in net.parameters():
+        p.requires_grad_(True)
+    assert net.wants_grad()
+    part = net(enerf_fx.batch(DEV))["rgb_level1"]                # differentiable path, same ray slice
+    assert part.requires_grad and part.shape[1] == N - N // 3
+    assert_close(part, want[:, N // 3:], name="train path, ray_range")
