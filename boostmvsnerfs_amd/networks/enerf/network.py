@@ -26,10 +26,11 @@ from .nerf import NeRF
 
 class LevelState:
     """What one cascade level hands to the next (and to the renderer)."""
-    __slots__ = ("depth", "std", "near_far", "feature_volume", "depth_values")
+    __slots__ = ("depth", "std", "near_far", "feature_volume", "depth_values", "keep")
 
     def __init__(self):
         self.depth = self.std = self.near_far = self.feature_volume = self.depth_values = None
+        self.keep = None      # tensors a side stream still reads: kept alive until the level state dies
 
 
 class Network(nn.Module):
@@ -47,7 +48,12 @@ class Network(nn.Module):
         # inference: run the level-0 cascade chain on a second stream under FeatureNet's top-down path.
         # Off by default: measured +1.2 % frames/s under graph replay (the concurrent kernels slow each other) and it
         # takes the source features of the level-1 sweep out of L2 (that kernel: 29.1 -> 32.7 us).
-        self.overlap_front = os.environ.get("BMV_OVERLAP", "0") == "1"
+        # 0: one stream; 1: the whole level-0 chain on a side stream under FeatureNet's top-down path; 2: only what follows
+        # the level-0 sweep (regulariser + depth regression) -- the sweep stays on the main stream.  By default the fork
+        # is used under HIP-graph capture only (replay: +3 % frames/s); issued eagerly a 512x640 frame is bound by the
+        # host's ~45 launches and the extra stream traffic costs 3 % (BMV_OVERLAP_EAGER=1 forks there too).
+        self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
+        self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
         self._side_stream = None
 
     # ------------------------------------------------------------------ 2-D features
@@ -61,8 +67,10 @@ class Network(nn.Module):
                 "level_2": fine.reshape(B, V, -1, H, W)}
 
     # ------------------------------------------------------------------ cost volume of one level
-    def level_front(self, i, feats_i, views, batch, prev, view_ids=None):
+    def level_front(self, i, feats_i, views, batch, prev, view_ids=None, fork_after_sweep=None):
         """Plane sweep + regulariser + depth regression (network.py:81-90).
+        `fork_after_sweep`: a side stream that takes everything AFTER the sweep (regulariser, depth regression); the
+        caller joins it.  The sweep itself stays on the current stream.
         `views` = (src_inps, src_exts, src_ixts) of the S views of this cost volume.  With `view_ids` (B,S) int32
         (inference), `feats_i` and `src_inps` hold ALL source views and the kernels pick the volume's views by index
         (no gathered copies); src_exts / src_ixts are the S picked ones either way."""
@@ -90,6 +98,15 @@ class Network(nn.Module):
             variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values)
         else:
             variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
+        if fork_after_sweep is not None:
+            fork_after_sweep.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(fork_after_sweep):
+                st.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
+                st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
+            # the variance volume was allocated on the current stream and is read on the side one: it must not go back
+            # to the allocator (and be handed to the next main-stream allocation) before the caller has joined
+            st.keep = (variance, depth_prob)
+            return st
         st.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
         if train:
             st.depth, st.std = A.DepthRegress.apply(depth_prob, st.depth_values, cc.depth_inv[i])
@@ -215,15 +232,18 @@ class Network(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
-        side.wait_stream(main)
         level0 = p2_cl.reshape(B, V, -1, H // 4, W // 4)
-        with torch.cuda.stream(side):
-            st0 = self.level_front(0, level0, views, batch, None)
+        if self.overlap_front == 2:
+            st0 = self.level_front(0, level0, views, batch, None, fork_after_sweep=side)
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                st0 = self.level_front(0, level0, views, batch, None)
         f1, f0 = fn.engine_top_down(c0, c1, p2)
         main.wait_stream(side)
         if not torch.cuda.is_current_stream_capturing():   # (a graph capture owns its memory pool)
-            for name in LevelState.__slots__:    # allocated under the side stream, consumed on the main one
-                t = getattr(st0, name)
+            for name in ("depth", "std", "near_far", "feature_volume", "depth_values"):
+                t = getattr(st0, name)           # allocated under the side stream, consumed on the main one
                 if t is not None:
                     t.record_stream(main)
         feats = {"level_0": level0, "level_1": f1.reshape(B, V, -1, H // 2, W // 2),
@@ -250,7 +270,10 @@ class Network(nn.Module):
         self.ensure_rays(batch)
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         st0 = None
-        if self.overlap_front and engine_ok(self.feature_net, batch["src_inps"]):
+        if self._side_stream is None and batch["src_inps"].is_cuda:
+            self._side_stream = torch.cuda.Stream()          # created outside any capture
+        if (self.overlap_front and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
+                and engine_ok(self.feature_net, batch["src_inps"])):
             feats, st0 = self._front_overlapped(batch, views)
         else:
             feats = self.forward_feat(batch["src_inps"])
