@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_
 sweep_win_kernel(const WinArgs a) {
   constexpr int NT = TXW * TYH * DP, NW = NT / 64;
   static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
-  static_assert((TXW * TYH) % 64 == 0, "a wave covers 64 voxels of ONE plane");
+  static_assert((TXW * TYH) % 32 == 0, "a half wave covers 32 voxels of ONE plane");
   static_assert(8 * S <= 64, "corner lanes");
   __shared__ float2 slots[NW];
   extern __shared__ __attribute__((aligned(64))) char win[];  // NB windows of cap records (64 B each)
@@ -137,7 +137,8 @@ sweep_win_kernel(const WinArgs a) {
   const int kx = blockIdx.x >> 3;
   const int chh0 = kx & (a.chalves - 1);         // chalves is 1 or 2 (1 when the halves are done in-kernel)
   const int pg = kx >> (a.chalves - 1);
-  const int j = (int)__umulhi((unsigned)blockIdx.y, (unsigned)a.tiles_x_magic);   // blockIdx.y / tiles_x
+  // blockIdx.y / tiles_x (magic 0 = one tile column: 2^32 / 1 + 1 does not fit the multiplier)
+  const int j = a.tiles_x_magic ? (int)__umulhi((unsigned)blockIdx.y, (unsigned)a.tiles_x_magic) : (int)blockIdx.y;
   const int tx = blockIdx.y - j * a.tiles_x;
   const int ty = band * a.tyb + j;
   if (ty * TYH >= a.h) return;  // whole workgroup, before any barrier
@@ -518,6 +519,10 @@ const Variant kVariants[] = {
     {32, 2, 8, 2, 640},   // 13
     {32, 4, 1, 1, 256},   // 14
     {32, 2, 2, 2, 320},   // 15
+    {16, 2, 8, 2, 256},   // 16: 256 threads x 8 planes (a wave = two planes of 32 voxels): 5 workgroups per CU
+    {16, 2, 8, 1, 448},   // 17: the level-0 default (23.3 us against 27.4 for the 512-thread tile 9)
+    {16, 2, 8, 1, 320},   // 18
+    {32, 1, 8, 1, 448},   // 19: rows of 32 voxels (whole 128-byte lines): 26.9 us
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -564,8 +569,10 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   if ((size_t)C * D * h * w * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;        // 32-bit volume offsets
   if (variant < 0) {
     // default by the source / volume scale: same resolution (cascade level 1: neighbours in a plane share texels)
-    // or finer source (level 0: the planes of a pixel share texels along its epipolar line)
-    variant = (float)Ws / (float)w <= 1.5f ? 0 : 9;
+    // or finer source (level 0: the planes of a pixel share texels along its epipolar line: 8 planes per workgroup, and
+    // 256-thread workgroups -- a wave is two planes of 16 x 2 voxels -- so that 5 are resident per CU: 2560 workgroups
+    // are two rounds of the chip where the 512-thread tile 9 needed 2.5)
+    variant = (float)Ws / (float)w <= 1.5f ? 0 : 17;
   }
   if (variant >= kNumVariants) return BMV_ERR_UNSUPPORTED;
   Variant v = kVariants[variant];
@@ -589,7 +596,7 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   if (C == 32 && S == 3 && v.txw == 16 && v.tyh == 4 && v.dp == 8 && getenv("BMV_SWEEP_WIN_NH") && atoi(getenv("BMV_SWEEP_WIN_NH")) == 2)
     a.nh = 2, a.chalves = 1;
   a.cap = v.cap;
-  a.tiles_x_magic = (unsigned)(((unsigned long long)1 << 32) / (unsigned)a.tiles_x) + 1u;
+  a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)(((unsigned long long)1 << 32) / (unsigned)a.tiles_x) + 1u;
   if (a.tiles_x * a.tyb >= 65536) return BMV_ERR_UNSUPPORTED;
   a.flags = 0;
   if (const char* e = getenv("BMV_SWEEP_WIN_FLAGS")) a.flags = atoi(e);
@@ -612,6 +619,9 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   V(32, 2, 8, 2)
   V(32, 4, 1, 1)
   V(32, 2, 2, 2)
+  V(16, 2, 8, 2)
+  V(16, 2, 8, 1)
+  V(32, 1, 8, 1)
 #undef V
   if (rc != BMV_OK) return rc;
   BMV_LAUNCH_END("bmv_sweep_variance_fwd(win)");

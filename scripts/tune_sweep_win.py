@@ -73,7 +73,7 @@ def timed(fn, iters, per_graph=20):
     return s.elapsed_time(e) / (reps * per_graph) * 1e3
 
 
-variants = [int(v) for v in a.variants.split(",") if v] or list(range(16))
+variants = [int(v) for v in a.variants.split(",") if v] or list(range(20))
 caps = [int(c) for c in a.caps.split(",") if c] or [0]
 for lvl, (impl, args, kwargs) in enumerate(calls):
     feats, proj, dv = args[:3]
