@@ -88,6 +88,13 @@ def parse():
     ap.add_argument("--pipelined", action="store_true",
                     help="do not synchronize after every timed step (the un-bracketed replay rate; NOT the run.py metric)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="graph replay: the frame with event brackets is replayed on every Nth timed step, the same "
+                         "frame captured without them on the others (six event records cost a 1 ms frame ~3 %%); 1 = "
+                         "brackets on every step")
+    ap.add_argument("--cut-sweeps", action="store_true",
+                    help="graph replay: keep the plane sweeps as ordinary launches between graphs (round 1's way of "
+                         "timing them) instead of event-record nodes inside one graph")
     ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1: let MIOpen search its convolution solvers (torch.backends.cudnn.benchmark).  Only the "
@@ -334,15 +341,33 @@ def main():
     if args.graph and not wl.get("train") and not args.all_kernel_events and wl["net"] in ("enerf", "boost_enerf"):
         try:
             from boostmvsnerfs_amd.framegraph import FrameGraph
-            fg = FrameGraph(net, batch, cut=None if args.no_kernel_events else "all")
-            replay = fg.replay
+            # the kernels of `roofline` are bracketed by event-record nodes INSIDE the one graph of a frame
+            # (csrc/timing.hip); --cut-sweeps restores round 1's form (the sweeps as ordinary launches between graphs)
+            ktimer.forget_graph_events()
+            sampled = {"n": 0, "every": 1, "evented": True}
+            if args.cut_sweeps and not args.no_kernel_events:
+                fg = FrameGraph(net, batch, cut="all")
+                replay = fg.replay
+            else:
+                fg = FrameGraph(net, batch, cut=None, events=not args.no_kernel_events)
+                replay = fg.replay
+                if fg.events and args.event_every > 1:
+                    fg_plain = FrameGraph(net, batch, cut=None)        # same frame, no brackets
+                    sampled["every"] = args.event_every
+
+                    def replay():   # noqa: F811
+                        sampled["evented"] = sampled["n"] % sampled["every"] == 0
+                        sampled["n"] += 1
+                        return fg.replay() if sampled["evented"] else fg_plain.replay()
 
             def step():   # noqa: F811
                 with torch.no_grad():
                     return finish(replay())
             for _ in range(2):
                 step()
-            graph_note = f"{len(fg.graphs)} graph(s)" + (f" + {len(fg.sweeps)} eager plane sweep(s)" if fg.sweeps else "")
+            graph_note = f"{len(fg.graphs)} graph(s)" + (f" + {len(fg.sweeps)} eager plane sweep(s)" if fg.sweeps else "") \
+                + (f" with in-graph event brackets on every {sampled['every']}. step" if fg.events and sampled["every"] > 1
+                   else " with in-graph event brackets" if fg.events else "")
         except Exception as e:   # keep the eager path: the bench must still produce its line
             print(f"[bench] HIP-graph capture failed, staying eager: {type(e).__name__}: {e}", file=sys.stderr)
             graph_note = f"capture failed ({type(e).__name__})"
@@ -415,6 +440,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if step is not eager_step:
+        sampled["n"] = 0               # the first timed step carries the brackets
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -422,6 +449,8 @@ def main():
             if gather is not None:
                 gather.flush()
             torch.cuda.synchronize()       # the reference's per-step bracket (run.py:117-123)
+            if step is eager_step or sampled["evented"]:
+                ktimer.collect()           # in-graph event brackets of the replay that just finished
     if gather is not None:
         gather.flush()                 # every exchange issued in the timed region completes inside it
     torch.cuda.synchronize()
@@ -429,6 +458,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.pipelined:
+        ktimer.collect()               # no per-step synchronize: the brackets of the last replay only
     ktimer.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

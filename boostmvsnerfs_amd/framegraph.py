@@ -10,6 +10,11 @@ sweep issued on the capture stream): the graphs hold everything between them and
 stay ordinary launches, so HIP events on the stream can time exactly those kernels inside a timed region
 (bench.py's `roofline`).  `cut=None` captures the frame as one graph.
 
+`events=True` (with `cut=None`): the kernels `ktimer` is set to time are bracketed INSIDE the graph by event-record
+nodes (csrc/timing.hip), so the frame stays one graph and the brackets cost no graph boundary (a cut costs the frame
+~20 us of idle stream per sweep: end of graph -> event -> launch -> event -> next graph).  `ktimer.collect()` after
+a synchronize reads the brackets of the replay that just finished.
+
 The batch tensors are the graph's static inputs: refresh them in place (`copy_`) between replays.  The
 returned dict holds the static output tensors of the captured pass.
 """
@@ -21,9 +26,12 @@ from . import ktimer, ops
 
 
 class FrameGraph:
-    def __init__(self, net, batch, cut=-1, warmup=2):
+    def __init__(self, net, batch, cut=-1, warmup=2, events=False):
+        if events and cut is not None:
+            raise ValueError("FrameGraph: in-graph event brackets are for the uncut capture (cut=None)")
         self.net, self.batch = net, batch
         self.cut = cut
+        self.events = events
         self.graphs = []
         self.sweeps = []            # (impl, args, kwargs) of the eager sweep launched after graph i
         self.out = None
@@ -81,9 +89,11 @@ class FrameGraph:
                 ops.sweep_hook = hook
                 try:
                     g_a.capture_begin(capture_error_mode="thread_local")
+                    ktimer.enabled = self.events          # brackets become event-record nodes of the graph
                     try:
                         self.out = self.net(self.batch)
                     finally:
+                        ktimer.enabled = False
                         self.graphs[-1].capture_end()
                 finally:
                     ops.sweep_hook = None

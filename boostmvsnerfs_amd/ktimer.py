@@ -1,23 +1,74 @@
 """Optional per-kernel timing with HIP events on the stream the kernels run on
 (torch's current stream).  Off by default; bench.py switches it on so the
-roofline numbers come from the timed region itself."""
+roofline numbers come from the timed region itself.
+
+Two kinds of bracket:
+* eager launches: a pair of events per launch, read after a device synchronize (`summary`);
+* launches captured into a HIP graph (`framegraph.FrameGraph(events=True)`): ONE pair per captured launch, recorded
+  as event-record nodes of the graph (`bmv_event_record`, csrc/timing.hip: torch refuses event records during
+  capture on ROCm).  Every replay re-stamps the pair; `collect()` -- after a synchronize, before the next replay --
+  appends the durations of the replay that just finished.
+"""
 import contextlib
+import ctypes
 
 import torch
 
 enabled = False
 only = None          # optional tuple of name prefixes: time just these kernels (two event records cost ~10 us of host time)
-_records = {}
+_records = {}        # name -> [(start, end)] torch events of eager launches
+_graph_pairs = {}    # name -> [(start, end)] events living in captured graphs
+_graph_us = {}       # name -> [us] collected from the graph pairs
+
+
+class _Event:
+    """hipEvent_t through the C-ABI (works under stream capture, see the module docstring)."""
+
+    def __init__(self):
+        from . import _lib
+        self._lib = _lib
+        self.h = ctypes.c_void_p()
+        _lib.check(_lib.load().bmv_event_create(ctypes.byref(self.h)), "bmv_event_create")
+
+    def record(self):
+        self._lib.check(self._lib.load().bmv_event_record(self.h, self._lib.stream()), "bmv_event_record")
+
+    def elapsed_us(self, end):
+        us = ctypes.c_float()
+        self._lib.check(self._lib.load().bmv_event_elapsed_us(self.h, end.h, ctypes.byref(us)), "bmv_event_elapsed_us")
+        return us.value
+
+    def __del__(self):
+        try:
+            self._lib.load().bmv_event_destroy(self.h)
+        except Exception:
+            pass
 
 
 def reset():
+    """Forget the collected durations (the event pairs of live graphs stay: they belong to the graphs)."""
     _records.clear()
+    _graph_us.clear()
+
+
+def forget_graph_events():
+    _graph_pairs.clear()
+    _graph_us.clear()
 
 
 @contextlib.contextmanager
 def region(name):
     if not enabled or (only is not None and not name.startswith(only)):
         yield
+        return
+    if torch.cuda.is_current_stream_capturing():
+        s, e = _Event(), _Event()
+        s.record()
+        try:
+            yield
+        finally:
+            e.record()
+            _graph_pairs.setdefault(name, []).append((s, e))
         return
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
@@ -29,10 +80,22 @@ def region(name):
         _records.setdefault(name, []).append((s, e))
 
 
+def collect():
+    """Durations of the in-graph brackets for the replay that just completed (call after a synchronize)."""
+    if not enabled:
+        return
+    for name, pairs in _graph_pairs.items():
+        if only is not None and not name.startswith(only):
+            continue
+        _graph_us.setdefault(name, []).extend(s.elapsed_us(e) for s, e in pairs)
+
+
 def summary():
     """name -> (launches, mean ms, min ms); call after a device synchronize."""
     out = {}
-    for name, evs in _records.items():
-        ms = [s.elapsed_time(e) for s, e in evs]
-        out[name] = (len(ms), sum(ms) / len(ms), min(ms))
+    names = set(_records) | set(_graph_us)
+    for name in names:
+        ms = [s.elapsed_time(e) for s, e in _records.get(name, [])] + [u * 1e-3 for u in _graph_us.get(name, [])]
+        if ms:
+            out[name] = (len(ms), sum(ms) / len(ms), min(ms))
     return out

@@ -272,7 +272,8 @@ class Network(nn.Module):
         st0 = None
         if self._side_stream is None and batch["src_inps"].is_cuda:
             self._side_stream = torch.cuda.Stream()          # created outside any capture
-        if (self.overlap_front and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
+        if (self.overlap_front and batch["src_inps"].is_cuda
+                and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
                 and engine_ok(self.feature_net, batch["src_inps"])):
             feats, st0 = self._front_overlapped(batch, views)
         else:

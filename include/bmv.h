@@ -393,6 +393,17 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 int bmv_make_rays(const float* tar_ext, const float* tar_ixt, int B, int h, int w, double scale, float* rays,
                   bmv_stream_t stream);
 
+/* ==== section 8(d): HIP-event brackets that work inside HIP-graph capture ====================================
+ * The reference times a frame with torch.cuda.synchronize brackets (run.py:117-123); the per-kernel durations of the
+ * roofline figures come from HIP events on the launch stream.  bmv_event_record on a stream that is CAPTURING adds an
+ * event-record node to the graph being captured (every replay stamps the event at that point); otherwise it is
+ * hipEventRecord.  bmv_event_elapsed_us needs both events complete (synchronise first). */
+typedef void* bmv_event_t; /* hipEvent_t */
+int bmv_event_create(bmv_event_t* ev);
+int bmv_event_destroy(bmv_event_t ev);
+int bmv_event_record(bmv_event_t ev, bmv_stream_t stream);
+int bmv_event_elapsed_us(bmv_event_t start, bmv_event_t end, float* us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,52 @@ def test_boost_replay_equals_eager(tmp_path):
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_event_brackets_inside_a_graph():
+    """FrameGraph(events=True): the sweeps and the renderer are bracketed by event-record nodes of the ONE graph
+    (csrc/timing.hip; bench.py's roofline durations).  The replay returns the eager result, every replay re-stamps the
+    brackets, and a bracket reads a plausible duration: positive, and no longer than the whole replay."""
+    import time
+
+    from boostmvsnerfs_amd import ktimer
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.framegraph import FrameGraph
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    cfg = make_cfg("enerf_eval")
+    cfg.enerf.cas_config.volume_planes = [16, 8]
+    set_cfg(cfg)
+    torch.manual_seed(0)
+    net = Network().eval().to(DEV)
+    batch = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    want = _eager(net, batch)
+    ktimer.reset()
+    ktimer.forget_graph_events()
+    ktimer.only = ("sweep_variance", "render_rays")
+    try:
+        fg = FrameGraph(net, batch, cut=None, events=True)
+        assert len(fg.graphs) == 1 and not fg.sweeps
+        ktimer.enabled = True
+        walls = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = fg.replay()
+            torch.cuda.synchronize()
+            walls.append((time.perf_counter() - t0) * 1e3)
+            ktimer.collect()
+        ks = ktimer.summary()
+    finally:
+        ktimer.enabled, ktimer.only = False, None
+        ktimer.forget_graph_events()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    sweeps = {n: v for n, v in ks.items() if n.startswith("sweep_variance")}
+    render = {n: v for n, v in ks.items() if n.startswith("render_rays")}
+    assert len(sweeps) == 2 and len(render) == 1, ks
+    for name, (launches, mean_ms, min_ms) in ks.items():
+        assert launches == 3, (name, launches)
+        assert 0.0 < min_ms <= mean_ms < max(walls), (name, mean_ms, walls)
+    with pytest.raises(ValueError):
+        FrameGraph(net, batch, cut=-1, events=True)
