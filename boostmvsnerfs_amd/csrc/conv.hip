@@ -530,10 +530,10 @@ void conv_splitk_kernel(ConvArgs a) {
   for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* ap = lds + (wave * 4 + (lane >> 4)) * T::PS + (lane & 15) * S;
-  for (int stage = 0; stage < nstage; ++stage) {
-    // 16 channels of the tile; channels past Cin (last stage) must read as 0: the offsets stay below 2^31 because
-    // (Cin + 15) * plane * 4 is checked on the host
-    float pre[16][T::NSLOT];
+  // 16 channels of the tile -> registers; channels past Cin (last stage) must read as 0: the offsets stay below 2^31
+  // because (Cin + 15) * plane * 4 is checked on the host
+  float pre[16][T::NSLOT];
+  auto load_stage = [&](int stage) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int ch = stage * 16 + c;
@@ -543,12 +543,28 @@ void conv_splitk_kernel(ConvArgs a) {
         pre[c][j] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ch < a.Cin ? goff[j] + cb : 0x80000000u, 0, 0));
     }
-    const int ks = stage * 4 + wave;  // this wave's k-step
-    float wv[T::TAPS];
+  };
+  // taps whose input plane lies outside the volume multiply zeros: the deep levels are 1-2 planes thick, so up to 2/3
+  // of a 3x3x3 filter (wave-uniform: a workgroup is one output plane)
+  bool zin[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) zin[kd] = !IS3D || (iz0 + kd >= 0 && iz0 + kd < a.D);
+  // stride 1: the loads of stage s + 1 are in flight during the MFMAs of stage s (the tile registers are free once
+  // they are in LDS); the stride-2 tile is 64 registers in a 256-register kernel and stays single-buffered
+  constexpr bool PREFETCH = false;   // tried twice (tile only; tile + weights double-buffered): slower, see DESIGN 4.7
+  float wv[T::TAPS], wnext[T::TAPS];
+  auto load_w = [&](int stage, float (&w)[T::TAPS]) {   // this wave's k-step of the stage
+    const int ks = stage * 4 + wave;
     if (ks < nk) {
 #pragma unroll
-      for (int t = 0; t < T::TAPS; ++t) wv[t] = wp[(size_t)ks * (T::TAPS * 64) + t * 64];
+      for (int t = 0; t < T::TAPS; ++t)
+        if (zin[t / (K * K)]) w[t] = wp[(size_t)ks * (T::TAPS * 64) + t * 64];
     }
+  };
+  if (PREFETCH) load_stage(0), load_w(0, wv);
+  for (int stage = 0; stage < nstage; ++stage) {
+    if (!PREFETCH) load_stage(stage), load_w(stage, wv);
+    const int ks = stage * 4 + wave;
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 16; ++c)
@@ -556,9 +572,13 @@ void conv_splitk_kernel(ConvArgs a) {
       for (int j = 0; j < T::NSLOT; ++j)
         if ((j + 1) * 256 <= T::SLOTS || tid + 256 * j < T::SLOTS) lds[c * T::PS + tid + 256 * j] = pre[c][j];
     __syncthreads();
+    // the weights of a deep layer are cold in L2 when it starts (a first-touch read is ~2 us): next stage's are
+    // requested a whole stage ahead, like the tile
+    if (PREFETCH && stage + 1 < nstage) load_stage(stage + 1), load_w(stage + 1, wnext);
     if (ks < nk) {
 #pragma unroll
-      for (int kd = 0; kd < KD; ++kd)
+      for (int kd = 0; kd < KD; ++kd) {
+        if (!zin[kd]) continue;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh)
 #pragma unroll
@@ -569,6 +589,11 @@ void conv_splitk_kernel(ConvArgs a) {
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r], 0,
                                                             0, 0);
           }
+      }
+    }
+    if (PREFETCH) {
+#pragma unroll
+      for (int t = 0; t < T::TAPS; ++t) wv[t] = wnext[t];
     }
   }
 #pragma unroll
@@ -641,6 +666,7 @@ void convT3d_splitk_kernel(ConvArgs a) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = lds + (wave * 4 + (lane >> 4)) * PS + (lane & 15);
+  const bool z1 = mz + 1 < a.D;   // the second input plane exists (else its taps multiply zeros)
   for (int stage = 0; stage < nstage; ++stage) {
     float pre[16];
 #pragma unroll
@@ -666,17 +692,19 @@ void convT3d_splitk_kernel(ConvArgs a) {
       for (int q = 0; q < 8; ++q) {
         const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
 #pragma unroll
-        for (int dz = 0; dz <= pz; ++dz)
+        for (int dz = 0; dz <= pz; ++dz) {
+          const int kz = pz ? 2 * dz : 1, oz = pz ? 1 - dz : 0;
+          if (oz == 1 && !z1) continue;
 #pragma unroll
           for (int dy = 0; dy <= py; ++dy)
 #pragma unroll
             for (int dx = 0; dx <= px; ++dx) {
-              const int kz = pz ? 2 * dz : 1, oz = pz ? 1 - dz : 0;
               const int ky = py ? 2 * dy : 1, oy = py ? 1 - dy : 0;
               const int kx = px ? 2 * dx : 1, ox = px ? 1 - dx : 0;
               acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[(kz * 3 + ky) * 3 + kx], ap[(oz * 2 + oy) * RS + ox],
                                                             acc[q], 0, 0, 0);
             }
+        }
       }
     }
   }

@@ -283,6 +283,63 @@ __global__ void __launch_bounds__(64) depth_regress_kernel(const float* __restri
   std_[(size_t)b * hw + i] = sqrtf(fmaxf(var, 1e-10f));
 }
 
+// The coarse level (64 planes on a few thousand pixels) is 80 one-wave workgroups for the kernel above, each issuing
+// ~2500 dependent instructions: latency, not throughput.  Here a pixel is FOUR lanes (16 planes each; lane = pixel %
+// 16 + 16 * quarter, so a plane's 16 pixels are one 64-byte run), the four partial results meet by two shuffles.
+template <int DT>
+__global__ void __launch_bounds__(64) depth_regress_quad_kernel(const float* __restrict__ prob,
+                                                                 const float* __restrict__ dv, int hw, int depth_inv,
+                                                                 float* __restrict__ depth, float* __restrict__ std_) {
+  static_assert(DT % 4 == 0, "planes per quarter");
+  constexpr int Q = DT / 4;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x, q = lane >> 4;
+  const int i = blockIdx.x * 16 + (lane & 15);
+  const int ic = i < hw ? i : hw - 1;
+  const float* p = prob + ((size_t)b * DT + q * Q) * hw + ic;
+  const float* v = dv + ((size_t)b * DT + q * Q) * hw + ic;
+  float e[Q], val[Q];
+#pragma unroll
+  for (int d = 0; d < Q; ++d) {
+    e[d] = p[(size_t)d * hw];
+    val[d] = v[(size_t)d * hw];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int d = 0; d < Q; ++d) mx = fmaxf(mx, e[d]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float den = 0.f;
+#pragma unroll
+  for (int d = 0; d < Q; ++d) {
+    e[d] = expf(e[d] - mx);
+    den += e[d];
+    if (depth_inv) val[d] = 1.f / fmaxf(val[d], 1e-6f);
+  }
+  den += __shfl_xor(den, 16);
+  den += __shfl_xor(den, 32);
+  float mean = 0.f, var = 0.f;
+#pragma unroll
+  for (int d = 0; d < Q; ++d) {
+    e[d] = e[d] / den;
+    mean += e[d] * val[d];
+  }
+  mean += __shfl_xor(mean, 16);
+  mean += __shfl_xor(mean, 32);
+#pragma unroll
+  for (int d = 0; d < Q; ++d) {
+    float df = val[d] - mean;
+    var += e[d] * (df * df);
+  }
+  var += __shfl_xor(var, 16);
+  var += __shfl_xor(var, 32);
+  if (q == 0 && i < hw) {
+    depth[(size_t)b * hw + i] = mean;
+    std_[(size_t)b * hw + i] = sqrtf(fmaxf(var, 1e-10f));
+  }
+}
+
+
 }  // namespace bmv
 
 using namespace bmv;
@@ -439,6 +496,11 @@ int bmv_depth_regress_fwd(const float* depth_prob, const float* depth_values, in
 #define DR(DT)                                                                                                 \
   hipLaunchKernelGGL(depth_regress_kernel<DT>, dim3(cdiv(h * w, 64), B), dim3(64), 0, as_stream(stream), depth_prob, \
                      depth_values, D, h * w, depth_inv, depth, std_)
+  if (D == 64 && h * w <= 65536) {   // coarse level: four lanes per pixel
+    hipLaunchKernelGGL(depth_regress_quad_kernel<64>, dim3(cdiv(h * w, 16), B), dim3(64), 0, as_stream(stream),
+                       depth_prob, depth_values, h * w, depth_inv, depth, std_);
+    BMV_LAUNCH_END("bmv_depth_regress_fwd");
+  }
   switch (D) {
     case 8: DR(8); break;
     case 16: DR(16); break;

@@ -65,6 +65,23 @@ def test_depth_regress(ops, enerf_fx):
         assert_close(s, enerf_fx.t(f"cap/depth_regression#{lvl}.1"), rtol=1e-4, atol_scale=1e-5, name=f"std{lvl}")
 
 
+@pytest.mark.parametrize("D,h,w,inv", [(64, 64, 80, True), (64, 7, 9, True), (64, 5, 13, False), (32, 6, 10, True),
+                                        (12, 5, 7, False)])
+def test_depth_regress_all_plane_counts(ops, D, h, w, inv):
+    """a5 at the plane counts of the shipped configs: 64 planes on a small map take the four-lanes-per-pixel kernel
+    (ragged pixel counts: the last 16-pixel group is partial), 32 / 8 the one-thread kernels, 12 the generic loop."""
+    from oracle import enerf as O
+    torch.manual_seed(D + h)
+    prob = torch.randn(2, D, h, w) * 3
+    prob[0, :, 0, 0] = -40.0                       # a pixel whose logits are all equal and tiny
+    prob[1, D // 2, 1, 1] = 60.0                   # a one-hot pixel
+    dv = torch.rand(2, D, h, w) * 3 + 0.5
+    want_d, want_s = O.depth_regress(prob, dv, inv)
+    d, s = ops.depth_regress(prob.to(DEV), dv.to(DEV), inv)
+    assert_close(d, want_d, rtol=1e-5, atol_scale=0, name="depth")
+    assert_close(s, want_s, rtol=1e-4, atol_scale=1e-5, name="std")
+
+
 def test_rays_and_samples(ops, enerf_fx):
     b = enerf_fx.batch(DEV)
     c = tiny_cfg(enerf_fx).enerf.cas_config
