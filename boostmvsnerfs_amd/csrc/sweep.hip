@@ -86,28 +86,30 @@ __global__ void proj_mats_kernel(const float* __restrict__ src_exts, const float
 // ---------------------------------------------------------------------------
 // a2
 // ---------------------------------------------------------------------------
+// grid.z = groups of 8 planes (a 64-plane level on a 64 x 80 map is otherwise 20 workgroups of 64 divisions per thread)
 __global__ void depth_values_uniform_kernel(const float* __restrict__ near_far, int D, int hw, int depth_inv,
                                             float* __restrict__ dv, float* __restrict__ nf_out) {
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
   float n = near_far[b * 2], f = near_far[b * 2 + 1];
-  float first = 0.f, last = 0.f;
   float step = D > 1 ? 1.f / (float)(D - 1) : 0.f;
-  for (int d = 0; d < D; ++d) {
+  auto value = [&](int d) {
     // torch.linspace(0, 1, D): start + d*step for the first half, end - (D-1-d)*step after
     float t = d < D / 2 ? (float)d * step : 1.f - (float)(D - 1 - d) * step;
-    float v = depth_inv ? 1.f / (1.f / n + t * (1.f / f - 1.f / n)) : n + (f - n) * t;
-    dv[((size_t)b * D + d) * hw + i] = v;
-    if (d == 0) first = v;
-    if (d == D - 1) last = v;
+    return depth_inv ? 1.f / (1.f / n + t * (1.f / f - 1.f / n)) : n + (f - n) * t;
+  };
+  const int d0 = blockIdx.z * 8, d1 = min(D, d0 + 8);
+  for (int d = d0; d < d1; ++d) dv[((size_t)b * D + d) * hw + i] = value(d);
+  if (blockIdx.z == 0) {
+    float first = value(0), last = value(D - 1);
+    if (depth_inv) {
+      first = 1.f / fmaxf(first, 1e-6f);
+      last = 1.f / fmaxf(last, 1e-6f);
+    }
+    nf_out[((size_t)b * 2 + 0) * hw + i] = first;
+    nf_out[((size_t)b * 2 + 1) * hw + i] = last;
   }
-  if (depth_inv) {
-    first = 1.f / fmaxf(first, 1e-6f);
-    last = 1.f / fmaxf(last, 1e-6f);
-  }
-  nf_out[((size_t)b * 2 + 0) * hw + i] = first;
-  nf_out[((size_t)b * 2 + 1) * hw + i] = last;
 }
 
 __global__ void depth_values_cascade_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
@@ -362,7 +364,7 @@ int bmv_depth_values_uniform(const float* near_far, int B, int D, int h, int w, 
                              float* near_far_out, bmv_stream_t stream) {
   BMV_REQUIRE(near_far && depth_values && near_far_out, "bmv_depth_values_uniform: null pointer");
   BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bmv_depth_values_uniform: bad shape");
-  hipLaunchKernelGGL(depth_values_uniform_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(depth_values_uniform_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8)), dim3(256), 0, as_stream(stream),
                      near_far, D, h * w, depth_inv, depth_values, near_far_out);
   BMV_LAUNCH_END("bmv_depth_values_uniform");
 }
