@@ -326,7 +326,7 @@ def main():
         dist.barrier()
     # ---- warm-up (eager).  The first step pays module loads / allocator growth: kernel events start after it.
     ktimer.reset()
-    ktimer.only = ("render_rays", "mvs_render", "sweep_variance", "mvs_sweep")
+    ktimer.only = ("render_rays", "mvs_render", "sweep_variance", "mvs_sweep", "empty_bracket")
     for i in range(args.warmup):
         ktimer.enabled = (not args.no_kernel_events) and i > 0
         step()
@@ -435,7 +435,7 @@ def main():
     ktimer.enabled = not args.no_kernel_events
     # HIP events around the kernels the roofline objects are built from; --all-kernel-events times every launch
     # (two event records per launch: ~0.3 ms of host time per frame, the frame is then host-bound)
-    ktimer.only = None if args.all_kernel_events else ("sweep_variance", "render_rays", "mvs_render", "mvs_sweep")
+    ktimer.only = None if args.all_kernel_events else ("sweep_variance", "render_rays", "mvs_render", "mvs_sweep", "empty_bracket")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -504,6 +504,11 @@ def main():
                             "achieved": L["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": L["frac"],
                             "traffic": L["traffic"], "algorithmic_bytes": L["algorithmic_bytes"], "avg_us": L["avg_us"],
                             "launches": L["launches"], "levels": levels}
+                if "empty_bracket" in kernels:
+                    # what the same pair of event records reads with NOTHING between them in the same graph: every
+                    # bracket includes a share of it (rocprofv3's own begin/end stamps of the sweeps read ~4 us less
+                    # than the brackets); reported, not subtracted
+                    roofline["event_bracket_empty_us"] = kernels["empty_bracket"]["avg_us"]
             rname = next((n for n in kernels if n.startswith("render_rays[feat=8")), None)
             if rname:
                 rays_launch = N // world if (args.shard == "rays" and world > 1) else N
