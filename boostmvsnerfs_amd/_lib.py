@@ -109,6 +109,7 @@ SIGNATURES = {
     "bmv_bn_chunks": [c_i, c_l],
     "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f],
     "bmv_bn_train_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_f, c_f, c_f, c_f, c_f],
+    "bmv_fpn_smooth_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "bmv_event_create": [C.POINTER(C.c_void_p)],
     "bmv_event_destroy": [C.c_void_p],
     "bmv_event_record": [C.c_void_p, C.c_void_p],

@@ -134,6 +134,25 @@ def fpn_topdown(fine, coarse, weight, bias, out=None):
     return out
 
 
+def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None):
+    """conv3x3(bilinear_x2(coarse, align_corners=True) + conv1x1(fine, lat_weight, lat_bias); wpack, bias) -> (B,Cout,H,W):
+    FeatureNet's last top-down step and the smoothing conv that consumes it as ONE launch (the 32-channel
+    full-resolution map between them is never written).  wpack / bias: `pack_conv` of the 3x3 layer (Cout <= 8)."""
+    B, Cf, H, W = fine.shape
+    C = coarse.shape[1]
+    assert coarse.shape == (B, C, H // 2, W // 2)
+    if out is None:
+        out = torch.empty(B, Cout, H, W, device=fine.device, dtype=torch.float32)
+    w = lat_weight.detach().reshape(C, Cf).contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"fpn_smooth[{Cf}+{C}->{Cout},{H}x{W}]"):
+        rc = lib.bmv_fpn_smooth_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"), dptr(w, "w_lat"),
+                                    dptr(lat_bias.detach().contiguous(), "b_lat"), dptr(wpack, "wpack"), dptr(bias, "bias"),
+                                    dptr(out), B, Cf, C, Cout, H, W, 1.0, stream())
+    _lib.check(rc, "fpn_smooth_fwd")
+    return out
+
+
 def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):
     """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
     ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout))."""

@@ -474,6 +474,170 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE
 }
 
 // ---------------------------------------------------------------------------------------------------
+// FPN top-down step FUSED into the smoothing convolution that consumes it (feature_net.py:24-36: smooth0(p0) with
+// p0 = bilinear_x2(p1) + lat0(c0)): p0 is 32 channels at full resolution -- 126 MB written by the top-down kernel and
+// read back by the 3x3 convolution at 512x640x3 views -- and exists only between the two.  Here the convolution's
+// tile producer builds the 4-channel chunk of p0 it is about to consume: the coarse tile of the chunk goes to LDS
+// (double-buffered, ~13x tap reuse), each thread evaluates its tile slots with exactly the expression of
+// fpn_topdown_kernel (bias, 8 lateral FMAs in order, the bilinear term) and writes them where the plain kernel's
+// loads would have landed; slots outside the image are the convolution's zero padding.  The MFMA part is
+// conv_mfma_kernel<1,3,1,1,R,0,PAIR> unchanged (row pairing, 8 output channels).
+// ---------------------------------------------------------------------------------------------------
+struct FpnSmoothArgs {
+  const float* fine;    // (B, 8, H, W)
+  const float* coarse;  // (B, C, H/2, W/2) planar
+  const float* wlat;    // (C, 8)
+  const float* blat;    // (C)
+  const float* wpack;   // smoothing conv, row-paired pack
+  const float* bias;    // (16)
+  float* out;           // (B, Cout, H, W)
+  int B, C, Cout, H, W;
+  float slope;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
+  using T = ConvTile<1, 3, 1, 1, R, 0, true>;
+  constexpr int CF = 8;
+  constexpr int CH = T::TYH / 2 + 3, CW = T::RS / 2 + 3, CN = CH * CW;   // coarse rows / columns under a tile
+  static_assert(CN <= 256, "one coarse texel per thread");
+  __shared__ float lds[4 * T::PS];
+  __shared__ float cl[2][4][CN];
+  const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
+  const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int ty = bid % nty;
+  const int b = bid / nty;
+  const int x0 = tx * 16, y0 = ty * T::TY;
+  const int ix0 = x0 - 1, iy0 = y0 - 1;
+  const int Hc = a.H / 2, Wc = a.W / 2;
+  const int hw = a.H * a.W, hwc = Hc * Wc;
+  // first coarse row / column any slot of the tile touches
+  const int cy0 = upsample_axis(max(iy0, 0), Hc, a.H).i0, cx0 = upsample_axis(max(ix0, 0), Wc, a.W).i0;
+
+  // this thread's tile slots: the fine-map values, the bilinear weights and the four tap offsets in the LDS coarse tile
+  float f[T::NSLOT][CF], l1y[T::NSLOT], l1x[T::NSLOT];
+  int o00[T::NSLOT], o01[T::NSLOT], o10[T::NSLOT], o11[T::NSLOT];
+  bool ok[T::NSLOT];
+  const float* fp = a.fine + (size_t)b * CF * hw;
+#pragma unroll
+  for (int j = 0; j < T::NSLOT; ++j) {
+    const int slot = tid + 256 * j;
+    const int sx = slot % T::RS, sy = slot / T::RS;
+    const int gx = ix0 + sx, gy = iy0 + sy;
+    ok[j] = (slot < T::SLOTS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    const int qx = ok[j] ? gx : 0, qy = ok[j] ? gy : 0;
+#pragma unroll
+    for (int i = 0; i < CF; ++i) f[j][i] = fp[(size_t)i * hw + qy * a.W + qx];
+    const Lerp1 ly = upsample_axis(qy, Hc, a.H), lx = upsample_axis(qx, Wc, a.W);
+    l1y[j] = ly.l1, l1x[j] = lx.l1;
+    const int ry0 = min(max(ly.i0 - cy0, 0), CH - 1), ry1 = min(max(ly.i1 - cy0, 0), CH - 1);
+    const int rx0 = min(max(lx.i0 - cx0, 0), CW - 1), rx1 = min(max(lx.i1 - cx0, 0), CW - 1);
+    o00[j] = ry0 * CW + rx0, o01[j] = ry0 * CW + rx1, o10[j] = ry1 * CW + rx0, o11[j] = ry1 * CW + rx1;
+  }
+  // coarse texel of this thread (one per channel of a chunk)
+  unsigned goffc = 0x80000000u;
+  if (tid < CN) {
+    const int cy = cy0 + tid / CW, cx = cx0 + tid % CW;
+    if (cy < Hc && cx < Wc) goffc = 4u * (unsigned)(cy * Wc + cx);
+  }
+  __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.coarse + (size_t)b * a.C * hwc), 0, (int)(4u * (unsigned)(a.C * hwc)), 0x00020000);
+  const int nchunk = a.C / 4;
+  const float* wp = a.wpack + lane;
+
+  f32x4 acc[T::NACC];
+#pragma unroll
+  for (int r = 0; r < T::NACC; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float cpre[4];
+  auto load_coarse = [&](int chunk) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      cpre[c] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rsc, goffc + 4u * (unsigned)((chunk * 4 + c) * hwc), 0, 0));
+  };
+  auto store_coarse = [&](int buf) {
+    if (tid < CN) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cl[buf][c][tid] = cpre[c];
+    }
+  };
+  load_coarse(0);
+  store_coarse(0);
+  if (nchunk > 1) load_coarse(1);
+  __syncthreads();
+
+  const float* ap = lds + (lane >> 4) * T::PS + rg * T::ROWBASE + (lane & 15);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // weights of this k-step: requested before the producer, consumed after the barrier
+    float wv[T::TAPS];
+#pragma unroll
+    for (int t = 0; t < T::TAPS; ++t) wv[t] = wp[(size_t)chunk * (T::TAPS * 64) + t * 64];
+    // p0 chunk -> LDS tile (previous MFMAs are behind the barrier at the end of the last iteration)
+    const int buf = chunk & 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = chunk * 4 + c;
+      const float bl = a.blat[ch];
+      const float* wl = a.wlat + ch * CF;
+#pragma unroll
+      for (int j = 0; j < T::NSLOT; ++j) {
+        if ((j + 1) * 256 > T::SLOTS && tid + 256 * j >= T::SLOTS) continue;
+        float v = bl;
+#pragma unroll
+        for (int i = 0; i < CF; ++i) v = fmaf(wl[i], f[j][i], v);
+        const float t00 = cl[buf][c][o00[j]], t01 = cl[buf][c][o01[j]], t10 = cl[buf][c][o10[j]], t11 = cl[buf][c][o11[j]];
+        const float l0x = 1.f - l1x[j], l0y = 1.f - l1y[j];
+        v += l0y * (l0x * t00 + l1x[j] * t01) + l1y[j] * (l0x * t10 + l1x[j] * t11);
+        lds[c * T::PS + tid + 256 * j] = ok[j] ? v : 0.f;
+      }
+    }
+    // next chunk's coarse tile into the other buffer (last read by the producer of chunk - 1, two barriers ago)
+    if (chunk + 1 < nchunk) {
+      store_coarse(buf ^ 1);
+      if (chunk + 2 < nchunk) load_coarse(chunk + 2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j <= 3; ++j)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float w = wv[j * 3 + kw];
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p)
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(2 * p + j) * T::RS + kw], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x0090);
+      }
+    __syncthreads();
+  }
+
+  // epilogue of the row-paired kernel: lane = output x, registers = 4 consecutive output channels of row y
+  const int x = x0 + (lane & 15);
+  const int g = lane >> 4;
+  const int co0 = 4 * (g & 1);
+  if (x >= a.W || co0 >= a.Cout) return;
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
+  const int ybase = y0 + rg * R;
+#pragma unroll
+  for (int r = 0; r < T::NACC; ++r) {
+    const int y = ybase + 2 * r + (g >> 1);
+    if (y >= a.H) continue;
+    const size_t o = (((size_t)b * a.Cout + co0) * a.H + y) * a.W + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[r][j] + bs[j];
+      v = fmaxf(v, 0.f) + a.slope * fminf(v, 0.f);
+      if (co0 + j < a.Cout) a.out[o + (size_t)j * hw] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Split-K tiling for the deep U-Net levels (a few thousand voxels, 32-64 channels): with one 4-row x 16-column
 // tile per workgroup those launches are a few hundred workgroups whose waves each walk ALL k-steps in sequence,
 // exposing one global-load latency per k-step (measured 16-30 % MFMA-pipe occupancy).  Here every wave covers all
@@ -933,6 +1097,31 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");
+}
+
+int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_lat, const float* b_lat,
+                       const float* wpack, const float* bias, float* out, int B, int Cf, int C, int Cout, int H, int W,
+                       float act_slope, bmv_stream_t stream) {
+  using namespace bmv;
+  BMV_REQUIRE(fine && coarse && w_lat && b_lat && wpack && bias && out, "fpn_smooth: null pointer");
+  BMV_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_smooth: bad shape");
+  BMV_REQUIRE(Cf == 8 && C % 4 == 0 && C > 0 && Cout > 0 && Cout <= 8,
+              "fpn_smooth: built for 8 lateral channels, C %% 4 == 0 and <= 8 output channels (Cf=%d, C=%d, Cout=%d)", Cf,
+              C, Cout);
+  BMV_REQUIRE((size_t)C * (H / 2) * (W / 2) < (1u << 29), "fpn_smooth: one coarse batch item must stay below 2 GiB");
+  FpnSmoothArgs a;
+  a.fine = fine, a.coarse = coarse, a.wlat = w_lat, a.blat = b_lat, a.wpack = wpack, a.bias = bias, a.out = out;
+  a.B = B, a.C = C, a.Cout = Cout, a.H = H, a.W = W, a.slope = act_slope;
+  static const int rows = getenv("BMV_FPN_SMOOTH_R") ? atoi(getenv("BMV_FPN_SMOOTH_R")) : 8;
+  hipStream_t st = as_stream(stream);
+  if (rows == 4) {
+    using T = ConvTile<1, 3, 1, 1, 4, 0, true>;
+    hipLaunchKernelGGL(fpn_smooth_kernel<4>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+  } else {
+    using T = ConvTile<1, 3, 1, 1, 8, 0, true>;
+    hipLaunchKernelGGL(fpn_smooth_kernel<8>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+  }
+  BMV_LAUNCH_END("fpn_smooth_fwd");
 }
 
 }  // extern "C"

@@ -36,6 +36,8 @@ def _engine_ok(module, x):
             and os.environ.get("BMV_CNN", "engine") != "torch")
 
 
+FUSE_FPN_SMOOTH = os.environ.get("BMV_FPN_FUSE", "1") == "1"
+
 class _Packed:
     """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
     bump `_version`; `.to()` / `.cuda()` replace storage and change `data_ptr`)."""
@@ -159,9 +161,13 @@ class FeatureNet(nn.Module):
         """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
-        p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
         f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last=True)
-        f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
+        if FUSE_FPN_SMOOTH:
+            # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written
+            f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0"], 8)
+        else:
+            p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
+            f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
         return f1.permute(0, 3, 1, 2), f0
 
     def _forward_engine(self, x):

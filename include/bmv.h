@@ -384,6 +384,15 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
                         int Cf, int C, int H, int W, int coarse_channels_last, bmv_stream_t stream);
 
+/* FPN top-down step fused into the smoothing convolution that consumes it (feature_net.py:24-36, smooth0(p0) with
+ * p0 = bilinear_x2(p1, align_corners=True) + lat0(c0)): out (B,Cout,H,W) = act(conv3x3(p0; wpack) + bias), p0
+ * (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2)) + conv1x1(fine (B,8,H,W); w_lat (C,8)) + b_lat built chunk by chunk
+ * in the convolution's tile producer and never written (C = 32 at full resolution is 126 MB per frame each way).
+ * wpack / bias: bmv_conv_pack_weights layout for (Cin = C, Cout <= 8, k = 3, stride 1: row-paired). */
+int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_lat, const float* b_lat,
+                       const float* wpack, const float* bias, float* out, int B, int Cf, int C, int Cout, int H, int W,
+                       float act_slope, bmv_stream_t stream);
+
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,
  * tar_ixt (B,3,3) at full resolution, render scale (rows 0-1 of the intrinsics are multiplied by it, :28-31) and the

@@ -106,6 +106,30 @@ def test_fpn_topdown(Cf, H, W):
     _close(convnet.fpn_topdown(fine, coarse, w, b), want)
 
 
+@pytest.mark.parametrize("H,W,rows", [(64, 96, 8), (34, 50, 8), (6, 70, 8), (64, 96, 4), (18, 22, 4)])
+def test_fpn_smooth_fused_equals_the_two_launches(H, W, rows, monkeypatch):
+    """bmv_fpn_smooth_fwd = smooth0(bilinear_x2(p1) + lat0(c0)) in one launch: against torch, and against the two
+    launches it replaces (same weights pack, same per-element expression for the intermediate map)."""
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(H + W)
+    fine = torch.randn(2, 8, H, W, generator=g).to(DEV)
+    coarse = torch.randn(2, 32, H // 2, W // 2, generator=g).to(DEV)
+    wl = torch.randn(32, 8, 1, 1, generator=g).to(DEV)
+    bl = torch.randn(32, generator=g).to(DEV)
+    ws = (torch.randn(8, 32, 3, 3, generator=g) / (32 * 9 / 8) ** 0.5).to(DEV)
+    bs = torch.randn(8, generator=g).to(DEV)
+    p0 = F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(fine, wl, bl)
+    want = F.conv2d(p0, ws, bs, padding=1)
+    wp, bp = convnet.pack_conv(ws, bs)
+    two = convnet.conv_fwd(convnet.fpn_topdown(fine, coarse, wl, bl), wp, bp, 8, 1, 3)
+    import os
+    if rows != int(os.environ.get("BMV_FPN_SMOOTH_R", "8")):
+        pytest.skip("the tile height is read once per process (BMV_FPN_SMOOTH_R): run the suite with it set to cover this case")
+    got = convnet.fpn_smooth(fine, coarse, wl, bl, wp, bp, 8)
+    _close(got, want)
+    assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
+
+
 def _randomise_bn(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
