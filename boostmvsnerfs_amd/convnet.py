@@ -134,23 +134,52 @@ def fpn_topdown(fine, coarse, weight, bias, out=None):
     return out
 
 
-def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None):
+class LookupRecords:
+    """(..., H, W, 12) per-pixel lookup records of the fused renderer for one or more source views:
+    [feature ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] (include/bmv.h, bmv_render_args.im_packed).  Stands where the planar
+    8-channel feature map would (`feats['level_2']`); the source colours ride along."""
+    EVEN_ODD = (0, 2, 4, 6, 1, 3, 5, 7)      # output-channel order the smoothing conv's weights are packed in
+
+    def __init__(self, t):
+        assert t.shape[-1] == 12
+        self.t = t
+
+    def reshape_views(self, B, V):
+        return LookupRecords(self.t.reshape(B, V, *self.t.shape[-3:]))
+
+    def __getitem__(self, idx):          # views picked out of an all-views tensor: (B, n_all, ...)[bi, ids]
+        return LookupRecords(self.t[idx])
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, rgb=None):
     """conv3x3(bilinear_x2(coarse, align_corners=True) + conv1x1(fine, lat_weight, lat_bias); wpack, bias) -> (B,Cout,H,W):
     FeatureNet's last top-down step and the smoothing conv that consumes it as ONE launch (the 32-channel
     full-resolution map between them is never written).  wpack / bias: `pack_conv` of the 3x3 layer (Cout <= 8)."""
     B, Cf, H, W = fine.shape
     C = coarse.shape[1]
     assert coarse.shape == (B, C, H // 2, W // 2)
-    if out is None:
-        out = torch.empty(B, Cout, H, W, device=fine.device, dtype=torch.float32)
     w = lat_weight.detach().reshape(C, Cf).contiguous()
     lib = _lib.load()
+    packed = None
+    if rgb is not None:
+        # `rgb` (B,3,H,W): write the renderer's lookup records instead of the planar map; wpack / bias must have been
+        # packed with the output channels in LookupRecords.EVEN_ODD order
+        assert tuple(rgb.shape) == (B, 3, H, W) and Cout == 8
+        packed = torch.empty(B, H, W, 12, device=fine.device, dtype=torch.float32)
+    elif out is None:
+        out = torch.empty(B, Cout, H, W, device=fine.device, dtype=torch.float32)
     with ktimer.region(f"fpn_smooth[{Cf}+{C}->{Cout},{H}x{W}]"):
         rc = lib.bmv_fpn_smooth_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"), dptr(w, "w_lat"),
                                     dptr(lat_bias.detach().contiguous(), "b_lat"), dptr(wpack, "wpack"), dptr(bias, "bias"),
-                                    dptr(out), B, Cf, C, Cout, H, W, 1.0, stream())
+                                    None if packed is not None else dptr(out),
+                                    dptr(rgb.contiguous(), "rgb") if packed is not None else None,
+                                    dptr(packed) if packed is not None else None, B, Cf, C, Cout, H, W, 1.0, stream())
     _lib.check(rc, "fpn_smooth_fwd")
-    return out
+    return LookupRecords(packed) if packed is not None else out
 
 
 def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):

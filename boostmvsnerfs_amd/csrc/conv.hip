@@ -490,7 +490,9 @@ struct FpnSmoothArgs {
   const float* blat;    // (C)
   const float* wpack;   // smoothing conv, row-paired pack
   const float* bias;    // (16)
-  float* out;           // (B, Cout, H, W)
+  float* out;           // (B, Cout, H, W), or null when `packed` is written instead
+  const float* rgb;     // (B, 3, H, W): with `packed`
+  float* packed;        // (B, H, W, 12) lookup records of the fused renderer: [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0]
   int B, C, Cout, H, W;
   float slope;
 };
@@ -623,6 +625,34 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
   const int ybase = y0 + rg * R;
+  if (a.packed) {
+    // one record per pixel, everything a bilinear tap of the renderer needs from this view: the wpack rows were
+    // permuted on the host so that MFMA rows 0-3 are channels 0 2 4 6 and rows 4-7 channels 1 3 5 7 (the two lane
+    // halves of the renderer's MLP take even / odd channels); the source colours ride along
+    const int q = g & 1;
+    const float* cp = a.rgb + (size_t)b * 3 * hw;
+#pragma unroll
+    for (int r = 0; r < T::NACC; ++r) {
+      const int y = ybase + 2 * r + (g >> 1);
+      if (y >= a.H) continue;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = acc[r][j] + bs[j];
+        v[j] = fmaxf(t, 0.f) + a.slope * fminf(t, 0.f);
+      }
+      const size_t pix = (size_t)y * a.W + x;
+      float* rec = a.packed + ((size_t)b * hw + pix) * 12;
+      *reinterpret_cast<f32x4*>(rec + 4 * q) = v;
+      float2 c;
+      if (q == 0)
+        c.x = cp[pix], c.y = cp[2 * (size_t)hw + pix];
+      else
+        c.x = cp[(size_t)hw + pix], c.y = 0.f;
+      *reinterpret_cast<float2*>(rec + 8 + 2 * q) = c;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < T::NACC; ++r) {
     const int y = ybase + 2 * r + (g >> 1);
@@ -1100,10 +1130,11 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 }
 
 int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_lat, const float* b_lat,
-                       const float* wpack, const float* bias, float* out, int B, int Cf, int C, int Cout, int H, int W,
-                       float act_slope, bmv_stream_t stream) {
+                       const float* wpack, const float* bias, float* out, const float* rgb, float* packed_out, int B,
+                       int Cf, int C, int Cout, int H, int W, float act_slope, bmv_stream_t stream) {
   using namespace bmv;
-  BMV_REQUIRE(fine && coarse && w_lat && b_lat && wpack && bias && out, "fpn_smooth: null pointer");
+  BMV_REQUIRE(fine && coarse && w_lat && b_lat && wpack && bias && (out || packed_out), "fpn_smooth: null pointer");
+  BMV_REQUIRE(!packed_out || (rgb && Cout == 8), "fpn_smooth: lookup records need the source colours and 8 channels");
   BMV_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_smooth: bad shape");
   BMV_REQUIRE(Cf == 8 && C % 4 == 0 && C > 0 && Cout > 0 && Cout <= 8,
               "fpn_smooth: built for 8 lateral channels, C %% 4 == 0 and <= 8 output channels (Cf=%d, C=%d, Cout=%d)", Cf,
@@ -1111,6 +1142,7 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
   BMV_REQUIRE((size_t)C * (H / 2) * (W / 2) < (1u << 29), "fpn_smooth: one coarse batch item must stay below 2 GiB");
   FpnSmoothArgs a;
   a.fine = fine, a.coarse = coarse, a.wlat = w_lat, a.blat = b_lat, a.wpack = wpack, a.bias = bias, a.out = out;
+  a.rgb = rgb, a.packed = packed_out;
   a.B = B, a.C = C, a.Cout = Cout, a.H = H, a.W = W, a.slope = act_slope;
   static const int rows = getenv("BMV_FPN_SMOOTH_R") ? atoi(getenv("BMV_FPN_SMOOTH_R")) : 8;
   hipStream_t st = as_stream(stream);

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
 __device__ float g_stamps[512 * 4 * 8];
 #endif
 
-template <int FEAT_CH, int NS, bool INV>
+template <int FEAT_CH, int NS, bool INV, bool PK = false>
 #ifndef BMV_RENDER_WPS
 #define BMV_RENDER_WPS 2   // workgroups (= waves per SIMD) resident per CU
 #endif
@@ -100,8 +100,13 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
   for (int i = 0; i < 3; ++i) {
     // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
     const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
-    rs_f[i] = make_rsrc(a.im_feat + vslot * FEAT_CH * plane, (size_t)FEAT_CH * plane * 4);
-    rs_c[i] = make_rsrc(a.rgb_src + vslot * 3 * plane, (size_t)3 * plane * 4);
+    if constexpr (PK) {
+      rs_f[i] = make_rsrc(a.im_packed + vslot * 12 * plane, (size_t)12 * plane * 4);   // 48-byte records
+      rs_c[i] = rs_f[i];
+    } else {
+      rs_f[i] = make_rsrc(a.im_feat + vslot * FEAT_CH * plane, (size_t)FEAT_CH * plane * 4);
+      rs_c[i] = make_rsrc(a.rgb_src + vslot * 3 * plane, (size_t)3 * plane * 4);
+    }
   }
   const int nrays = a.ray_end - a.ray_begin;
   const int ntiles = (nrays + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
@@ -153,10 +158,35 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
     for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
       const Cam& cam = rc->cam[i];
       Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
+      if constexpr (PK) {
+        // lookup records: this half's four feature channels are one 16-byte load per tap, its two colour slots one
+        // 8-byte load (taps outside the image carry weight 0 and offset 0, as in the planar path)
+        static_assert(!PK || FEAT_CH == 8, "packed records hold 8 feature channels");
+        const unsigned of = h ? 16u : 0u, oc = 32u + (h ? 8u : 0u);
+        const unsigned o[4] = {(unsigned)t2.o00 * 48u, (unsigned)t2.o01 * 48u, (unsigned)t2.o10 * 48u, (unsigned)t2.o11 * 48u};
+        const float w[4] = {t2.w00, t2.w01, t2.w10, t2.w11};
+        float4 fq[4];
+        float2 cq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fq[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f[i], (int)(o[k] + of), 0, 0));
+          cq[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_f[i], (int)(o[k] + oc), 0, 0));
+        }
+        float v0 = fq[0].x * w[0], v1 = fq[0].y * w[0], v2 = fq[0].z * w[0], v3 = fq[0].w * w[0];
+        float c0 = cq[0].x * w[0], c1 = cq[0].y * w[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          v0 += fq[k].x * w[k], v1 += fq[k].y * w[k], v2 += fq[k].z * w[k], v3 += fq[k].w * w[k];
+          c0 += cq[k].x * w[k], c1 += cq[k].y * w[k];
+        }
+        if (a.rgb_affine) c0 = c0 * 0.5f + 0.5f, c1 = c1 * 0.5f + 0.5f;
+        if (h) c1 = 0.f;   // the last slot of the odd half is padding
+        fin[i][0] = v0, fin[i][1] = v1, fin[i][2] = v2, fin[i][3] = v3, fin[i][4] = c0, fin[i][5] = c1;
+      }
       Taps2 t2h = t2;  // same taps as byte offsets, one channel plane further for the odd half
       tap_bytes(t2h, h ? (int)plane : 0);
 #pragma unroll
-      for (int j = 0; j < L::KFC; ++j) {
+      for (int j = 0; j < (PK ? 0 : L::KFC); ++j) {
         int c = 2 * j + h;  // channel of [feature, rgb]
         float v = 0.f;
         if (2 * j + 1 < FEAT_CH) {  // both halves read a feature channel
@@ -320,8 +350,8 @@ static unsigned render_grid() {
 int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   const unsigned kRenderGrid = render_grid();
   BMV_REQUIRE(a, "bmv_render_rays_fwd: null args");
-  BMV_REQUIRE(a->rays && a->depth && a->std && a->near_far && a->volume && a->im_feat && a->rgb_src && a->src_exts &&
-                  a->src_ixts && a->tar_ext && a->blob && a->out0 && a->out1 && a->out2,
+  BMV_REQUIRE(a->rays && a->depth && a->std && a->near_far && a->volume && (a->im_packed || (a->im_feat && a->rgb_src)) &&
+                  a->src_exts && a->src_ixts && a->tar_ext && a->blob && a->out0 && a->out1 && a->out2,
               "bmv_render_rays_fwd: null pointer");
   BMV_REQUIRE(a->S == 3, "bmv_render_rays_fwd: S=%d, the MLP is built for 3 source views", a->S);
   BMV_REQUIRE(a->B > 0 && a->N > 0 && a->hv > 0 && a->wv > 0 && a->Dv > 0 && a->Hr > 1 && a->Wr > 1,
@@ -332,6 +362,22 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
   if (a->ray_begin == a->ray_end) return BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
+#define RENDER_CASE_PK(FC, NSV, INVV)                                                                               \
+  if (a->im_packed && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                            \
+    size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
+    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, true>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
+    int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
+    unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, true>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
+    BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
+  }
+  RENDER_CASE_PK(8, 2, false)
+  RENDER_CASE_PK(8, 1, false)
+  RENDER_CASE_PK(8, 4, false)
+  RENDER_CASE_PK(8, 8, false)
+#undef RENDER_CASE_PK
+  BMV_REQUIRE(!a->im_packed, "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d", a->feat_ch,
+              a->Ns, a->depth_inv);
 #define RENDER_CASE(FC, NSV, INVV)                                                                                  \
   if (a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                                            \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \

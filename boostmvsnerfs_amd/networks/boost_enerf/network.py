@@ -242,7 +242,13 @@ class Network(enerf_network.Network):
             if len(self._sel_cache) > 64:
                 self._sel_cache.clear()
             self._sel_cache[key] = sel
-        feats = self.forward_feat(batch["all_src_inps"])            # all N views once
+        # all N views once; inference: the full-resolution map as the fused renderer's lookup records
+        self.feature_net.pack_lookup = (self.wants_lookup_records()
+                                        and enerf_network.engine_ok(self.feature_net, batch["all_src_inps"]))
+        try:
+            feats = self.forward_feat(batch["all_src_inps"])
+        finally:
+            self.feature_net.pack_lookup = False
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K
         ret = {}

@@ -126,6 +126,7 @@ class FeatureNet(nn.Module):
         self.smooth1 = Conv2d(32, 16, 3, padding=1)
         self.smooth0 = Conv2d(32, 8, 3, padding=1)
         self._packed = _Packed()
+        self.pack_lookup = False     # engine path: emit the full-resolution map as the renderer's lookup records
 
     @staticmethod
     def _top_down(coarse, lateral):
@@ -140,7 +141,10 @@ class FeatureNet(nn.Module):
             **{f"conv{i}.{j}": _pack_cbr(getattr(self, f"conv{i}")[j]) for i in range(3) for j in range(2)},
             "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
             "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
-            "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias)})
+            "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias),
+            # the same layer with its output channels in the order of the renderer's lookup records
+            "smooth0_eo": convnet.pack_conv(self.smooth0.weight[list(convnet.LookupRecords.EVEN_ODD)],
+                                            self.smooth0.bias[list(convnet.LookupRecords.EVEN_ODD)])})
 
     def engine_bottom_up(self, x):
         """Encoder + top layer: (c0, c1, p2, p2) with p2 a (N,32,H/4,W/4) view of the channel-last buffer the level-0
@@ -157,12 +161,16 @@ class FeatureNet(nn.Module):
         p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
         return c0, c1, p2, p2
 
-    def engine_top_down(self, c0, c1, p2):
-        """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar)."""
+    def engine_top_down(self, c0, c1, p2, rgb=None):
+        """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar).  With `rgb` (the source images
+        (N,3,H,W)) the full-resolution map comes out as the fused renderer's lookup records instead
+        (convnet.LookupRecords: feature channels + colours of a pixel in one 48-byte record)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
         f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last=True)
-        if FUSE_FPN_SMOOTH:
+        if rgb is not None:
+            f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
+        elif FUSE_FPN_SMOOTH:
             # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0"], 8)
         else:
@@ -174,7 +182,7 @@ class FeatureNet(nn.Module):
         """Same graph, one launch per conv block.  The two maps the plane sweeps read come out channel-last
         (returned as (N,C,H,W) views of (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
         c0, c1, p2, p2_cl = self.engine_bottom_up(x)
-        f1, f0 = self.engine_top_down(c0, c1, p2)
+        f1, f0 = self.engine_top_down(c0, c1, p2, rgb=x if self.pack_lookup else None)
         return p2_cl, f1, f0
 
     def forward(self, x):

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import autograd as A
-from ... import ops
+from ... import convnet, ops
 from ...config import cfg
 from .cnn import CostRegNet, FeatureNet, MinCostRegNet, engine_ok
 from .nerf import NeRF
@@ -53,6 +53,7 @@ class Network(nn.Module):
         # is used under HIP-graph capture only (replay: +3 % frames/s); issued eagerly a 512x640 frame is bound by the
         # host's ~45 launches and the extra stream traffic costs 3 % (BMV_OVERLAP_EAGER=1 forks there too).
         self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
+        self.lookup_records = os.environ.get("BMV_LOOKUP_RECORDS", "1") == "1"
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
         self._side_stream = None
 
@@ -64,7 +65,18 @@ class Network(nn.Module):
         coarse, mid, fine = self.feature_net(x.reshape(B * V, C, H, W))
         return {"level_0": coarse.reshape(B, V, -1, H // 4, W // 4),
                 "level_1": mid.reshape(B, V, -1, H // 2, W // 2),
-                "level_2": fine.reshape(B, V, -1, H, W)}
+                "level_2": fine.reshape_views(B, V) if isinstance(fine, convnet.LookupRecords) else fine.reshape(B, V, -1, H, W)}
+
+    def wants_lookup_records(self):
+        """The full-resolution feature map can leave FeatureNet as the fused renderer's lookup records (one 48-byte
+        record per pixel: 8 feature channels + the source colours) when nothing but that kernel reads it: inference,
+        and every rendered level that takes its image features from level 2 does so at render scale 1."""
+        cc = cfg.enerf.cas_config
+        if not self.lookup_records or self.wants_grad():
+            return False
+        users = [i for i in range(cc.num) if cc.render_if[i] and cc.render_im_feat_level[i] == 2]
+        return bool(users) and all(cc.render_scale[i] == 1.0 and cc.im_ibr_scale[i] == 1.0
+                                   and getattr(self, f"nerf_{i}").feat_ch - 3 == 8 for i in users)
 
     # ------------------------------------------------------------------ cost volume of one level
     def level_front(self, i, feats_i, views, batch, prev, view_ids=None, fork_after_sweep=None):
@@ -178,7 +190,12 @@ class Network(nn.Module):
         Hr, Wr = int(H * rs), int(W * rs)
         if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
             raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
-        if rs == 1.0:
+        packed = None
+        if isinstance(im_feat, convnet.LookupRecords):
+            if rs != 1.0:
+                raise ValueError("lookup records carry the source colours at full resolution (render_scale 1)")
+            packed, im_feat, rgb_src, affine = im_feat.t, None, None, True
+        elif rs == 1.0:
             rgb_src, affine = src_inps, True
         else:
             if view_ids is not None:
@@ -195,7 +212,7 @@ class Network(nn.Module):
                                 src_ixts, batch["tar_ext"], nerf.packed_weights(), feat_ch=nerf.feat_ch - 3,
                                 Ns=cc.num_samples[i], depth_inv=cc.depth_inv[i], Hr=Hr, Wr=Wr, render_scale=rs,
                                 rgb_affine=affine, white_bkgd=cfg.enerf.white_bkgd, mode=mode,
-                                ray_range=(c0, min(c0 + chunk, end)), outs=outs, view_ids=view_ids)
+                                ray_range=(c0, min(c0 + chunk, end)), outs=outs, view_ids=view_ids, im_packed=packed)
             outs = o      # every chunk writes its own ray slice of the same buffers
         if (begin, end) != (0, N):
             outs = tuple(t[:, begin:end] for t in outs)
@@ -239,7 +256,7 @@ class Network(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 st0 = self.level_front(0, level0, views, batch, None)
-        f1, f0 = fn.engine_top_down(c0, c1, p2)
+        f1, f0 = fn.engine_top_down(c0, c1, p2, rgb=x.reshape(B * V, C, H, W) if fn.pack_lookup else None)
         main.wait_stream(side)
         if not torch.cuda.is_current_stream_capturing():   # (a graph capture owns its memory pool)
             for name in ("depth", "std", "near_far", "feature_volume", "depth_values"):
@@ -247,7 +264,7 @@ class Network(nn.Module):
                 if t is not None:
                     t.record_stream(main)
         feats = {"level_0": level0, "level_1": f1.reshape(B, V, -1, H // 2, W // 2),
-                 "level_2": f0.reshape(B, V, -1, H, W)}
+                 "level_2": f0.reshape_views(B, V) if isinstance(f0, convnet.LookupRecords) else f0.reshape(B, V, -1, H, W)}
         return feats, st0
 
     # ------------------------------------------------------------------ forward
@@ -272,12 +289,16 @@ class Network(nn.Module):
         st0 = None
         if self._side_stream is None and batch["src_inps"].is_cuda:
             self._side_stream = torch.cuda.Stream()          # created outside any capture
-        if (self.overlap_front and batch["src_inps"].is_cuda
-                and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
-                and engine_ok(self.feature_net, batch["src_inps"])):
-            feats, st0 = self._front_overlapped(batch, views)
-        else:
-            feats = self.forward_feat(batch["src_inps"])
+        self.feature_net.pack_lookup = self.wants_lookup_records() and engine_ok(self.feature_net, batch["src_inps"])
+        try:
+            if (self.overlap_front and batch["src_inps"].is_cuda
+                    and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
+                    and engine_ok(self.feature_net, batch["src_inps"])):
+                feats, st0 = self._front_overlapped(batch, views)
+            else:
+                feats = self.forward_feat(batch["src_inps"])
+        finally:
+            self.feature_net.pack_lookup = False
         render = self.render_level_train if self.wants_grad() else self.render_level
         ret = {}
         st = None

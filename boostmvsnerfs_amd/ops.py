@@ -305,11 +305,13 @@ def blend(raws, masks, z_vals, normalise):
 
 def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext, blob, *, feat_ch,
                 Ns, depth_inv, Hr, Wr, render_scale, rgb_affine, white_bkgd=False, mode=0, ray_range=None, outs=None,
-                view_ids=None):
+                view_ids=None, im_packed=None):
     """Fused a6..a12 (+a14).  mode 0 -> (rgb, depth, weights); mode 1 -> (raw, z_vals, mask).
     ray_range=(begin, end) renders only those rays; the outputs keep the full (B,N,...) shape and
     only that slice is written.  view_ids (B,S) int32: im_feat / rgb_src hold ALL n_all source views and the
-    cost volume's view i is view_ids[b, i] (src_exts / src_ixts are already the S picked ones)."""
+    cost volume's view i is view_ids[b, i] (src_exts / src_ixts are already the S picked ones).
+    im_packed (B, S | n_all, Hr, Wr, 12): the views' lookup records (convnet.LookupRecords) instead of im_feat /
+    rgb_src (which may then be None): one 16-byte + one 8-byte load per tap and lane half."""
     B, N = rays.shape[:2]
     S = src_exts.shape[1]
     _, _, Dv, hv, wv = volume.shape
@@ -328,14 +330,22 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
         o0 = torch.empty(B, N, Ns, 4, device=dev, dtype=torch.float32)
         o1 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)
         o2 = torch.empty(B, N, Ns, device=dev, dtype=torch.float32)
-    if tuple(im_feat.shape[-2:]) != (Hr, Wr) or tuple(rgb_src.shape[-2:]) != (Hr, Wr):
-        raise ValueError(f"im_feat {tuple(im_feat.shape)} / rgb_src {tuple(rgb_src.shape)} must be at the render "
-                         f"resolution ({Hr},{Wr})")
+    if im_packed is not None:
+        if tuple(im_packed.shape[-3:]) != (Hr, Wr, 12) or int(feat_ch) != 8 or im_packed.dim() != 5:
+            raise ValueError(f"im_packed {tuple(im_packed.shape)}: expected (B,views,{Hr},{Wr},12) records and feat_ch 8")
+        n_views = im_packed.shape[1]
+        names = ("rays", "depth", "std", "near_far", "volume", "src_exts", "src_ixts", "tar_ext", "im_packed")
+        held = [_c(t) for t in (rays, depth, std, near_far, volume, src_exts, src_ixts, tar_ext, im_packed)]
+    else:
+        if tuple(im_feat.shape[-2:]) != (Hr, Wr) or tuple(rgb_src.shape[-2:]) != (Hr, Wr):
+            raise ValueError(f"im_feat {tuple(im_feat.shape)} / rgb_src {tuple(rgb_src.shape)} must be at the render "
+                             f"resolution ({Hr},{Wr})")
+        n_views = im_feat.shape[1]
+        names = ("rays", "depth", "std", "near_far", "volume", "im_feat", "rgb_src", "src_exts", "src_ixts", "tar_ext")
+        held = [_c(t) for t in (rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext)]
     begin, end = ray_range if ray_range is not None else (0, N)
-    held = [_c(t) for t in (rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, src_ixts, tar_ext)]
     a = _lib.RenderArgs()
-    for name, t in zip(("rays", "depth", "std", "near_far", "volume", "im_feat", "rgb_src", "src_exts", "src_ixts",
-                        "tar_ext"), held):
+    for name, t in zip(names, held):
         setattr(a, name, dptr(t, name))
     a.blob = dptr(blob, "blob")
     a.B, a.N, a.S, a.feat_ch, a.Ns, a.depth_inv = B, N, S, int(feat_ch), int(Ns), int(bool(depth_inv))
@@ -345,10 +355,11 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     a.ray_begin, a.ray_end = int(begin), int(end)
     a.out0, a.out1, a.out2 = dptr(o0), dptr(o1), dptr(o2)
     if view_ids is not None:
-        if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S) or im_feat.shape[1] != rgb_src.shape[1]:
+        if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S) or (
+                im_packed is None and im_feat.shape[1] != rgb_src.shape[1]):
             raise ValueError("render_rays: view_ids must be int32 (B,S); im_feat / rgb_src must hold the same n_all views")
         view_ids = _c(view_ids)
-        a.view_ids, a.n_all = dptr(view_ids, "view_ids", torch.int32), int(im_feat.shape[1])
+        a.view_ids, a.n_all = dptr(view_ids, "view_ids", torch.int32), int(n_views)
     else:
         a.view_ids, a.n_all = None, 0
     lib = _lib.load()

@@ -177,6 +177,9 @@ typedef struct {
   float* out2;            /* weights | mask */
   const int* view_ids;    /* NULL, or (B,S): im_feat / rgb_src are (B,n_all,...) and view i is view_ids[b*S + i] */
   int n_all;
+  const float* im_packed; /* NULL, or (B,S|n_all,Hr,Wr,12) lookup records [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] written by
+                             bmv_fpn_smooth_fwd (feat_ch = 8): a bilinear tap of a view is then 2 loads per lane half
+                             instead of 6; im_feat / rgb_src are not read */
 } bmv_render_args;
 int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
 
@@ -388,10 +391,14 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
  * p0 = bilinear_x2(p1, align_corners=True) + lat0(c0)): out (B,Cout,H,W) = act(conv3x3(p0; wpack) + bias), p0
  * (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2)) + conv1x1(fine (B,8,H,W); w_lat (C,8)) + b_lat built chunk by chunk
  * in the convolution's tile producer and never written (C = 32 at full resolution is 126 MB per frame each way).
- * wpack / bias: bmv_conv_pack_weights layout for (Cin = C, Cout <= 8, k = 3, stride 1: row-paired). */
+ * wpack / bias: bmv_conv_pack_weights layout for (Cin = C, Cout <= 8, k = 3, stride 1: row-paired).
+ * With `packed_out` (B,H,W,12) (and rgb (B,3,H,W), Cout = 8; `out` may be null) the epilogue writes the fused renderer's
+ * lookup records instead of the planar map: [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] per pixel, where "ch i" is MFMA row
+ * order -- the caller packs the weights with output channels permuted to 0 2 4 6 1 3 5 7 -- and r g b are the source
+ * image's (bmv_render_args.im_packed). */
 int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_lat, const float* b_lat,
-                       const float* wpack, const float* bias, float* out, int B, int Cf, int C, int Cout, int H, int W,
-                       float act_slope, bmv_stream_t stream);
+                       const float* wpack, const float* bias, float* out, const float* rgb, float* packed_out, int B,
+                       int Cf, int C, int Cout, int H, int W, float act_slope, bmv_stream_t stream);
 
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,

@@ -177,16 +177,56 @@ def _network(fx, preset="enerf_eval"):
     return net.to(DEV).eval()
 
 
-def test_network_forward_matches_reference(ops, enerf_fx):
+@pytest.mark.parametrize("records", [True, False])
+def test_network_forward_matches_reference(ops, enerf_fx, records):
+    """The reference's output dict for the fixture batch, through both forms of the renderer's image lookups: 48-byte
+    per-pixel records written by FeatureNet's fused last layer (the default at inference), and the planar maps."""
+    from boostmvsnerfs_amd import convnet
     net = _network(enerf_fx)
-    with torch.no_grad():
-        out = net(enerf_fx.batch(DEV))
+    net.lookup_records = records
+    seen = []
+    real = ops.render_rays
+
+    def spy(*a, **k):
+        seen.append(k.get("im_packed") is not None)
+        return real(*a, **k)
+    ops.render_rays = spy
+    try:
+        with torch.no_grad():
+            out = net(enerf_fx.batch(DEV))
+    finally:
+        ops.render_rays = real
+    assert seen and seen[-1] == records                        # the form under test is the one the last level ran
     want = enerf_fx.group("out")
     assert set(out) == set(want)
     for k in want:
         assert_close(out[k], want[k], name=k)
     mse = float(((out["rgb_level1"].cpu() - want["rgb_level1"]) ** 2).mean())
     assert mse < 1e-8, f"PSNR delta too large (mse between renders {mse:.3e})"
+
+
+def test_lookup_records_layout(ops, enerf_fx):
+    """convnet.LookupRecords as FeatureNet writes them: record = [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] of the planar
+    8-channel map and the source image at that pixel."""
+    net = _network(enerf_fx)
+    x = enerf_fx.batch(DEV)["src_inps"][0]
+    fn = net.feature_net
+    with torch.no_grad():
+        _, _, planar = fn(x)
+        fn.pack_lookup = True
+        try:
+            _, _, rec = fn(x)
+        finally:
+            fn.pack_lookup = False
+    t = rec.t
+    assert t.shape == (x.shape[0], x.shape[2], x.shape[3], 12)
+    p = planar.permute(0, 2, 3, 1)
+    scale = float(p.abs().max())
+    assert float((t[..., 0:4] - p[..., 0::2]).abs().max()) <= 1e-6 * scale
+    assert float((t[..., 4:8] - p[..., 1::2]).abs().max()) <= 1e-6 * scale
+    c = x.permute(0, 2, 3, 1)
+    assert torch.equal(t[..., 8], c[..., 0]) and torch.equal(t[..., 9], c[..., 2]) and torch.equal(t[..., 10], c[..., 1])
+    assert float(t[..., 11].abs().max()) == 0.0
 
 
 def test_render_rays_and_batchify_keep_the_reference_signature(ops, enerf_fx):
