@@ -73,7 +73,9 @@ def sweep_bytes(S, C, Hs, Ws, D, h, w):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps; default 400 for the ENeRF inference workloads (1-4 ms frames: `value` is the MEAN "
+                         "of the per-step brackets and a single host hiccup of 2 ms moves a 30-step mean by 7 %%), 30 otherwise")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default="views", choices=["views", "rays", "volumes"],
@@ -100,7 +102,11 @@ def parse():
                     help="1: let MIOpen search its convolution solvers (torch.backends.cudnn.benchmark).  Only the "
                          "training workloads still run convolutions on MIOpen (inference uses csrc/conv.hip), and "
                          "its search for the 3-D fp32 backward solvers takes > 15 min: off by default")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        w = WORKLOADS[args.workload]
+        args.steps = 400 if (w["net"] in ("enerf", "boost_enerf") and not w.get("train")) else 30
+    return args
 
 
 def build(args, rank, dev):
@@ -442,6 +448,10 @@ def main():
     torch.cuda.synchronize()
     if step is not eager_step:
         sampled["n"] = 0               # the first timed step carries the brackets
+    import gc
+    gc.collect()
+    gc.disable()                       # a generation-2 collection inside a 1 ms step is a 1-3 ms outlier (timeit does the same)
+    step_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -449,6 +459,7 @@ def main():
             if gather is not None:
                 gather.flush()
             torch.cuda.synchronize()       # the reference's per-step bracket (run.py:117-123)
+            step_marks.append(time.perf_counter())
             if step is eager_step or sampled["evented"]:
                 ktimer.collect()           # in-graph event brackets of the replay that just finished
     if gather is not None:
@@ -458,6 +469,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if args.pipelined:
         ktimer.collect()               # no per-step synchronize: the brackets of the last replay only
     ktimer.enabled = False
@@ -469,6 +481,12 @@ def main():
     if rank == 0:
         frames = args.steps * (world if args.shard == "views" else 1)
         value = frames * N / dt / 1e6
+        if len(step_marks) > 2:
+            # spread of the per-step brackets inside the timed region (`value` is the mean: one host hiccup of a few ms
+            # in a 30-step run moves it by 10 %)
+            d = sorted(b - a for a, b in zip([t0] + step_marks[:-1], step_marks))
+            extra["step_ms"] = {"min": d[0] * 1e3, "median": d[len(d) // 2] * 1e3, "p90": d[int(len(d) * 0.9)] * 1e3,
+                                "max": d[-1] * 1e3, "what": "per-step wall time of the timed region on rank 0"}
         ks = ktimer.summary()
         ks_timed = set(ks)
         for name, v in warm_kernels.items():          # graph mode: the renderer's events come from the eager warm-up

@@ -35,7 +35,7 @@ class RenderArgs(C.Structure):
                 + [("render_scale", C.c_float)]
                 + [(n, C.c_int) for n in ("rgb_affine", "white_bkgd", "mode", "ray_begin", "ray_end")]
                 + [(n, C.c_void_p) for n in ("out0", "out1", "out2")]
-                + [("view_ids", C.c_void_p), ("n_all", C.c_int), ("im_packed", C.c_void_p)])
+                + [("view_ids", C.c_void_p), ("n_all", C.c_int), ("im_packed", C.c_void_p), ("vol_packed", C.c_int)])
 
 
 class MvsMlpParams(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "bmv_bn_chunks": [c_i, c_l],
     "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f],
     "bmv_bn_train_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_f, c_f, c_f, c_f, c_f],
+    "bmv_conv_heads_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "bmv_fpn_smooth_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "bmv_event_create": [C.POINTER(C.c_void_p)],
     "bmv_event_destroy": [C.c_void_p],

@@ -155,6 +155,35 @@ class LookupRecords:
         return self.t.shape
 
 
+class VolumeRecords:
+    """(B, D, h, w, 8) feature volume as the fused renderer reads it: a voxel's 8 channels in one 32-byte record,
+    [ch 0 2 4 6 | ch 1 3 5 7] (include/bmv.h, bmv_conv_heads_fwd / bmv_render_args.vol_packed)."""
+    ORDER = (0, 2, 4, 6, 1, 3, 5, 7, 8)      # output-channel order the 9-channel head conv's weights are packed in
+
+    def __init__(self, t):
+        assert t.dim() == 5 and t.shape[-1] == 8
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def conv_heads_records(x, wpack, bias):
+    """x (B,Cin,D,H,W) -> (VolumeRecords (B,D,H,W,8), depth logits (B,D,H,W)): feat_conv + depth_conv as one 3x3x3
+    convolution whose epilogue writes the renderer's volume records (wpack / bias packed in VolumeRecords.ORDER)."""
+    B, Cin, D, H, W = x.shape
+    rec = torch.empty(B, D, H, W, 8, device=x.device, dtype=torch.float32)
+    dp = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
+    x = x if x.is_contiguous() else x.contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"conv[{Cin}->9 records,k3x3x3,s1,{D}x{H}x{W}]"):
+        rc = lib.bmv_conv_heads_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"), dptr(rec), dptr(dp),
+                                    B, Cin, D, H, W, stream())
+    _lib.check(rc, "conv_heads_fwd")
+    return VolumeRecords(rec), dp
+
+
 def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, rgb=None):
     """conv3x3(bilinear_x2(coarse, align_corners=True) + conv1x1(fine, lat_weight, lat_bias); wpack, bias) -> (B,Cout,H,W):
     FeatureNet's last top-down step and the smoothing conv that consumes it as ONE launch (the 32-channel

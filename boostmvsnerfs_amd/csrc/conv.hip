@@ -45,7 +45,8 @@ struct ConvArgs {
   float* out;          // (B, Cout, Do, Ho, Wo) or channel-last (B, Do, Ho, Wo, Cout)
   int B, Cin, D, H, W, Cout, Do, Ho, Wo;
   float slope;  // activation: v > 0 ? v : slope * v  (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky ReLU)
-  int channels_last;
+  int channels_last;   // 0 planar, 1 channel-last, 2 = the renderer's volume records (bmv_conv_heads_fwd)
+  float* out2;         // mode 2: channel 8 (the depth logits), planar (B, Do, Ho, Wo)
 };
 
 // MAP: 0 = 2-D (row groups along y), 1 = 3-D with the block's 4/NCT row groups along z, 2 = 3-D along y
@@ -222,7 +223,17 @@ void conv_mfma_kernel(ConvArgs a) {
       v[j] = acc[r][j] + bs[j];
       v[j] = fmaxf(v[j], 0.f) + a.slope * fminf(v[j], 0.f);
     }
-    if (a.channels_last) {
+    if (a.channels_last == 2) {
+      // 8 feature channels as one 32-byte record per voxel (MFMA rows 0-7: the caller packed the weights with the
+      // output channels in the renderer's even | odd order), row 8 -- the depth logit -- planar
+      const size_t vox = (((size_t)b * a.Do + z) * a.Ho + y) * a.Wo + x;
+      if (co0 < 8) {
+        f32x4 q = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(a.out + vox * 8 + co0) = q;
+      } else {
+        a.out2[vox] = v[0];
+      }
+    } else if (a.channels_last) {
       const size_t o = ((((size_t)b * a.Do + z) * a.Ho + y) * a.Wo + x) * a.Cout + co0;
       if ((a.Cout & 3) == 0) {
         f32x4 q = {v[0], v[1], v[2], v[3]};
@@ -1066,7 +1077,7 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = Cout;
   const int p = k / 2, pd = kd / 2;
   a.Do = (D + 2 * pd - kd) / stride + 1, a.Ho = (H + 2 * p - k) / stride + 1, a.Wo = (W + 2 * p - k) / stride + 1;
-  a.slope = act_slope, a.channels_last = out_channels_last;
+  a.slope = act_slope, a.channels_last = out_channels_last ? 1 : 0, a.out2 = nullptr;
   hipStream_t st = as_stream(stream);
   if (kd == 1 && k == 3 && stride == 1)
     dispatch_conv<1, 3, 1, 8, 2, false>(a, st);
@@ -1082,6 +1093,21 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
     BMV_REQUIRE(false, "conv: kernel (%d,%d,%d) stride %d is not one of the shapes of FeatureNet / CostRegNet", kd, k,
                 k, stride);
   BMV_LAUNCH_END("conv_fwd");
+}
+
+int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
+                       int B, int Cin, int D, int H, int W, bmv_stream_t stream) {
+  using namespace bmv;
+  BMV_REQUIRE(in && wpack && bias && records_out && depth_out, "conv_heads: null pointer");
+  BMV_REQUIRE(B > 0 && Cin > 0 && Cin < 16 && D > 0 && H > 0 && W > 0, "conv_heads: bad shape (Cin=%d)", Cin);
+  BMV_REQUIRE((size_t)Cin * D * H * W < (1u << 29), "conv_heads: one batch item must stay below 2 GiB");
+  ConvArgs a;
+  a.in = in, a.wpack = wpack, a.bias = bias, a.skip = nullptr, a.out = records_out, a.out2 = depth_out;
+  a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = 9;
+  a.Do = D, a.Ho = H, a.Wo = W;
+  a.slope = 1.f, a.channels_last = 2;
+  dispatch_conv<3, 3, 1, 8, 2, true>(a, as_stream(stream));     // Cin < 16: never the split-K form
+  BMV_LAUNCH_END("conv_heads_fwd");
 }
 
 int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B,

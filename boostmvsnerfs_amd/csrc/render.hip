@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
 __device__ float g_stamps[512 * 4 * 8];
 #endif
 
-template <int FEAT_CH, int NS, bool INV, bool PK = false>
+// PK: 0 = planar lookups, 1 = image lookups from 48-byte records, 3 = image and volume lookups from records
+template <int FEAT_CH, int NS, bool INV, int PK = 0>
 #ifndef BMV_RENDER_WPS
 #define BMV_RENDER_WPS 2   // workgroups (= waves per SIMD) resident per CU
 #endif
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
   for (int i = 0; i < 3; ++i) {
     // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
     const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
-    if constexpr (PK) {
+    if constexpr (PK != 0) {
       rs_f[i] = make_rsrc(a.im_packed + vslot * 12 * plane, (size_t)12 * plane * 4);   // 48-byte records
       rs_c[i] = rs_f[i];
     } else {
@@ -146,10 +147,22 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
       // the half's channel offset (h * cs) goes into the 32-bit tap offsets once: every load is then
       // `wave-uniform plane pointer + 32-bit lane offset` instead of a 64-bit per-lane address
       const int hoff = h ? (int)cs : 0;
+      if constexpr ((PK & 2) != 0) {
+        // (Dv,hv,wv,8) records [ch 0 2 4 6 | ch 1 3 5 7]: this half's four channels of a tap are one 16-byte load
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t3.o[k] = (t3.o[k] + hoff) * 4;   // byte offsets (a volume stays below 2 GiB)
+        for (int k = 0; k < 8; ++k) {
+          const float4 q = __builtin_bit_cast(
+              float4, __builtin_amdgcn_raw_buffer_load_b128(rs_vol, (int)((unsigned)t3.o[k] * 32u + (h ? 16u : 0u)), 0, 0));
+          acc.x += q.x * t3.w[k], acc.y += q.y * t3.w[k], acc.z += q.z * t3.w[k], acc.w += q.w * t3.w[k];
+        }
+        vox[0] = acc.x, vox[1] = acc.y, vox[2] = acc.z, vox[3] = acc.w;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch_buf(rs_vol, t3, (unsigned)(2 * j) * (unsigned)cs * 4u);
+        for (int k = 0; k < 8; ++k) t3.o[k] = (t3.o[k] + hoff) * 4;   // byte offsets (a volume stays below 2 GiB)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vox[j] = tap3_fetch_buf(rs_vol, t3, (unsigned)(2 * j) * (unsigned)cs * 4u);
+      }
     }
     BMV_FENCE();
     RSTAMP(2)
@@ -158,10 +171,10 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
     for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
       const Cam& cam = rc->cam[i];
       Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
-      if constexpr (PK) {
+      if constexpr (PK != 0) {
         // lookup records: this half's four feature channels are one 16-byte load per tap, its two colour slots one
         // 8-byte load (taps outside the image carry weight 0 and offset 0, as in the planar path)
-        static_assert(!PK || FEAT_CH == 8, "packed records hold 8 feature channels");
+        static_assert(PK == 0 || FEAT_CH == 8, "packed records hold 8 feature channels");
         const unsigned of = h ? 16u : 0u, oc = 32u + (h ? 8u : 0u);
         const unsigned o[4] = {(unsigned)t2.o00 * 48u, (unsigned)t2.o01 * 48u, (unsigned)t2.o10 * 48u, (unsigned)t2.o11 * 48u};
         const float w[4] = {t2.w00, t2.w01, t2.w10, t2.w11};
@@ -186,7 +199,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
       Taps2 t2h = t2;  // same taps as byte offsets, one channel plane further for the odd half
       tap_bytes(t2h, h ? (int)plane : 0);
 #pragma unroll
-      for (int j = 0; j < (PK ? 0 : L::KFC); ++j) {
+      for (int j = 0; j < (PK != 0 ? 0 : L::KFC); ++j) {
         int c = 2 * j + h;  // channel of [feature, rgb]
         float v = 0.f;
         if (2 * j + 1 < FEAT_CH) {  // both halves read a feature channel
@@ -362,22 +375,27 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
   if (a->ray_begin == a->ray_end) return BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
-#define RENDER_CASE_PK(FC, NSV, INVV)                                                                               \
-  if (a->im_packed && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                            \
+#define RENDER_CASE_PK(FC, NSV, INVV, PKV)                                                                          \
+  if (a->im_packed && (a->vol_packed ? 3 : 1) == PKV && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) { \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
-    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, true>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
+    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, PKV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
-    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, true>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, PKV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
-  RENDER_CASE_PK(8, 2, false)
-  RENDER_CASE_PK(8, 1, false)
-  RENDER_CASE_PK(8, 4, false)
-  RENDER_CASE_PK(8, 8, false)
+  RENDER_CASE_PK(8, 2, false, 1)
+  RENDER_CASE_PK(8, 2, false, 3)
+  RENDER_CASE_PK(8, 1, false, 1)
+  RENDER_CASE_PK(8, 1, false, 3)
+  RENDER_CASE_PK(8, 4, false, 1)
+  RENDER_CASE_PK(8, 4, false, 3)
+  RENDER_CASE_PK(8, 8, false, 1)
+  RENDER_CASE_PK(8, 8, false, 3)
 #undef RENDER_CASE_PK
-  BMV_REQUIRE(!a->im_packed, "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d", a->feat_ch,
-              a->Ns, a->depth_inv);
+  BMV_REQUIRE(!a->im_packed && !a->vol_packed,
+              "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d (volume records: %d)",
+              a->feat_ch, a->Ns, a->depth_inv, a->vol_packed);
 #define RENDER_CASE(FC, NSV, INVV)                                                                                  \
   if (a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                                            \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \

@@ -218,6 +218,12 @@ class Network(enerf_network.Network):
         return ret
 
     def forward(self, batch):
+        try:
+            return self._forward_boost(batch)
+        finally:
+            self.set_volume_records(False)
+
+    def _forward_boost(self, batch):
         if self.view_selection_outputs is None:
             raise RuntimeError("Network(preprocess=True) only supports forward_view_selection()")
         cc = cfg.enerf.cas_config
@@ -245,6 +251,7 @@ class Network(enerf_network.Network):
         # all N views once; inference: the full-resolution map as the fused renderer's lookup records
         self.feature_net.pack_lookup = (self.wants_lookup_records()
                                         and enerf_network.engine_ok(self.feature_net, batch["all_src_inps"]))
+        self.set_volume_records(self.feature_net.pack_lookup)
         try:
             feats = self.forward_feat(batch["all_src_inps"])
         finally:

@@ -214,6 +214,7 @@ class _CostReg(nn.Module):
         self.depth_conv = nn.Sequential(Conv3d(8, 1, 3, padding=1, bias=False))
         self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
         self._packed = _Packed()
+        self.volume_records = False   # engine path: emit the feature volume as the renderer's voxel records
 
     def _apply(self, fn, *args, **kwargs):
         self._packed.invalidate()
@@ -228,7 +229,10 @@ class _CostReg(nn.Module):
                 up = getattr(self, name)
                 P[name] = convnet.pack_convT(*convnet.fold_bn(up[0].weight, up[1], out_dim=1))
             # feat_conv (8 ch) and depth_conv (1 ch) read the same tensor: one 9-channel convolution
-            P["heads"] = convnet.pack_conv(torch.cat([self.feat_conv[0].weight, self.depth_conv[0].weight], 0), None)
+            heads = torch.cat([self.feat_conv[0].weight, self.depth_conv[0].weight], 0)
+            P["heads"] = convnet.pack_conv(heads, None)
+            # the same layer with its output channels in the order of the renderer's volume records
+            P["heads_rec"] = convnet.pack_conv(heads[list(convnet.VolumeRecords.ORDER)], None)
             return P
         return self._packed.get(self, build)
 
@@ -243,6 +247,8 @@ class _CostReg(nn.Module):
             y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2)
         y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
         y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
+        if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
+            return convnet.conv_heads_records(y, *P["heads_rec"])
         heads = convnet.conv_fwd(y, *P["heads"], 9, 3, 3)
         return heads[:, :8], heads[:, 8]
 

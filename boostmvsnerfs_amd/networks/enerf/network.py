@@ -54,6 +54,7 @@ class Network(nn.Module):
         # host's ~45 launches and the extra stream traffic costs 3 % (BMV_OVERLAP_EAGER=1 forks there too).
         self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
         self.lookup_records = os.environ.get("BMV_LOOKUP_RECORDS", "1") == "1"
+        self.volume_records = os.environ.get("BMV_VOLUME_RECORDS", "1") == "1"
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
         self._side_stream = None
 
@@ -66,6 +67,14 @@ class Network(nn.Module):
         return {"level_0": coarse.reshape(B, V, -1, H // 4, W // 4),
                 "level_1": mid.reshape(B, V, -1, H // 2, W // 2),
                 "level_2": fine.reshape_views(B, V) if isinstance(fine, convnet.LookupRecords) else fine.reshape(B, V, -1, H, W)}
+
+    def set_volume_records(self, on):
+        """With image records on, the regulariser of every level rendered from them writes its feature volume as voxel
+        records too (convnet.VolumeRecords: the renderer's record kernels take both)."""
+        cc = cfg.enerf.cas_config
+        for i in range(cc.num):
+            getattr(self, f"cost_reg_{i}").volume_records = bool(on and self.volume_records and cc.render_if[i]
+                                                                 and cc.render_im_feat_level[i] == 2)
 
     def wants_lookup_records(self):
         """The full-resolution feature map can leave FeatureNet as the fused renderer's lookup records (one 48-byte
@@ -261,6 +270,8 @@ class Network(nn.Module):
         if not torch.cuda.is_current_stream_capturing():   # (a graph capture owns its memory pool)
             for name in ("depth", "std", "near_far", "feature_volume", "depth_values"):
                 t = getattr(st0, name)           # allocated under the side stream, consumed on the main one
+                if isinstance(t, convnet.VolumeRecords):
+                    t = t.t
                 if t is not None:
                     t.record_stream(main)
         feats = {"level_0": level0, "level_1": f1.reshape(B, V, -1, H // 2, W // 2),
@@ -283,6 +294,12 @@ class Network(nn.Module):
         return batch
 
     def forward(self, batch):
+        try:
+            return self._forward(batch)
+        finally:
+            self.set_volume_records(False)       # the modules go back to planar outputs for any other caller
+
+    def _forward(self, batch):
         cc = cfg.enerf.cas_config
         self.ensure_rays(batch)
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
@@ -290,6 +307,7 @@ class Network(nn.Module):
         if self._side_stream is None and batch["src_inps"].is_cuda:
             self._side_stream = torch.cuda.Stream()          # created outside any capture
         self.feature_net.pack_lookup = self.wants_lookup_records() and engine_ok(self.feature_net, batch["src_inps"])
+        self.set_volume_records(self.feature_net.pack_lookup)
         try:
             if (self.overlap_front and batch["src_inps"].is_cuda
                     and (self.overlap_eager or torch.cuda.is_current_stream_capturing())

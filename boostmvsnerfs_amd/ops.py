@@ -314,7 +314,14 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     rgb_src (which may then be None): one 16-byte + one 8-byte load per tap and lane half."""
     B, N = rays.shape[:2]
     S = src_exts.shape[1]
-    _, _, Dv, hv, wv = volume.shape
+    vol_packed = not torch.is_tensor(volume)   # convnet.VolumeRecords: (B,Dv,hv,wv,8) voxel records
+    if vol_packed:
+        if im_packed is None:
+            raise ValueError("render_rays: volume records come with image records (im_packed)")
+        volume = volume.t
+        _, Dv, hv, wv, _ = volume.shape
+    else:
+        _, _, Dv, hv, wv = volume.shape
     dev = rays.device
     if outs is not None:
         o0, o1, o2 = outs
@@ -354,6 +361,7 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     a.rgb_affine, a.white_bkgd, a.mode = int(bool(rgb_affine)), int(bool(white_bkgd)), int(mode)
     a.ray_begin, a.ray_end = int(begin), int(end)
     a.out0, a.out1, a.out2 = dptr(o0), dptr(o1), dptr(o2)
+    a.vol_packed = int(vol_packed)
     if view_ids is not None:
         if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S) or (
                 im_packed is None and im_feat.shape[1] != rgb_src.shape[1]):

@@ -180,6 +180,8 @@ typedef struct {
   const float* im_packed; /* NULL, or (B,S|n_all,Hr,Wr,12) lookup records [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] written by
                              bmv_fpn_smooth_fwd (feat_ch = 8): a bilinear tap of a view is then 2 loads per lane half
                              instead of 6; im_feat / rgb_src are not read */
+  int vol_packed;         /* 1: `volume` is (B,Dv,hv,wv,8) records [ch 0 2 4 6 | ch 1 3 5 7] (bmv_conv_heads_fwd); needs
+                             im_packed */
 } bmv_render_args;
 int bmv_render_rays_fwd(const bmv_render_args* args, bmv_stream_t stream);
 
@@ -386,6 +388,15 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
  * coarse_channels_last: coarse is (B,H/2,W/2,C) (the coarsest map is kept only in the sweep's layout) */
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
                         int Cf, int C, int H, int W, int coarse_channels_last, bmv_stream_t stream);
+
+/* feat_conv + depth_conv of a cost regulariser (cost_reg_net.py:43-44, 83-84) as one 9-channel 3x3x3 convolution whose
+ * epilogue writes what the fused renderer reads: records_out (B,D,H,W,8), the 8 feature channels of a voxel as one
+ * 32-byte record in MFMA row order (the caller packs the weights with output channels 0 2 4 6 1 3 5 7 8, so a record is
+ * [even | odd]: a trilinear tap is one 16-byte load per lane half, bmv_render_args.vol_packed), and depth_out
+ * (B,D,H,W), channel 8 (the depth logits bmv_depth_regress_fwd reads).  wpack / bias: bmv_conv_pack_weights layout for
+ * (Cin, Cout = 9, 3x3x3, stride 1). */
+int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
+                       int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
 /* FPN top-down step fused into the smoothing convolution that consumes it (feature_net.py:24-36, smooth0(p0) with
  * p0 = bilinear_x2(p1, align_corners=True) + lat0(c0)): out (B,Cout,H,W) = act(conv3x3(p0; wpack) + bias), p0
