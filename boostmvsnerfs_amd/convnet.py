@@ -155,6 +155,21 @@ class LookupRecords:
         return self.t.shape
 
 
+def conv0_fused(x, w0, b0, wpack, bias, Cout, out=None):
+    """relu(conv3x3(relu(conv3x3(x (B,3,H,W); w0 (8,3,3,3)) + b0); wpack) + bias): FeatureNet's first block (two
+    ConvBnReLU, batch norm folded) as one launch; `wpack` / `bias` = pack_conv of the second layer."""
+    B, _, H, W = x.shape
+    assert x.shape[1] == 3 and tuple(w0.shape) == (8, 3, 3, 3)
+    if out is None:
+        out = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"conv0_fused[3->8->{Cout},{H}x{W}]"):
+        rc = lib.bmv_conv0_fused_fwd(dptr(x.contiguous(), "x"), dptr(w0, "w0"), dptr(b0, "b0"), dptr(wpack, "wpack"),
+                                     dptr(bias, "bias"), dptr(out), B, Cout, H, W, 0.0, 0.0, stream())
+    _lib.check(rc, "conv0_fused_fwd")
+    return out
+
+
 class VolumeRecords:
     """(B, D, h, w, 8) feature volume as the fused renderer reads it: a voxel's 8 channels in one 32-byte record,
     [ch 0 2 4 6 | ch 1 3 5 7] (include/bmv.h, bmv_conv_heads_fwd / bmv_render_args.vol_packed)."""

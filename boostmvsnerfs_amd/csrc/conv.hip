@@ -679,6 +679,134 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// FeatureNet's first block as one launch (feature_net.py:8-10, conv0 = ConvBnReLU(3,8) + ConvBnReLU(8,8)): the first
+// layer has 3 input channels -- 27 FMAs per output -- so the second layer's tile producer computes it instead of
+// reading it: the 3-channel image tile (+2 pixels of halo) goes to LDS once, each thread evaluates its tile slots of
+// the 8-channel intermediate 4 channels (one k-step) at a time, weights wave-uniform; slots outside the image are the
+// second layer's zero padding.  The intermediate map (31 MB at 512x640x3 views, written and read back) and one launch
+// disappear.  MFMA part: the row-paired 8 -> 8 kernel unchanged.
+// ---------------------------------------------------------------------------------------------------
+struct Conv0Args {
+  const float* in;      // (B, 3, H, W)
+  const float* w0;      // (8, 3, 3, 3) first layer, batch norm folded
+  const float* b0;      // (8)
+  const float* wpack;   // second layer, row-paired pack (Cin = 8, Cout <= 8)
+  const float* bias;    // (16)
+  float* out;           // (B, Cout, H, W)
+  int B, Cout, H, W;
+  float slope0, slope1;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
+  using T = ConvTile<1, 3, 1, 1, R, 0, true>;
+  constexpr int IH = T::TYH + 2, IW = T::RS + 2, IN = IH * IW;   // image tile under the intermediate tile
+  constexpr int NIN = (3 * IN + 255) / 256;
+  __shared__ float lds[4 * T::PS];
+  __shared__ float img[3 * IN];
+  const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
+  const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int ty = bid % nty;
+  const int b = bid / nty;
+  const int x0 = tx * 16, y0 = ty * T::TY;
+  const int ix0 = x0 - 1, iy0 = y0 - 1;          // origin of the intermediate tile (second layer's halo)
+  const int hw = a.H * a.W;
+
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (size_t)b * 3 * hw), 0,
+                                                                  (int)(4u * (unsigned)(3 * hw)), 0x00020000);
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    const int e = tid + 256 * j;
+    if (e < 3 * IN) {
+      const int c = e / IN, r = e - c * IN, sy = r / IW, sx = r - sy * IW;
+      const int gx = ix0 - 1 + sx, gy = iy0 - 1 + sy;
+      const bool ok = (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+      img[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             rsrc, ok ? 4u * (unsigned)(c * hw + gy * a.W + gx) : 0x80000000u, 0, 0));
+    }
+  }
+  bool ok[T::NSLOT];
+  int ibase[T::NSLOT];
+#pragma unroll
+  for (int j = 0; j < T::NSLOT; ++j) {
+    const int slot = tid + 256 * j;
+    const int sx = slot % T::RS, sy = slot / T::RS;
+    const int gx = ix0 + sx, gy = iy0 + sy;
+    ok[j] = (slot < T::SLOTS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    ibase[j] = (slot < T::SLOTS) ? sy * IW + sx : 0;   // top-left input of the slot's 3x3 window
+  }
+  const float* wp = a.wpack + lane;
+  f32x4 acc[T::NACC];
+#pragma unroll
+  for (int r = 0; r < T::NACC; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = lds + (lane >> 4) * T::PS + rg * T::ROWBASE + (lane & 15);
+  __syncthreads();   // image tile complete
+#pragma unroll 1
+  for (int chunk = 0; chunk < 2; ++chunk) {
+    float wv[T::TAPS];
+#pragma unroll
+    for (int t = 0; t < T::TAPS; ++t) wv[t] = wp[(size_t)chunk * (T::TAPS * 64) + t * 64];
+#pragma unroll
+    for (int j = 0; j < T::NSLOT; ++j) {
+      if ((j + 1) * 256 > T::SLOTS && tid + 256 * j >= T::SLOTS) continue;
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = a.b0[chunk * 4 + c];
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float x = img[ci * IN + ibase[j] + ky * IW + kx];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaf(a.w0[((chunk * 4 + c) * 3 + ci) * 9 + ky * 3 + kx], x, v[c]);
+          }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float r = fmaxf(v[c], 0.f) + a.slope0 * fminf(v[c], 0.f);
+        lds[c * T::PS + tid + 256 * j] = ok[j] ? r : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j <= 3; ++j)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float w = wv[j * 3 + kw];
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p)
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(2 * p + j) * T::RS + kw], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x0090);
+      }
+    __syncthreads();
+  }
+  const int x = x0 + (lane & 15);
+  const int g = lane >> 4;
+  const int co0 = 4 * (g & 1);
+  if (x >= a.W || co0 >= a.Cout) return;
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
+  const int ybase = y0 + rg * R;
+#pragma unroll
+  for (int r = 0; r < T::NACC; ++r) {
+    const int y = ybase + 2 * r + (g >> 1);
+    if (y >= a.H) continue;
+    const size_t o = (((size_t)b * a.Cout + co0) * a.H + y) * a.W + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[r][j] + bs[j];
+      v = fmaxf(v, 0.f) + a.slope1 * fminf(v, 0.f);
+      if (co0 + j < a.Cout) a.out[o + (size_t)j * hw] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Split-K tiling for the deep U-Net levels (a few thousand voxels, 32-64 channels): with one 4-row x 16-column
 // tile per workgroup those launches are a few hundred workgroups whose waves each walk ALL k-steps in sequence,
 // exposing one global-load latency per k-step (measured 16-30 % MFMA-pipe occupancy).  Here every wave covers all
@@ -1153,6 +1281,27 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");
+}
+
+int bmv_conv0_fused_fwd(const float* in, const float* w0, const float* b0, const float* wpack, const float* bias,
+                        float* out, int B, int Cout, int H, int W, float slope0, float slope1, bmv_stream_t stream) {
+  using namespace bmv;
+  BMV_REQUIRE(in && w0 && b0 && wpack && bias && out, "conv0_fused: null pointer");
+  BMV_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 8, "conv0_fused: bad shape (Cout=%d)", Cout);
+  BMV_REQUIRE((size_t)3 * H * W < (1u << 29), "conv0_fused: one batch item must stay below 2 GiB");
+  Conv0Args a;
+  a.in = in, a.w0 = w0, a.b0 = b0, a.wpack = wpack, a.bias = bias, a.out = out;
+  a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.slope0 = slope0, a.slope1 = slope1;
+  static const int rows = getenv("BMV_CONV0_R") ? atoi(getenv("BMV_CONV0_R")) : 4;
+  hipStream_t st = as_stream(stream);
+  if (rows == 8) {
+    using T = ConvTile<1, 3, 1, 1, 8, 0, true>;
+    hipLaunchKernelGGL(conv0_fused_kernel<8>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+  } else {
+    using T = ConvTile<1, 3, 1, 1, 4, 0, true>;
+    hipLaunchKernelGGL(conv0_fused_kernel<4>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+  }
+  BMV_LAUNCH_END("conv0_fused_fwd");
 }
 
 int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_lat, const float* b_lat,

@@ -37,6 +37,7 @@ def _engine_ok(module, x):
 
 
 FUSE_FPN_SMOOTH = os.environ.get("BMV_FPN_FUSE", "1") == "1"
+FUSE_CONV0 = os.environ.get("BMV_CONV0_FUSE", "1") == "1"
 
 class _Packed:
     """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
@@ -139,6 +140,8 @@ class FeatureNet(nn.Module):
     def _blobs(self):
         return self._packed.get(self, lambda: {
             **{f"conv{i}.{j}": _pack_cbr(getattr(self, f"conv{i}")[j]) for i in range(3) for j in range(2)},
+            # first layer of the first block, folded, as the fused kernel's producer reads it ((8,3,3,3), (8))
+            "conv0.0_raw": tuple(t.float().contiguous() for t in convnet.fold_bn(self.conv0[0].conv.weight, self.conv0[0].bn)),
             "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
             "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias),
@@ -151,8 +154,11 @@ class FeatureNet(nn.Module):
         sweep reads.  The coarsest map is all the level-0 cost volume needs, so a caller can start that cascade level
         while `engine_top_down` is still running."""
         P = self._blobs()
-        c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
-        c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
+        if FUSE_CONV0:    # the 3-channel first layer is computed in the second layer's tile producer: one launch
+            c0 = convnet.conv0_fused(x, *P["conv0.0_raw"], *P["conv0.1"], 8)
+        else:
+            c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
+            c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
         c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
         c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)

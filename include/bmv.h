@@ -398,6 +398,13 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
                        int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
+/* FeatureNet's first block as one launch (feature_net.py:8-10: ConvBnReLU(3,8) + ConvBnReLU(8,Cout<=8), eval-mode batch
+ * norm folded): out (B,Cout,H,W) = act1(conv3x3(act0(conv3x3(in (B,3,H,W); w0 (8,3,3,3)) + b0); wpack) + bias); the
+ * 8-channel intermediate is computed in the second layer's tile producer and never written.  wpack / bias:
+ * bmv_conv_pack_weights layout for (Cin = 8, Cout, k = 3, stride 1: row-paired); act_i = v > 0 ? v : slope_i * v. */
+int bmv_conv0_fused_fwd(const float* in, const float* w0, const float* b0, const float* wpack, const float* bias,
+                        float* out, int B, int Cout, int H, int W, float slope0, float slope1, bmv_stream_t stream);
+
 /* FPN top-down step fused into the smoothing convolution that consumes it (feature_net.py:24-36, smooth0(p0) with
  * p0 = bilinear_x2(p1, align_corners=True) + lat0(c0)): out (B,Cout,H,W) = act(conv3x3(p0; wpack) + bias), p0
  * (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2)) + conv1x1(fine (B,8,H,W); w_lat (C,8)) + b_lat built chunk by chunk

@@ -130,6 +130,26 @@ def test_fpn_smooth_fused_equals_the_two_launches(H, W, rows, monkeypatch):
     assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (34, 50), (5, 7), (18, 130)])
+def test_conv0_fused_equals_the_two_launches(H, W):
+    """bmv_conv0_fused_fwd = relu(conv(relu(conv(x)))) of FeatureNet's first block in one launch, against torch and
+    against the two engine launches it replaces."""
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(2, 3, H, W, generator=g).to(DEV)
+    w0 = (torch.randn(8, 3, 3, 3, generator=g) / 3).to(DEV)
+    b0 = torch.randn(8, generator=g).to(DEV) * 0.3
+    w1 = (torch.randn(8, 8, 3, 3, generator=g) / 6).to(DEV)
+    b1 = torch.randn(8, generator=g).to(DEV) * 0.3
+    want = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, b0, padding=1)), w1, b1, padding=1))
+    wp0, bp0 = convnet.pack_conv(w0, b0)
+    wp1, bp1 = convnet.pack_conv(w1, b1)
+    two = convnet.conv_fwd(convnet.conv_fwd(x, wp0, bp0, 8, 1, 3, relu=True), wp1, bp1, 8, 1, 3, relu=True)
+    got = convnet.conv0_fused(x, w0.contiguous(), b0.contiguous(), wp1, bp1, 8)
+    _close(got, want)
+    assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
+
+
 def _randomise_bn(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
