@@ -19,7 +19,7 @@ run() {  # name workload marker markers-per-step steps warmup extra...
 WL=${*:-"c2 c1 c3 c4 c5"}
 for w in $WL; do
   case $w in
-    c2) run r2_config2_enerf512x640 enerf_512x640_3src_64planes "render_rays_kernel" 1 10 3 ;;
+    c2) run r2_config2_enerf512x640 enerf_512x640_3src_64planes "render_rays_kernel" 1 20 5 ;;
     c1) run r2_config1_enerf256x320 enerf_256x320_3src_32planes "render_rays_kernel" 1 10 3 ;;
     c3) run r2_config3_enerf_ours480x736_k4 enerf_ours_480x736_6src_k4 "blend_kernel" 1 8 3 ;;
     c4) run r2_config4_mvsnerf_ours_128planes_k4 mvsnerf_ours_224x352_128planes_k4 "blend_kernel" 1 4 2 ;;
