@@ -97,9 +97,9 @@ def parse():
     ap.add_argument("--spinup-steps", type=int, default=100,
                     help="ENeRF inference workloads (ms-scale frames): untimed replays of the step right before the timed "
                          "region, so that it starts from the steady state of a serving renderer (0 = cold start)")
-    ap.add_argument("--cut-sweeps", action="store_true",
-                    help="graph replay: keep the plane sweeps as ordinary launches between graphs (round 1's way of "
-                         "timing them) instead of event-record nodes inside one graph")
+    ap.add_argument("--in-graph-sweeps", action="store_true",
+                    help="bracketed frames: keep the frame ONE graph and bracket the plane sweeps with event-record nodes "
+                         "instead of launching them between graphs with events bound to their dispatch")
     ap.add_argument("--all-kernel-events", action="store_true", help="HIP events around every hot-path launch")
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1: let MIOpen search its convolution solvers (torch.backends.cudnn.benchmark).  Only the "
@@ -354,11 +354,15 @@ def main():
             # (csrc/timing.hip); --cut-sweeps restores round 1's form (the sweeps as ordinary launches between graphs)
             ktimer.forget_graph_events()
             sampled = {"n": 0, "every": 1, "evented": True}
-            if args.cut_sweeps and not args.no_kernel_events:
-                fg = FrameGraph(net, batch, cut="all")
+            if args.no_kernel_events:
+                fg = FrameGraph(net, batch, cut=None)
                 replay = fg.replay
             else:
-                fg = FrameGraph(net, batch, cut=None, events=not args.no_kernel_events)
+                # bracketed frames: the sweeps are ordinary launches between the graphs, their events bound to their
+                # own dispatch (hipExtLaunchKernelGGL: the kernel's begin and end); the renderer is bracketed by
+                # event-record nodes inside its graph.  --in-graph-sweeps keeps the frame one graph and brackets the
+                # sweeps with event-record nodes too (they then read ~2.5 us more).
+                fg = FrameGraph(net, batch, cut=None if args.in_graph_sweeps else "all", events=True)
                 replay = fg.replay
                 if fg.events and args.event_every > 1:
                     fg_plain = FrameGraph(net, batch, cut=None)        # same frame, no brackets

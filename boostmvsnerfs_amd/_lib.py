@@ -116,6 +116,8 @@ SIGNATURES = {
     "bmv_event_destroy": [C.c_void_p],
     "bmv_event_record": [C.c_void_p, C.c_void_p],
     "bmv_event_elapsed_us": [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)],
+    "bmv_bind_next_launch": [C.c_void_p, C.c_void_p],
+    "bmv_launch_events_pending": [],
     "bmv_version": [],
 }
 

@@ -17,6 +17,15 @@ namespace bmv {
 
 void set_error(const char* fmt, ...);
 
+// Events the NEXT sweep launch of this thread binds to its own dispatch (bmv_bind_next_launch, csrc/timing.hip):
+// hipExtLaunchKernelGGL start / stop events read the kernel's begin and end, a hipEventRecord pair around a launch reads
+// ~2.5 us more (scripts/ubench/ext_events.hip).  take_launch_events() hands them over once.
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchEvents take_launch_events();
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+
 #define BMV_REQUIRE(cond, ...)                  \
   do {                                          \
     if (!(cond)) {                              \

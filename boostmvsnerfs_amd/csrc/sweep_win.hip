@@ -25,6 +25,8 @@
 // permutation is applied to the per-lane SOURCE address.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "bmv_common.hpp"
 
 namespace bmv {
@@ -540,7 +542,11 @@ int launch_one(const WinArgs& a, int B, hipStream_t stream) {
     allowed = lds;
   }
   dim3 grid(8u * (unsigned)(a.chalves * a.pgroups), (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  const LaunchEvents ev = take_launch_events();
+  if (ev.start)   // bench.py's roofline bracket: events bound to this dispatch (bmv_bind_next_launch)
+    hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev.start, ev.stop, 0, a);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   return BMV_OK;
 }
 

@@ -7,9 +7,30 @@
 // was captured between them in the LAST replay.
 #include "bmv_common.hpp"
 
+namespace bmv {
+static thread_local LaunchEvents g_launch_events;
+LaunchEvents take_launch_events() {
+  LaunchEvents e = g_launch_events;
+  g_launch_events = LaunchEvents{};
+  return e;
+}
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_launch_events.start = start, g_launch_events.stop = stop; }
+}  // namespace bmv
+
 using namespace bmv;
 
 extern "C" {
+
+int bmv_bind_next_launch(bmv_event_t start, bmv_event_t stop) {
+  BMV_REQUIRE((start == nullptr) == (stop == nullptr), "bmv_bind_next_launch: one event without the other");
+  set_launch_events(reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop));
+  return BMV_OK;
+}
+
+int bmv_launch_events_pending(void) {   // 1: the events of bmv_bind_next_launch were not taken by a launch (and are dropped)
+  const LaunchEvents e = take_launch_events();
+  return e.start ? 1 : 0;
+}
 
 int bmv_event_create(bmv_event_t* ev) {
   BMV_REQUIRE(ev, "bmv_event_create: null pointer");

@@ -10,10 +10,11 @@ sweep issued on the capture stream): the graphs hold everything between them and
 stay ordinary launches, so HIP events on the stream can time exactly those kernels inside a timed region
 (bench.py's `roofline`).  `cut=None` captures the frame as one graph.
 
-`events=True` (with `cut=None`): the kernels `ktimer` is set to time are bracketed INSIDE the graph by event-record
-nodes (csrc/timing.hip), so the frame stays one graph and the brackets cost no graph boundary (a cut costs the frame
-~20 us of idle stream per sweep: end of graph -> event -> launch -> event -> next graph).  `ktimer.collect()` after
-a synchronize reads the brackets of the replay that just finished.
+`events=True`: the kernels `ktimer` is set to time are bracketed INSIDE the graphs by event-record nodes
+(csrc/timing.hip); `ktimer.collect()` after a synchronize reads the brackets of the replay that just finished.  With
+`cut="all"` as well (bench.py's bracketed frames) the sweeps are ordinary launches between the graphs whose events are
+bound to their own dispatch (`ktimer.region(bind=True)`: they read the kernel's begin and end), the renderer keeps its
+in-graph bracket.
 
 The batch tensors are the graph's static inputs: refresh them in place (`copy_`) between replays.  The
 returned dict holds the static output tensors of the captured pass.
@@ -27,8 +28,6 @@ from . import ktimer, ops
 
 class FrameGraph:
     def __init__(self, net, batch, cut=-1, warmup=2, events=False):
-        if events and cut is not None:
-            raise ValueError("FrameGraph: in-graph event brackets are for the uncut capture (cut=None)")
         self.net, self.batch = net, batch
         self.cut = cut
         self.events = events

@@ -17,6 +17,8 @@ import torch
 enabled = False
 only = None          # optional tuple of name prefixes: time just these kernels (two event records cost ~10 us of host time)
 _records = {}        # name -> [(start, end)] torch events of eager launches
+_bound = {}          # name -> [(start, end)] events bound to a launch's own dispatch
+_no_bind = set()     # names whose launch path does not take bound events
 _graph_pairs = {}    # name -> [(start, end)] events living in captured graphs
 _graph_us = {}       # name -> [us] collected from the graph pairs
 
@@ -48,6 +50,7 @@ class _Event:
 def reset():
     """Forget the collected durations (the event pairs of live graphs stay: they belong to the graphs)."""
     _records.clear()
+    _bound.clear()
     _graph_us.clear()
 
 
@@ -57,9 +60,25 @@ def forget_graph_events():
 
 
 @contextlib.contextmanager
-def region(name):
+def region(name, bind=False):
+    """`bind=True` (plane sweeps): outside a capture the pair is BOUND to the kernel's own dispatch
+    (bmv_bind_next_launch -> hipExtLaunchKernelGGL: the events read the kernel's begin and end) instead of recorded
+    around the launch; a launch path that does not take them falls back to the recorded pair from then on."""
     if not enabled or (only is not None and not name.startswith(only)):
         yield
+        return
+    if bind and name not in _no_bind and not torch.cuda.is_current_stream_capturing():
+        from . import _lib
+        lib = _lib.load()
+        s, e = _Event(), _Event()
+        _lib.check(lib.bmv_bind_next_launch(s.h, e.h), "bmv_bind_next_launch")
+        try:
+            yield
+        finally:
+            if lib.bmv_launch_events_pending():
+                _no_bind.add(name)                       # this shape runs another kernel: recorded pairs next time
+            else:
+                _bound.setdefault(name, []).append((s, e))
         return
     if torch.cuda.is_current_stream_capturing():
         s, e = _Event(), _Event()
@@ -93,9 +112,10 @@ def collect():
 def summary():
     """name -> (launches, mean ms, min ms); call after a device synchronize."""
     out = {}
-    names = set(_records) | set(_graph_us)
+    names = set(_records) | set(_graph_us) | set(_bound)
     for name in names:
-        ms = [s.elapsed_time(e) for s, e in _records.get(name, [])] + [u * 1e-3 for u in _graph_us.get(name, [])]
+        ms = ([s.elapsed_time(e) for s, e in _records.get(name, [])] + [u * 1e-3 for u in _graph_us.get(name, [])]
+              + [s.elapsed_us(e) * 1e-3 for s, e in _bound.get(name, [])])
         if ms:
             out[name] = (len(ms), sum(ms) / len(ms), min(ms))
     return out

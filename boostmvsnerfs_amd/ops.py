@@ -124,7 +124,7 @@ def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=cl.device, dtype=torch.float32)
     lib = _lib.load()
-    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]"):
+    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]", bind=True):
         rc = lib.bmv_sweep_variance_views_fwd(dptr(cl, "feats_all"), dptr(_c(view_ids), "view_ids", torch.int32), n_all,
                                               dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"), B, S, C_,
                                               Hs, Ws, D, h, w, dptr(out), stream())
@@ -151,7 +151,7 @@ def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=N
     lib = _lib.load()
     args = (dptr(_c(feats), "feats"), dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"), B, S, C_, Hs,
             Ws, D, h, w, dptr(out), layout, int(algo), stream())
-    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]"):
+    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]", bind=True):
         rc = lib.bmv_sweep_variance_fwd(*args)
     _lib.check(rc, "sweep_variance")
     return out

@@ -437,6 +437,12 @@ int bmv_event_create(bmv_event_t* ev);
 int bmv_event_destroy(bmv_event_t ev);
 int bmv_event_record(bmv_event_t ev, bmv_stream_t stream);
 int bmv_event_elapsed_us(bmv_event_t start, bmv_event_t end, float* us);
+/* Bind `start` / `stop` to the NEXT plane-sweep launch of this thread (bmv_sweep_variance_fwd /
+ * bmv_sweep_variance_views_fwd, windowed kernel): the launch goes through hipExtLaunchKernelGGL and the events read the
+ * kernel's own begin and end (a record pair around a launch reads ~2.5 us more; scripts/ubench/ext_events.hip).  Not
+ * for a capturing stream.  bmv_launch_events_pending() after the call: 1 if no launch took them (they are dropped). */
+int bmv_bind_next_launch(bmv_event_t start, bmv_event_t stop);
+int bmv_launch_events_pending(void);
 
 #ifdef __cplusplus
 }

@@ -117,5 +117,46 @@ def test_event_brackets_inside_a_graph():
     for name, (launches, mean_ms, min_ms) in ks.items():
         assert launches == 3, (name, launches)
         assert 0.0 < min_ms <= mean_ms < max(walls), (name, mean_ms, walls)
-    with pytest.raises(ValueError):
-        FrameGraph(net, batch, cut=-1, events=True)
+
+
+def test_bound_events_on_the_sweeps_between_graphs():
+    """FrameGraph(cut="all", events=True), bench.py's bracketed frame: the sweeps are ordinary launches between the
+    graphs with events BOUND to their dispatch (bmv_bind_next_launch -> hipExtLaunchKernelGGL), the renderer keeps its
+    in-graph bracket; results equal the eager ones and every bracket reads a plausible duration."""
+    from boostmvsnerfs_amd import ktimer
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.framegraph import FrameGraph
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    cfg = make_cfg("enerf_eval")
+    cfg.enerf.cas_config.volume_planes = [16, 8]
+    set_cfg(cfg)
+    torch.manual_seed(0)
+    net = Network().eval().to(DEV)
+    batch = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    want = _eager(net, batch)
+    ktimer.reset()
+    ktimer.forget_graph_events()
+    ktimer.only = ("sweep_variance", "render_rays")
+    try:
+        fg = FrameGraph(net, batch, cut="all", events=True)
+        assert len(fg.sweeps) == 2 and len(fg.graphs) == 3
+        ktimer.reset()
+        ktimer.enabled = True
+        for _ in range(3):
+            got = fg.replay()
+            torch.cuda.synchronize()
+            ktimer.collect()
+        ks = ktimer.summary()
+        assert not ktimer._no_bind                       # the windowed sweep took the bound events
+    finally:
+        ktimer.enabled, ktimer.only = False, None
+        ktimer.forget_graph_events()
+        ktimer.reset()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    sweeps = {n: v for n, v in ks.items() if n.startswith("sweep_variance")}
+    render = {n: v for n, v in ks.items() if n.startswith("render_rays")}
+    assert len(sweeps) == 2 and len(render) == 1, ks
+    for name, (launches, mean_ms, min_ms) in ks.items():
+        assert launches == 3 and 0.0 < min_ms <= mean_ms < 5.0, (name, launches, mean_ms)
