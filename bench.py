@@ -558,6 +558,11 @@ def main():
                 mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "achieved": tf,
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                         "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
+                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d) (50.9 kFLOP/sample); the kernel EXECUTES 26.2
+                # kFLOP/sample (the view-shared parts of global_fc / color.0 are computed once, csrc/mlp.hpp): the share of
+                # the matrix pipe's time it actually uses is the executed figure
+                ex = 26.2e3 * rays_launch * cc.num_samples[1] / kernels[rname]["avg_us"] / 1e6
+                mfma.update({"executed_tflops": ex, "mfma_issue_frac": ex / FP32_MFMA_PEAK_TFLOPS})
         else:
             Ns = cc.num_samples[0]
             rname = f"mvs_render[Ns={Ns}]"
