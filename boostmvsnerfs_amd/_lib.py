@@ -54,6 +54,8 @@ class MvsRenderArgs(C.Structure):
 SIGNATURES = {
     "bmv_proj_mats": [c_f, c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_f, c_f],
     "bmv_depth_values_uniform": [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_frame_setup": [c_f, c_f, c_f, c_f, C.POINTER(C.c_float), C.POINTER(C.c_float), c_i, c_i, c_i, c_f, c_f, c_i, c_i,
+                        c_i, c_i, c_f, c_f, c_f],
     "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],

@@ -21,11 +21,10 @@ void set_error(const char* fmt, ...) {
 // a1: one thread per (b, s).  The 4x4 inverse is done in fp64 (Gauss-Jordan with
 // partial pivoting); the result is rounded to fp32 once.
 // ---------------------------------------------------------------------------
-__global__ void proj_mats_kernel(const float* __restrict__ src_exts, const float* __restrict__ src_ixts,
-                                 const float* __restrict__ tar_ext, const float* __restrict__ tar_ixt,
-                                 float src_scale, float tar_scale, int B, int S, float* __restrict__ proj) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * S) return;
+__device__ __forceinline__ void proj_mats_one(int idx, const float* __restrict__ src_exts,
+                                              const float* __restrict__ src_ixts, const float* __restrict__ tar_ext,
+                                              const float* __restrict__ tar_ixt, float src_scale, float tar_scale,
+                                              int S, float* __restrict__ proj) {
   int b = idx / S;
   const float* Es = src_exts + (size_t)idx * 16;
   const float* Ks = src_ixts + (size_t)idx * 9;
@@ -83,12 +82,21 @@ __global__ void proj_mats_kernel(const float* __restrict__ src_exts, const float
     }
 }
 
+__global__ void proj_mats_kernel(const float* __restrict__ src_exts, const float* __restrict__ src_ixts,
+                                 const float* __restrict__ tar_ext, const float* __restrict__ tar_ixt,
+                                 float src_scale, float tar_scale, int B, int S, float* __restrict__ proj) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * S) return;
+  proj_mats_one(idx, src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale, S, proj);
+}
+
 // ---------------------------------------------------------------------------
 // a2
 // ---------------------------------------------------------------------------
 // grid.z = groups of 8 planes (a 64-plane level on a 64 x 80 map is otherwise 20 workgroups of 64 divisions per thread)
-__global__ void depth_values_uniform_kernel(const float* __restrict__ near_far, int D, int hw, int depth_inv,
-                                            float* __restrict__ dv, float* __restrict__ nf_out) {
+__device__ __forceinline__ void depth_values_uniform_group(int zgroup, const float* __restrict__ near_far, int D,
+                                                           int hw, int depth_inv, float* __restrict__ dv,
+                                                           float* __restrict__ nf_out) {
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
@@ -99,9 +107,9 @@ __global__ void depth_values_uniform_kernel(const float* __restrict__ near_far, 
     float t = d < D / 2 ? (float)d * step : 1.f - (float)(D - 1 - d) * step;
     return depth_inv ? 1.f / (1.f / n + t * (1.f / f - 1.f / n)) : n + (f - n) * t;
   };
-  const int d0 = blockIdx.z * 8, d1 = min(D, d0 + 8);
+  const int d0 = zgroup * 8, d1 = min(D, d0 + 8);
   for (int d = d0; d < d1; ++d) dv[((size_t)b * D + d) * hw + i] = value(d);
-  if (blockIdx.z == 0) {
+  if (zgroup == 0) {
     float first = value(0), last = value(D - 1);
     if (depth_inv) {
       first = 1.f / fmaxf(first, 1e-6f);
@@ -110,6 +118,40 @@ __global__ void depth_values_uniform_kernel(const float* __restrict__ near_far, 
     nf_out[((size_t)b * 2 + 0) * hw + i] = first;
     nf_out[((size_t)b * 2 + 1) * hw + i] = last;
   }
+}
+
+__global__ void depth_values_uniform_kernel(const float* __restrict__ near_far, int D, int hw, int depth_inv,
+                                            float* __restrict__ dv, float* __restrict__ nf_out) {
+  depth_values_uniform_group(blockIdx.z, near_far, D, hw, depth_inv, dv, nf_out);
+}
+
+// Everything a frame needs from the cameras alone, one launch (inference: three tiny launches -- the projection
+// matrices of each cascade level and level 0's hypotheses -- otherwise sit in front of the sweeps, ~5 us each of launch
+// and single-thread fp64 latency): grid.z = plane groups of the hypotheses + one slice for the projection matrices.
+struct FrameSetupArgs {
+  const float* src_exts;
+  const float* src_ixts;
+  const float* tar_ext;
+  const float* tar_ixt;
+  const float* near_far;
+  float* proj;        // (L, B, S, 3, 4)
+  float* dv;          // (B, D, h, w)
+  float* nf_out;      // (B, 2, h, w)
+  float src_scale[4], tar_scale[4];
+  int L, B, S, D, hw, depth_inv;
+};
+__global__ void frame_setup_kernel(FrameSetupArgs a) {
+  const int zgroups = (a.D + 7) / 8;
+  if ((int)blockIdx.z < zgroups) {
+    depth_values_uniform_group(blockIdx.z, a.near_far, a.D, a.hw, a.depth_inv, a.dv, a.nf_out);
+    return;
+  }
+  if (blockIdx.y != 0) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, per = a.B * a.S;
+  if (idx >= a.L * per) return;
+  const int l = idx / per;
+  proj_mats_one(idx - l * per, a.src_exts, a.src_ixts, a.tar_ext, a.tar_ixt, a.src_scale[l], a.tar_scale[l], a.S,
+                a.proj + (size_t)l * per * 12);
 }
 
 __global__ void depth_values_cascade_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
@@ -367,6 +409,25 @@ int bmv_depth_values_uniform(const float* near_far, int B, int D, int h, int w, 
   hipLaunchKernelGGL(depth_values_uniform_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8)), dim3(256), 0, as_stream(stream),
                      near_far, D, h * w, depth_inv, depth_values, near_far_out);
   BMV_LAUNCH_END("bmv_depth_values_uniform");
+}
+
+int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* tar_ext, const float* tar_ixt,
+                    const float* src_scales, const float* tar_scales, int L, int B, int S, float* proj,
+                    const float* near_far, int D, int h, int w, int depth_inv, float* depth_values,
+                    float* near_far_out, bmv_stream_t stream) {
+  BMV_REQUIRE(src_exts && src_ixts && tar_ext && tar_ixt && src_scales && tar_scales && proj && near_far &&
+                  depth_values && near_far_out,
+              "bmv_frame_setup: null pointer");
+  BMV_REQUIRE(L > 0 && L <= 4 && B > 0 && S > 0 && D > 0 && h > 0 && w > 0, "bmv_frame_setup: bad shape (L=%d)", L);
+  BMV_REQUIRE(L * B * S <= 256 * (int)cdiv(h * w, 256), "bmv_frame_setup: %d projection matrices do not fit one grid slice",
+              L * B * S);
+  FrameSetupArgs a;
+  a.src_exts = src_exts, a.src_ixts = src_ixts, a.tar_ext = tar_ext, a.tar_ixt = tar_ixt, a.near_far = near_far;
+  a.proj = proj, a.dv = depth_values, a.nf_out = near_far_out;
+  for (int l = 0; l < L; ++l) a.src_scale[l] = src_scales[l], a.tar_scale[l] = tar_scales[l];
+  a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
+  hipLaunchKernelGGL(frame_setup_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a);
+  BMV_LAUNCH_END("bmv_frame_setup");
 }
 
 int bmv_depth_values_cascade(const float* depth, const float* std_, const float* near_far, int B, int h0, int w0,

@@ -54,6 +54,8 @@ class Network(nn.Module):
         # host's ~45 launches and the extra stream traffic costs 3 % (BMV_OVERLAP_EAGER=1 forks there too).
         self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
         self.lookup_records = os.environ.get("BMV_LOOKUP_RECORDS", "1") == "1"
+        self.frame_setup = os.environ.get("BMV_FRAME_SETUP", "1") == "1"
+        self._pre = None
         self.volume_records = os.environ.get("BMV_VOLUME_RECORDS", "1") == "1"
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
         self._side_stream = None
@@ -88,7 +90,19 @@ class Network(nn.Module):
                                    and getattr(self, f"nerf_{i}").feat_ch - 3 == 8 for i in users)
 
     # ------------------------------------------------------------------ cost volume of one level
-    def level_front(self, i, feats_i, views, batch, prev, view_ids=None, fork_after_sweep=None):
+    def camera_only(self, views, batch):
+        """What a frame needs from the cameras alone -- the projection matrices of every cascade level and level 0's
+        uniform hypotheses -- as ONE launch (ops.frame_setup) instead of three in front of the sweeps (inference)."""
+        cc = cfg.enerf.cas_config
+        src_inps, src_exts, src_ixts = views
+        H, W = src_inps.shape[-2:]
+        proj, dv0 = ops.frame_setup(src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"],
+                                    [cc.im_feat_scale[i] for i in range(cc.num)], [cc.volume_scale[i] for i in range(cc.num)],
+                                    batch["near_far"], cc.volume_planes[0], int(H * cc.volume_scale[0]),
+                                    int(W * cc.volume_scale[0]), cc.depth_inv[0])
+        return {"proj": proj, "dv0": dv0}
+
+    def level_front(self, i, feats_i, views, batch, prev, view_ids=None, fork_after_sweep=None, pre=None):
         """Plane sweep + regulariser + depth regression (network.py:81-90).
         `fork_after_sweep`: a side stream that takes everything AFTER the sweep (regulariser, depth regression); the
         caller joins it.  The sweep itself stays on the current stream.
@@ -102,7 +116,9 @@ class Network(nn.Module):
         D = cc.volume_planes[i]
         st = LevelState()
         train = self.wants_grad()             # fine-tuning: autograd Functions (HIP forward + HIP backward)
-        if prev is None or prev.depth is None:
+        if (prev is None or prev.depth is None) and pre is not None and i == 0:
+            st.depth_values, st.near_far = pre["dv0"]
+        elif prev is None or prev.depth is None:
             st.depth_values, st.near_far = ops.depth_values_uniform(batch["near_far"], D, h, w, cc.depth_inv[i])
         else:
             if not cc.depth_inv[i - 1] or cc.depth_inv[i]:
@@ -111,8 +127,8 @@ class Network(nn.Module):
                 st.depth_values, st.near_far = A.DepthValuesCascade.apply(prev.depth, prev.std, prev.near_far, h, w, D)
             else:
                 st.depth_values, st.near_far = ops.depth_values_cascade(prev.depth, prev.std, prev.near_far, h, w, D)
-        proj = ops.proj_mats(src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"], cc.im_feat_scale[i],
-                             cc.volume_scale[i])
+        proj = pre["proj"][i] if pre is not None else ops.proj_mats(
+            src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"], cc.im_feat_scale[i], cc.volume_scale[i])
         if train:
             variance = A.SweepVariance.apply(feats_i, proj, st.depth_values, self.sweep_algo)
         elif view_ids is not None:
@@ -253,6 +269,7 @@ class Network(nn.Module):
         x = batch["src_inps"]
         B, V, C, H, W = x.shape
         fn = self.feature_net
+        self._pre = self.camera_only(views, batch) if self.frame_setup else None
         c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
         main = torch.cuda.current_stream()
         if self._side_stream is None:
@@ -260,7 +277,7 @@ class Network(nn.Module):
         side = self._side_stream
         level0 = p2_cl.reshape(B, V, -1, H // 4, W // 4)
         if self.overlap_front == 2:
-            st0 = self.level_front(0, level0, views, batch, None, fork_after_sweep=side)
+            st0 = self.level_front(0, level0, views, batch, None, fork_after_sweep=side, pre=self._pre)
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -314,6 +331,8 @@ class Network(nn.Module):
                     and engine_ok(self.feature_net, batch["src_inps"])):
                 feats, st0 = self._front_overlapped(batch, views)
             else:
+                self._pre = self.camera_only(views, batch) if (self.frame_setup and not self.wants_grad()
+                                                               and batch["src_inps"].is_cuda) else None
                 feats = self.forward_feat(batch["src_inps"])
         finally:
             self.feature_net.pack_lookup = False
@@ -321,7 +340,8 @@ class Network(nn.Module):
         ret = {}
         st = None
         for i in range(cc.num):
-            st = st0 if (i == 0 and st0 is not None) else self.level_front(i, feats[f"level_{i}"], views, batch, st)
+            st = st0 if (i == 0 and st0 is not None) else self.level_front(i, feats[f"level_{i}"], views, batch, st,
+                                                                           pre=self._pre)
             if not cc.render_if[i]:
                 continue
             rgb, depth, weights = render(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)

@@ -51,6 +51,24 @@ def depth_values_uniform(near_far, D, h, w, depth_inv):
     return dv, nf
 
 
+def frame_setup(src_exts, src_ixts, tar_ext, tar_ixt, src_scales, tar_scales, near_far, D, h, w, depth_inv):
+    """proj_mats of every cascade level + depth_values_uniform of level 0 in ONE launch (what a frame needs from the
+    cameras alone): ([proj_l (B,S,3,4)], (depth_values (B,D,h,w), near_far (B,2,h,w)))."""
+    B, S = src_exts.shape[:2]
+    L = len(src_scales)
+    dev = src_exts.device
+    proj = torch.empty(L, B, S, 3, 4, device=dev, dtype=torch.float32)
+    dv = torch.empty(B, D, h, w, device=dev, dtype=torch.float32)
+    nf = torch.empty(B, 2, h, w, device=dev, dtype=torch.float32)
+    ss = (C.c_float * L)(*[float(v) for v in src_scales])
+    ts = (C.c_float * L)(*[float(v) for v in tar_scales])
+    lib = _lib.load()
+    _lib.check(lib.bmv_frame_setup(dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"),
+                                   dptr(_c(tar_ixt), "tar_ixt"), ss, ts, L, B, S, dptr(proj), dptr(_c(near_far), "near_far"),
+                                   D, h, w, int(bool(depth_inv)), dptr(dv), dptr(nf), stream()), "frame_setup")
+    return [proj[l] for l in range(L)], (dv, nf)
+
+
 def depth_values_cascade(depth, std, near_far, h, w, D):
     B, h0, w0 = depth.shape
     dv = torch.empty(B, D, h, w, device=depth.device, dtype=torch.float32)

@@ -40,6 +40,14 @@ int bmv_proj_mats(const float* src_exts, const float* src_ixts, const float* tar
  * near_far (B,2) -> depth_values (B,D,h,w), near_far_out (B,2,h,w) (= 1/clamp(.,1e-6) if depth_inv) */
 int bmv_depth_values_uniform(const float* near_far, int B, int D, int h, int w, int depth_inv,
                              float* depth_values, float* near_far_out, bmv_stream_t stream);
+/* a1 + a2 of a whole frame in one launch (inference): the projection matrices of all L <= 4 cascade levels
+ * (proj (L,B,S,3,4), level l with src_scales[l] / tar_scales[l] -- host arrays) and level 0's uniform hypotheses
+ * (depth_values (B,D,h,w), near_far_out (B,2,h,w)): bmv_proj_mats x L + bmv_depth_values_uniform, same arithmetic. */
+int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* tar_ext, const float* tar_ixt,
+                    const float* src_scales, const float* tar_scales, int L, int B, int S, float* proj,
+                    const float* near_far, int D, int h, int w, int depth_inv, float* depth_values,
+                    float* near_far_out, bmv_stream_t stream);
+
 /* cascade level (:112-153, prev level in disparity, this level in depth): bilinear
  * (align_corners) upsample of depth/std (B,h0,w0) and near_far (B,2,h0,w0) to (h,w);
  * [depth+std, depth-std] clamped to near_far, inverted, D planes uniform in depth. */

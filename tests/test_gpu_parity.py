@@ -58,6 +58,22 @@ def test_warp_and_sweep(ops, enerf_fx, algo):
         assert_close(var, enerf_fx.t(f"cap/build_feature_volume#{lvl}.0"), name=f"var{lvl}")
 
 
+def test_frame_setup_equals_the_separate_launches(ops, enerf_fx):
+    """bmv_frame_setup = proj_mats of both levels + depth_values_uniform of level 0 in one launch, bit for bit."""
+    b = enerf_fx.batch(DEV)
+    c = tiny_cfg(enerf_fx).enerf.cas_config
+    H, W = b["src_inps"].shape[-2:]
+    h, w = int(H * c.volume_scale[0]), int(W * c.volume_scale[0])
+    proj, (dv, nf) = ops.frame_setup(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"],
+                                     [c.im_feat_scale[i] for i in range(2)], [c.volume_scale[i] for i in range(2)],
+                                     b["near_far"], c.volume_planes[0], h, w, c.depth_inv[0])
+    for lvl in range(2):
+        want = ops.proj_mats(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"], c.im_feat_scale[lvl], c.volume_scale[lvl])
+        assert torch.equal(proj[lvl], want), lvl
+    dv2, nf2 = ops.depth_values_uniform(b["near_far"], c.volume_planes[0], h, w, c.depth_inv[0])
+    assert torch.equal(dv, dv2) and torch.equal(nf, nf2)
+
+
 def test_depth_regress(ops, enerf_fx):
     for lvl, inv in ((0, True), (1, False)):
         d, s = ops.depth_regress(g(enerf_fx, f"cap/cost_reg_{lvl}#0.1"), g(enerf_fx, f"cap/get_depth_values#{lvl}.0"), inv)
