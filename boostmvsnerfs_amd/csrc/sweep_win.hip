@@ -100,6 +100,13 @@ struct WinArgs {
 #undef BMV_WIN_WPE
 #define BMV_WIN_WPE(threads) BMV_WIN_WPE_FIXED
 #endif
+// Cache-policy bits of the variance stores.  2 = non-temporal: the volume (42 MB per level, more than the 32 MB of L2)
+// is written once and streams out -- level 1 22.9 -> 21.35 us, level 0 23.5 -> 21.8 us stand-alone (1 = sc0: no change;
+// 17 / 19 = sc1: slower).  The consumer (the regulariser's first layer) then finds less of it in L2: the frame as a
+// whole is unchanged (348.2 vs 347.5 Mray/s, scripts/ab_sweep_nt.sh); -DBMV_WIN_STORE_AUX=0 restores cached stores.
+#ifndef BMV_WIN_STORE_AUX
+#define BMV_WIN_STORE_AUX 2
+#endif
 #ifndef BMV_WIN_TAPBUF
 #define BMV_WIN_TAPBUF 2
 #endif
@@ -407,16 +414,16 @@ sweep_win_kernel(const WinArgs a) {
       for (int q = 0; q < 4; ++q) {
         float m;
         m = acc[q].x * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].x * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].x * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
         soff += cstride;
         m = acc[q].y * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].y * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].y * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
         soff += cstride;
         m = acc[q].z * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].z * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].z * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
         soff += cstride;
         m = acc[q].w * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].w * inv_s - m * m), orsrc, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].w * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
         soff += cstride;
       }
     }
