@@ -101,9 +101,10 @@ struct WinArgs {
 #define BMV_WIN_WPE(threads) BMV_WIN_WPE_FIXED
 #endif
 // Cache-policy bits of the variance stores.  2 = non-temporal: the volume (42 MB per level, more than the 32 MB of L2)
-// is written once and streams out -- level 1 22.9 -> 21.35 us, level 0 23.5 -> 21.8 us stand-alone (1 = sc0: no change;
-// 17 / 19 = sc1: slower).  The consumer (the regulariser's first layer) then finds less of it in L2: the frame as a
-// whole is unchanged (348.2 vs 347.5 Mray/s, scripts/ab_sweep_nt.sh); -DBMV_WIN_STORE_AUX=0 restores cached stores.
+// is written once and streams out -- level 1 (rows of 32 voxels = whole lines) 22.9 -> 21.35 us stand-alone (1 = sc0:
+// no change; 17 / 19 = sc1: slower).  The consumer (the regulariser's first layer) then finds less of it in L2: the
+// frame as a whole is unchanged (scripts/ab_sweep_nt.sh); -DBMV_WIN_STORE_AUX=0 restores cached stores.  Applied only
+// to tiles whose rows are whole 128-byte lines (kStoreAux in the kernel).
 #ifndef BMV_WIN_STORE_AUX
 #define BMV_WIN_STORE_AUX 2
 #endif
@@ -118,6 +119,9 @@ template <int TXW, int TYH, int DP, int S, int NB, int NH>
 __global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(BMV_WIN_WPE(TXW* TYH* DP), 8)))
 sweep_win_kernel(const WinArgs a) {
   constexpr int NT = TXW * TYH * DP, NW = NT / 64;
+  // non-temporal stores only where a wave row is a whole 128-byte line: for 16-pixel rows (64-byte half lines) the
+  // streaming stores are not merged in L2 any more and WRITE_SIZE grows from 43.5 to 52.6 MB for the 41.9 MB volume
+  constexpr int kStoreAux = TXW >= 32 ? BMV_WIN_STORE_AUX : 0;
   static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
   static_assert((TXW * TYH) % 32 == 0, "a half wave covers 32 voxels of ONE plane");
   static_assert(8 * S <= 64, "corner lanes");
@@ -414,16 +418,16 @@ sweep_win_kernel(const WinArgs a) {
       for (int q = 0; q < 4; ++q) {
         float m;
         m = acc[q].x * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].x * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].x * inv_s - m * m), orsrc, (int)voff, (int)soff, kStoreAux);
         soff += cstride;
         m = acc[q].y * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].y * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].y * inv_s - m * m), orsrc, (int)voff, (int)soff, kStoreAux);
         soff += cstride;
         m = acc[q].z * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].z * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].z * inv_s - m * m), orsrc, (int)voff, (int)soff, kStoreAux);
         soff += cstride;
         m = acc[q].w * inv_s;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].w * inv_s - m * m), orsrc, (int)voff, (int)soff, BMV_WIN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[q].w * inv_s - m * m), orsrc, (int)voff, (int)soff, kStoreAux);
         soff += cstride;
       }
     }
