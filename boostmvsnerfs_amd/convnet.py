@@ -155,6 +155,21 @@ class LookupRecords:
         return self.t.shape
 
 
+def conv_top(x, wpack, bias, wpack_top, bias_top, relu=True):
+    """conv1x1(act(conv3x3(x (B,32,H,W)))) -> (B,H,W,32) channel-last: FeatureNet's conv2.1 + toplayer as one launch
+    (the 1x1 layer is a second stage of the 3x3 layer's workgroups).  Both packs from `pack_conv`."""
+    B, C, H, W = x.shape
+    assert C == 32
+    out = torch.empty(B, H, W, 32, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"conv_top[32->32->32,{H}x{W}]"):
+        rc = lib.bmv_conv_top_fwd(dptr(x.contiguous(), "x"), dptr(wpack, "wpack"), dptr(bias, "bias"),
+                                  dptr(wpack_top, "wpack_top"), dptr(bias_top, "bias_top"), dptr(out), B, H, W,
+                                  _slope(relu, None), stream())
+    _lib.check(rc, "conv_top_fwd")
+    return out
+
+
 def conv0_fused(x, w0, b0, wpack, bias, Cout, out=None):
     """relu(conv3x3(relu(conv3x3(x (B,3,H,W); w0 (8,3,3,3)) + b0); wpack) + bias): FeatureNet's first block (two
     ConvBnReLU, batch norm folded) as one launch; `wpack` / `bias` = pack_conv of the second layer."""

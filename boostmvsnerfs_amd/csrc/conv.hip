@@ -47,6 +47,8 @@ struct ConvArgs {
   float slope;  // activation: v > 0 ? v : slope * v  (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky ReLU)
   int channels_last;   // 0 planar, 1 channel-last, 2 = the renderer's volume records (bmv_conv_heads_fwd)
   float* out2;         // mode 2: channel 8 (the depth logits), planar (B, Do, Ho, Wo)
+  const float* w2;     // second stage (TOP): packed 1x1 weights [2 tiles][8 chunks][4][16] and bias (32)
+  const float* b2;
 };
 
 // MAP: 0 = 2-D (row groups along y), 1 = 3-D with the block's 4/NCT row groups along z, 2 = 3-D along y
@@ -84,11 +86,18 @@ constexpr int conv_wpe(int KD, int K, int S, int NCT, int R, int MAP, bool PAIR)
   return 1;
 }
 
-template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
+// TOP (FeatureNet's conv2.1 + toplayer, feature_net.py:14-16): a 1x1 convolution 32 -> 32 on this layer's output as a
+// second stage of the same workgroup -- the activated tile goes to LDS, each wave finishes two rows x both output
+// tiles with 32 MFMAs and writes the channel-last map the level-0 sweep reads; the 32-channel intermediate is never
+// written and one launch disappears from the head of the frame.  Needs both output tiles in the workgroup (NCT = 2).
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, bool TOP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_wpe(KD, K, S, NCT, R, MAP, PAIR), 8)))
 void conv_mfma_kernel(ConvArgs a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   __shared__ float lds[4 * T::PS];
+  constexpr int TPS = T::TY * 16 + 16;   // plane stride of the second stage's tile: 16 (mod 32) for TY = 8
+  __shared__ float top[TOP ? 32 * TPS : 1];
+  static_assert(!TOP || (NCT == 2 && MAP == 0 && !PAIR && T::TY == 8 && KD == 1), "second stage: 32 channels x 8 rows per block");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = wave % NCT, rg = wave / NCT;
   const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + T::TY - 1) / T::TY, ntz = (a.Do + T::TZ - 1) / T::TZ;
@@ -207,6 +216,40 @@ void conv_mfma_kernel(ConvArgs a) {
   const int g = lane >> 4;
   const int co0 = PAIR ? 4 * (g & 1) : cot * 16 + 4 * g;
   const int z = (MAP == 1) ? z0 + rg : z0;
+  if constexpr (TOP) {
+    // stage 1 -> LDS: act(conv + bias), [32 channels][8 rows][16 x]
+#pragma unroll
+    for (int r = 0; r < T::NACC; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[r][j] + a.bias[co0 + j];
+        v = fmaxf(v, 0.f) + a.slope * fminf(v, 0.f);
+        top[(co0 + j) * TPS + (rg * R + r) * 16 + (lane & 15)] = v;
+      }
+    __syncthreads();
+    // stage 2: wave w finishes rows 2w, 2w+1 for both output tiles; 8 k-steps of 4 channels each
+    const float* w2 = a.w2 + lane;
+    const float* bp = top + g * TPS + (lane & 15);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      float wv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wv[c] = w2[(t2 * 8 + c) * 64];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * wave + rr;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], bp[4 * c * TPS + row * 16], o, 0, 0, 0);
+        const int y = y0 + row, oc = t2 * 16 + 4 * g;
+        if (x < a.Wo && y < a.Ho) {
+          f32x4 q = {o[0] + a.b2[oc], o[1] + a.b2[oc + 1], o[2] + a.b2[oc + 2], o[3] + a.b2[oc + 3]};
+          *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.Ho + y) * a.Wo + x) * 32 + oc) = q;
+        }
+      }
+    }
+    return;
+  }
   if (x >= a.Wo || co0 >= a.Cout || z >= a.Do) return;
   float bs[4];
 #pragma unroll
@@ -1281,6 +1324,23 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");
+}
+
+int bmv_conv_top_fwd(const float* in, const float* wpack, const float* bias, const float* wpack_top,
+                     const float* bias_top, float* out, int B, int H, int W, float act_slope, bmv_stream_t stream) {
+  using namespace bmv;
+  BMV_REQUIRE(in && wpack && bias && wpack_top && bias_top && out, "conv_top: null pointer");
+  BMV_REQUIRE(B > 0 && H > 0 && W > 0, "conv_top: bad shape");
+  BMV_REQUIRE((size_t)32 * H * W < (1u << 29), "conv_top: one batch item must stay below 2 GiB");
+  ConvArgs a;
+  a.in = in, a.wpack = wpack, a.bias = bias, a.skip = nullptr, a.out = out, a.out2 = nullptr;
+  a.w2 = wpack_top, a.b2 = bias_top;
+  a.B = B, a.Cin = 32, a.D = 1, a.H = H, a.W = W, a.Cout = 32, a.Do = 1, a.Ho = H, a.Wo = W;
+  a.slope = act_slope, a.channels_last = 1;
+  using T = ConvTile<1, 3, 1, 2, 4, 0, false>;
+  dim3 grid(cdiv(W, 16) * cdiv(H, T::TY) * B, 1);
+  hipLaunchKernelGGL((conv_mfma_kernel<1, 3, 1, 2, 4, 0, false, true>), grid, dim3(256), 0, as_stream(stream), a);
+  BMV_LAUNCH_END("conv_top_fwd");
 }
 
 int bmv_conv0_fused_fwd(const float* in, const float* w0, const float* b0, const float* wpack, const float* bias,

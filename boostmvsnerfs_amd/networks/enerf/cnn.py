@@ -38,6 +38,7 @@ def _engine_ok(module, x):
 
 FUSE_FPN_SMOOTH = os.environ.get("BMV_FPN_FUSE", "1") == "1"
 FUSE_CONV0 = os.environ.get("BMV_CONV0_FUSE", "1") == "1"
+FUSE_TOP = os.environ.get("BMV_TOP_FUSE", "1") == "1"
 
 class _Packed:
     """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
@@ -162,9 +163,12 @@ class FeatureNet(nn.Module):
         c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
         c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
-        c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
         # the coarsest map is written once, channel-last (the level-0 sweep's layout); the top-down step reads it so
-        p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
+        if FUSE_TOP:      # conv2.1 + toplayer: the 1x1 layer is a second stage of the 3x3 layer's workgroups
+            p2 = convnet.conv_top(c2, *P["conv2.1"], *P["toplayer"]).permute(0, 3, 1, 2)
+        else:
+            c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
+            p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
         return c0, c1, p2, p2
 
     def engine_top_down(self, c0, c1, p2, rgb=None):

@@ -406,6 +406,12 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
                        int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
+/* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last =
+ * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights
+ * layout for (32, 32, k = 3 | 1, stride 1).  The 3x3 layer's output is finished in LDS by the same workgroup. */
+int bmv_conv_top_fwd(const float* in, const float* wpack, const float* bias, const float* wpack_top,
+                     const float* bias_top, float* out, int B, int H, int W, float act_slope, bmv_stream_t stream);
+
 /* FeatureNet's first block as one launch (feature_net.py:8-10: ConvBnReLU(3,8) + ConvBnReLU(8,Cout<=8), eval-mode batch
  * norm folded): out (B,Cout,H,W) = act1(conv3x3(act0(conv3x3(in (B,3,H,W); w0 (8,3,3,3)) + b0); wpack) + bias); the
  * 8-channel intermediate is computed in the second layer's tile producer and never written.  wpack / bias:

@@ -150,6 +150,26 @@ def test_conv0_fused_equals_the_two_launches(H, W):
     assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
 
 
+@pytest.mark.parametrize("H,W", [(32, 48), (17, 35), (8, 16), (3, 5)])
+def test_conv_top_fused_equals_the_two_launches(H, W):
+    """bmv_conv_top_fwd = conv1x1(relu(conv3x3(x))) with 32 channels throughout, channel-last output: against torch and
+    against the two engine launches it replaces."""
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(H * W + 1)
+    x = torch.randn(2, 32, H, W, generator=g).to(DEV)
+    w1 = (torch.randn(32, 32, 3, 3, generator=g) / 12).to(DEV)
+    b1 = torch.randn(32, generator=g).to(DEV) * 0.3
+    w2 = (torch.randn(32, 32, 1, 1, generator=g) / 4).to(DEV)
+    b2 = torch.randn(32, generator=g).to(DEV) * 0.3
+    want = F.conv2d(F.relu(F.conv2d(x, w1, b1, padding=1)), w2, b2).permute(0, 2, 3, 1)
+    wp1, bp1 = convnet.pack_conv(w1, b1)
+    wp2, bp2 = convnet.pack_conv(w2, b2)
+    two = convnet.conv_fwd(convnet.conv_fwd(x, wp1, bp1, 32, 1, 3, relu=True), wp2, bp2, 32, 1, 1, channels_last=True)
+    got = convnet.conv_top(x, wp1, bp1, wp2, bp2)
+    _close(got, want)
+    assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
+
+
 def _randomise_bn(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
