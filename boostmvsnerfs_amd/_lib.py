@@ -175,4 +175,9 @@ def dptr(t, name="tensor", dtype=torch.float32):
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device.  Called once per launch: the raw-handle getters
+    cost ~0.5 us where `torch.cuda.current_stream().cuda_stream` costs ~8 us (0.3 ms per eager 512x640 frame)."""
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:      # a torch build without the private getters
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
