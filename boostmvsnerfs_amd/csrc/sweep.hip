@@ -458,6 +458,9 @@ int bmv_sweep_split_launch(const float* feats, const float* proj, const float* d
 int bmv_sweep_win_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                          int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
                          hipStream_t stream);
+int bmv_sweep_ring_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B, int S,
+                          int C, int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all,
+                          int variant, hipStream_t stream);
 // split-geometry kernel (sweep_split.hip) by default: 26.9 / 27.4 us vs 31.4 / 29.0 us (level 0 / 1, config 2);
 // BMV_SWEEP_SPLIT=0 selects the all-quad-layout kernel of sweep_tiled.hip
 // windowed kernel (sweep_win.hip) first unless BMV_SWEEP_WIN=0
@@ -500,7 +503,7 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
               "bmv_sweep_variance_fwd: bad shape");
   BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
   BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) ||
-                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || (algo >= 40 && algo < 100)) && feat_layout == 1),
+                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || algo == 6 || (algo >= 40 && algo < 200)) && feat_layout == 1),
               "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d", algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
   if (feat_layout == 1) {
@@ -519,6 +522,12 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
       }
     }
     rc = BMV_ERR_UNSUPPORTED;
+    if (algo == 6 || algo >= 100) {   // persistent ring of LDS windows (sweep_ring.hip)
+      rc = bmv_sweep_ring_launch(feats, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                 algo >= 100 ? algo - 100 : -1, as_stream(stream));
+      if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: ring sweep does not cover this shape / variant");
+      return rc;
+    }
     if (algo == 4 || algo >= 40 || (algo == 0 && prefer_win())) {   // LDS-staged exact windows (sweep_win.hip)
       rc = bmv_sweep_win_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
                                 algo >= 40 ? algo - 40 : -1, as_stream(stream));

@@ -1,0 +1,895 @@
+// Plane sweep as a PERSISTENT producer / consumer pipeline over a ring of LDS windows (a3+a4, channel-last features,
+// C in {16, 32}).  Reference: lib/networks/enerf/utils.py:57-95 (homo_warp), :324-351 (build_feature_volume).
+//
+// Round 3.  sweep_win.hip (round 2) measured where the time goes: 1160 vector instructions per 64 voxels (288 of
+// them the blend), a prologue of dependent latencies per workgroup (depth load -> range -> windows -> fill -> blend),
+// and phases that do not overlap.  This kernel keeps its decomposition -- a UNIT is TXW x TYH pixels x DP planes x 16
+// channels, lane = voxel, the taps of one source view are read from an LDS copy of their bounding box -- and changes
+// everything around it:
+//   * workgroups are persistent: each walks a contiguous run of units of its XCD band; a step = (unit, view).
+//   * a workgroup is NW consumer waves + ONE producer wave.  The windows live in a ring of R slots.  In step k the
+//     consumers blend the window of slot k % R while the producer issues the fill of step k + R - 1 (LDS-DMA) into the
+//     slot step k - 1 has just released and then waits until the fill of step k + 1 has landed; ONE workgroup barrier
+//     ends the step.  The producer also turns the consumers' range of 1 / depth of the next unit into its windows.
+//     (First version of this round: every wave issued its share of the fill.  The stamps showed the issuing waves
+//     blocked ~130 cycles per piece behind the texture addresser -- 64 B / clk / CU for fills and stores together -- so
+//     the blend of a step started ~1000 cycles late; now only the producer queues there.)
+//   * the producer's vector-memory instructions are DMA pieces only, issued from inline asm and counted by hand:
+//     vmcnt is in issue order, so "step k + 1 has landed" is s_waitcnt vmcnt(<pieces issued since>), which leaves the
+//     younger fill in flight.  (hipcc would wait for vmcnt(0) before the first LDS read.)
+//   * windows are NOT clipped to the image: the fill writes zeros for texels outside (the DMA's buffer range check,
+//     requested per lane), so the blend has no validity logic at all -- grid_sample's zero padding is in the data.
+//   * the 16-byte slices of a record are read in a per-lane order (slice q ^ key, key = (lane >> 2) & 3): the 16 lanes
+//     of a ds_read_b128 group then hit 16 different bank quads with a plain linear copy in LDS and tap addresses that
+//     are ONE shift-add per slice (the row below and the right neighbour are instruction offsets); the 16 variances
+//     are put back into channel order by 32 v_cndmask before the stores.
+//   * a unit whose box cannot be bounded (a corner behind the camera, non-finite hypotheses) or does not fit a slot
+//     gathers that view from global memory with the full tap logic: correctness never depends on the window.
+#include <stdlib.h>
+
+#include <hip/hip_ext.h>
+
+#include "bmv_common.hpp"
+
+namespace bmv {
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// min and max over every 16-lane row (4 DPP steps each; the two chains fill each other's DPP wait states)
+__device__ __forceinline__ void row_min_max16(float& lo, float& hi) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(lo), "+v"(hi));
+}
+// min and max over every group of 8 lanes (3 DPP steps), two pairs at once
+__device__ __forceinline__ void oct_min_max2x(float& lo0, float& hi0, float& lo1, float& hi1) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_min_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+}
+
+// s_waitcnt vmcnt(ADD + p) for a wave-uniform run-time p in 0..31: all but the ADD + p youngest vector-memory operations
+// of this wave are done.  A binary tree of scalar branches (the instruction takes an immediate).  A larger p waits for
+// MORE (never for less).
+#define BMV_WAITVM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+template <int ADD>
+__device__ __forceinline__ void wait_vm(int p) {
+  p = __builtin_amdgcn_readfirstlane(p);
+  if (p < 16) {
+    if (p < 8) {
+      if (p < 4) {
+        if (p < 2) {
+          if (p < 1) {
+            BMV_WAITVM(ADD + 0);
+          } else {
+            BMV_WAITVM(ADD + 1);
+          }
+        } else {
+          if (p < 3) {
+            BMV_WAITVM(ADD + 2);
+          } else {
+            BMV_WAITVM(ADD + 3);
+          }
+        }
+      } else {
+        if (p < 6) {
+          if (p < 5) {
+            BMV_WAITVM(ADD + 4);
+          } else {
+            BMV_WAITVM(ADD + 5);
+          }
+        } else {
+          if (p < 7) {
+            BMV_WAITVM(ADD + 6);
+          } else {
+            BMV_WAITVM(ADD + 7);
+          }
+        }
+      }
+    } else {
+      if (p < 12) {
+        if (p < 10) {
+          if (p < 9) {
+            BMV_WAITVM(ADD + 8);
+          } else {
+            BMV_WAITVM(ADD + 9);
+          }
+        } else {
+          if (p < 11) {
+            BMV_WAITVM(ADD + 10);
+          } else {
+            BMV_WAITVM(ADD + 11);
+          }
+        }
+      } else {
+        if (p < 14) {
+          if (p < 13) {
+            BMV_WAITVM(ADD + 12);
+          } else {
+            BMV_WAITVM(ADD + 13);
+          }
+        } else {
+          if (p < 15) {
+            BMV_WAITVM(ADD + 14);
+          } else {
+            BMV_WAITVM(ADD + 15);
+          }
+        }
+      }
+    }
+  } else {
+    if (p < 24) {
+      if (p < 20) {
+        if (p < 18) {
+          if (p < 17) {
+            BMV_WAITVM(ADD + 16);
+          } else {
+            BMV_WAITVM(ADD + 17);
+          }
+        } else {
+          if (p < 19) {
+            BMV_WAITVM(ADD + 18);
+          } else {
+            BMV_WAITVM(ADD + 19);
+          }
+        }
+      } else {
+        if (p < 22) {
+          if (p < 21) {
+            BMV_WAITVM(ADD + 20);
+          } else {
+            BMV_WAITVM(ADD + 21);
+          }
+        } else {
+          if (p < 23) {
+            BMV_WAITVM(ADD + 22);
+          } else {
+            BMV_WAITVM(ADD + 23);
+          }
+        }
+      }
+    } else {
+      if (p < 28) {
+        if (p < 26) {
+          if (p < 25) {
+            BMV_WAITVM(ADD + 24);
+          } else {
+            BMV_WAITVM(ADD + 25);
+          }
+        } else {
+          if (p < 27) {
+            BMV_WAITVM(ADD + 26);
+          } else {
+            BMV_WAITVM(ADD + 27);
+          }
+        }
+      } else {
+        if (p < 30) {
+          if (p < 29) {
+            BMV_WAITVM(ADD + 28);
+          } else {
+            BMV_WAITVM(ADD + 29);
+          }
+        } else {
+          if (p < 31) {
+            BMV_WAITVM(ADD + 30);
+          } else {
+            BMV_WAITVM(ADD + 31);
+          }
+        }
+      }
+    }
+  }
+}
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KB of LDS at lds_byte (wave-uniform), lane l at + 16 l.  Invisible to
+// the compiler's wait-count bookkeeping on purpose (see the file header).
+__device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_byte, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+// mask ? b : a per lane, mask = a 64-bit lane mask in scalar registers (written as asm so that the compiler cannot
+// merge two select stages into one 16-way select on a computed index: it did, 45 instructions per output)
+__device__ __forceinline__ float lane_select(float a, float b, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
+
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+__device__ __forceinline__ float4 lds4(const char* base, unsigned byte) {
+  return *reinterpret_cast<const float4*>(base + byte);
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() fence may wait for vmcnt(0))
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float rl(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+}  // namespace
+
+struct RingArgs {
+  const float* feats;
+  const float* proj;
+  const float* dv;
+  float* out;
+  const int* view_ids;
+  int n_all, C, Hs, Ws, D, h, w;
+  int tiles_x, tiles_y, tyb, pgroups, chalves, cap;
+  int units;   // units of one XCD band: tyb x pgroups x chalves x tiles_x
+  int chunk;   // units per workgroup
+  int dv_ps, dv_rs, dv_cs;   // strides of the hypotheses in elements: plane, row, column ((B,D) planes: rs = cs = 0)
+  long long dv_bs;           // batch stride
+  int flags;   // tuning: 1 no fill, 2 no blend, 4 no store, 64 stamps (BMV_RING_STAMPS builds)
+};
+
+// window of one (unit, view): texel box [wx, wx + wc) x [wy, wy + wr), NOT clipped to the image
+// mode: 0 = no tap can carry weight (box outside the image), 1 = box inside the image, 2 = box crosses the border
+// (the fill asks for zeros outside), 3 = no usable bound / does not fit a slot: gather from global memory
+template <int S>
+struct Windows {
+  int wx[S], wy[S], wc[S], wr[S], mode[S], drow[S], dcol[S];
+};
+
+#ifndef BMV_RING_XW
+#define BMV_RING_XW 0   // experiment: idle waves added to the workgroup (dispatch / residency probes)
+#endif
+#ifndef BMV_RING_WPE3
+#define BMV_RING_WPE3 3
+#endif
+// WPE = waves per SIMD the register allocator leaves room for
+template <int TXW, int TYH, int DP, int S, int R, int WPE>
+__global__ void __launch_bounds__(TXW* TYH* DP + 64 + 64 * BMV_RING_XW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+sweep_ring_kernel(const RingArgs a) {
+  constexpr int NT = TXW * TYH * DP, NW = NT / 64, LA = R - 1;
+  constexpr int SXP = S - LA;       // producer: the step of unit i at which it builds the windows of unit i + 1
+  constexpr int SXC = S - LA - 1;   // consumers: the step of unit i at which they leave the range of unit i + 1
+  static_assert(NT % 64 == 0 && NT + 64 <= 1024, "workgroup size");
+  static_assert((TXW * TYH) % 32 == 0, "a half wave covers 32 voxels of ONE plane");
+  static_assert(8 * S <= 64, "corner lanes");
+  static_assert(LA >= 1 && LA <= S - 1, "ring depth vs views");
+  __shared__ float2 slots[NW];
+  __shared__ int wtab[2][S][4];   // per unit parity and view: mode, window columns, -(wy * wc + wx)
+  extern __shared__ __attribute__((aligned(64))) char win[];  // R slots of cap records (64 B each)
+#ifdef BMV_RING_STAMPS
+  // tuning (flags & 64, with flags & 4): shader-clock stamps -- per step, consumer wave 0: step begins / blend done;
+  // producer: fills issued / next window landed -- dumped to `out` as cycles since kernel entry
+  __shared__ unsigned long long stamps[80];
+#define BMV_STAMP(i)                                                            \
+  if ((a.flags & 64) && (threadIdx.x == 0 || threadIdx.x == TXW * TYH * DP) && (i) < 80) {                  \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    stamps[i] = __builtin_amdgcn_s_memtime();                                   \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  }
+#else
+#define BMV_STAMP(i)
+#endif
+
+  const int b = blockIdx.z;
+  const int band = blockIdx.x & 7;   // = the XCD whose L2 holds this band's source rows
+  const int n0 = (int)(blockIdx.x >> 3) * a.chunk;
+  const int nu = min(a.chunk, a.units - n0);
+  if (nu <= 0) return;
+  const int C = a.C, Hs = a.Hs, Ws = a.Ws, D = a.D, h = a.h, w = a.w;
+  const unsigned REC = (unsigned)C * 4u;
+  const size_t hw = (size_t)h * w;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // unit n of the band -> (tile row j, plane group pg, channel half chh, tile column tx), tx fastest: consecutive
+  // units are neighbouring tiles of one plane group (overlapping windows, similar shapes)
+  struct Unit {
+    int tx, chh, pg, j;
+  };
+  Unit uc;
+  {
+    int n = n0, q = n / a.tiles_x;
+    uc.tx = n - q * a.tiles_x, n = q, q = n / a.chalves;
+    uc.chh = n - q * a.chalves, n = q, q = n / a.pgroups;
+    uc.pg = n - q * a.pgroups, uc.j = q;
+  }
+  auto advance = [&](Unit& u) {
+    if (++u.tx == a.tiles_x) {
+      u.tx = 0;
+      if (++u.chh == a.chalves) {
+        u.chh = 0;
+        if (++u.pg == a.pgroups) u.pg = 0, ++u.j;
+      }
+    }
+  };
+  Unit un = uc;
+  advance(un);
+
+  const int item_views = a.view_ids ? a.n_all : S;
+  const char* fbytes = reinterpret_cast<const char*>(a.feats + (size_t)b * item_views * Hs * Ws * C);
+  unsigned vbase[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    vbase[s] = (unsigned)(a.view_ids ? a.view_ids[b * S + s] : s) * (unsigned)(Hs * Ws) * REC;
+
+  if (wave > NW) {   // (idle probe waves: they only take part in the barriers)
+    barrier_lds();
+    barrier_lds();
+    for (int k = 0; k < nu * S; ++k) barrier_lds();
+    return;
+  }
+  if (wave == NW) {
+    // =============================================================================================== producer
+    __builtin_amdgcn_s_setprio(2);
+    // corner lanes (lane < 8 S): corner lane & 7 of the unit's box in (x, y, 1/depth), view lane >> 3
+    float cP[12];
+    {
+      const float* Pc = a.proj + ((size_t)b * S + min(lane >> 3, S - 1)) * 12;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) cP[j] = Pc[j];
+    }
+    i32x4 rsrc;
+    {
+      const unsigned long long p = reinterpret_cast<unsigned long long>(fbytes);
+      rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+      rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+      rsrc.z = __builtin_amdgcn_readfirstlane((int)((size_t)item_views * Hs * Ws * REC));
+      rsrc.w = 0x00020000;
+    }
+    const unsigned win_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)win;
+
+    // ---- windows of a unit from the consumers' range of 1 / depth: a projected coordinate is a ratio of affine
+    // functions of (x, y, 1/depth), so over the unit's box its extremes sit on the 8 corners (while the box is in
+    // front of the camera).  Also leaves what the consumers need in wtab[par].
+    auto windows = [&](const Unit& u, Windows<S>& W, int par) {
+      float ilo = INFINITY, ihi = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const float2 v = slots[k];
+        ilo = fminf(ilo, v.x), ihi = fmaxf(ihi, v.y);
+      }
+      const int ty = band * a.tyb + u.j;
+      const int bx0 = u.tx * TXW, bx1 = min(bx0 + TXW, w) - 1, by0 = ty * TYH, by1 = min(by0 + TYH, h) - 1;
+      const bool nothing = (by0 >= h) | (ty >= a.tiles_y);   // a unit below the volume (the last band may be short)
+      const float X = (float)((lane & 1) ? bx1 : bx0), Y = (float)((lane & 2) ? by1 : by0), I = (lane & 4) ? ihi : ilo;
+      const float px = cP[0] * X + cP[1] * Y + cP[2] + cP[3] * I;
+      const float py = cP[4] * X + cP[5] * Y + cP[6] + cP[7] * I;
+      const float pz = cP[8] * X + cP[9] * Y + cP[10] + cP[11] * I;
+      const bool bad = !(pz > 1e-6f);
+      const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
+      const float uu = px * iz, vv = py * iz;
+      float ulo = bad ? -INFINITY : uu, uhi = bad ? INFINITY : uu, vlo = bad ? -INFINITY : vv, vhi = bad ? INFINITY : vv;
+      oct_min_max2x(ulo, uhi, vlo, vhi);
+      // texel range [floor(lo), floor(hi) + 1] with a rounding margin
+      const float fx_lo = floorf(ulo - 0.01f), fx_hi = floorf(uhi + 0.01f) + 1.f;
+      const float fy_lo = floorf(vlo - 0.01f), fy_hi = floorf(vhi + 0.01f) + 1.f;
+      const float fwc = fx_hi - fx_lo + 1.f, fwr = fy_hi - fy_lo + 1.f;
+      // (comparisons that fail on NaN / infinity)
+      const bool bounded = (fwc >= 2.f) && (fwc <= 4096.f) && (fwr >= 2.f) && (fwr <= 4096.f) && (fabsf(fx_lo) < 1e6f) && (fabsf(fy_lo) < 1e6f);
+      const bool outside = (fx_hi < 0.f) | (fx_lo > (float)(Ws - 1)) | (fy_hi < 0.f) | (fy_lo > (float)(Hs - 1));
+      const bool inside = (fx_lo >= 0.f) & (fx_hi <= (float)(Ws - 1)) & (fy_lo >= 0.f) & (fy_hi <= (float)(Hs - 1));
+      const int x_lo = bounded ? (int)fx_lo : 0, y_lo = bounded ? (int)fy_lo : 0;
+      const int wc_l = bounded ? (int)fwc : 1, wr_l = bounded ? (int)fwr : 1;
+      const bool fits = bounded & ((wc_l * wr_l) <= a.cap);
+      int mode_l = !bounded ? 3 : outside ? 0 : !fits ? 3 : inside ? 1 : 2;
+      if (nothing) mode_l = 0;
+      // per piece a lane's record advances by 16: (rows, columns) of that step
+      int drow_l = (int)(16.f * __builtin_amdgcn_rcpf((float)wc_l));
+      drow_l += ((drow_l + 1) * wc_l <= 16) ? 1 : 0;
+      drow_l -= (drow_l * wc_l > 16) ? 1 : 0;
+      const int dcol_l = 16 - drow_l * wc_l;
+      if ((lane & 7) == 0 && lane < 8 * S) {
+        int* t = wtab[par][lane >> 3];
+        t[0] = mode_l, t[1] = wc_l, t[2] = -(y_lo * wc_l + x_lo);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        W.wx[s] = __builtin_amdgcn_readlane(x_lo, 8 * s), W.wy[s] = __builtin_amdgcn_readlane(y_lo, 8 * s);
+        W.wc[s] = __builtin_amdgcn_readlane(wc_l, 8 * s), W.wr[s] = __builtin_amdgcn_readlane(wr_l, 8 * s);
+        W.mode[s] = __builtin_amdgcn_readlane(mode_l, 8 * s);
+        W.drow[s] = __builtin_amdgcn_readlane(drow_l, 8 * s), W.dcol[s] = __builtin_amdgcn_readlane(dcol_l, 8 * s);
+      }
+    };
+
+    // ---- fill of one window into ring slot `slot`: piece p = records [16 p, 16 p + 16) of the row-major box, lane =
+    // (record lane >> 2, slice lane & 3), a plain copy.  Returns the number of pieces (= DMA instructions) issued.
+    const int lrec = lane >> 2;
+    const unsigned lslice = (unsigned)(lane & 3) * 16u;
+    auto issue_fill = [&](const Windows<S>& W, int s, int slot, unsigned hoff) -> int {
+      const int mode = W.mode[s];
+      if (mode == 0 || mode == 3 || (a.flags & 1)) return 0;
+      const int wc = W.wc[s], ntex = wc * W.wr[s];
+      const int npieces = (ntex + 15) >> 4;
+      unsigned dst = win_base + (unsigned)slot * (unsigned)a.cap * 64u;
+      int row = (int)((float)lrec * __builtin_amdgcn_rcpf((float)wc));
+      int col = lrec - row * wc;
+      if (col >= wc) col -= wc, ++row;
+      if (col < 0) col += wc, --row;
+      unsigned off = vbase[s] + hoff + (unsigned)(__mul24(W.wy[s] + row, Ws) + W.wx[s] + col) * REC + lslice;
+      const unsigned step = (unsigned)(W.drow[s] * Ws + W.dcol[s]) * REC, wrap = (unsigned)(Ws - wc) * REC;
+      const int dcol = W.dcol[s], drow = W.drow[s];
+      if (mode == 1) {
+        for (int p = 0; p < npieces; ++p) {
+          dma_piece(rsrc, dst, off, 0u);
+          dst += 1024u;
+          col += dcol, off += step;
+          if (col >= wc) col -= wc, off += wrap;
+        }
+      } else {   // the box crosses the image border: texels outside are requested out of range (the DMA writes zeros)
+        int gy = W.wy[s] + row, gx = W.wx[s] + col;
+        for (int p = 0; p < npieces; ++p) {
+          const bool ok = ((unsigned)gy < (unsigned)Hs) & ((unsigned)gx < (unsigned)Ws);
+          dma_piece(rsrc, dst, ok ? off : 0x80000000u, 0u);
+          dst += 1024u;
+          col += dcol, gx += dcol, gy += drow, off += step;
+          if (col >= wc) col -= wc, gx -= wc, ++gy, off += wrap;
+        }
+      }
+      return npieces;
+    };
+
+    Windows<S> wcur, wnxt;
+    int pc[2 * S];   // pieces of the fills of (current unit, view s) at [s], (next unit, view s) at [S + s]
+#pragma unroll
+    for (int s = 0; s < 2 * S; ++s) pc[s] = 0;
+    barrier_lds();   // P1: the consumers' range of the first unit
+    windows(uc, wcur, 0);
+#pragma unroll
+    for (int m = 0; m < LA; ++m) pc[m] = issue_fill(wcur, m, m, (unsigned)uc.chh * 64u);
+    {
+      int younger = 0;
+#pragma unroll
+      for (int m = 1; m < LA; ++m) younger += pc[m];
+      wait_vm<0>(younger);
+    }
+    barrier_lds();   // P2: window of step 0 landed, wtab[0] written
+    int sr = 0;      // ring slot of the current step
+    for (int i = 0; i < nu; ++i) {
+      const bool more = i + 1 < nu;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (s == SXP && more) windows(un, wnxt, (i + 1) & 1);
+        {
+          const int t = s + LA;
+          const int sw = (sr + LA) % R;
+          if (t < S)
+            pc[t] = issue_fill(wcur, t, sw, (unsigned)uc.chh * 64u);
+          else if (more)
+            pc[t] = issue_fill(wnxt, t - S, sw, (unsigned)un.chh * 64u);
+          else
+            pc[t] = 0;
+        }
+        BMV_STAMP(4 + 4 * (i * S + s) + 2)
+        // the window of the NEXT step has landed: all but the younger fills
+        int younger = 0;
+#pragma unroll
+        for (int m = 2; m <= LA; ++m) younger += pc[s + m];
+        wait_vm<0>(younger);
+        BMV_STAMP(4 + 4 * (i * S + s) + 3)
+        barrier_lds();
+        sr = (sr + 1 == R) ? 0 : sr + 1;
+      }
+      wcur = wnxt;
+#pragma unroll
+      for (int s = 0; s < S; ++s) pc[s] = pc[S + s], pc[S + s] = 0;
+      uc = un;
+      advance(un);
+    }
+    return;
+  }
+
+  // ================================================================================================= consumers
+  const int lx = tid % TXW, ly = (tid / TXW) % TYH, ld = tid / (TXW * TYH);
+  // projection rows of all views, in VECTOR registers on purpose: 12 S scalar registers would push everything else
+  // into spill lanes, and a v_fma with two scalar sources needs a v_mov first
+  float P[S][12];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      P[s][j] = a.proj[((size_t)b * S + s) * 12 + j];
+      asm volatile("" : "+v"(P[s][j]));
+    }
+  __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(fbytes), 0, (int)((size_t)item_views * Hs * Ws * REC), 0x00020000);   // gather path
+  const float* dvb = a.dv + (size_t)b * a.dv_bs;
+
+  // per-lane slice order: accumulator group q holds slice q ^ key of the 64-byte record
+  const unsigned key = (unsigned)(lane >> 2) & 3u;
+  unsigned cq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cq[q] = ((unsigned)q ^ key) * 16u;
+
+  // ---- per-unit lane coordinates
+  struct Vox {
+    int x, y, d;
+    bool inb;
+    float fx, fy;
+    unsigned dvoff;   // element offset of this voxel's hypothesis
+  };
+  auto voxel = [&](const Unit& u) {
+    Vox v;
+    const int ty = band * a.tyb + u.j;
+    v.x = u.tx * TXW + lx, v.y = ty * TYH + ly, v.d = u.pg * DP + ld;
+    v.inb = (v.x < w) & (v.y < h) & (v.d < D);
+    const int xc = min(v.x, w - 1), yc = min(v.y, h - 1), dc = min(v.d, D - 1);
+    v.fx = (float)xc, v.fy = (float)yc;
+    v.dvoff = (unsigned)(__mul24(dc, a.dv_ps) + __mul24(yc, a.dv_rs) + __mul24(xc, a.dv_cs));
+    return v;
+  };
+
+  // ---- range of 1/depth of a unit: every wave leaves its (min, max) in `slots`
+  auto range_to_slots = [&](float inv_depth) {
+    float ilo = inv_depth, ihi = inv_depth;
+    row_min_max16(ilo, ihi);
+    const float l0 = rl(ilo, 0), l1 = rl(ilo, 16), l2 = rl(ilo, 32), l3 = rl(ilo, 48);
+    const float h0 = rl(ihi, 0), h1 = rl(ihi, 16), h2 = rl(ihi, 32), h3 = rl(ihi, 48);
+    ilo = fminf(fminf(l0, l1), fminf(l2, l3)), ihi = fmaxf(fmaxf(h0, h1), fmaxf(h2, h3));
+    if (lane == 0) slots[wave] = make_float2(ilo, ihi);
+  };
+
+  float4 acc[4], acc2[4];
+  auto blend4 = [&](int q, float4 t00, float4 t01, float4 t10, float4 t11, float a00, float a01, float a10, float a11) {
+    float4 v;
+    v.x = t00.x * a00 + t01.x * a01 + t10.x * a10 + t11.x * a11;
+    v.y = t00.y * a00 + t01.y * a01 + t10.y * a10 + t11.y * a11;
+    v.z = t00.z * a00 + t01.z * a01 + t10.z * a10 + t11.z * a11;
+    v.w = t00.w * a00 + t01.w * a01 + t10.w * a10 + t11.w * a11;
+    acc[q].x += v.x, acc[q].y += v.y, acc[q].z += v.z, acc[q].w += v.w;
+    acc2[q].x += v.x * v.x, acc2[q].y += v.y * v.y, acc2[q].z += v.z * v.z, acc2[q].w += v.w * v.w;
+  };
+
+  // ---- one view of one unit from its staged window: no validity logic (zeros are in the window)
+  // wc = window columns, kk = ring slot * cap - (wy * wc + wx): both wave-uniform
+  auto blend_fast = [&](int s, int wc, int kk, const Vox& v, float inv_depth) {
+    const float px = P[s][0] * v.fx + (P[s][1] * v.fy + (P[s][3] * inv_depth + P[s][2]));
+    const float py = P[s][4] * v.fx + (P[s][5] * v.fy + (P[s][7] * inv_depth + P[s][6]));
+    const float pz = P[s][8] * v.fx + (P[s][9] * v.fy + (P[s][11] * inv_depth + P[s][10]));
+    const float iz = __builtin_amdgcn_rcpf(pz);
+    // uv / ((W-1)/2) - 1 followed by grid_sample's ((g+1)/2) (W-1) is the identity up to rounding
+    const float ix = px * iz, iy = py * iz;
+    const int tx0 = floor_to_int(ix), ty0 = floor_to_int(iy);
+    const float ax = __builtin_amdgcn_fractf(ix), ay = __builtin_amdgcn_fractf(iy);
+    const unsigned rec = (unsigned)(__mul24(ty0, wc) + tx0 + kk);
+    const unsigned rowb = (unsigned)wc * 64u;
+    const float bx = 1.f - ax, by = 1.f - ay;
+    const float w00 = bx * by, w01 = ax * by, w10 = bx * ay, w11 = ax * ay;
+    unsigned a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a0[q] = (rec << 6) + cq[q], a1[q] = a0[q] + rowb;
+    // two slices in flight: the reads of slice q + 1 are issued before the blend of slice q
+    float4 t00 = lds4(win, a0[0]), t01 = lds4(win, a0[0] + 64u), t10 = lds4(win, a1[0]), t11 = lds4(win, a1[0] + 64u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 n00, n01, n10, n11;
+      if (q < 3) n00 = lds4(win, a0[q + 1]), n01 = lds4(win, a0[q + 1] + 64u), n10 = lds4(win, a1[q + 1]), n11 = lds4(win, a1[q + 1] + 64u);
+      __builtin_amdgcn_sched_barrier(0);
+      blend4(q, t00, t01, t10, t11, w00, w01, w10, w11);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 3) t00 = n00, t01 = n01, t10 = n10, t11 = n11;
+    }
+  };
+
+  // ---- the same view gathered from global memory with the full zero-padding logic (rare)
+  auto blend_slow = [&](int s, const Vox& v, float inv_depth, unsigned hoff) {
+    const float px = P[s][0] * v.fx + P[s][1] * v.fy + P[s][2] + P[s][3] * inv_depth;
+    const float py = P[s][4] * v.fx + P[s][5] * v.fy + P[s][6] + P[s][7] * inv_depth;
+    const float pz = P[s][8] * v.fx + P[s][9] * v.fy + P[s][10] + P[s][11] * inv_depth;
+    const float iz = __builtin_amdgcn_rcpf(fmaxf(pz, 1e-6f));
+    const float ix = px * iz, iy = py * iz;
+    const float flx = floorf(ix), fly = floorf(iy);
+    // clamp before the int conversion (also maps NaN into range): anything outside ends with both taps invalid
+    const int tx0 = (int)__builtin_amdgcn_fmed3f(flx, -2.f, (float)Ws), ty0 = (int)__builtin_amdgcn_fmed3f(fly, -2.f, (float)Hs);
+    const bool vx0 = (unsigned)tx0 < (unsigned)Ws, vx1 = (unsigned)(tx0 + 1) < (unsigned)Ws;
+    const bool vy0 = (unsigned)ty0 < (unsigned)Hs, vy1 = (unsigned)(ty0 + 1) < (unsigned)Hs;
+    const float ax = ix - flx, ay = iy - fly;
+    const bool any = (vx0 | vx1) & (vy0 | vy1);
+    if (!__any(any)) return;
+    const float wx0 = vx0 ? 1.f - ax : 0.f, wx1 = vx1 ? ax : 0.f;
+    const float wy0 = (vy0 & any) ? 1.f - ay : 0.f, wy1 = (vy1 & any) ? ay : 0.f;
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    // a tap outside the image has weight 0 and is parked on its in-image neighbour
+    const int gx = any ? (vx0 ? tx0 : tx0 + 1) : 0, gy = any ? (vy0 ? ty0 : ty0 + 1) : 0;
+    const unsigned g00 = vbase[s] + hoff + (unsigned)(gy * Ws + gx) * REC;
+    const unsigned gdx = (any && vx0 && vx1) ? REC : 0u, gdy = (any && vy0 && vy1) ? (unsigned)Ws * REC : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned o = g00 + cq[q];
+      i32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_c, o, 0, 0);
+      i32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_c, o + gdx, 0, 0);
+      i32x4 rc = __builtin_amdgcn_raw_buffer_load_b128(rsrc_c, o + gdy, 0, 0);
+      i32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(rsrc_c, o + gdx + gdy, 0, 0);
+      blend4(q, *reinterpret_cast<float4*>(&ra), *reinterpret_cast<float4*>(&rb), *reinterpret_cast<float4*>(&rc),
+             *reinterpret_cast<float4*>(&rd), w00, w01, w10, w11);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- variance of a unit: back into channel order (2 x 16 v_cndmask), one dword per lane and channel, scalar
+  // channel offsets (lanes outside the volume store out of range)
+  auto store_unit = [&](const Unit& u, const Vox& v) {
+    const float inv_s = 1.f / (float)S;
+    float V[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m;
+      m = acc[q].x * inv_s, V[q][0] = acc2[q].x * inv_s - m * m;
+      m = acc[q].y * inv_s, V[q][1] = acc2[q].y * inv_s - m * m;
+      m = acc[q].z * inv_s, V[q][2] = acc2[q].z * inv_s - m * m;
+      m = acc[q].w * inv_s, V[q][3] = acc2[q].w * inv_s - m * m;
+    }
+    // lane masks of key & 1 and key & 2 (key = (lane >> 2) & 3)
+    const unsigned long long m1 = 0xf0f0f0f0f0f0f0f0ull, m2 = 0xff00ff00ff00ff00ull;
+    float T[4][4], Wn[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[c][j] = lane_select(V[c][j], V[c ^ 1][j], m1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Wn[c][j] = lane_select(T[c][j], T[c ^ 2][j], m2);
+    const unsigned cstride = (unsigned)(D * hw) * 4u;
+    __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + (size_t)b * C * D * hw, 0, (int)((size_t)C * D * hw * 4), 0x00020000);
+    const unsigned voff = (v.inb && !(a.flags & 4)) ? (unsigned)((size_t)v.d * hw + (size_t)v.y * w + v.x) * 4u : 0x80000000u;
+    unsigned soff = (unsigned)u.chh * 16u * cstride;
+    constexpr int kAux = TXW >= 32 ? 2 : 0;   // non-temporal where a wave row is a whole 128-byte line (sweep_win.hip)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Wn[c][j]), orsrc, (int)voff, (int)soff, kAux);
+        soff += cstride;
+      }
+  };
+
+  // ---- what the producer left for a unit: mode, window columns and -(wy * wc + wx) per view
+  int wmode[S], wcol[S], wk0[S];
+  auto read_wtab = [&](int par) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      wmode[s] = __builtin_amdgcn_readfirstlane(wtab[par][s][0]);
+      wcol[s] = __builtin_amdgcn_readfirstlane(wtab[par][s][1]);
+      wk0[s] = __builtin_amdgcn_readfirstlane(wtab[par][s][2]);
+    }
+  };
+
+  BMV_STAMP(0)
+#ifdef BMV_RING_STAMPS
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  Unit u2 = un;
+  advance(u2);
+  Vox vc = voxel(uc), vn = voxel(un);
+  // hypotheses of the first two units (plain loads: the consumers' vector-memory traffic is all compiler-visible)
+  float idc = __builtin_amdgcn_rcpf(dvb[vc.dvoff]);
+  float idn = __builtin_amdgcn_rcpf(dvb[vn.dvoff]);
+  range_to_slots(idc);
+  barrier_lds();   // P1
+  barrier_lds();   // P2: the producer has staged step 0 and written wtab[0]
+  read_wtab(0);
+  BMV_STAMP(1)
+  int sr = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = acc2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int i = 0; i < nu; ++i) {
+    const bool more = i + 1 < nu;
+    float idn2 = idn;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      BMV_STAMP(4 + 4 * (i * S + s) + 0)
+      if (s == SXC && more) range_to_slots(idn);
+      if (s == (S > 2 ? 1 : 0)) idn2 = dvb[voxel(u2).dvoff];   // hypotheses of the unit after next: used a step or more later
+      if (!(a.flags & 2)) {
+        const int mode = wmode[s];
+        if (mode == 1 || mode == 2)
+          blend_fast(s, wcol[s], sr * a.cap + wk0[s], vc, idc);
+        else if (mode == 3)
+          blend_slow(s, vc, idc, (unsigned)uc.chh * 64u);
+      }
+      BMV_STAMP(4 + 4 * (i * S + s) + 1)
+      barrier_lds();
+      sr = (sr + 1 == R) ? 0 : sr + 1;
+    }
+    store_unit(uc, vc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = acc2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    idc = idn, idn = __builtin_amdgcn_rcpf(idn2);
+    uc = un, vc = vn, un = u2;
+    vn = voxel(un);
+    advance(u2);
+    if (more) read_wtab((i + 1) & 1);
+  }
+#ifdef BMV_RING_STAMPS
+  if ((a.flags & 64) && threadIdx.x == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    float* o = a.out + (size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 80;
+    const unsigned long long t0 = stamps[0];
+    o[0] = (float)(unsigned)(t0 & 0xffffffu), o[1] = (float)(unsigned)((t0 >> 24) & 0xffffffu);
+    o[2] = (float)(unsigned)(t2 - t0), o[3] = (float)nu;
+    o[4] = (float)(unsigned)(stamps[1] - t0);
+    for (int k = 0; k < 4 * nu * S && k + 4 < 70; ++k) o[5 + k] = (float)(unsigned)(stamps[4 + k] - t0);
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    o[76] = (float)(xcc & 0xf), o[77] = (float)((hwid >> 8) & 0xf), o[78] = (float)((hwid >> 13) & 0x7);   // XCC, CU, SE
+    o[79] = (float)((hwid >> 12) & 0x1);   // SH
+    o[75] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);   // 100 MHz ticks over the workgroup's life
+  }
+#endif
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+namespace {
+
+struct RingVariant {
+  int txw, tyh, dp, r, cap, wpc;   // tile, ring slots, records per slot, workgroups per CU the grid is sized for
+};
+// tuning table (algo 100 + i); caps in 64-byte records, multiples of 16
+const RingVariant kRing[] = {
+    {32, 8, 1, 3, 416, 2},   // 0: level 1 (source at the volume's resolution)
+    {32, 8, 1, 2, 416, 3},   // 1
+    {16, 2, 8, 3, 416, 2},   // 2: level 0 (source at twice the resolution, 8 planes share a window)
+    {16, 2, 8, 2, 416, 3},   // 3
+    {32, 4, 1, 3, 256, 3},   // 4
+    {32, 4, 1, 2, 256, 4},   // 5
+    {16, 4, 4, 3, 416, 2},   // 6
+    {16, 4, 4, 2, 416, 3},   // 7
+    {32, 8, 1, 3, 416, 1},   // 8: one workgroup per CU (no co-resident partner)
+    {16, 2, 8, 3, 320, 3},   // 9
+    {32, 8, 1, 3, 320, 3},   // 10: smaller slots, 3 per CU (boxes beyond 320 records gather)
+};
+constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int TXW, int TYH, int DP, int S, int R>
+int ring_launch_one(RingArgs& a, int B, int wpc, hipStream_t stream) {
+  constexpr int WPE = R == 2 ? 4 : BMV_RING_WPE3;   // two slots: three workgroups of 5 waves per CU; three slots: two
+  auto kern = sweep_ring_kernel<TXW, TYH, DP, S, R, WPE>;
+  const size_t lds = (size_t)R * a.cap * 64;
+  static size_t allowed = 0;
+  if (lds > allowed) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return BMV_ERR_UNSUPPORTED;
+    }
+    allowed = lds;
+  }
+  // workgroups per band: the chip holds num_cus x wpc of them; every one walks `chunk` consecutive units of its band
+  int target = num_cus() * wpc / (8 * B);
+  if (const char* e = getenv("BMV_SWEEP_RING_WGS")) target = atoi(e) / (8 * B);
+  if (target < 1) target = 1;
+  a.chunk = (a.units + target - 1) / target;
+  if (const char* e = getenv("BMV_SWEEP_RING_CHUNK")) a.chunk = atoi(e) > 0 ? atoi(e) : a.chunk;
+  const int per_band = (a.units + a.chunk - 1) / a.chunk;
+  dim3 grid(8u * (unsigned)per_band, 1, B), block(TXW * TYH * DP + 64 + 64 * BMV_RING_XW);
+  if (getenv("BMV_SWEEP_RING_DEBUG")) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), (int)block.x, lds);
+    fprintf(stderr, "[ring] grid %u x %u threads, lds %zu, chunk %d, occupancy API: %d blocks / CU (%s)\n", grid.x, block.x,
+            lds, a.chunk, nb, hipGetErrorString(e));
+  }
+  const LaunchEvents ev = take_launch_events();
+  if (ev.start)   // bench.py's roofline bracket: events bound to this dispatch (bmv_bind_next_launch)
+    hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev.start, ev.stop, 0, a);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  return BMV_OK;
+}
+
+template <int TXW, int TYH, int DP, int R>
+int ring_launch_s(RingArgs& a, int B, int S, int wpc, hipStream_t stream) {
+  if (S == 3) return ring_launch_one<TXW, TYH, DP, 3, R>(a, B, wpc, stream);
+  if constexpr (R == 2) {
+    if (S == 2) return ring_launch_one<TXW, TYH, DP, 2, R>(a, B, wpc, stream);
+  }
+  if (S == 4) return ring_launch_one<TXW, TYH, DP, 4, R>(a, B, wpc, stream);
+  return BMV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// dv_plane_uniform: depth_values is (B,D) -- one hypothesis per plane (cascade level 0) -- instead of (B,D,h,w)
+extern "C" int bmv_sweep_ring_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B,
+                                     int S, int C, int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids,
+                                     int n_all, int variant, hipStream_t stream) {
+  if ((C != 16 && C != 32) || S < 2 || S > 4) return BMV_ERR_UNSUPPORTED;
+  if ((size_t)(view_ids ? n_all : S) * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;
+  if (Hs >= (1 << 14) - 2 || Ws >= (1 << 14) - 2) return BMV_ERR_UNSUPPORTED;
+  if ((size_t)C * D * h * w * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;   // 32-bit volume offsets
+  if ((size_t)D * h * w * 4 >= ((size_t)1 << 31)) return BMV_ERR_UNSUPPORTED;
+  if (variant < 0) variant = (float)Ws / (float)w <= 1.5f ? 0 : 2;
+  if (variant >= kNumRing) return BMV_ERR_UNSUPPORTED;
+  RingVariant v = kRing[variant];
+  if (S == 2 && v.r == 3) v.r = 2;   // (ring depth is bounded by the views of a unit)
+  if (const char* e = getenv("BMV_SWEEP_RING_CAP")) {
+    int c = atoi(e);
+    if (c >= 16) v.cap = (c + 15) & ~15;
+  }
+  if (const char* e = getenv("BMV_SWEEP_RING_WPC")) {
+    int c = atoi(e);
+    if (c >= 1) v.wpc = c;
+  }
+  RingArgs a;
+  a.feats = feats, a.proj = proj, a.dv = dv, a.out = out, a.view_ids = view_ids, a.n_all = n_all;
+  a.C = C, a.Hs = Hs, a.Ws = Ws, a.D = D, a.h = h, a.w = w;
+  a.tiles_x = (w + v.txw - 1) / v.txw;
+  a.tiles_y = (h + v.tyh - 1) / v.tyh;
+  a.tyb = (a.tiles_y + 7) / 8;
+  a.pgroups = (D + v.dp - 1) / v.dp;
+  a.chalves = C / 16;
+  a.cap = v.cap;
+  a.units = a.tyb * a.pgroups * a.chalves * a.tiles_x;
+  a.chunk = 1;
+  if (dv_plane_uniform)
+    a.dv_ps = 1, a.dv_rs = 0, a.dv_cs = 0, a.dv_bs = D;
+  else
+    a.dv_ps = h * w, a.dv_rs = w, a.dv_cs = 1, a.dv_bs = (long long)D * h * w;
+  a.flags = 0;
+  if (const char* e = getenv("BMV_SWEEP_RING_FLAGS")) a.flags = atoi(e);
+  int rc = BMV_ERR_UNSUPPORTED;
+#define V(TXW, TYH, DP, R) \
+  if (v.txw == TXW && v.tyh == TYH && v.dp == DP && v.r == R) rc = ring_launch_s<TXW, TYH, DP, R>(a, B, S, v.wpc, stream);
+  V(32, 8, 1, 3)
+  V(32, 8, 1, 2)
+  V(16, 2, 8, 3)
+  V(16, 2, 8, 2)
+  V(32, 4, 1, 3)
+  V(32, 4, 1, 2)
+  V(16, 4, 4, 3)
+  V(16, 4, 4, 2)
+#undef V
+  if (rc != BMV_OK) return rc;
+  BMV_LAUNCH_END("bmv_sweep_variance_fwd(ring)");
+}

@@ -22,6 +22,8 @@ ap.add_argument("--H", type=int, default=512)
 ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--save", default="")
 ap.add_argument("--flags", default="0")
+ap.add_argument("--ring", default="", help="ring-sweep variants (csrc/sweep_ring.hip, algo 100 + i), e.g. 0,1,2")
+ap.add_argument("--ring-env", default="", help="semicolon-separated env settings tried per ring variant, e.g. 'BMV_SWEEP_RING_WPC=2;BMV_SWEEP_RING_WPC=3'")
 a = ap.parse_args()
 
 cfg = make_cfg("enerf_eval")
@@ -73,7 +75,7 @@ def timed(fn, iters, per_graph=20):
     return s.elapsed_time(e) / (reps * per_graph) * 1e3
 
 
-variants = [int(v) for v in a.variants.split(",") if v] or list(range(20))
+variants = [int(v) for v in a.variants.split(",") if v and int(v) >= 0] if a.variants else list(range(20))
 caps = [int(c) for c in a.caps.split(",") if c] or [0]
 for lvl, (impl, args, kwargs) in enumerate(calls):
     feats, proj, dv = args[:3]
@@ -109,5 +111,21 @@ for lvl, (impl, args, kwargs) in enumerate(calls):
                 us = timed(lambda: ops._sweep_variance(cl, proj, dv, algo=40 + v, channels_last=True, out=obuf), a.iters)
                 print(f"  variant {v:2d} cap {cap:4d} flags {fl}  {us:7.2f} us  {nbytes/us/1e3:7.0f} GB/s  "
                       f"frac {nbytes/us/1e3/8000:.3f}  max|d| {err:.2e} (mean|ref| {scale:.2e})", flush=True)
+    for v in [int(x) for x in a.ring.split(",") if x]:
+        for envs in (a.ring_env.split(";") if a.ring_env else [""]):
+            sets = dict(kv.split("=") for kv in envs.split(",") if kv)
+            os.environ.update(sets)
+            try:
+                out = ops._sweep_variance(cl, proj, dv, algo=100 + v, channels_last=True)
+                torch.cuda.synchronize()
+                err = (out - ref).abs().max().item()
+                us = timed(lambda: ops._sweep_variance(cl, proj, dv, algo=100 + v, channels_last=True, out=obuf), a.iters)
+                print(f"  ring {v:2d} {envs:40s} {us:7.2f} us  {nbytes/us/1e3:7.0f} GB/s  frac {nbytes/us/1e3/8000:.3f}  "
+                      f"max|d| {err:.2e} (mean|ref| {scale:.2e})", flush=True)
+            except RuntimeError as e:
+                print(f"  ring {v:2d} {envs}: {str(e)[:90]}")
+            finally:
+                for k in sets:
+                    os.environ.pop(k, None)
 os.environ.pop("BMV_SWEEP_WIN_CAP", None)
 os.environ.pop("BMV_SWEEP_WIN_FLAGS", None)

@@ -302,9 +302,12 @@ def test_sweep_extreme_coordinates(ops):
     assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
     # channel-last kernels (16 channels): the windowed kernel sees an EMPTY tap box for every view
     feats16 = torch.randn(1, 3, 16, 16, 20, device=DEV)
-    for algo in (4, 5, 2):
+    for algo in (4, 5, 2, 6, 101):
         var = ops.sweep_variance(feats16, proj, dv, algo=algo)
         assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0, algo
+
+
+RING_ALGOS = tuple(range(100, 111))     # csrc/sweep_ring.hip: the persistent ring-of-windows sweep, tuning variants
 
 
 @pytest.mark.parametrize("level", [0, 1])
@@ -328,7 +331,7 @@ def test_sweep_kernels_agree_at_scale(ops, level):
         dv = (3.0 + 2.0 * torch.rand(1, 1, h, w) + torch.linspace(-1.5, 1.5, cfgl["D"]).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
     fd, Pd, dvd = feats.to(DEV), P.to(DEV), dv.to(DEV)
-    for algo in (1, 2, 3, 4, 5, 0) + tuple(range(40, 60)):
+    for algo in (1, 2, 3, 4, 5, 6, 0) + tuple(range(40, 60)) + RING_ALGOS:
         if algo == 3 and level == 0:
             with pytest.raises(RuntimeError, match="LDS sweep does not cover"):
                 ops.sweep_variance(fd, Pd, dvd, algo=3)      # 2x source scale stays on the gather kernel
@@ -343,6 +346,20 @@ def test_sweep_kernels_agree_at_scale(ops, level):
             assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} algo {algo} cap 48")
     finally:
         del os.environ["BMV_SWEEP_WIN_CAP"]
+    # ring kernel with slots far below the tap boxes: every view of every unit takes the global-gather path
+    os.environ["BMV_SWEEP_RING_CAP"] = "48"
+    try:
+        for algo in (6, 101, 102):
+            assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} ring algo {algo} cap 48")
+    finally:
+        del os.environ["BMV_SWEEP_RING_CAP"]
+    # ... and with slots that hold SOME of the boxes (staged and gathered views in one unit)
+    os.environ["BMV_SWEEP_RING_CAP"] = "256"
+    try:
+        for algo in (100, 102):
+            assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} ring algo {algo} cap 256")
+    finally:
+        del os.environ["BMV_SWEEP_RING_CAP"]
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 16, 37, 53, 5, 19, 45), (2, 4, 32, 40, 24, 7, 21, 13), (1, 3, 16, 9, 7, 3, 33, 70),
@@ -362,7 +379,7 @@ def test_sweep_windowed_ragged_shapes(ops, shape):
                                     [0.0, 0.0, 1.0, 0.05 * s]])
     dv = (2.0 + torch.rand(B, 1, h, w) + torch.linspace(0.0, 3.0, D).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
-    for algo in (4, 40, 42, 46, 49, 51, 57, 59, 5):
+    for algo in (4, 40, 42, 46, 49, 51, 57, 59, 5, 6) + RING_ALGOS:
         got = ops.sweep_variance(feats.to(DEV), P.to(DEV), dv.to(DEV), algo=algo)
         assert_close(got, want, name=f"shape {shape} algo {algo}")
 
