@@ -461,11 +461,22 @@ int bmv_sweep_win_launch(const float* feats, const float* proj, const float* dv,
 int bmv_sweep_ring_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B, int S,
                           int C, int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all,
                           int variant, hipStream_t stream);
+int bmv_sweep_zp_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B, int S, int C,
+                        int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
+                        hipStream_t stream);
 // split-geometry kernel (sweep_split.hip) by default: 26.9 / 27.4 us vs 31.4 / 29.0 us (level 0 / 1, config 2);
 // BMV_SWEEP_SPLIT=0 selects the all-quad-layout kernel of sweep_tiled.hip
 // windowed kernel (sweep_win.hip) first unless BMV_SWEEP_WIN=0
 static bool prefer_win() {
   static const bool v = !(getenv("BMV_SWEEP_WIN") && atoi(getenv("BMV_SWEEP_WIN")) == 0);
+  return v;
+}
+// zero-padded windows (sweep_zp.hip, round 3) instead of the windowed kernel of round 2: BMV_SWEEP_ZP=1.  Stand-alone
+// (back-to-back launches on resident inputs) it is 3-8 % faster (27 % fewer vector instructions); inside the frame, where
+// the source maps come from cold caches, the two read the same 22-24 us, so the default stays the kernel whose rounding
+// the training-path gradient fixtures were recorded with.
+static bool prefer_zp() {
+  static const bool v = getenv("BMV_SWEEP_ZP") && atoi(getenv("BMV_SWEEP_ZP")) == 1;
   return v;
 }
 static bool prefer_split() {
@@ -480,7 +491,10 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
   BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_views_fwd: bad shape");
   int rc = BMV_ERR_UNSUPPORTED;
-  if (prefer_win())
+  if (prefer_zp())
+    rc = bmv_sweep_zp_launch(feats_all, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
+                             as_stream(stream));
+  if (rc == BMV_ERR_UNSUPPORTED && prefer_win())
     rc = bmv_sweep_win_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
                               as_stream(stream));
   if (rc == BMV_ERR_UNSUPPORTED && prefer_split())
@@ -503,7 +517,7 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
               "bmv_sweep_variance_fwd: bad shape");
   BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
   BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) ||
-                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || algo == 6 || (algo >= 40 && algo < 200)) && feat_layout == 1),
+                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || algo == 6 || algo == 7 || (algo >= 40 && algo < 400)) && feat_layout == 1),
               "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d", algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
   if (feat_layout == 1) {
@@ -522,11 +536,22 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
       }
     }
     rc = BMV_ERR_UNSUPPORTED;
+    if (algo == 7 || algo >= 200) {   // zero-padded LDS windows (sweep_zp.hip); 300 + i: planes known to be constant
+      rc = bmv_sweep_zp_launch(feats, proj, depth_values, algo >= 300 ? 2 : 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                               algo >= 300 ? algo - 300 : algo >= 200 ? algo - 200 : -1, as_stream(stream));
+      if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: zero-padded sweep does not cover this shape / variant");
+      return rc;
+    }
     if (algo == 6 || algo >= 100) {   // persistent ring of LDS windows (sweep_ring.hip)
       rc = bmv_sweep_ring_launch(feats, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
                                  algo >= 100 ? algo - 100 : -1, as_stream(stream));
       if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: ring sweep does not cover this shape / variant");
       return rc;
+    }
+    if (algo == 0 && prefer_zp()) {
+      rc = bmv_sweep_zp_launch(feats, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0, -1,
+                               as_stream(stream));
+      if (rc != BMV_ERR_UNSUPPORTED) return rc;
     }
     if (algo == 4 || algo >= 40 || (algo == 0 && prefer_win())) {   // LDS-staged exact windows (sweep_win.hip)
       rc = bmv_sweep_win_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,

@@ -23,6 +23,7 @@ ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--save", default="")
 ap.add_argument("--flags", default="0")
 ap.add_argument("--ring", default="", help="ring-sweep variants (csrc/sweep_ring.hip, algo 100 + i), e.g. 0,1,2")
+ap.add_argument("--zp", default="", help="zero-padded-window variants (csrc/sweep_zp.hip, algo 200 + i; 300 + i on plane-uniform hypotheses)")
 ap.add_argument("--ring-env", default="", help="semicolon-separated env settings tried per ring variant, e.g. 'BMV_SWEEP_RING_WPC=2;BMV_SWEEP_RING_WPC=3'")
 a = ap.parse_args()
 
@@ -111,6 +112,18 @@ for lvl, (impl, args, kwargs) in enumerate(calls):
                 us = timed(lambda: ops._sweep_variance(cl, proj, dv, algo=40 + v, channels_last=True, out=obuf), a.iters)
                 print(f"  variant {v:2d} cap {cap:4d} flags {fl}  {us:7.2f} us  {nbytes/us/1e3:7.0f} GB/s  "
                       f"frac {nbytes/us/1e3/8000:.3f}  max|d| {err:.2e} (mean|ref| {scale:.2e})", flush=True)
+    pu = bool((dv == dv[:, :, :1, :1]).all())
+    for v in [int(x) for x in a.zp.split(",") if x]:
+        for base in ([200, 300] if pu else [200]):
+            try:
+                out = ops._sweep_variance(cl, proj, dv, algo=base + v, channels_last=True)
+                torch.cuda.synchronize()
+                err = (out - ref).abs().max().item()
+                us = timed(lambda: ops._sweep_variance(cl, proj, dv, algo=base + v, channels_last=True, out=obuf), a.iters)
+                print(f"  zp {v:2d} {'plane-uniform' if base == 300 else 'per-voxel   '}  {us:7.2f} us  {nbytes/us/1e3:7.0f} GB/s  "
+                      f"frac {nbytes/us/1e3/8000:.3f}  max|d| {err:.2e} (mean|ref| {scale:.2e})", flush=True)
+            except RuntimeError as e:
+                print(f"  zp {v:2d}: {str(e)[:90]}")
     for v in [int(x) for x in a.ring.split(",") if x]:
         for envs in (a.ring_env.split(";") if a.ring_env else [""]):
             sets = dict(kv.split("=") for kv in envs.split(",") if kv)

@@ -302,12 +302,14 @@ def test_sweep_extreme_coordinates(ops):
     assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
     # channel-last kernels (16 channels): the windowed kernel sees an EMPTY tap box for every view
     feats16 = torch.randn(1, 3, 16, 16, 20, device=DEV)
-    for algo in (4, 5, 2, 6, 101):
+    for algo in (4, 5, 2, 6, 101, 7, 201, 302):
         var = ops.sweep_variance(feats16, proj, dv, algo=algo)
         assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0, algo
 
 
 RING_ALGOS = tuple(range(100, 111))     # csrc/sweep_ring.hip: the persistent ring-of-windows sweep, tuning variants
+ZP_ALGOS = tuple(range(200, 213))       # csrc/sweep_zp.hip: zero-padded windows, tuning variants
+ZP_PU_ALGOS = tuple(range(300, 313))    # ... told that every plane of the hypotheses is constant (cascade level 0)
 
 
 @pytest.mark.parametrize("level", [0, 1])
@@ -331,7 +333,7 @@ def test_sweep_kernels_agree_at_scale(ops, level):
         dv = (3.0 + 2.0 * torch.rand(1, 1, h, w) + torch.linspace(-1.5, 1.5, cfgl["D"]).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
     fd, Pd, dvd = feats.to(DEV), P.to(DEV), dv.to(DEV)
-    for algo in (1, 2, 3, 4, 5, 6, 0) + tuple(range(40, 60)) + RING_ALGOS:
+    for algo in (1, 2, 3, 4, 5, 6, 7, 0) + tuple(range(40, 60)) + RING_ALGOS + ZP_ALGOS + (ZP_PU_ALGOS if level == 0 else ()):
         if algo == 3 and level == 0:
             with pytest.raises(RuntimeError, match="LDS sweep does not cover"):
                 ops.sweep_variance(fd, Pd, dvd, algo=3)      # 2x source scale stays on the gather kernel
@@ -346,6 +348,14 @@ def test_sweep_kernels_agree_at_scale(ops, level):
             assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} algo {algo} cap 48")
     finally:
         del os.environ["BMV_SWEEP_WIN_CAP"]
+    # zero-padded windows with an LDS budget below the tap boxes: whole views gathered from global memory
+    for cap in ("48", "256"):
+        os.environ["BMV_SWEEP_ZP_CAP"] = cap
+        try:
+            for algo in (7, 201, 202) + ((302,) if level == 0 else ()):
+                assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} zp algo {algo} cap {cap}")
+        finally:
+            del os.environ["BMV_SWEEP_ZP_CAP"]
     # ring kernel with slots far below the tap boxes: every view of every unit takes the global-gather path
     os.environ["BMV_SWEEP_RING_CAP"] = "48"
     try:
@@ -379,7 +389,7 @@ def test_sweep_windowed_ragged_shapes(ops, shape):
                                     [0.0, 0.0, 1.0, 0.05 * s]])
     dv = (2.0 + torch.rand(B, 1, h, w) + torch.linspace(0.0, 3.0, D).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
-    for algo in (4, 40, 42, 46, 49, 51, 57, 59, 5, 6) + RING_ALGOS:
+    for algo in (4, 40, 42, 46, 49, 51, 57, 59, 5, 6, 7) + RING_ALGOS + ZP_ALGOS:
         got = ops.sweep_variance(feats.to(DEV), P.to(DEV), dv.to(DEV), algo=algo)
         assert_close(got, want, name=f"shape {shape} algo {algo}")
 
