@@ -216,8 +216,10 @@ def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
     elif wl["net"] == "enerf":
         from oracle import enerf as O   # checker / baseline only
         timed(lambda: O.enerf_forward(state_dict, make_batch(64, 96), cfg))          # page-in / thread-pool warm-up
-        dt = timed(lambda: O.enerf_forward(state_dict, clone_batch(batch_cpu), cfg))
+        keep = {}
+        dt = timed(lambda: keep.update(O.enerf_forward(state_dict, clone_batch(batch_cpu), cfg)))
         sample = f"1 frame {H}x{W} (whole workload), oracle/enerf.py torch-CPU fp32, {dt:.2f} s"
+        cpu_baseline.last_frame = keep           # the checker's frame: bench compares the GPU frame with it (parity_max_rel)
     elif wl["net"] == "mvsnerf" and wl["samples"] <= 32:
         from oracle import mvsnerf as M
         dt = timed(lambda: M.mvsnerf_forward(state_dict, clone_batch(batch_cpu), cfg))
@@ -318,7 +320,13 @@ def main():
     else:
         def step():
             with torch.no_grad():
-                return finish(net(batch))
+                return finish(net(batch))           # the drop-in call: replays its own HIP graph from the 2nd call on
+
+        _eager_call = getattr(net, "_forward_checked", net)    # the same frame as ~42 eager launches (BMV_AUTOGRAPH=0)
+
+        def eager_only_step():
+            with torch.no_grad():
+                return finish(_eager_call(batch))
 
     # MIOpen's solver search writes its per-user find-db: rank 0 searches first with a collective-free forward,
     # the other ranks then hit the finished db instead of N processes searching (and locking the db) at once.
@@ -347,7 +355,12 @@ def main():
     # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
     eager_step = step
-    if args.graph and not wl.get("train") and not args.all_kernel_events and wl["net"] in ("enerf", "boost_enerf"):
+    sampled = {"n": 0, "every": 1, "evented": True}
+    if not wl.get("train"):
+        eager_step = eager_only_step
+        if not (args.graph and hasattr(net, "_autograph")) or args.all_kernel_events:
+            step = eager_only_step           # --no-graph / per-launch events: every timed step is eager launches
+    if args.graph and not wl.get("train") and not args.all_kernel_events and wl["net"] in ("enerf", "boost_enerf") and hasattr(net, "_autograph"):
         try:
             from boostmvsnerfs_amd.framegraph import FrameGraph
             # the kernels of `roofline` are bracketed by event-record nodes INSIDE the one graph of a frame
@@ -355,8 +368,8 @@ def main():
             ktimer.forget_graph_events()
             sampled = {"n": 0, "every": 1, "evented": True}
             if args.no_kernel_events:
-                fg = FrameGraph(net, batch, cut=None)
-                replay = fg.replay
+                fg = None
+                replay = lambda: net(batch)   # noqa: E731  (Network.forward replays its own graph)
             else:
                 # bracketed frames: the sweeps are ordinary launches between the graphs, their events bound to their
                 # own dispatch (hipExtLaunchKernelGGL: the kernel's begin and end); the renderer is bracketed by
@@ -365,22 +378,25 @@ def main():
                 fg = FrameGraph(net, batch, cut=None if args.in_graph_sweeps else "all", events=True)
                 replay = fg.replay
                 if fg.events and args.event_every > 1:
-                    fg_plain = FrameGraph(net, batch, cut=None)        # same frame, no brackets
+                    # plain steps are the drop-in call itself, `net(batch)`: Network.forward replays the graph it
+                    # captured of the same frame (autograph.AutoGraph); every `event_every`-th step replays the
+                    # bracketed capture instead (the measurement instrument)
                     sampled["every"] = args.event_every
 
                     def replay():   # noqa: F811
                         sampled["evented"] = sampled["n"] % sampled["every"] == 0
                         sampled["n"] += 1
-                        return fg.replay() if sampled["evented"] else fg_plain.replay()
+                        return fg.replay() if sampled["evented"] else net(batch)
 
             def step():   # noqa: F811
                 with torch.no_grad():
                     return finish(replay())
-            for _ in range(2):
+            for _ in range(4):
                 step()
-            graph_note = f"{len(fg.graphs)} graph(s)" + (f" + {len(fg.sweeps)} eager plane sweep(s)" if fg.sweeps else "") \
-                + (f" with in-graph event brackets on every {sampled['every']}. step" if fg.events and sampled["every"] > 1
-                   else " with in-graph event brackets" if fg.events else "")
+            ag = net._autograph.stats
+            graph_note = (f"net(batch) replaying its own HIP graph (autograph: {ag['captures']} capture(s), {ag['copies']} input copies)"
+                          + ("" if fg is None else f"; every {sampled['every']}. step a bracketed capture instead: {len(fg.graphs)} graph(s)"
+                             + (f" + {len(fg.sweeps)} eager plane sweep(s) with dispatch-bound events" if fg.sweeps else "")))
         except Exception as e:   # keep the eager path: the bench must still produce its line
             print(f"[bench] HIP-graph capture failed, staying eager: {type(e).__name__}: {e}", file=sys.stderr)
             graph_note = f"capture failed ({type(e).__name__})"
@@ -459,6 +475,20 @@ def main():
     # reported as `config.spinup_steps`.
     spinup_steps = args.spinup_steps if (wl["net"] in ("enerf", "boost_enerf") and not wl.get("train")) else 0
     ktimer.enabled = False
+    if spinup_steps and not args.pipelined:
+        # the same per-step bracket started COLD (the device idle for 50 ms first): what `--spinup-steps 0` would report
+        n_c = min(args.steps, 20)
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+        t_c = time.perf_counter()
+        for _ in range(n_c):
+            step()
+            if gather is not None:
+                gather.flush()
+            torch.cuda.synchronize()
+        t_c = (time.perf_counter() - t_c) / n_c
+        extra["value_cold"] = {"value": N * (world if args.shard == "views" else 1) / t_c / 1e6, "ms_per_step": t_c * 1e3,
+                               "what": f"the timed bracket over {n_c} steps started after 50 ms of idle, no spin-up (rank 0's clock)"}
     for _ in range(spinup_steps):      # a fixed count: every rank issues the same collectives
         step()
         if gather is not None:
@@ -537,13 +567,17 @@ def main():
                     levels[f"level{lvl}"] = {"achieved": k["GB/s"], "frac": k["GB/s"] / HBM_PEAK_GBS, "avg_us": k["avg_us"],
                                              "min_us": k["min_us"], "launches": k["launches"], "algorithmic_bytes": nb,
                                              "traffic": pmc.get(f"sweep_level{lvl}_hbm_bytes"),
+                                             "traffic_source": ("profiles/sweep_pmc.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE on this "
+                                                                "frame's sweep inputs, collected in its own passes, NOT in this run)"
+                                                                if pmc.get(f"sweep_level{lvl}_hbm_bytes") else None),
                                              "timed": "HIP events in the timed region" if name in ks_timed else "HIP events in the eager warm-up"}
             if levels:
                 worst = min(levels, key=lambda n: levels[n]["frac"])
                 L = levels[worst]
                 roofline = {"bound": "hbm", "kernel": f"sweep_variance {worst} (a3+a4 fused plane sweep; the worse of the two cascade levels)",
                             "achieved": L["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": L["frac"],
-                            "traffic": L["traffic"], "algorithmic_bytes": L["algorithmic_bytes"], "avg_us": L["avg_us"],
+                            "traffic": L["traffic"], "traffic_source": L["traffic_source"],
+                            "algorithmic_bytes": L["algorithmic_bytes"], "avg_us": L["avg_us"],
                             "launches": L["launches"], "levels": levels}
                 if "empty_bracket" in kernels:
                     # what the same pair of event records reads with NOTHING between them in the same graph: every
@@ -553,16 +587,18 @@ def main():
             rname = next((n for n in kernels if n.startswith("render_rays[feat=8")), None)
             if rname:
                 rays_launch = N // world if (args.shard == "rays" and world > 1) else N
-                flops = 50.9e3 * rays_launch * cc.num_samples[1]      # SURVEY.md 8(d) algorithmic FLOPs of a11
-                tf = flops / kernels[rname]["avg_us"] / 1e6
-                mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "achieved": tf,
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
-                        "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
-                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d) (50.9 kFLOP/sample); the kernel EXECUTES 26.2
-                # kFLOP/sample (the view-shared parts of global_fc / color.0 are computed once, csrc/mlp.hpp): the share of
-                # the matrix pipe's time it actually uses is the executed figure
+                # the kernel EXECUTES 26.2 kFLOP/sample on the matrix pipe (the view-shared parts of global_fc / color.0
+                # are computed once, csrc/mlp.hpp); SURVEY 8(d)'s ALGORITHMIC count of the reference's layers is 50.9.
+                # `achieved` / `frac` = executed FLOPs over the kernel's time = the share of the fp32 matrix peak the
+                # kernel really uses; the algorithmic figure is a named side field (it can exceed the executed one's
+                # roofline share because work was REMOVED, not because the pipe is full)
                 ex = 26.2e3 * rays_launch * cc.num_samples[1] / kernels[rname]["avg_us"] / 1e6
-                mfma.update({"executed_tflops": ex, "mfma_issue_frac": ex / FP32_MFMA_PEAK_TFLOPS})
+                alg = 50.9e3 * rays_launch * cc.num_samples[1] / kernels[rname]["avg_us"] / 1e6
+                mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "achieved": ex,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / FP32_MFMA_PEAK_TFLOPS,
+                        "flops_counted": "executed (26.2 kFLOP / sample)", "algorithmic_tflops": alg,
+                        "algorithmic_over_peak": alg / FP32_MFMA_PEAK_TFLOPS,
+                        "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
         else:
             Ns = cc.num_samples[0]
             rname = f"mvs_render[Ns={Ns}]"
@@ -607,6 +643,21 @@ def main():
             cb = cpu_baseline(args, cfg, wl, sd_cpu, batch_cpu, _SELECTION)
             if cb is not None:
                 line["cpu_baseline"] = cb
+            ref = getattr(cpu_baseline, "last_frame", None)
+            if ref and not wl.get("train"):
+                # the frame the timed steps rendered against the oracle's frame of the same weights and batch:
+                # max |d| / (|want| + rms(want)) per output (the tests' bar is 1e-3 on it)
+                with torch.no_grad():
+                    got = net(batch)
+                par = {}
+                for k, want in ref.items():
+                    if k in got and torch.is_tensor(want):
+                        g = got[k].detach().float().cpu().reshape(want.shape)
+                        rms = float(want.pow(2).mean().sqrt())
+                        par[k] = float(((g - want).abs() / (want.abs() + rms + 1e-30)).max())
+                line["parity_max_rel"] = {"per_output": par, "max": max(par.values()) if par else None,
+                                          "against": "oracle/enerf.py enerf_forward on the same weights and batch (the cpu_baseline frame)",
+                                          "tolerance": 1e-3}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -49,49 +49,27 @@ def ensure_view_selection(cfg, make_preprocess_network, batches):
     return path
 
 
-def _graph_key(batch, network):
-    """What a captured frame is specialised to beyond tensor VALUES: shapes, and -- for the K-volume networks, whose
-    forward looks its cost volumes up in view_selection.json by (scene, target view) -- the selected triplets."""
-    shapes = tuple((k, tuple(v.shape)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
-    sel = None
-    table = getattr(network, "view_selection_outputs", None)
-    if table is not None:
-        meta = batch["meta"]
-        sel = tuple(tuple(table[f"{s}_{v}"]) for s, v in zip(meta["scene"], meta["tar_view"]))
-    return shapes, sel
-
-
-def evaluate(network, batches, on_output=None, graph=False):
+def evaluate(network, batches, on_output=None, graph=None):
     """run.py:113-129.  Returns {'net_time': [...], 'FPS': ..., 'Mray/s': ...} with the reference's definition of FPS
     (mean over iterations 2..n when n > 1) and the rays of the last rendered level per second next to it.
 
-    graph=True: after the first (eager) iteration the forward is captured into a HIP graph (framegraph.FrameGraph) on
-    static copies of the batch; later batches of the same shapes (and, for the K-volume networks, the same selected
-    triplets) are copied into those buffers INSIDE the timed bracket and replayed -- the host cost of a frame drops from
-    ~45 launches to one; anything else falls back to the eager call.  The outputs handed to `on_output` are then the
-    graph's static tensors: consume them before the next iteration."""
+    The bracket is around `network(batch)` and nothing else.  The networks of this package replay a HIP graph of the
+    frame from the second call with the same shapes on (autograph.AutoGraph, inside `forward`): the iteration that
+    triggers a capture pays for it inside its own bracket, batches that arrive as new tensors are copied into the
+    captured buffers inside the bracket too, and the outputs handed to `on_output` are then the graph's static
+    tensors (consume them before the next iteration).  graph=False times the eager launches instead
+    (`network._forward_checked`); `stats` reports how many iterations were eager / captures / replays."""
     network.eval()
     net_time, rays = [], 0
-    fg, fg_key, static = None, None, None
+    call = network
+    if graph is False and hasattr(network, "_forward_checked"):
+        call = network._forward_checked
     for it, batch in enumerate(batches):
         batch = to_cuda(batch)
-        key = _graph_key(batch, network) if graph else None
-        if graph and it > 0 and (fg is None or key != fg_key):
-            from .framegraph import FrameGraph
-            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-            # forward may ADD keys to the batch (rays built on the device from the target camera): give every call a
-            # fresh shallow copy, so that such tensors are rebuilt inside the captured frame instead of being baked in
-            fg, fg_key = FrameGraph(lambda b: network(dict(b)), static, cut=None), key   # untimed, like a warm-up iteration
         with torch.no_grad():
             torch.cuda.synchronize()
             start = time.time()
-            if fg is not None and key == fg_key:
-                for k, v in batch.items():
-                    if torch.is_tensor(v):
-                        static[k].copy_(v)
-                output = fg.replay()
-            else:
-                output = network(batch)
+            output = call(batch)
             torch.cuda.synchronize()
             end = time.time()
         net_time.append(end - start)
@@ -100,4 +78,8 @@ def evaluate(network, batches, on_output=None, graph=False):
         if on_output is not None:
             on_output(output, batch)
     mean = sum(net_time[1:]) / (len(net_time) - 1) if len(net_time) > 1 else net_time[0]
-    return {"net_time": net_time, "FPS": 1.0 / mean, "Mray/s": rays / mean / 1e6}
+    res = {"net_time": net_time, "FPS": 1.0 / mean, "Mray/s": rays / mean / 1e6}
+    ag = getattr(network, "_autograph", None)
+    if ag is not None:
+        res["stats"] = dict(ag.stats)
+    return res

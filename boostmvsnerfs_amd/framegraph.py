@@ -28,7 +28,8 @@ from . import ktimer, ops
 
 class FrameGraph:
     def __init__(self, net, batch, cut=-1, warmup=2, events=False):
-        self.net, self.batch = net, batch
+        # (a network with a self-capturing forward -- autograph.AutoGraph -- is captured through its eager entry point)
+        self.net, self.batch = getattr(net, "_forward_checked", net), batch
         self.cut = cut
         self.events = events
         self.graphs = []

@@ -217,11 +217,20 @@ class Network(enerf_network.Network):
         batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
         return ret
 
-    def forward(self, batch):
+    def _forward_checked(self, batch):           # (forward itself, with the self-capturing replay, is the base class's)
         try:
             return self._forward_boost(batch)
         finally:
             self.set_volume_records(False)
+
+    def _autograph_key(self, batch):
+        """A captured K-volume frame is specialised to the cost-volume triplets view_selection.json selects for the
+        batch's targets (they are baked into the graph as device constants) and to the capture hook of the tests."""
+        if self.view_selection_outputs is None:
+            return None
+        meta = batch["meta"]
+        return (tuple(tuple(self.view_selection_outputs[f"{s}_{v}"]) for s, v in zip(meta["scene"], meta["tar_view"])),
+                int(cfg.enerf.cas_config.k_best), self.capture is not None)
 
     def _forward_boost(self, batch):
         if self.view_selection_outputs is None:

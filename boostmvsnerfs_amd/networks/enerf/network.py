@@ -58,6 +58,8 @@ class Network(nn.Module):
         self._pre = None
         self.volume_records = os.environ.get("BMV_VOLUME_RECORDS", "1") == "1"
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
+        from ...autograph import AutoGraph
+        object.__setattr__(self, "_autograph", AutoGraph(self))
         self._side_stream = None
 
     # ------------------------------------------------------------------ 2-D features
@@ -167,7 +169,7 @@ class Network(nn.Module):
         B = src_inps.shape[0]
         H, W = src_inps.shape[-2:]
         rs = cc.render_scale[i]
-        Hr, Wr = int(H * rs), int(W * rs)
+        Hr, Wr = ops.scaled_size(H, W, rs)
         up = cc.render_scale[i] / cc.im_ibr_scale[i]
         if up != 1.0:      # network.py:29-32 (no shipped config takes this branch; torch's resize, as there)
             b_, s_, c_, h_, w_ = im_feat.shape
@@ -212,7 +214,7 @@ class Network(nn.Module):
         src_inps, src_exts, src_ixts = views
         H, W = src_inps.shape[-2:]
         rs = cc.render_scale[i]
-        Hr, Wr = int(H * rs), int(W * rs)
+        Hr, Wr = ops.scaled_size(H, W, rs)
         if cc.render_scale[i] / cc.im_ibr_scale[i] != 1.0:
             raise NotImplementedError("im_feat must be at the render resolution (true for every shipped config)")
         packed = None
@@ -306,15 +308,34 @@ class Network(nn.Module):
         src = batch["all_src_inps"] if "all_src_inps" in batch and "src_inps" not in batch else batch["src_inps"]
         H, W = src.shape[-2:]
         for i in range(cc.num):
-            if cc.render_if[i] and f"rays_{i}" not in batch:
+            have = batch.get(f"rays_{i}")
+            # (rays this function built on an earlier call are rebuilt: the caller may have moved the camera in place)
+            if cc.render_if[i] and (have is None or getattr(have, "_bmv_built_rays", False)):
                 batch[f"rays_{i}"] = ops.make_rays(batch["tar_ext"], batch["tar_ixt"], H, W, cc.render_scale[i])
         return batch
 
     def forward(self, batch):
+        """Inference on the GPU replays a HIP graph of the frame from the second call with the same shapes on
+        (autograph.AutoGraph: the drop-in call itself, not a separate harness; BMV_AUTOGRAPH=0 keeps every call eager);
+        training and everything else run the launches one by one."""
+        if self._autograph.usable(batch):
+            return self._autograph(batch)
+        return self._forward_checked(batch)
+
+    def _forward_checked(self, batch):
         try:
             return self._forward(batch)
         finally:
             self.set_volume_records(False)       # the modules go back to planar outputs for any other caller
+
+    def _autograph_key(self, batch):
+        return None
+
+    def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() replace storage: captured graphs are stale
+        ag = self.__dict__.get("_autograph")
+        if ag is not None:
+            ag.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _forward(self, batch):
         cc = cfg.enerf.cas_config

@@ -27,17 +27,33 @@ def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):
     return out
 
 
+def scaled_size(H, W, scale):
+    """(h, w) of a level rendered at `scale` -- ONE definition for the ray grid, the renderer's Hr x Wr and the loss
+    side.  The reference computes it twice: the network with int(H * scale) (lib/networks/enerf/network.py:26-27), the
+    dataset with cv2.resize's rounding (lib/datasets/enerf_utils.py:62-66); they agree whenever H * scale is integral
+    (true for every shipped size), and a configuration where they would not is refused here instead of rendering a
+    ray grid the network reshapes to a different size."""
+    if scale == 1.0:
+        return int(H), int(W)
+    h, w = int(H * scale), int(W * scale)
+    if (h, w) != (int(round(H * scale)), int(round(W * scale))):
+        raise ValueError(f"render scale {scale} of a {H}x{W} target: int() and round() disagree on the scaled size "
+                         f"({h}x{w} vs {int(round(H * scale))}x{int(round(W * scale))}); the reference's network and dataset would too")
+    return h, w
+
+
 def make_rays(tar_ext, tar_ixt, H, W, scale=1.0):
     """batch['rays_i'] of the full-image branch of `build_rays` (lib/datasets/enerf_utils.py:25-31, 62-71), built on
     the device from the target camera: (B, h * w, 8) = [origin | direction | x, y] with h x w the size cv2.resize
     gives the scaled target image there (round(H*scale) x round(W*scale)); the size is computed HERE, once, and
     handed to the kernel."""
     B = tar_ext.shape[0]
-    h, w = (int(H), int(W)) if scale == 1.0 else (int(round(H * scale)), int(round(W * scale)))
+    h, w = scaled_size(H, W, scale)
     rays = torch.empty(B, h * w, 8, device=tar_ext.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.bmv_make_rays(dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), B, h, w,
                                  float(scale), dptr(rays), stream()), "make_rays")
+    rays._bmv_built_rays = True      # built from the batch's camera, not handed over by the caller: rebuilt when reused
     return rays
 
 

@@ -133,7 +133,7 @@ def test_evaluate_harness_bootstraps_view_selection_and_times_like_run_py(enerf_
 
 
 def test_evaluate_harness_graph_mode_equals_eager(enerf_fx, boost_fx, tmp_path):
-    """evaluate(graph=True): frames 2.. are HIP-graph replays on static copies of the batch; the outputs must be the
+    """evaluate(): frames 2.. are HIP-graph replays issued by Network.forward itself (autograph); the outputs must be the
     eager ones for batches whose VALUES differ (other source images and cameras), for ENeRF and for the K-volume
     network (graph keyed by the selected triplets)."""
     import copy
@@ -169,6 +169,9 @@ def test_evaluate_harness_graph_mode_equals_eager(enerf_fx, boost_fx, tmp_path):
     _, eager = run(net, batches, False)
     res, graphed = run(net, batches, True)
     assert len(res["net_time"]) == len(batches)
+    # the drop-in call itself captured and replayed: first batch eager, second captures, the rest replay with their
+    # tensors copied into the captured buffers
+    assert res["stats"]["captures"] == 1 and res["stats"]["replays"] == len(batches) - 1 and res["stats"]["copies"] > 0
     for a, b in zip(eager, graphed):
         assert set(a) == set(b)
         for k in a:

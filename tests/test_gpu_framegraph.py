@@ -160,3 +160,72 @@ def test_bound_events_on_the_sweeps_between_graphs():
     assert len(sweeps) == 2 and len(render) == 1, ks
     for name, (launches, mean_ms, min_ms) in ks.items():
         assert launches == 3 and 0.0 < min_ms <= mean_ms < 5.0, (name, launches, mean_ms)
+
+
+def test_forward_captures_itself():
+    """autograph.AutoGraph behind Network.forward: the drop-in call replays a HIP graph from the second call with the
+    same shapes on -- on the caller's own resident tensors (no copies), with in-place input changes picked up, new
+    tensors copied in, a parameter update re-capturing, and another shape falling back to an eager first call."""
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    cfg = make_cfg("enerf_eval")
+    cfg.enerf.cas_config.volume_planes = [16, 8]
+    set_cfg(cfg)
+    torch.manual_seed(0)
+    net = Network().eval().to(DEV)
+    ag = net._autograph
+
+    def eager(b):
+        with torch.no_grad():
+            return {k: v.clone() for k, v in net._forward_checked(dict(b)).items()}
+
+    batch = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    want = eager(batch)
+    with torch.no_grad():
+        outs = [{k: v.clone() for k, v in net(batch).items()} for _ in range(4)]
+    torch.cuda.synchronize()
+    assert ag.stats["eager"] == 1 and ag.stats["captures"] == 1 and ag.stats["replays"] == 3 and ag.stats["copies"] == 0
+    for o in outs:
+        for k in want:
+            assert torch.equal(o[k], want[k]), k
+    # the caller moves the camera IN PLACE in its resident batch: the replay reads the same tensors
+    batch["tar_ext"][..., 0, 3] += 0.05
+    want2 = eager(batch)
+    with torch.no_grad():
+        got2 = net(batch)
+    assert ag.stats["captures"] == 1 and ag.stats["copies"] == 0
+    assert not torch.equal(want2["rgb_level1"], want["rgb_level1"])
+    for k in want2:
+        assert torch.equal(got2[k], want2[k]), k
+    # a new batch (other tensors, same shapes): copied into the captured buffers, same graph
+    other = clone_batch(make_batch(128, 160, n_views=3, seed=1), DEV)
+    want3 = eager(other)
+    with torch.no_grad():
+        got3 = net(other)
+    assert ag.stats["captures"] == 1 and ag.stats["copies"] > 0
+    for k in want3:
+        assert torch.equal(got3[k], want3[k]), k
+    # a parameter update invalidates the captured frame
+    with torch.no_grad():
+        net.nerf_1.lr0[0].weight.mul_(1.01) if hasattr(net.nerf_1, "lr0") else next(net.nerf_1.parameters()).mul_(1.01)
+    want4 = eager(other)
+    with torch.no_grad():
+        got4 = net(other)
+        got4 = {k: v.clone() for k, v in got4.items()}
+    assert ag.stats["captures"] == 2
+    for k in want4:
+        assert torch.equal(got4[k], want4[k]), k
+    # another size: first call eager
+    small = clone_batch(make_batch(64, 96, n_views=3, seed=0), DEV)
+    n_eager = ag.stats["eager"]
+    with torch.no_grad():
+        got5 = net(small)
+    assert ag.stats["eager"] == n_eager + 1 and ag.stats["captures"] == 2
+    want5 = eager(small)
+    for k in want5:
+        assert torch.equal(got5[k], want5[k]), k
+    # training / autograd never replays
+    net.train()
+    assert not ag.usable(batch)
+    net.eval()
