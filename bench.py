@@ -249,6 +249,40 @@ def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
             "host_cpus": os.cpu_count()}
 
 
+def make_exchange(shard, world, rank, N, dev, net, wl, k_best, level, pipelined=False, sync_gather=False):
+    """The exchange step of a sharding mode on one rank: sets the network's ray / volume shard and returns
+    (finish, gather, vshard) -- `finish(out)` turns this rank's forward output into the gathered frame(s) with ONE
+    collective per step (all-gather of (rgb, depth) tiles; for `volumes` an all-to-all of the K-volume stacks first).
+    World 1: identity.  Runs on any torch.distributed backend (RCCL here, gloo in tests/test_sharding_gloo.py, which
+    drives this very function with a stub renderer)."""
+    from boostmvsnerfs_amd import sharding
+    rgb_key, depth_key = f"rgb_level{level}", f"depth_level{level}"
+    if shard == "rays" and world > 1:
+        net.ray_range = sharding.ray_slice(N, world, rank)
+    vshard = None
+    if shard == "volumes" and world > 1:
+        if wl["net"] != "boost_enerf" or wl.get("train"):
+            raise SystemExit("--shard volumes is the cost-volume parallelism of the boost_enerf inference workloads")
+        vshard = sharding.VolumeShard(world, rank, k_best, N)
+        net.volume_ids, net.ray_range = vshard.volumes, vshard.ray_range
+    gather = sharding.TileGather(world, N if shard == "views" else None, dev) if (world > 1 and vshard is None) else None
+
+    def finish(out):
+        if vshard is not None:
+            raws, zs, ms = vshard.exchange(*out[f"stacks_level{level}"])
+            fused = net.merge_mlp_outputs(raws, ms, zs)
+            return vshard.gather_tiles(fused["rgb"], fused["depth"])
+        if gather is not None:
+            if shard == "views":
+                if sync_gather or not pipelined:
+                    return gather.all_gather_frames(out[rgb_key], out[depth_key])
+                # the exchange of frame i runs on RCCL's stream under the kernels of frame i+1
+                return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
+            return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
+        return out
+    return finish, gather, vshard
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -274,30 +308,8 @@ def main():
     H, W = wl["H"], wl["W"]
     N = H * W
     rgb_key, depth_key = f"rgb_level{level}", f"depth_level{level}"
-    if args.shard == "rays" and world > 1:
-        net.ray_range = sharding.ray_slice(N, world, rank)
-    vshard = None
-    if args.shard == "volumes" and world > 1:
-        if wl["net"] != "boost_enerf" or wl.get("train"):
-            raise SystemExit("--shard volumes is the cost-volume parallelism of the boost_enerf inference workloads")
-        vshard = sharding.VolumeShard(world, rank, int(cc.k_best), N)
-        net.volume_ids, net.ray_range = vshard.volumes, vshard.ray_range
-    gather = sharding.TileGather(world, N if args.shard == "views" else None, dev) if (world > 1 and vshard is None) else None
-
-    def finish(out):
-        """The exchange step of the sharding mode on one rank's output."""
-        if vshard is not None:
-            raws, zs, ms = vshard.exchange(*out[f"stacks_level{level}"])
-            fused = net.merge_mlp_outputs(raws, ms, zs)
-            return vshard.gather_tiles(fused["rgb"], fused["depth"])
-        if gather is not None:
-            if args.shard == "views":
-                if args.sync_gather or not args.pipelined:
-                    return gather.all_gather_frames(out[rgb_key], out[depth_key])
-                # the exchange of frame i runs on RCCL's stream under the kernels of frame i+1
-                return gather.all_gather_frames_pipelined(out[rgb_key], out[depth_key])
-            return gather.all_gather_ray_tiles(out[rgb_key], out[depth_key], N)
-        return out
+    finish, gather, vshard = make_exchange(args.shard, world, rank, N, dev, net, wl, int(cc.k_best) if "k_best" in wl else 1,
+                                           level, pipelined=args.pipelined, sync_gather=args.sync_gather)
 
     if wl.get("train"):
         # fine-tune step (trainer.py:44-63): every rank trains on its own target view, DDP averages the

@@ -176,8 +176,11 @@ class Blend(torch.autograd.Function):
 class NerfMLP(torch.autograd.Function):
     """a11.  forward: MFMA kernel.  backward: three launches inside bmv_nerf_mlp_bwd (csrc/mlp_bwd.hip): the data
     path (input gradients; pre-activation gradients and layer inputs parked as per-tile matrices), every weight and
-    bias gradient as MFMA products over the sample dimension, and a deterministic reduction into tensors of the
-    parameters' shapes."""
+    bias gradient as MFMA products over the sample dimension, and a fixed-order reduction of the per-workgroup partials
+    into tensors of the parameters' shapes.  NOT bit-reproducible from run to run as a whole: the two 1-wide heads
+    whose inputs are not parked (agg_w_fc, color.2: 96 values) are accumulated with float atomics in the data-path
+    kernel (mlp_bwd.hip), and so are the scatter gradients of VoxFeat / ImgFeat / SweepVariance (backward.hip);
+    everything else is."""
 
     @staticmethod
     def forward(ctx, vox_feat, img_feat_rgb_dir, feat_ch, *params):

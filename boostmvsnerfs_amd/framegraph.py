@@ -35,7 +35,10 @@ class FrameGraph:
         self.graphs = []
         self.sweeps = []            # (impl, args, kwargs) of the eager sweep launched after graph i
         self.out = None
+        self.event_pairs = []       # the event-record nodes' events: owned by this graph (ktimer may forget them)
+        before = set(map(id, ktimer.graph_pairs_snapshot()))
         self._capture(warmup)
+        self.event_pairs = [p for p in ktimer.graph_pairs_snapshot() if id(p) not in before]
 
     # ------------------------------------------------------------------ capture
     def _count_sweeps(self):

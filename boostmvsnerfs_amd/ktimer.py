@@ -55,8 +55,16 @@ def reset():
 
 
 def forget_graph_events():
+    """Stop COLLECTING from the event pairs of earlier captures.  The pairs themselves stay alive as long as the
+    FrameGraph that recorded them does (`graph_pairs_snapshot` -> FrameGraph.event_pairs): a replay of such a graph
+    still stamps valid events."""
     _graph_pairs.clear()
     _graph_us.clear()
+
+
+def graph_pairs_snapshot():
+    """Every (start, end) pair recorded into a capture so far (the caller -- FrameGraph -- keeps the ones it added)."""
+    return [p for pairs in _graph_pairs.values() for p in pairs]
 
 
 @contextlib.contextmanager

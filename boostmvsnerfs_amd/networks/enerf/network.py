@@ -88,8 +88,13 @@ class Network(nn.Module):
         if not self.lookup_records or self.wants_grad():
             return False
         users = [i for i in range(cc.num) if cc.render_if[i] and cc.render_im_feat_level[i] == 2]
+        # ... and: level 2 is never SWEPT as cost-volume features (a third cascade level would hand the records to
+        # the plane sweep), and the renderer has a record kernel for the level's sample count
+        if cc.num > 2:
+            return False
         return bool(users) and all(cc.render_scale[i] == 1.0 and cc.im_ibr_scale[i] == 1.0
-                                   and getattr(self, f"nerf_{i}").feat_ch - 3 == 8 for i in users)
+                                   and getattr(self, f"nerf_{i}").feat_ch - 3 == 8
+                                   and int(cc.num_samples[i]) in (1, 2, 4, 8) for i in users)
 
     # ------------------------------------------------------------------ cost volume of one level
     def camera_only(self, views, batch):

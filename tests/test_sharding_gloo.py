@@ -137,6 +137,88 @@ def test_volume_sharding_exchange_and_blend(world, K, n_rays):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# bench.py's OWN exchange wiring (bench.make_exchange: the function its timed step calls), with a stub renderer
+# ---------------------------------------------------------------------------------------------------------------
+class _StubNet:
+    """What bench.make_exchange touches of a network: the ray / volume shard attributes and the K-volume fusion."""
+    ray_range = None
+    volume_ids = None
+
+    @staticmethod
+    def merge_mlp_outputs(raws, ms, zs):
+        from oracle import enerf as O
+        return O.blend(raws, O.normalise_masks(ms), zs)
+
+
+def _bench_worker(rank, world, port, n_rays, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench                      # importing bench.py needs no GPU
+        from oracle import enerf as O
+        torch.manual_seed(0)              # the same "scene" on every rank
+        Ns, level = 2, 1
+        raws = torch.rand(1, K, n_rays, Ns, 4)
+        zs = torch.rand(1, K, n_rays, Ns) + 2
+        ms = torch.randint(0, 4, (1, K, n_rays, Ns)).float() / 3
+        full = O.blend(raws, O.normalise_masks(ms), zs)
+        ok = {}
+        # --shard rays: the network renders [begin, end) of the frame, finish() reassembles it
+        net = _StubNet()
+        finish, gather, vshard = bench.make_exchange("rays", world, rank, n_rays, "cpu", net, {"net": "enerf"}, 1, level)
+        b, e = net.ray_range
+        out = {"rgb_level1": full["rgb"][:, b:e], "depth_level1": full["depth"][:, b:e]}
+        frame = finish(out)
+        ok["rays"] = vshard is None and torch.equal(frame[:, :3], full["rgb"][0]) and torch.equal(frame[:, 3], full["depth"][0])
+        # --shard views (synchronous and pipelined): every rank its own frame, all frames everywhere
+        for pipelined in (False, True):
+            net = _StubNet()
+            finish, gather, _ = bench.make_exchange("views", world, rank, n_rays, "cpu", net, {"net": "enerf"}, 1, level,
+                                                    pipelined=pipelined)
+            assert net.ray_range is None
+            got = None
+            for i in range(3):
+                got = finish({"rgb_level1": full["rgb"] * (rank + 1 + i), "depth_level1": full["depth"] + rank})
+            if pipelined:
+                got = gather.flush()
+            ok[f"views{int(pipelined)}"] = all(torch.equal(got[r, :, :3], full["rgb"][0] * (r + 3)) and
+                                                 torch.equal(got[r, :, 3], full["depth"][0] + r) for r in range(world))
+        # --shard volumes: volume subsets x ray ranges, all-to-all, sharded fusion, tile gather
+        net = _StubNet()
+        finish, gather, vshard = bench.make_exchange("volumes", world, rank, n_rays, "cpu", net, {"net": "boost_enerf"}, K, level)
+        b, e = net.ray_range
+        stacks = tuple(t[:, net.volume_ids, b:e].contiguous() for t in (raws, zs, ms))
+        frame = finish({"stacks_level1": stacks})
+        ok["volumes"] = gather is None and torch.equal(frame[:, :3], full["rgb"][0]) and torch.equal(frame[:, 3], full["depth"][0])
+        # world-1 semantics of the same function: identity
+        f1, g1, v1 = bench.make_exchange("views", 1, 0, n_rays, "cpu", _StubNet(), {"net": "enerf"}, 1, level)
+        ok["identity"] = g1 is None and v1 is None and f1(out) is out
+        q.put((rank, {k: bool(v) for k, v in ok.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,n_rays", [(2, 4, 101), (4, 2, 96)])
+def test_bench_exchange_wiring(world, K, n_rays):
+    """bench.py --gpus N --shard {rays, views, volumes}: the exchange its timed step runs, on gloo."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, n_rays, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok.values()), (rank, ok)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # fine-tune leg under DDP (lib/train/trainers/trainer.py:15-22: SyncBatchNorm conversion + DistributedDataParallel
 # with find_unused_parameters around the loss wrapper): construction + one step on 2 ranks.  The HIP forward cannot
 # run on CPU, so the network's forward is replaced by a surrogate that touches every parameter; what is under test
