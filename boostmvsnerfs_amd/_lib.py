@@ -78,6 +78,7 @@ SIGNATURES = {
     "bmv_mvs_proj_mats": [c_f, c_f, c_i, c_i, c_f, c_f],
     "bmv_resize_bilinear": [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_mvs_sweep_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    "bmv_mvs_sweep_cl_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_mvs_mlp_blob_size": [],
     "bmv_mvs_mlp_pack_weights": [C.POINTER(MvsMlpParams), c_f, c_f],
     "bmv_mvs_mlp_fwd": [c_f, c_f, c_l, c_f, c_f],

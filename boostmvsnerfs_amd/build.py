@@ -25,6 +25,8 @@ if os.environ.get("BMV_CONV_DEFS"):   # e.g. "-DBMV_CONV_WPE_TUNED=0": the convo
     EXTRA_FLAGS["conv.hip"] = os.environ["BMV_CONV_DEFS"].split()
 if os.environ.get("BMV_RING_DEFS"):   # tuning builds of the ring-pipelined sweep
     EXTRA_FLAGS["sweep_ring.hip"] = os.environ["BMV_RING_DEFS"].split()
+if os.environ.get("BMV_MVS_DEFS"):
+    EXTRA_FLAGS["mvs.hip"] = os.environ["BMV_MVS_DEFS"].split()
 if os.environ.get("BMV_ZP_DEFS"):
     EXTRA_FLAGS["sweep_zp.hip"] = os.environ["BMV_ZP_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"

@@ -158,6 +158,137 @@ __global__ void __launch_bounds__(256) mvs_sweep_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// a19 + a20 on CHANNEL-LAST features (round 3).  The kernel above gathers every tap of every channel as its own dword
+// (35 channels x 4 taps x 2 warped views = 280 scattered loads per voxel): at 128 planes it runs 298 us for the 297 MB
+// it writes -- bound by the texture addresser, not by the stores.  Here the features are channel-last (B,S,h,w,C) and
+// FOUR lanes share a voxel: lane (voxel, sub) reads the 16-byte slices sub and 4 + sub of a tap's 128-byte record, so
+// one load instruction of a wave covers 16 voxels x 64 contiguous bytes (16 half lines) instead of 64 lanes x 16 bytes
+// of 64 different lines (the first channel-last version, lane = voxel: 182 us -- the addresser works per line
+// touched).  A lane keeps 8 channels (16 accumulators): no register pressure, full occupancy.  The 9 colour channels
+// are split over the 4 lanes of a voxel (planar dword gathers).  Stores: one dword per lane through a buffer
+// descriptor, 4 channels x 16 consecutive voxels per instruction; the volume (297 MB) is written once and read once by
+// the regulariser: `nt`.  Geometry as above but with v_rcp_f32 for the three quotients (1 ulp; the tests hold both
+// kernels to the reference's volume at the project tolerance).
+// ---------------------------------------------------------------------------
+template <int S, int AUX>
+__global__ void __launch_bounds__(256) mvs_sweep_cl_kernel(const float* __restrict__ imgs,
+                                                            const float* __restrict__ feats_cl,
+                                                            const float* __restrict__ proj,
+                                                            const float* __restrict__ depth_values, int h, int w, int D,
+                                                            int pad, float* __restrict__ out) {
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  constexpr int C = 32;
+  const int b = blockIdx.y;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
+  const unsigned nvox = (unsigned)D * hp * wp;
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned i = gid >> 2, sub = gid & 3u;
+  const bool live = i < nvox;
+  const unsigned ic = live ? i : nvox - 1;
+  const int xp = (int)(ic % wp), yp = (int)((ic / wp) % hp), d = (int)(ic / ((unsigned)hp * wp));
+  const int x = xp - pad, y = yp - pad;
+  const bool inside = x >= 0 && x < w && y >= 0 && y < h;
+  const size_t plane = (size_t)h * w;
+  const float inv_depth = __builtin_amdgcn_rcpf(depth_values[b * D + d]);
+  __amdgpu_buffer_rsrc_t frs = make_rsrc(feats_cl + (size_t)b * S * plane * C, (size_t)S * plane * C * 4);
+  __amdgpu_buffer_rsrc_t ors = make_rsrc(out + (size_t)b * (3 * S + C) * nvox, (size_t)(3 * S + C) * nvox * 4);
+  __amdgpu_buffer_rsrc_t irs = make_rsrc(imgs + (size_t)b * S * 3 * plane, (size_t)S * 3 * plane * 4);
+  const unsigned cst = nvox * 4u;                      // byte stride of an output channel
+  const unsigned ovoff = live ? i * 4u : 0x80000000u;  // lanes past the volume store out of range
+  const unsigned sl = sub * 16u;                       // this lane's slices of a record: bytes [sl, sl+16) and [64+sl, ..)
+  const float fx = (float)x, fy = (float)y;
+
+  // accumulators: channels 4 sub .. 4 sub + 3 and 16 + 4 sub .. ; reference view first (un-warped, zero-padded,
+  // network.py:907-918)
+  float4 acc[2], acc2[2];
+  {
+    const unsigned r0 = inside ? (unsigned)(y * w + x) * (C * 4u) + sl : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(frs, r0 + 64u * j, 0, 0);
+      const float4 f = *reinterpret_cast<float4*>(&v);
+      acc[j] = f;
+      acc2[j] = make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w);
+    }
+  }
+  // the 9 colour channels (3 S) over the 4 lanes of a voxel: lane sub writes colours sub, sub + 4, sub + 8
+  float col[3] = {0.f, 0.f, 0.f};
+  if (sub < 3) {   // colour `sub` is channel sub of the reference view
+    const unsigned o = inside ? (unsigned)(sub * plane + (size_t)y * w + x) * 4u : 0x80000000u;
+    col[0] = ld_buf(irs, o, 0);
+  }
+  float count = 1.f;
+#pragma unroll
+  for (int s = 1; s < S; ++s) {
+    const float* P = proj + ((size_t)b * S + s) * 12;
+    const float px = P[0] * fx + P[1] * fy + P[2] + P[3] * inv_depth;
+    const float py = P[4] * fx + P[5] * fy + P[6] + P[7] * inv_depth;
+    const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] * inv_depth;
+    const float iz = __builtin_amdgcn_rcpf(pz);          // no z clamp in this variant (utils.py:617)
+    const float gx = (px * iz) / ((float)(w - 1) * 0.5f) - 1.f;
+    const float gy = (py * iz) / ((float)(h - 1) * 0.5f) - 1.f;
+    count += (gx > -1.f && gx < 1.f && gy > -1.f && gy < 1.f) ? 1.f : 0.f;
+    const Taps2 t = taps_zeros(unnorm(gx, w), unnorm(gy, h), w, h);
+    // colours 3 s + c of this view: colour index cc = sub + 4 j -> (view cc / 3, channel cc % 3)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int cc = (int)sub + 4 * j;
+      if (cc / 3 == s) {
+        const unsigned cb = (unsigned)((s * 3 + cc % 3) * plane) * 4u;
+        float v = ld_buf(irs, cb + (unsigned)t.o00 * 4u, 0) * t.w00;
+        v += ld_buf(irs, cb + (unsigned)t.o01 * 4u, 0) * t.w01;
+        v += ld_buf(irs, cb + (unsigned)t.o10 * 4u, 0) * t.w10;
+        v += ld_buf(irs, cb + (unsigned)t.o11 * 4u, 0) * t.w11;
+        col[j] = v;
+      }
+    }
+    // the 4 taps as byte offsets of channel-last records (in-bounds by construction: taps_zeros parks invalid taps)
+    const unsigned vb = (unsigned)s * (unsigned)plane * (C * 4u) + sl;
+    const unsigned o00 = vb + (unsigned)t.o00 * (C * 4u), o01 = vb + (unsigned)t.o01 * (C * 4u);
+    const unsigned o10 = vb + (unsigned)t.o10 * (C * 4u), o11 = vb + (unsigned)t.o11 * (C * 4u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      i32x4 a00 = __builtin_amdgcn_raw_buffer_load_b128(frs, o00 + 64u * j, 0, 0);
+      i32x4 a01 = __builtin_amdgcn_raw_buffer_load_b128(frs, o01 + 64u * j, 0, 0);
+      i32x4 a10 = __builtin_amdgcn_raw_buffer_load_b128(frs, o10 + 64u * j, 0, 0);
+      i32x4 a11 = __builtin_amdgcn_raw_buffer_load_b128(frs, o11 + 64u * j, 0, 0);
+      const float4 f00 = *reinterpret_cast<float4*>(&a00), f01 = *reinterpret_cast<float4*>(&a01);
+      const float4 f10 = *reinterpret_cast<float4*>(&a10), f11 = *reinterpret_cast<float4*>(&a11);
+      // same accumulation order as tap_fetch / aten's grid_sampler_2d: nw, ne, sw, se
+      float4 v;
+      v.x = f00.x * t.w00, v.x += f01.x * t.w01, v.x += f10.x * t.w10, v.x += f11.x * t.w11;
+      v.y = f00.y * t.w00, v.y += f01.y * t.w01, v.y += f10.y * t.w10, v.y += f11.y * t.w11;
+      v.z = f00.z * t.w00, v.z += f01.z * t.w01, v.z += f10.z * t.w10, v.z += f11.z * t.w11;
+      v.w = f00.w * t.w00, v.w += f01.w * t.w01, v.w += f10.w * t.w10, v.w += f11.w * t.w11;
+      acc[j].x += v.x, acc[j].y += v.y, acc[j].z += v.z, acc[j].w += v.w;
+      acc2[j].x += v.x * v.x, acc2[j].y += v.y * v.y, acc2[j].z += v.z * v.z, acc2[j].w += v.w * v.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const unsigned cc = sub + 4u * j;
+    // (colour 9, 10, 11 do not exist for S = 3: those lanes store out of range)
+    // (scalar offsets cannot differ per lane: the colour's channel offset goes into the vector offset)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, col[j]), ors,
+                                          (int)((live && cc < 3u * S) ? i * 4u + cc * cst : 0x80000000u), 0, AUX);
+  }
+  const float inv = 1.f / count;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned cb = ovoff + (3u * S + 16u * j + 4u * sub) * cst;     // first of this lane's 4 channels
+    float m;
+    m = acc[j].x * inv;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[j].x * inv - m * m), ors, (int)(live ? cb : 0x80000000u), (int)(0 * cst), AUX);
+    m = acc[j].y * inv;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[j].y * inv - m * m), ors, (int)(live ? cb : 0x80000000u), (int)(1 * cst), AUX);
+    m = acc[j].z * inv;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[j].z * inv - m * m), ors, (int)(live ? cb : 0x80000000u), (int)(2 * cst), AUX);
+    m = acc[j].w * inv;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[j].w * inv - m * m), ors, (int)(live ? cb : 0x80000000u), (int)(3 * cst), AUX);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // a25: Renderer_ours (6 x 128) on fp32 MFMA, same transposed orientation as mlp.hpp
 // (sample on the lane, neurons in accumulators, outputs of a layer are the B operands of
 // the next).  The 0.5 MB of weights does not fit LDS: the packed blob is a sequence of
@@ -764,6 +895,29 @@ int bmv_mvs_sweep_fwd(const float* imgs, const float* feats, const float* proj, 
   hipLaunchKernelGGL((mvs_sweep_kernel<32, 3>), dim3(cdiv(nvox, 256), B), dim3(256), 0, as_stream(stream), imgs, feats,
                      proj, depth_values, h, w, D, pad, volume);
   BMV_LAUNCH_END("bmv_mvs_sweep_fwd");
+}
+
+int bmv_mvs_sweep_cl_fwd(const float* imgs, const float* feats_cl, const float* proj, const float* depth_values, int B,
+                         int S, int C, int h, int w, int D, int pad, float* volume, bmv_stream_t stream) {
+  BMV_REQUIRE(imgs && feats_cl && proj && depth_values && volume, "bmv_mvs_sweep_cl_fwd: null pointer");
+  BMV_REQUIRE(B > 0 && h > 1 && w > 1 && D > 0 && pad >= 0, "bmv_mvs_sweep_cl_fwd: bad shape");
+  if (C != 32 || S != 3) {
+    set_error("bmv_mvs_sweep_cl_fwd: built for C=32 feature channels and S=3 views (got C=%d S=%d)", C, S);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  const size_t nvox = (size_t)D * (h + 2 * pad) * (w + 2 * pad);
+  if ((3 * S + C) * nvox * 4 >= ((size_t)1 << 31) || (size_t)S * h * w * C * 4 >= ((size_t)1 << 31)) {
+    set_error("bmv_mvs_sweep_cl_fwd: one batch item of the volume / the features must stay below 2 GiB (32-bit offsets)");
+    return BMV_ERR_UNSUPPORTED;
+  }
+  static const int aux = getenv("BMV_MVS_SWEEP_AUX") ? atoi(getenv("BMV_MVS_SWEEP_AUX")) : 2;
+  if (aux == 2)   // (4 lanes per voxel)
+    hipLaunchKernelGGL((mvs_sweep_cl_kernel<3, 2>), dim3(cdiv(4 * nvox, 256), B), dim3(256), 0, as_stream(stream), imgs,
+                       feats_cl, proj, depth_values, h, w, D, pad, volume);
+  else
+    hipLaunchKernelGGL((mvs_sweep_cl_kernel<3, 0>), dim3(cdiv(4 * nvox, 256), B), dim3(256), 0, as_stream(stream), imgs,
+                       feats_cl, proj, depth_values, h, w, D, pad, volume);
+  BMV_LAUNCH_END("bmv_mvs_sweep_cl_fwd");
 }
 
 int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* src_ixts, int N, int Ns, int V,

@@ -95,12 +95,15 @@ class FeatureNet(nn.Module):
         for m, (wp, bp) in zip(blocks, P):
             x = convnet.conv_fwd(x, wp, bp, m.conv.out_channels, 1, m.conv.kernel_size[0], m.conv.stride[0],
                                  slope=m.bn.slope)
-        return convnet.conv_fwd(x, *P[-1], 32, 1, 1)
+        # the padded sweep reads the map channel-last (a tap = 8 loads of 16 bytes): written so by the 1x1 layer,
+        # returned as a (N,32,h,w) VIEW of the (N,h,w,32) buffer (`.contiguous()` gives the reference tensor)
+        return convnet.conv_fwd(x, *P[-1], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
 
     def forward(self, x):
         B, V, C, H, W = x.shape
         if _engine_ok(self, x):
-            return self._forward_engine(x.reshape(B * V, C, H, W)).view(B, V, 32, H // 4, W // 4)
+            y = self._forward_engine(x.reshape(B * V, C, H, W))            # (B*V, 32, h, w) channel-last strides
+            return y.unflatten(0, (B, V))
         y = self.toplayer(self.conv2(self.conv1(self.conv0(x.reshape(B * V, C, H, W)))))
         return y.view(B, V, 32, H // 4, W // 4)
 
@@ -253,7 +256,11 @@ class Network(nn.Module):
         batch["src_inps"] = batch["all_src_inps"][bi, ids]
         batch["src_exts"] = batch["all_src_exts"][bi, ids]
         batch["src_ixts"] = batch["all_src_ixts"][bi, ids]
-        f = feats[bi, ids]
+        cl = feats.permute(0, 1, 3, 4, 2)
+        if cl.is_contiguous():      # engine path: pick the views in the channel-last layout the padded sweep reads
+            f = cl[bi, ids].permute(0, 1, 4, 2, 3)
+        else:
+            f = feats[bi, ids]
         h, w = f.shape[-2:]
         proj = ops.mvs_proj_mats(batch["src_exts"], batch["src_ixts"])
         small = ops.resize_bilinear(batch["src_inps"], h, w)

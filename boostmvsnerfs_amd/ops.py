@@ -431,11 +431,24 @@ def resize_bilinear(x, h, w):
     return out
 
 
-def mvs_sweep(imgs_small, feats, proj, depth_values, pad):
+def mvs_sweep(imgs_small, feats, proj, depth_values, pad, algo=0):
+    """a19 + a20.  feats (B,S,C,h,w): a reference-layout tensor, or a (B,S,C,h,w) VIEW of a channel-last (B,S,h,w,C)
+    buffer (what MVSNeRF's FeatureNet returns on the engine path).  algo 0: the channel-last kernel (a planar input is
+    converted first: one transpose launch); algo 1: the reference-layout gather kernel of round 1."""
     B, S, C_, h, w = feats.shape
     D = depth_values.shape[1]
     out = torch.empty(B, 3 * S + C_, D, h + 2 * pad, w + 2 * pad, device=feats.device, dtype=torch.float32)
     lib = _lib.load()
+    cl = feats.permute(0, 1, 3, 4, 2)
+    if algo == 0 and C_ == 32 and S == 3:
+        if not cl.is_contiguous():
+            cl = nchw_to_nhwc(feats)
+        args = (dptr(_c(imgs_small), "imgs"), dptr(cl, "feats_cl"), dptr(_c(proj), "proj"),
+                dptr(_c(depth_values), "depth_values"), B, S, C_, h, w, D, int(pad), dptr(out), stream())
+        with ktimer.region(f"mvs_sweep[C={C_},D={D},{h}x{w},pad={pad}]"):
+            rc = lib.bmv_mvs_sweep_cl_fwd(*args)
+        _lib.check(rc, "mvs_sweep_cl")
+        return out
     args = (dptr(_c(imgs_small), "imgs"), dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
             dptr(_c(depth_values), "depth_values"), B, S, C_, h, w, D, int(pad), dptr(out), stream())
     with ktimer.region(f"mvs_sweep[C={C_},D={D},{h}x{w},pad={pad}]"):

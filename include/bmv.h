@@ -298,6 +298,12 @@ int bmv_resize_bilinear(const float* src, int n, int C, int H, int W, int h, int
  *   reference + warped source features, c = 1 / (1 + number of source views whose grid is inside). */
 int bmv_mvs_sweep_fwd(const float* imgs, const float* feats, const float* proj, const float* depth_values, int B,
                       int S, int C, int h, int w, int D, int pad, float* volume, bmv_stream_t stream);
+/* The same sweep on CHANNEL-LAST features feats_cl (B,S,h,w,C) (what MVSNeRF's FeatureNet writes on the engine path;
+ * bmv_nchw_to_nhwc converts): four lanes share a voxel and read 64 contiguous bytes of a tap's record per load (round 3:
+ * 298 -> 134 us at 128 planes).  imgs stay planar (B,S,3,h,w).  Same outputs up to v_rcp_f32 vs IEEE division (1 ulp of
+ * the tap coordinates). */
+int bmv_mvs_sweep_cl_fwd(const float* imgs, const float* feats_cl, const float* proj, const float* depth_values, int B,
+                         int S, int C, int h, int w, int D, int pad, float* volume, bmv_stream_t stream);
 
 /* ---- a25 Renderer_ours parameters          lib/networks/mvsnerf/network.py:153-229
  * D=6, W=128, input_ch=63, input_ch_feat=20, input_ch_views=3 (network.py:803-805) */

@@ -47,8 +47,23 @@ def test_proj_resize_sweep(fx):
     want_small = torch.nn.functional.interpolate(b["all_src_inps"][0].cpu(), (16, 24), mode="bilinear", align_corners=False)
     assert_close(small[0], want_small, rtol=1e-5, atol_scale=1e-6, name="resize")
     dv, _, _ = M.depth_planes(b["depth_ranges"].cpu(), 8)
-    vol = ops.mvs_sweep(small, fx.t("cap/feature#0", DEV), fx.t("cap/get_proj_mats#0", DEV), dv[None].to(DEV), 24)
+    feats = fx.t("cap/feature#0", DEV)
+    vol = ops.mvs_sweep(small, feats, fx.t("cap/get_proj_mats#0", DEV), dv[None].to(DEV), 24)
     assert_close(vol, fx.t("cap/build_volume_costvar_img#0"), name="cost volume")
+    # the channel-last kernel (default; a planar input is transposed first) and the reference-layout gather kernel
+    # of round 1 do the same arithmetic up to v_rcp_f32 vs IEEE division and FMA contraction; a channel-last VIEW, as FeatureNet's
+    # engine path returns it, is read in place (bit-equal to the transposed planar input)
+    vol1 = ops.mvs_sweep(small, feats, fx.t("cap/get_proj_mats#0", DEV), dv[None].to(DEV), 24, algo=1)
+    assert_close(vol1, fx.t("cap/build_volume_costvar_img#0"), name="cost volume (reference-layout kernel)")
+    assert_close(vol, vol1, rtol=1e-4, atol_scale=1e-4, name="channel-last vs reference-layout kernel")   # (v_rcp vs IEEE division)
+    view = ops.nchw_to_nhwc(feats).permute(0, 1, 4, 2, 3)
+    assert not view.is_contiguous()
+    assert torch.equal(ops.mvs_sweep(small, view, fx.t("cap/get_proj_mats#0", DEV), dv[None].to(DEV), 24), vol)
+    # ragged: a volume whose voxel count is not a multiple of the workgroup, other pad
+    dv3 = dv[None, :3].contiguous().to(DEV)
+    assert_close(ops.mvs_sweep(small, feats, fx.t("cap/get_proj_mats#0", DEV), dv3, 5),
+                 ops.mvs_sweep(small, feats, fx.t("cap/get_proj_mats#0", DEV), dv3, 5, algo=1), rtol=1e-4, atol_scale=1e-4,
+                 name="ragged volume")
 
 
 def _blob(fx):
