@@ -56,6 +56,20 @@ class FrameGraph:
         return calls
 
     def _capture(self, warmup):
+        # graphs of earlier frames (this module's, or the ones Network.forward captures of itself) may be garbage by
+        # now: destroy them BEFORE the capture starts and keep the collector out of it (a hipGraphExec destroyed by a
+        # collection in the middle of a multi-stream capture crashed the process; torch.cuda.graph() collects first too)
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_inner(warmup)
+        finally:
+            if gc_was:
+                gc.enable()
+
+    def _capture_inner(self, warmup):
         was_enabled, ktimer.enabled = ktimer.enabled, False
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())

@@ -59,6 +59,10 @@ class Network(enerf_network.Network):
         self._sel_cache = {}
         self._streams = []
         self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
+        # the K cost volumes as one batch through the regularisers instead of K chains on K streams (round 3; opt-in:
+        # measured 3.29 ms against 3.15 ms per 480x736 K = 4 frame -- the frame is 4 x 0.7 ms of render launches, and
+        # under K streams the regularisers' short launches already hide under the other volumes' renders)
+        self.batched_volumes = os.environ.get("BMV_BOOST_BATCHED", "0") == "1"
         # multi-GPU, `--shard volumes` (boostmvsnerfs_amd/sharding.py VolumeShard): build and render only these cost
         # volumes (indices into the K selected ones) and return their stacked (raw, z, mask) instead of the fused picture
         self.volume_ids = None
@@ -217,6 +221,67 @@ class Network(enerf_network.Network):
         batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
         return ret
 
+    def _forward_batched(self, batch, feats, sel, sel32, cams, K):
+        """The K cost volumes as ONE batch (round 3): per cascade level K sweeps write the slices of a (K,C,D,h,w)
+        variance tensor, then ONE regulariser pass with batch K -- every launch of the U-Net carries K times the
+        workgroups of a single volume's, so its latency-bound interior layers (8-10 us each whatever their size) are
+        paid once per level instead of K times side by side on K streams -- one depth regression, one hypothesis
+        kernel, and K render launches (each fills the chip on its own).  Everything on the current stream."""
+        cc = cfg.enerf.cas_config
+        dev = batch["all_src_inps"].device
+        ks = list(range(K))
+        src_exts = torch.cat([cams[k][0] for k in ks], 0)               # (K,S,4,4): the K triplets as batch items
+        src_ixts = torch.cat([cams[k][1] for k in ks], 0)
+        tar_ext = batch["tar_ext"].expand(K, -1, -1).contiguous()
+        tar_ixt = batch["tar_ixt"].expand(K, -1, -1).contiguous()
+        near_far = batch["near_far"].expand(K, -1).contiguous()
+        H, W = batch["all_src_inps"].shape[-2:]
+        ret, st = {}, None
+        for i in range(cc.num):
+            h, w = int(H * cc.volume_scale[i]), int(W * cc.volume_scale[i])
+            D = cc.volume_planes[i]
+            cur = enerf_network.LevelState()
+            if st is None:
+                cur.depth_values, cur.near_far = ops.depth_values_uniform(near_far, D, h, w, cc.depth_inv[i])
+            else:
+                if not cc.depth_inv[i - 1] or cc.depth_inv[i]:
+                    raise NotImplementedError("cascade levels must go disparity -> depth")
+                cur.depth_values, cur.near_far = ops.depth_values_cascade(st.depth, st.std, st.near_far, h, w, D)
+            proj = ops.proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, cc.im_feat_scale[i], cc.volume_scale[i])
+            f_i = feats[f"level_{i}"]
+            variance = torch.empty(K, f_i.shape[2], D, h, w, device=dev)
+            for k in ks:
+                ops.sweep_variance_views(f_i, sel32[:, k], proj[k:k + 1], cur.depth_values[k:k + 1], out=variance[k:k + 1])
+            cur.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
+            cur.depth, cur.std = ops.depth_regress(depth_prob, cur.depth_values, cc.depth_inv[i])
+            st = cur
+            if not cc.render_if[i]:
+                continue
+            n_i, ns_i = batch[f"rays_{i}"].shape[1], cc.num_samples[i]
+            stacks = (torch.empty(1, K, n_i, ns_i, 4, device=dev), torch.empty(1, K, n_i, ns_i, device=dev),
+                      torch.empty(1, K, n_i, ns_i, device=dev))
+            im_feat = feats[f"level_{cc.render_im_feat_level[i]}"]
+            fv = st.feature_volume
+            for k in ks:
+                one = enerf_network.LevelState()
+                one.depth, one.std, one.near_far = st.depth[k:k + 1], st.std[k:k + 1], st.near_far[k:k + 1]
+                one.feature_volume = type(fv)(fv.t[k:k + 1]) if hasattr(fv, "t") else fv[k:k + 1]
+                views = (batch["all_src_inps"], *cams[k])
+                self.render_level(i, one, im_feat, views, batch, mode=1, outs=tuple(t[:, k] for t in stacks), view_ids=sel32[:, k])
+            raws, zs, ms = stacks
+            if self.ray_range is not None:   # the render launches wrote rays [begin, end) of the full-size buffers
+                b_, e_ = self.ray_range
+                raws, zs, ms = raws[:, :, b_:e_], zs[:, :, b_:e_], ms[:, :, b_:e_]
+            if self.capture is not None:     # tests: per-volume raw outputs / depths / visibility masks
+                self.capture[f"level{i}"] = (raws, zs, ms)
+            out = self.merge_mlp_outputs(raws.contiguous(), ms.contiguous(), zs.contiguous())
+            depth0, std0 = st.depth[:1], st.std[:1]                     # depth_mvs / std come from volume 0 only
+            out["depth_mvs"] = torch.reciprocal(depth0) if cc.depth_inv[i] else depth0
+            out["std"] = std0
+            ret.update({f"{k_}_level{i}": v for k_, v in out.items()})
+        batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
+        return ret
+
     def _forward_checked(self, batch):           # (forward itself, with the self-capturing replay, is the base class's)
         try:
             return self._forward_boost(batch)
@@ -226,11 +291,12 @@ class Network(enerf_network.Network):
     def _autograph_key(self, batch):
         """A captured K-volume frame is specialised to the cost-volume triplets view_selection.json selects for the
         batch's targets (they are baked into the graph as device constants) and to the capture hook of the tests."""
+        base = super()._autograph_key(batch) + (self.parallel_volumes, self.batched_volumes, self.by_index, self.capture is not None)
         if self.view_selection_outputs is None:
-            return None
+            return base
         meta = batch["meta"]
-        return (tuple(tuple(self.view_selection_outputs[f"{s}_{v}"]) for s, v in zip(meta["scene"], meta["tar_view"])),
-                int(cfg.enerf.cas_config.k_best), self.capture is not None)
+        return base + (tuple(tuple(self.view_selection_outputs[f"{s}_{v}"]) for s, v in zip(meta["scene"], meta["tar_view"])),
+                       int(cfg.enerf.cas_config.k_best))
 
     def _forward_boost(self, batch):
         if self.view_selection_outputs is None:
@@ -278,6 +344,8 @@ class Network(enerf_network.Network):
         if by_index:
             sel32 = sel.to(torch.int32)
             cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
+            if self.batched_volumes and self.volume_ids is None and B == 1:
+                return self._forward_batched(batch, feats, sel, sel32, cams, K)
             if (self.parallel_volumes or self.volume_ids is not None) and B == 1:
                 return self._forward_parallel(batch, feats, sel, sel32, cams, K)
         if self.volume_ids is not None:

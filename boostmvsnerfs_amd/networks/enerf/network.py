@@ -334,7 +334,10 @@ class Network(nn.Module):
             self.set_volume_records(False)       # the modules go back to planar outputs for any other caller
 
     def _autograph_key(self, batch):
-        return None
+        """What a captured frame is specialised to besides shapes and parameters: the execution switches of this module
+        (tests and tuning scripts flip them between calls)."""
+        return (self.sweep_algo, self.overlap_front, self.lookup_records, self.frame_setup, self.volume_records,
+                self.overlap_eager)
 
     def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() replace storage: captured graphs are stale
         ag = self.__dict__.get("_autograph")

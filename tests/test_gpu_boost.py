@@ -41,18 +41,20 @@ def test_view_selection_matches_reference(enerf_fx, boost_fx, tmp_path):
             assert_close(m, boost_fx.t(f"cap/sel/calc_mask#{i}.mask_level1"), rtol=1e-4, atol_scale=1e-5, name=f"vis{i}")
 
 
-@pytest.mark.parametrize("path", ["streams", "sequential", "graph"])
+@pytest.mark.parametrize("path", ["streams", "batched", "sequential", "graph"])
 def test_boost_forward_matches_reference(enerf_fx, boost_fx, tmp_path, path):
     """The reference's output dict (boost_enerf/network.py:172-237) through every execution path of the port:
-    `streams` = the default one (K cost-volume chains on K HIP streams, views picked by index), `sequential` = the
-    same chains on one stream, `graph` = the default path captured into a HIP graph and replayed (what bench.py
-    times)."""
+    `streams` = the default one (K cost-volume chains on K HIP streams, views picked by index), `batched` = the K
+    cost volumes as one batch through the regularisers, `sequential` = the chains on one stream, `graph` = the
+    default path captured into a HIP graph and replayed (what Network.forward does from the second call on)."""
     _cfg(boost_fx, tmp_path)
     with open(tmp_path / "view_selection.json", "w") as f:
         json.dump({"synthetic_0": [int(k) for k in boost_fx.raw["extra/k_best"]]}, f)
     net = _net(enerf_fx, preprocess=False)
     net.capture = {}
-    assert net.parallel_volumes                      # the default
+    assert net.parallel_volumes and not net.batched_volumes     # the defaults
+    if path == "batched":
+        net.batched_volumes = True
     if path == "sequential":
         net.parallel_volumes = False
     b = boost_fx.batch(DEV)
@@ -66,7 +68,7 @@ def test_boost_forward_matches_reference(enerf_fx, boost_fx, tmp_path, path):
         with torch.no_grad():
             out = net(b)
     ran_parallel = len(net._streams) > 0
-    assert ran_parallel == (path != "sequential")    # the path under test is the one that ran
+    assert ran_parallel == (path in ("streams", "graph"))       # the path under test is the one that ran
     want = boost_fx.group("out")
     assert set(out) == set(want)
     # visibility masks are a discontinuous test: count how many samples flipped vs the reference

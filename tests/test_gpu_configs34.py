@@ -69,6 +69,12 @@ def test_config3_execution_paths_agree_bit_for_bit(cfg3):
     want = _run(net, batch)                                  # default: K streams, views by index
     assert len(net._streams) == 4
     assert want["rgb_level1"].shape == (1, 480 * 736, 3) and bool(torch.isfinite(want["rgb_level1"]).all())
+    net.batched_volumes = True
+    batched = _run(net, batch)                               # the K volumes as one batch through the regularisers
+    net.batched_volumes = False
+    from conftest import assert_close
+    for k in want:   # (batch K picks other convolution tilings than batch 1: same values up to summation order)
+        assert_close(batched[k], want[k], rtol=1e-4, atol_scale=1e-4, name=f"{k}: one batch of K volumes vs K streams", max_outlier_frac=2e-3)
     net.parallel_volumes = False
     seq = _run(net, batch)
     net.by_index = False
