@@ -206,6 +206,17 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
+// ReLU as ONE instruction.  fmaxf(x, 0.f) on an MFMA result compiles to TWO v_max_f32: llvm.maxnum wants a
+// canonicalised operand and the compiler cannot prove an accumulator register is one, so it emits v_max x, x, x first
+// (round 3: 412 v_max in the MLP of a tile, ~190 of them such canonicalisations; fp32 MFMA and the vector ALU share the
+// SIMD's FMA lanes, so every vector instruction of the MLP adds to the tile's time).  v_max_f32 with a NaN operand
+// returns the other one: NaN -> 0, as fmaxf.
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // --------------------------------------------------------------------------
 // Per-lane inputs (lane = (sample s, half h)):
 //   fin[i][j]  j <  KFC : channel 2j+h of view i's [feature, rgb] vector (0 beyond FC)
@@ -230,13 +241,17 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
     float pre = Wv[L::V_VF + (j * 5 + 4) * 2] + Wv[L::V_VF + (j * 5 + 0) * 2] * dir[i][0] +
                 Wv[L::V_VF + (j * 5 + 1) * 2] * dir[i][1] + Wv[L::V_VF + (j * 5 + 2) * 2] * dir[i][2] +
                 Wv[L::V_VF + (j * 5 + 3) * 2] * dir[i][3];
-    return fin[i][j] + fmaxf(pre, 0.f);
+    return fin[i][j] + relu1(pre);
   };
-  // unbiased variance and mean over the 3 views (nerf.py:83-84)
+  // unbiased variance and mean over the 3 views (nerf.py:83-84); the f are kept for the per-view chain (feat_ch 8:
+  // 18 registers against 144 vector instructions to recompute them)
+  constexpr bool KEEP_F = KFC <= 6;
+  float fkeep[KEEP_F ? 3 : 1][KEEP_F ? KFC : 1];
   float var[KFC], mean[KFC];
 #pragma unroll
   for (int j = 0; j < KFC; ++j) {
     float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
+    if constexpr (KEEP_F) fkeep[0][j] = f0, fkeep[1][j] = f1, fkeep[2][j] = f2;
     float m = (f0 + f1 + f2) / 3.f;
     float d0 = f0 - m, d1 = f1 - m, d2 = f2 - m;
     mean[j] = m;
@@ -253,9 +268,9 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     g[i] = gsh;
-    BMV_CHAIN1(L::A_GV, KFC, BMV_MLP_G1, fval(i, t), g[i])
+    BMV_CHAIN1(L::A_GV, KFC, BMV_MLP_G1, (KEEP_F ? fkeep[KEEP_F ? i : 0][KEEP_F ? t : 0] : fval(i, t)), g[i])
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[i][r] = fmaxf(g[i][r], 0.f);
+    for (int r = 0; r < 16; ++r) g[i][r] = relu1(g[i][r]);
     BMV_FENCE();
   }
   // agg_w_fc + softmax over views + weighted sum (nerf.py:88-89)
@@ -281,7 +296,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   BMV_CHAIN1(L::A_FC, 16, BMV_MLP_G1, (aw[0] * g[0][t] + aw[1] * g[1][t] + aw[2] * g[2][t]), q)
   float im16[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) im16[r] = fmaxf(q[r], 0.f);
+  for (int r = 0; r < 8; ++r) im16[r] = relu1(q[r]);
   // lr0 (nerf.py:34-35): [vox(8), im(16)] -> 64
   f32x16 x[2];
 #pragma unroll
@@ -292,7 +307,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[tl][r] = fmaxf(x[tl][r], 0.f);
+    for (int r = 0; r < 16; ++r) x[tl][r] = relu1(x[tl][r]);
   // sigma head (nerf.py:38)
   {
     float s = 0.f;
@@ -322,7 +337,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += Wv[L::V_WC2 + (tl * 16 + r) * 2] * fmaxf(hc[tl][r], 0.f);
+      for (int r = 0; r < 16; ++r) s += Wv[L::V_WC2 + (tl * 16 + r) * 2] * relu1(hc[tl][r]);
     cl[i] = fmaxf(xhalf_sum(s) + bc2, 0.f);
     BMV_FENCE();
   }

@@ -287,6 +287,292 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the fused renderer (round 3; lookup records for image AND volume, feat_ch 8).
+//
+// In the kernel above the two waves of a SIMD each run gather (geometry, 56 record loads, tap arithmetic: ~22 k cycles)
+// and then the MLP (205 MFMAs = 13.2 k cycles of the matrix pipe) on their own tiles: tile period 48.6 k per wave, the
+// matrix pipe 0.49-0.52 busy.  A first split (1 MLP wave + 2 gather waves per SIMD) showed that an MLP wave ALONE needs
+// ~24 k cycles per tile -- between its MFMA chains sit ~1000 vector instructions and ~380 LDS reads (bias rows, ReLUs,
+// the 1-wide heads, softmaxes, compositing) that depend on the chains' results -- so one MLP wave per SIMD cannot fill
+// the pipe whatever feeds it.  Hence this shape: a workgroup is 8 MLP waves (waves 0-7: TWO per SIMD, one's vector
+// sections under the other's MFMAs) and 4 gather waves (waves 8-11: one per SIMD).  A gather wave works on 64 samples =
+// TWO tiles with lane = sample (the fused kernel computes every sample's geometry twice, once per lane half): 52
+// 16-byte loads per 64 samples (whole 32-byte voxel records, whole 48-byte pixel records), then writes the two tiles'
+// MLP inputs -- 36 dwords per MLP lane: fin[3][6], dir[3][4], vox[4], z, visibility, in the (sample, half) layout the
+// MLP's B operands want -- into the mailboxes of MLP waves 2g, 2g + 1 and raises their flags.  An MLP wave copies its
+// mailbox to registers, releases it, runs the MFMA chains and composites the ray.  No workgroup barrier after the
+// prologue: flags in LDS (in-order per wave), bounded spins (a protocol error ends the kernel with NaNs, not a hang).
+// Same arithmetic per value as render_rays_kernel (the same device functions, the same tap order): bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef BMV_RENDER_PC_SPIN
+#define BMV_RENDER_PC_SPIN (1 << 22)   // polls before a wave gives up
+#endif
+#ifndef BMV_RENDER_PC_PRIO
+#define BMV_RENDER_PC_PRIO 0
+#endif
+#ifndef BMV_RENDER_PC_GATHER
+#define BMV_RENDER_PC_GATHER 4   // gather waves per workgroup: 4 (one per SIMD, 168 registers) or 8 (two, 128 registers)
+#endif
+constexpr int kPcMlp = 8, kPcGather = BMV_RENDER_PC_GATHER, kPcBox = 36;   // waves per role, dwords per MLP lane of a mailbox
+
+#ifdef BMV_RENDER_PC_COUNT
+__device__ unsigned long long g_pc_spins[4];   // tuning: polls that found the flag not ready / waits, per role
+#endif
+__device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
+  for (int it = 0; it < BMV_RENDER_PC_SPIN; ++it) {
+    if (*flag == want) {
+#ifdef BMV_RENDER_PC_COUNT
+      if ((threadIdx.x & 31) == 0) {
+        atomicAdd(&g_pc_spins[want & 1], (unsigned long long)it);
+        atomicAdd(&g_pc_spins[2 + (want & 1)], 1ull);
+      }
+#endif
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+
+template <int NS, bool INV>
+__global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(bmv_render_args a) {
+  constexpr int FEAT_CH = 8;
+  using L = MlpLayout<FEAT_CH>;
+  static_assert(32 % NS == 0, "samples per ray must divide 32");
+  static_assert(L::KFC == 6 && L::KF == 8, "mailbox layout: 6 feature / colour slots + 2 direction slots per view");
+  static_assert(kPcGather == 4 || kPcGather == 8, "pair p goes to MLP waves 2 (p % 4), 2 (p % 4) + 1");
+  constexpr int RAYS_PER_TILE = 32 / NS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  RenderCams* rc = reinterpret_cast<RenderCams*>(lds + L::TOTAL);
+  // [kPcMlp] sequence words: 2 n = empty, waiting for this MLP wave's n-th job; 2 n + 1 = holds it (with more gather
+  // waves than pairs of MLP waves a mailbox has two producers taking turns: the count keeps them in order)
+  int* flags = reinterpret_cast<int*>(rc + 1);
+  float* boxes = reinterpret_cast<float*>(flags + 16);              // [kPcMlp][kPcBox][64 MLP lanes]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
+  if (threadIdx.x < 3)
+    load_cam(a.src_exts + ((size_t)b * 3 + threadIdx.x) * 16, a.src_ixts + ((size_t)b * 3 + threadIdx.x) * 9,
+             a.render_scale, rc->cam[threadIdx.x]);
+  if (threadIdx.x == 3) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 16) flags[threadIdx.x - 64] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = lane & 31;
+  const int k = s % NS;  // sample index along the ray
+  const int nrays = a.ray_end - a.ray_begin;
+  const int ntiles = (nrays + RAYS_PER_TILE - 1) / RAYS_PER_TILE;
+  // tiles of this workgroup: blockIdx.x + gridDim.x * j, j = 0 .. njobs - 1; job j belongs to MLP wave j % kPcMlp and
+  // is produced, together with job j ^ 1, by gather wave (j >> 1) % kPcGather
+  const int njobs = ntiles > (int)blockIdx.x ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const float inv_w = (float)(a.Wr - 1), inv_h = (float)(a.Hr - 1);
+
+  if (wave >= kPcMlp) {
+    // =============================================================================================== gather waves
+#ifdef BMV_RENDER_PC_GPRIO
+    __builtin_amdgcn_s_setprio(BMV_RENDER_PC_GPRIO);
+#endif
+    const int g = wave - kPcMlp;
+    const int half_tile = lane >> 5;                      // which of the pair's two tiles this lane's sample is in
+    const size_t hwv = (size_t)a.hv * a.wv;
+    const size_t plane = (size_t)a.Hr * a.Wr;
+    const float* depth = a.depth + b * hwv;
+    const float* std_ = a.std + b * hwv;
+    const float* nf = a.near_far + b * 2 * hwv;
+    const float* vol = a.volume + (size_t)b * 8 * a.Dv * hwv;
+    const __amdgpu_buffer_rsrc_t rs_vol = make_rsrc(vol, (size_t)8 * a.Dv * hwv * 4);
+    __amdgpu_buffer_rsrc_t rs_f[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
+      rs_f[i] = make_rsrc(a.im_packed + vslot * 12 * plane, (size_t)12 * plane * 4);   // 48-byte records
+    }
+    for (int p = g; 2 * p < njobs; p += kPcGather) {
+#ifdef BMV_RENDER_PC_FAKE_GATHER   // tuning: the MLP side alone (mailboxes filled with a constant, no lookups)
+      {
+        const int j_ = 2 * p + half_tile;
+        const int mw_ = 2 * (p & 3) + half_tile;
+        volatile int* fl_ = flags + mw_;
+        float* bx_ = boxes + (size_t)mw_ * kPcBox * 64 + s;
+        if (j_ < njobs) {
+          if (!pc_wait(fl_, 2 * (p >> 2))) return;
+          for (int q = 0; q < kPcBox; ++q) bx_[q * 64] = 0.25f, bx_[q * 64 + 32] = 0.25f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j_ < njobs && s == 0) *fl_ = 2 * (p >> 2) + 1;
+        continue;
+      }
+#endif
+      const int j = 2 * p + half_tile;                    // this lane's job; the odd one of the last pair may not exist
+      const bool job = j < njobs;
+      const int mw = 2 * (p & 3) + half_tile;             // the MLP wave that takes it, as its job number p >> 2
+      const int seq = 2 * (p >> 2);
+      volatile int* flag = flags + mw;                    // (lanes 0 / 32 raise the two flags)
+      float* box = boxes + (size_t)mw * kPcBox * 64 + s;  // MLP lane (s, h): + 32 h
+      const int tile = (int)blockIdx.x + (int)gridDim.x * (job ? j : 2 * p);
+      int ray = a.ray_begin + tile * RAYS_PER_TILE + s / NS;
+      int rr = ray < a.ray_end ? ray : a.ray_end - 1;
+      const float* r = a.rays + ((size_t)b * a.N + rr) * 8;
+      float o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
+      float px = r[6], py = r[7];
+      float rn, rf, vn, vf;
+      ray_bounds(depth, std_, nf, a.hv, a.wv, a.Hr, a.Wr, (int)px, (int)py, INV, rn, rf, vn, vf);
+      float z, xyz[3], dn;
+      sample_point(o, d, rn, rf, vn, vf, k, NS, INV, z, xyz, dn);
+      // The mailbox is written as the values are produced (holding both halves of all three views costs ~100
+      // registers): it must be empty NOW.  The consumer empties it right after copying it to registers, ~300 cycles into
+      // its 20 k-cycle tile, so this wait is almost always over before it starts.  (The poll is per lane; every lane of
+      // a half polls the same word.)
+      if (job && !pc_wait(flag, seq)) return;
+      {  // a9: trilinear lookup from (Dv,hv,wv,8) records [ch 0 2 4 6 | ch 1 3 5 7]: a tap is two 16-byte loads
+        Taps3 t3 = taps3_zeros(BMV_DIV(px, inv_w), BMV_DIV(py, inv_h), dn, a.wv, a.hv, a.Dv);
+        float4 e = {0.f, 0.f, 0.f, 0.f}, od = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float4 q0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_vol, (int)((unsigned)t3.o[kk] * 32u), 0, 0));
+          const float4 q1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_vol, (int)((unsigned)t3.o[kk] * 32u + 16u), 0, 0));
+          e.x += q0.x * t3.w[kk], e.y += q0.y * t3.w[kk], e.z += q0.z * t3.w[kk], e.w += q0.w * t3.w[kk];
+          od.x += q1.x * t3.w[kk], od.y += q1.y * t3.w[kk], od.z += q1.z * t3.w[kk], od.w += q1.w * t3.w[kk];
+          if (kk == 3) BMV_FENCE();
+        }
+        if (job) {
+          box[30 * 64] = e.x, box[31 * 64] = e.y, box[32 * 64] = e.z, box[33 * 64] = e.w;
+          box[30 * 64 + 32] = od.x, box[31 * 64 + 32] = od.y, box[32 * 64 + 32] = od.z, box[33 * 64 + 32] = od.w;
+        }
+      }
+      BMV_FENCE();
+      float vis = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
+        const Cam& cam = rc->cam[i];
+        Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
+        const unsigned ob[4] = {(unsigned)t2.o00 * 48u, (unsigned)t2.o01 * 48u, (unsigned)t2.o10 * 48u, (unsigned)t2.o11 * 48u};
+        const float w[4] = {t2.w00, t2.w01, t2.w10, t2.w11};
+        float4 fe[4], fo[4], cc[4];   // even channels | odd channels | r b g 0 of the four taps
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          fe[kk] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f[i], (int)ob[kk], 0, 0));
+          fo[kk] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f[i], (int)(ob[kk] + 16u), 0, 0));
+          cc[kk] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f[i], (int)(ob[kk] + 32u), 0, 0));
+        }
+        float4 ve = {fe[0].x * w[0], fe[0].y * w[0], fe[0].z * w[0], fe[0].w * w[0]};
+        float4 vo = {fo[0].x * w[0], fo[0].y * w[0], fo[0].z * w[0], fo[0].w * w[0]};
+        float cr = cc[0].x * w[0], cb = cc[0].y * w[0], cg = cc[0].z * w[0];
+#pragma unroll
+        for (int kk = 1; kk < 4; ++kk) {
+          ve.x += fe[kk].x * w[kk], ve.y += fe[kk].y * w[kk], ve.z += fe[kk].z * w[kk], ve.w += fe[kk].w * w[kk];
+          vo.x += fo[kk].x * w[kk], vo.y += fo[kk].y * w[kk], vo.z += fo[kk].z * w[kk], vo.w += fo[kk].w * w[kk];
+          cr += cc[kk].x * w[kk], cb += cc[kk].y * w[kk], cg += cc[kk].z * w[kk];
+        }
+        if (a.rgb_affine) cr = cr * 0.5f + 0.5f, cb = cb * 0.5f + 0.5f, cg = cg * 0.5f + 0.5f;
+        float dirv[4];
+        dir_feature(xyz, rc->tar_c, cam.c, dirv);
+        if (a.mode == 1) vis += visible(cam, xyz, inv_w, inv_h);
+        if (job) {   // MLP lane half 0: even channels, (r, b); half 1: odd channels, (g, 0)
+          float* bx = box + (i * 6) * 64;
+          bx[0 * 64] = ve.x, bx[1 * 64] = ve.y, bx[2 * 64] = ve.z, bx[3 * 64] = ve.w, bx[4 * 64] = cr, bx[5 * 64] = cb;
+          bx[0 * 64 + 32] = vo.x, bx[1 * 64 + 32] = vo.y, bx[2 * 64 + 32] = vo.z, bx[3 * 64 + 32] = vo.w;
+          bx[4 * 64 + 32] = cg, bx[5 * 64 + 32] = 0.f;
+          float* bd = box + (18 + i * 4) * 64;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bd[q * 64] = dirv[q], bd[q * 64 + 32] = dirv[q];
+        }
+        BMV_FENCE();
+      }
+      if (job) {
+        box[34 * 64] = z, box[34 * 64 + 32] = z;
+        box[35 * 64] = vis, box[35 * 64 + 32] = vis;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (job && s == 0) *flag = seq + 1;
+    }
+    return;
+  }
+
+  // ================================================================================================= MLP waves
+  __builtin_amdgcn_s_setprio(BMV_RENDER_PC_PRIO);
+  const int h = lane >> 5;
+  const int m = wave;
+  volatile int* flag = flags + m;
+  const float* box = boxes + (size_t)m * kPcBox * 64 + lane;
+  int seq = 0;
+  for (int j = m; j < njobs; j += kPcMlp, seq += 2) {
+    const int tile = (int)blockIdx.x + (int)gridDim.x * j;
+    int ray = a.ray_begin + tile * RAYS_PER_TILE + s / NS;
+    bool valid = ray < a.ray_end;
+    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    bool ok = pc_wait(flag, seq + 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) fin[i][q] = box[(i * 6 + q) * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dir[i][q] = box[(18 + i * 4 + q) * 64];
+      fin[i][L::KFC] = h ? dir[i][1] : dir[i][0];
+      fin[i][L::KFC + 1] = h ? dir[i][3] : dir[i][2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vox[q] = box[(30 + q) * 64];
+    const float z = box[34 * 64];
+    const float vis = box[35 * 64];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *flag = seq + 2;     // the next producer may refill while this tile runs through the MLP
+    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    if (!ok) res[0] = res[1] = res[2] = res[3] = __builtin_nanf("");   // protocol error: loud, not silent
+
+    if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
+      if (valid && h == 0) {
+        size_t pt = ((size_t)b * a.N + ray) * NS + k;
+        float4 o4 = {res[0], res[1], res[2], res[3]};
+        reinterpret_cast<float4*>(a.out0)[pt] = o4;
+        a.out1[pt] = z;
+        a.out2[pt] = vis / 3.f;
+      }
+      continue;
+    }
+    // a12: composite the NS samples of a ray; they sit on NS consecutive lanes.
+    float alpha = 1.f - __expf(-res[3]);
+    float om = 1.f - alpha + 1e-10f;
+    float T = 1.f;  // exclusive product of om over samples before k
+#pragma unroll
+    for (int jj = 1; jj < NS; ++jj) {
+      float prev = __shfl_up(om, jj, NS);
+      if (k >= jj) T *= prev;
+    }
+    float w = alpha * T;
+    float c0 = w * res[0], c1 = w * res[1], c2 = w * res[2];
+    float wmax = w;
+#pragma unroll
+    for (int mm = 1; mm < NS; mm <<= 1) {
+      c0 += __shfl_xor(c0, mm, NS);
+      c1 += __shfl_xor(c1, mm, NS);
+      c2 += __shfl_xor(c2, mm, NS);
+      wmax = fmaxf(wmax, __shfl_xor(wmax, mm, NS));
+    }
+    float ee = __expf(w - wmax), den = ee;
+#pragma unroll
+    for (int mm = 1; mm < NS; mm <<= 1) den += __shfl_xor(den, mm, NS);
+    float sm = BMV_DIV(ee, den);
+    float dz = sm * z, acc = sm;
+#pragma unroll
+    for (int mm = 1; mm < NS; mm <<= 1) {
+      dz += __shfl_xor(dz, mm, NS);
+      acc += __shfl_xor(acc, mm, NS);
+    }
+    if (a.white_bkgd) c0 += 1.f - acc, c1 += 1.f - acc, c2 += 1.f - acc;
+    if (valid && h == 0) {
+      size_t ro = (size_t)b * a.N + ray;
+      a.out2[ro * NS + k] = sm;
+      if (k == 0) {
+        a.out0[ro * 3] = c0, a.out0[ro * 3 + 1] = c1, a.out0[ro * 3 + 2] = c2;
+        a.out1[ro] = dz;
+      }
+    }
+  }
+}
+
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -300,6 +586,11 @@ using namespace bmv;
 
 extern "C" {
 
+#ifdef BMV_RENDER_PC_COUNT
+int bmv_debug_fetch_pc_spins(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pc_spins), sizeof(unsigned long long) * 4);
+}
+#endif
 #ifdef BMV_RENDER_STAMPS
 int bmv_debug_fetch_stamps(float* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(float) * 512 * 4 * 8);
@@ -375,6 +666,24 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
   if (a->ray_begin == a->ray_end) return BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
+  // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
+  static const bool use_pc = !(getenv("BMV_RENDER_PC") && atoi(getenv("BMV_RENDER_PC")) == 0);
+#define RENDER_CASE_PC(NSV)                                                                                          \
+  if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0) {            \
+    size_t lds = MlpLayout<8>::TOTAL * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * kPcBox * 64 * 4;           \
+    BMV_REQUIRE(set_lds(render_pc_kernel<NSV, false>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");        \
+    int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
+    static const unsigned pc_grid = getenv("BMV_RENDER_PC_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_PC_GRID")) : 256u; \
+    unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;                                        \
+    hipLaunchKernelGGL((render_pc_kernel<NSV, false>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,      \
+                       as_stream(stream), *a);                                                                      \
+    BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
+  }
+  RENDER_CASE_PC(2)
+  RENDER_CASE_PC(1)
+  RENDER_CASE_PC(4)
+  RENDER_CASE_PC(8)
+#undef RENDER_CASE_PC
 #define RENDER_CASE_PK(FC, NSV, INVV, PKV)                                                                          \
   if (a->im_packed && (a->vol_packed ? 3 : 1) == PKV && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) { \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
