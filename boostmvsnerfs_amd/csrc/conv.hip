@@ -1143,6 +1143,8 @@ static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
         // measured inside the frame (bench.py, graph replay): 4 rows per wave win for the 3 -> 8 / 8 -> 8 full-resolution
         // 2-D layers (more resident blocks), 8 rows for 32-channel inputs and the volumes (fewer halo loads)
         if (!IS3D && a.Cin <= 8) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
+        static const int r3d = getenv("BMV_CONV_PAIR_ROWS") ? atoi(getenv("BMV_CONV_PAIR_ROWS")) : 0;   // tuning
+        if (r3d == 4) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
         return launch_conv<KD, K, S, 1, RB, MB, true>(a, st);
       }
       return launch_conv<KD, K, S, 1, 2, MS, true>(a, st);
