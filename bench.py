@@ -314,7 +314,7 @@ def main():
     if wl.get("train"):
         # fine-tune step (trainer.py:44-63): every rank trains on its own target view, DDP averages the
         # gradients over RCCL (bucketed all-reduce overlapped with backward); no tile gather in training
-        from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
+        from boostmvsnerfs_amd.train import GraphedTrainStep, NetworkWrapper, make_optimizer, train_step
         gen = torch.Generator().manual_seed(rank)
         for i in range(cc.num):
             batch[f"rgb_{i}"] = torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=gen).to(dev)
@@ -326,8 +326,13 @@ def main():
                 output_device=local_rank, find_unused_parameters=True)
         optimizer = make_optimizer(net)
         gather = None
+        # forward + loss + backward as one HIP graph (clip + Adam eager); DDP's all-reduce hooks are host callbacks, so
+        # N > 1 stays eager
+        graphed_train = GraphedTrainStep(wrapper, optimizer) if (args.graph and world == 1) else None
 
         def step():
+            if graphed_train is not None:
+                return graphed_train(batch)
             return train_step(wrapper, optimizer, batch)
     else:
         def step():
@@ -366,6 +371,8 @@ def main():
     # as the GPU needs to run them).  The plane sweeps stay ordinary launches between the graphs so the HIP events
     # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
+    if not wl.get("train"):
+        graphed_train = None
     eager_step = step
     sampled = {"n": 0, "every": 1, "evented": True}
     if not wl.get("train"):
@@ -486,6 +493,9 @@ def main():
     # the contract's barrier + synchronize sits between it and the timed region.  `--spinup-steps 0` times the cold start;
     # reported as `config.spinup_steps`.
     spinup_steps = args.spinup_steps if (wl["net"] in ("enerf", "boost_enerf") and not wl.get("train")) else 0
+    if wl.get("train") and graphed_train is not None:
+        # the eager steps in front of the capture and the capturing step itself: untimed, reported like the spin-up
+        spinup_steps = max(0, graphed_train.eager_steps + 2 - args.warmup)
     ktimer.enabled = False
     if spinup_steps and not args.pipelined:
         # the same per-step bracket started COLD (the device idle for 50 ms first): what `--spinup-steps 0` would report
@@ -644,7 +654,10 @@ def main():
                        "gather": ("none" if world == 1 or wl.get("train") else
                                   "sync" if args.sync_gather or args.shard == "rays" or not args.pipelined
                                   else "pipelined (1 frame)"),
-                       "weights": "random init (seed 0)", "launch": graph_note, "spinup_steps": spinup_steps,
+                       "weights": "random init (seed 0)",
+                       "launch": (graph_note if graphed_train is None else
+                                  f"forward + loss + backward replayed as one HIP graph, clip + Adam eager ({graphed_train.stats})"),
+                       "spinup_steps": spinup_steps,
                        "bracket": ("train step" if wl.get("train") else "pipelined: one synchronize after the K steps" if args.pipelined
                                    else "run.py:117-123: device synchronize after every step")},
             # `value` is the aggregate over all ranks (the metric's "per GPU" names the 1-GPU headline config)

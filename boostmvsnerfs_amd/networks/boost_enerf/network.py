@@ -188,7 +188,7 @@ class Network(enerf_network.Network):
             s = self._streams[j]
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                vid = sel32[:, k]
+                vid = sel32[k]
                 views = (batch["all_src_inps"], *cams[k])
                 st = None
                 for i in range(cc.num):
@@ -251,7 +251,7 @@ class Network(enerf_network.Network):
             f_i = feats[f"level_{i}"]
             variance = torch.empty(K, f_i.shape[2], D, h, w, device=dev)
             for k in ks:
-                ops.sweep_variance_views(f_i, sel32[:, k], proj[k:k + 1], cur.depth_values[k:k + 1], out=variance[k:k + 1])
+                ops.sweep_variance_views(f_i, sel32[k], proj[k:k + 1], cur.depth_values[k:k + 1], out=variance[k:k + 1])
             cur.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
             cur.depth, cur.std = ops.depth_regress(depth_prob, cur.depth_values, cc.depth_inv[i])
             st = cur
@@ -267,7 +267,7 @@ class Network(enerf_network.Network):
                 one.depth, one.std, one.near_far = st.depth[k:k + 1], st.std[k:k + 1], st.near_far[k:k + 1]
                 one.feature_volume = type(fv)(fv.t[k:k + 1]) if hasattr(fv, "t") else fv[k:k + 1]
                 views = (batch["all_src_inps"], *cams[k])
-                self.render_level(i, one, im_feat, views, batch, mode=1, outs=tuple(t[:, k] for t in stacks), view_ids=sel32[:, k])
+                self.render_level(i, one, im_feat, views, batch, mode=1, outs=tuple(t[:, k] for t in stacks), view_ids=sel32[k])
             raws, zs, ms = stacks
             if self.ray_range is not None:   # the render launches wrote rays [begin, end) of the full-size buffers
                 b_, e_ = self.ray_range
@@ -342,7 +342,9 @@ class Network(enerf_network.Network):
                     and all(not feats[f"level_{i}"].is_contiguous()
                             and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous() for i in range(cc.num)))
         if by_index:
-            sel32 = sel.to(torch.int32)
+            # (B,K,3) -> K tensors (B,3); in range by construction: rows of combinations(range(N), 3) picked by the
+            # triplet numbers validated above, so no device read is spent on ops.check_view_ids
+            sel32 = [ops.mark_view_ids(sel[:, k].to(torch.int32).contiguous(), N) for k in range(K)]
             cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
             if self.batched_volumes and self.volume_ids is None and B == 1:
                 return self._forward_batched(batch, feats, sel, sel32, cams, K)
@@ -360,7 +362,7 @@ class Network(enerf_network.Network):
             for k in range(K):
                 ids = sel[:, k]
                 if by_index:
-                    vid = sel32[:, k]
+                    vid = sel32[k]
                     views = (batch["all_src_inps"], *cams[k])
                     states[k] = self.level_front(i, feats[f"level_{i}"], views, batch, states[k], view_ids=vid)
                     if not cc.render_if[i]:

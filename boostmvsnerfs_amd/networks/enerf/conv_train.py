@@ -10,7 +10,8 @@ dimension,
 which bmv_conv_wgrad computes with the voxel index as the MFMA k dimension (27 accumulator blocks per wave, no im2col
 copies; the first version of this file made 27 strided copies and one tall-skinny rocBLAS GEMM per layer: 4 ms of
 copies + ~5 ms of GEMMs per 512x640 step).  The forward runs on the inference engine with the weights repacked on the
-device, the data gradients are convolutions with transformed filters on the same engine (stride-2 5x5: MIOpen).
+device, the data gradients are convolutions with transformed filters on the same engine (stride-2 5x5: one 3x3
+convolution over the four input parities + a pixel shuffle).
 SURVEY.md section 8(f) ranks 1-2; module and parameter names are unchanged (subclasses of nn.Conv2d / nn.Conv3d /
 nn.ConvTranspose3d).
 """
@@ -92,8 +93,24 @@ class _ConvT3dFn(torch.autograd.Function):
         return gx, gw
 
 
+def _dgrad_5x5_stride2(gy, w):
+    """Data gradient of Conv2d(k=5, stride=2, padding=2) on even input sizes as ONE stride-1 3x3 convolution of gy on
+    the engine + a pixel shuffle.  y[o] = sum_k w[k] x[2o + k - 2], so dx[2j + r] = sum_t w[2t + r] gy[j + 1 - t]
+    (r = 0: t in 0..2, r = 1: t in 0..1): every input parity (ry, rx) is a <= 3x3-tap correlation of gy with the
+    sub-filter g_r[u] = w[2 (2 - u) + r] (tap 5 = 0).  The four parities are 4 Cin output channels of one convolution
+    in (ci, ry, rx) order -- exactly pixel_shuffle's layout.  36 tap products per input pixel instead of 25."""
+    Co, Ci = w.shape[:2]
+    wp = F.pad(w.detach(), (0, 1, 0, 1))                                     # (Co,Ci,6,6), index 5 = 0
+    idx = torch.tensor([[4, 2, 0], [5, 3, 1]], device=w.device)
+    g = wp[:, :, idx][..., idx]                                              # (Co,Ci,ry,uy,rx,ux)
+    g = g.permute(1, 2, 4, 0, 3, 5).reshape(4 * Ci, Co, 3, 3).contiguous()   # (ci,ry,rx | co | uy,ux)
+    planes = convnet.conv_fwd(gy, *convnet.pack_conv_dev(g, None, 1), 4 * Ci, 1, 3, 1)
+    return F.pixel_shuffle(planes, 2)
+
+
 class _Conv2dFn(torch.autograd.Function):
-    """nn.Conv2d (k in {1, 3, 5}, zero padding k // 2): forward on the engine, both gradients on MIOpen."""
+    """nn.Conv2d (k in {1, 3, 5}, zero padding k // 2): forward, data gradients and weight gradients on the engine
+    (odd input sizes under stride 2 fall back to aten)."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride):
@@ -109,14 +126,18 @@ class _Conv2dFn(torch.autograd.Function):
         gy = gy.contiguous()
         k = w.shape[-1]
         want_x, eng = ctx.needs_input_grad[0], _engine_forward(gy)
-        gx_engine = want_x and s == 1 and eng                      # stride 1: the convolution with the flipped, transposed filter
+        # stride 1: the convolution with the flipped, transposed filter; stride-2 5x5: four parity sub-filters
+        s2 = s == 2 and k == 5 and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and os.environ.get("BMV_TRAIN_DGRAD5", "1") != "0"
+        gx_engine = want_x and (s == 1 or s2) and eng
         gw_engine = ctx.needs_input_grad[1] and eng                # weight gradient: own MFMA kernel over (batch, pixel)
         gx = gw = gb = None
         if (want_x and not gx_engine) or (ctx.needs_input_grad[1] and not gw_engine):
             gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [s, s], [p, p], [1, 1], False, [0, 0], 1,
                                                             [want_x and not gx_engine, ctx.needs_input_grad[1] and not gw_engine, False])
-        if gx_engine:
+        if gx_engine and s == 1:
             gx = convnet.conv_fwd(gy, *convnet.pack_conv_dev(w, None, 1, transposed=True, flip=True), w.shape[1], 1, k, 1)
+        elif gx_engine:
+            gx = _dgrad_5x5_stride2(gy, w)
         if gw_engine:
             gw = _wgrad(F.pad(x, (p, p + (1 if s == 2 else 0), p, p)) if p else x, gy, s, 1, k)
         if has_b:

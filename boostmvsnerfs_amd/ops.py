@@ -135,6 +135,29 @@ def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=No
     return _sweep_variance(feats, proj, depth_values, algo, out, channels_last)
 
 
+def mark_view_ids(view_ids, n_all):
+    """The caller vouches that every entry of `view_ids` is in [0, n_all) (the K-volume networks: the indices are rows
+    of combinations(range(N), 3) picked by host-validated triplet numbers) -- no device read."""
+    view_ids._bmv_view_range = int(n_all)
+    return view_ids
+
+
+def check_view_ids(view_ids, n_all):
+    """The kernels index the all-views buffers with these ids: make sure they are in [0, n_all).  Costs one device ->
+    host read of (min, max) unless the tensor is already marked (mark_view_ids / an earlier check); cannot be done
+    inside a stream capture -- validate before capturing."""
+    if getattr(view_ids, "_bmv_view_range", None) == int(n_all):
+        return view_ids
+    if view_ids.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise ValueError("view_ids reach a kernel unvalidated inside a stream capture: call ops.check_view_ids(view_ids, "
+                         "n_all) before capturing")
+    if view_ids.numel():
+        lo, hi = (int(v) for v in view_ids.aminmax())
+        if lo < 0 or hi >= int(n_all):
+            raise ValueError(f"view_ids must lie in [0, {int(n_all)}): found [{lo}, {hi}] (a bad view_selection.json?)")
+    return mark_view_ids(view_ids, n_all)
+
+
 def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
     """Plane sweep over the S views `view_ids` (B,S) int32 picked from feats_all = ALL source views: a
     (B,n_all,C,Hs,Ws) view of a channel-last (B,n_all,Hs,Ws,C) buffer (what FeatureNet's engine path returns).
@@ -154,6 +177,7 @@ def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
     S = view_ids.shape[1]
     if view_ids.dtype != torch.int32 or view_ids.shape[0] != B:
         raise ValueError("view_ids must be int32 (B,S)")
+    check_view_ids(view_ids, n_all)
     _, D, h, w = depth_values.shape
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=cl.device, dtype=torch.float32)
@@ -400,6 +424,7 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
         if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S) or (
                 im_packed is None and im_feat.shape[1] != rgb_src.shape[1]):
             raise ValueError("render_rays: view_ids must be int32 (B,S); im_feat / rgb_src must hold the same n_all views")
+        check_view_ids(view_ids, n_views)
         view_ids = _c(view_ids)
         a.view_ids, a.n_all = dptr(view_ids, "view_ids", torch.int32), int(n_views)
     else:

@@ -126,3 +126,97 @@ def train_step(wrapper, optimizer, batch, clip=40.0):
     torch.nn.utils.clip_grad_value_(wrapper.parameters(), clip)
     optimizer.step()
     return loss.detach(), stats
+
+
+class GraphedTrainStep:
+    """`train_step` with forward + loss + backward of a step replayed as ONE HIP graph (trainer.py:44-63 is then three
+    host calls per step instead of ~900 eager launches; gradient clipping and the optimiser stay eager: Adam's step
+    counters live on the host).
+
+    Every kernel of the training path goes to the current stream and nothing on it reads the device from the host, so the
+    step captures unmodified.  A captured step is specialised to the shapes of the batch's tensors and -- for the
+    K-volume networks -- to the targets named in batch['meta'] (the triplets view_selection.json picks for them are
+    baked into the launches); a batch with another key is captured separately (up to `max_graphs`), the first
+    `eager_steps` steps with a key run eagerly (allocator pools, packed weights, MIOpen's solver picks settle there).
+    Batches that arrive as new tensors are copied into the captured buffers.  Parameters, batch-norm statistics and
+    gradients are updated in place, so the graph always reads the current ones.  Not under DDP (the bucketed all-reduce
+    hooks are host callbacks): a DistributedDataParallel wrapper falls back to `train_step`.
+
+    returns (loss, stats) like train_step; both are the graph's static tensors (valid until the next step)."""
+
+    def __init__(self, wrapper, optimizer, clip=40.0, eager_steps=3, max_graphs=4):
+        self.wrapper, self.optimizer, self.clip = wrapper, optimizer, clip
+        self.eager_steps, self.max_graphs = eager_steps, max_graphs
+        self.entries, self.seen = {}, {}
+        self.stats = {"eager": 0, "captures": 0, "replays": 0, "copies": 0}
+        self.disabled = isinstance(wrapper, nn.parallel.DistributedDataParallel)
+
+    @staticmethod
+    def _key(batch):
+        meta = batch.get("meta") or {}
+        targets = tuple(f"{s}_{v}" for s, v in zip(meta.get("scene", ()), meta.get("tar_view", ())))
+        shapes = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())
+                       if torch.is_tensor(v) and not getattr(v, "_bmv_built_rays", False))
+        return shapes, targets
+
+    def _finish(self):
+        torch.nn.utils.clip_grad_value_(self.wrapper.parameters(), self.clip)
+        self.optimizer.step()
+
+    def _fwd_bwd(self, batch):
+        out, loss, stats, _ = self.wrapper(batch)
+        loss = loss.mean()
+        loss.backward()
+        return loss.detach(), stats
+
+    def _capture(self, key, batch):
+        import gc
+        if len(self.entries) >= self.max_graphs:
+            del self.entries[min(self.entries, key=lambda k: self.entries[k]["hits"])]
+        static = {k: v for k, v in batch.items() if not getattr(v, "_bmv_built_rays", False)}
+        # gradients become allocations of the graph's private pool: every replay writes the same tensors, the optimiser
+        # reads them after the replay
+        self.optimizer.zero_grad(set_to_none=True)
+        gc.collect()
+        from . import ktimer
+        graph = torch.cuda.CUDAGraph()
+        was, ktimer.enabled = ktimer.enabled, False       # per-kernel event brackets are host-side objects: not in a graph
+        try:
+            with torch.cuda.graph(graph):
+                loss, stats = self._fwd_bwd(dict(static))
+        finally:
+            ktimer.enabled = was
+        e = {"graph": graph, "static": static, "loss": loss, "stats": stats, "hits": 0}
+        self.entries[key] = e
+        self.stats["captures"] += 1
+        return e
+
+    def __call__(self, batch):
+        if self.disabled or not self.wrapper.training:
+            self.stats["eager"] += 1
+            return train_step(self.wrapper, self.optimizer, batch, self.clip)
+        key = self._key(batch)
+        e = self.entries.get(key)
+        if e is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n < self.eager_steps:
+                self.stats["eager"] += 1
+                # (set_to_none: a later capture must not find gradients allocated outside its pool)
+                self.optimizer.zero_grad(set_to_none=True)
+                res = self._fwd_bwd(batch)
+                self._finish()
+                return res
+            e = self._capture(key, batch)
+        else:
+            for k, v in batch.items():
+                s = e["static"].get(k)
+                if torch.is_tensor(v) and s is not None and s is not v and not getattr(v, "_bmv_built_rays", False) \
+                        and not (s.data_ptr() == v.data_ptr() and s.stride() == v.stride()):
+                    s.copy_(v)
+                    self.stats["copies"] += 1
+        e["graph"].replay()
+        e["hits"] += 1
+        self.stats["replays"] += 1
+        self._finish()
+        return e["loss"], e["stats"]

@@ -372,10 +372,11 @@ def test_cost_reg_training_forward_matches_torch_modules(monkeypatch):
 
 @pytest.mark.parametrize("cin,cout,k,stride,bias,hw", [(3, 8, 3, 1, False, (37, 53)), (8, 16, 5, 2, False, (64, 96)),
                                                         (32, 32, 1, 1, True, (16, 24)), (32, 8, 3, 1, True, (40, 72)),
-                                                        (16, 32, 1, 1, True, (19, 21))])
+                                                        (16, 32, 1, 1, True, (19, 21)), (16, 32, 5, 2, False, (32, 48)),
+                                                        (8, 16, 5, 2, False, (63, 95))])
 def test_conv2d_training_module(cin, cout, k, stride, bias, hw):
-    """FeatureNet's convolutions under autograd: forward on the engine (weights repacked on the device), gradients
-    on MIOpen, vs float64."""
+    """FeatureNet's convolutions under autograd: forward, data gradient and weight gradient on the engine (the 5x5
+    stride-2 data gradient as one 3x3 convolution over the four input parities; odd sizes: aten), vs float64."""
     from boostmvsnerfs_amd.networks.enerf.conv_train import Conv2d
     torch.manual_seed(2)
     m = Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias).to(DEV)

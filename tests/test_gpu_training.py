@@ -187,3 +187,54 @@ def test_finetune_step_under_ddp_and_syncbn(enerf_fx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_graphed_train_step_equals_eager_steps(enerf_fx):
+    """train.GraphedTrainStep (forward + loss + backward replayed as one HIP graph, clip + Adam eager) against the
+    same number of eager train_step calls from the same start: training-mode batch norm (running statistics move),
+    new target tensors every step (copied into the captured buffers), 6 steps = 3 eager + 1 capture + 2 replays."""
+    import copy
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.train import GraphedTrainStep, NetworkWrapper, make_optimizer, train_step
+    set_cfg(tiny_cfg(enerf_fx, "enerf_pretrain"))
+    net_a = Network()
+    net_a.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net_a = net_a.to(DEV).train()
+    net_b = copy.deepcopy(net_a).train()
+    base = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in enerf_fx.batch().items()}
+    steps = []
+    for s in range(6):
+        b = dict(base)
+        for k, v in _targets({k: v for k, v in enerf_fx.batch().items()}, seed=s).items():
+            if k.startswith("rgb_"):
+                b[k] = v.to(DEV)
+        steps.append(b)
+    wa, wb = NetworkWrapper(net_a), NetworkWrapper(net_b)
+    oa, ob = make_optimizer(net_a), make_optimizer(net_b)
+    graphed = GraphedTrainStep(wa, oa)
+    losses_a, losses_b = [], []
+    for b in steps:
+        loss, stats = graphed(dict(b))
+        losses_a.append(float(loss))
+        assert "psnr_1" in stats
+        loss, _ = train_step(wb, ob, dict(b))
+        losses_b.append(float(loss))
+    assert graphed.stats["eager"] == 3 and graphed.stats["captures"] == 1 and graphed.stats["replays"] == 3
+    assert graphed.stats["copies"] >= 2 * 2          # the two replays after the capture step got new target tensors
+    for la, lb in zip(losses_a, losses_b):
+        assert abs(la - lb) <= 1e-4 * abs(lb), (losses_a, losses_b)
+    # scatter kernels use atomics: the two runs differ by summation order only
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    lr = 5e-4
+    for k in sa:
+        if not sa[k].is_floating_point():
+            assert torch.equal(sa[k], sb[k]), k
+            continue
+        # (an entry whose gradient is rounding noise may step either way under Adam: a few such entries per tensor,
+        # bounded by 2 lr per step)
+        d = (sa[k] - sb[k]).abs()
+        tol = 0.5 * lr + 1e-4 * float(sb[k].abs().max())
+        assert float((d > tol).float().mean()) <= 0.02, f"{k}: {float((d > tol).float().mean()):.2%} differ, max {float(d.max()):.3e}"
+        assert float(d.max()) <= 2 * lr * len(steps) + tol, f"{k}: {float(d.max()):.3e}"
+    assert sum(float((sa[k] - enerf_fx.group('sd')[k].to(DEV)).abs().max()) > 0 for k in sa) > 100   # ... and they did train
