@@ -93,6 +93,9 @@ class _ConvT3dFn(torch.autograd.Function):
         return gx, gw
 
 
+_PARITY_TAPS = {}
+
+
 def _dgrad_5x5_stride2(gy, w):
     """Data gradient of Conv2d(k=5, stride=2, padding=2) on even input sizes as ONE stride-1 3x3 convolution of gy on
     the engine + a pixel shuffle.  y[o] = sum_k w[k] x[2o + k - 2], so dx[2j + r] = sum_t w[2t + r] gy[j + 1 - t]
@@ -101,7 +104,9 @@ def _dgrad_5x5_stride2(gy, w):
     in (ci, ry, rx) order -- exactly pixel_shuffle's layout.  36 tap products per input pixel instead of 25."""
     Co, Ci = w.shape[:2]
     wp = F.pad(w.detach(), (0, 1, 0, 1))                                     # (Co,Ci,6,6), index 5 = 0
-    idx = torch.tensor([[4, 2, 0], [5, 3, 1]], device=w.device)
+    idx = _PARITY_TAPS.get(w.device)
+    if idx is None:                                                          # (host -> device copy: once, never inside a capture)
+        idx = _PARITY_TAPS[w.device] = torch.tensor([[4, 2, 0], [5, 3, 1]], device=w.device)
     g = wp[:, :, idx][..., idx]                                              # (Co,Ci,ry,uy,rx,ux)
     g = g.permute(1, 2, 4, 0, 3, 5).reshape(4 * Ci, Co, 3, 3).contiguous()   # (ci,ry,rx | co | uy,ux)
     planes = convnet.conv_fwd(gy, *convnet.pack_conv_dev(g, None, 1), 4 * Ci, 1, 3, 1)

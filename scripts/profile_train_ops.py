@@ -13,6 +13,7 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="enerf_ft_512x640_3src")
+    ap.add_argument("--stacks", action="store_true")
     ap.add_argument("--rows", type=int, default=40)
     ap.add_argument("--sort", default="self_cuda_time_total")
     a = ap.parse_args()

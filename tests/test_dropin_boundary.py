@@ -69,3 +69,22 @@ def test_boost_needs_view_selection(tmp_path):
     assert greedy_cover(m, 3) == [2]
     m[0, 0, 1] = 0.7
     assert greedy_cover(m, 3) == [2, 0]
+
+
+def test_view_ids_are_range_checked_on_the_host():
+    """The sweep and render kernels index the all-views buffers with `view_ids`: ops.check_view_ids refuses ids outside
+    [0, n_all) before any launch (one (min, max) read per tensor; marked tensors are not read again)."""
+    from boostmvsnerfs_amd import ops
+    good = torch.tensor([[0, 2, 5]], dtype=torch.int32)
+    assert ops.check_view_ids(good, 6) is good and good._bmv_view_range == 6
+    assert ops.check_view_ids(good, 6) is good                       # marked: no second read
+    with pytest.raises(ValueError, match=r"\[0, 5\)"):
+        ops.check_view_ids(good, 5)                                  # marked for 6 views, asked about 5: re-read, refused
+    with pytest.raises(ValueError, match="view_ids must lie"):
+        ops.check_view_ids(torch.tensor([[-1, 0, 1]], dtype=torch.int32), 6)
+    # the entry points check before anything is launched (CPU tensors never reach a kernel either way)
+    feats = torch.zeros(1, 6, 4, 8, 8).permute(0, 1, 2, 3, 4)
+    cl = torch.zeros(1, 6, 8, 8, 4).permute(0, 1, 4, 2, 3)
+    with pytest.raises(ValueError, match="view_ids must lie"):
+        ops.sweep_variance_views(cl, torch.tensor([[0, 1, 6]], dtype=torch.int32), torch.zeros(1, 3, 3, 4),
+                                 torch.zeros(1, 2, 4, 4))

@@ -71,22 +71,27 @@ def test_boost_forward_matches_reference(enerf_fx, boost_fx, tmp_path, path):
     assert ran_parallel == (path in ("streams", "graph"))       # the path under test is the one that ran
     want = boost_fx.group("out")
     assert set(out) == set(want)
-    # visibility masks are a discontinuous test: count how many samples flipped vs the reference
+    # visibility masks are a discontinuous test (a14: u, v in [0, 1], z > 0): count the samples that flipped vs the
+    # reference.  Measured on MI355X / ROCm 7.2: 0 of 12288 samples in every volume on all four paths; the ceiling
+    # below is that measurement plus two samples of slack for another fp32 evaluation order, NOT a fraction a real
+    # regression could hide behind (round 2 allowed 0.2 % = 24 samples).
+    FLIP_CEILING = 2
     masks = net.capture["level1"][2].cpu()
     flipped = torch.zeros(masks.shape[2], dtype=torch.bool)
     for k in range(masks.shape[1]):
         ref = boost_fx.t(f"cap/mask_viewport#{k}").reshape(masks[0, k].shape)
         diff = (masks[0, k] - ref).abs() > 1e-6
-        assert float(diff.float().mean()) < 2e-3, f"volume {k}: {int(diff.sum())} visibility flips"
+        print(f"[boost flips] path={path} volume {k}: {int(diff.sum())} of {diff.numel()} samples")
+        assert int(diff.sum()) <= FLIP_CEILING, f"volume {k}: {int(diff.sum())} visibility flips (ceiling {FLIP_CEILING})"
         flipped |= diff.any(-1)
     for k in want:
         if k in ("depth_mvs_level1", "std_level1"):
             assert_close(out[k], want[k], name=k)
             continue
-        # rays without a flipped sample must match to the 1e-3 bar; flipped ones (<0.2 %) may move by O(1/K)
+        # rays without a flipped sample must match to the 1e-3 bar; only the flipped ones may move (by O(1/K))
         g, w = out[k].cpu()[:, ~flipped], want[k][:, ~flipped]
         assert_close(g, w, name=k)
-        assert_close(out[k], want[k], name=k + " (all rays)", max_outlier_frac=2e-3)
+        assert_close(out[k], want[k], name=k + " (all rays)", max_outlier_frac=float(flipped.float().mean()))
     assert b["src_inps"].shape[1] == 3          # batch['src_*'] now hold the last triplet, as in the reference
 
 

@@ -96,7 +96,22 @@ def test_fused_sampler_and_mlp(fx):
     want_x = chunks(fx, "run_network_mvs")
     assert_close(x86[..., 63:], want_x[..., 63:], name="features + view direction")
     assert_close(x86[..., :3], want_x[..., :3], rtol=1e-4, atol_scale=1e-5, name="ndc")
-    assert_close(x86[..., :63], want_x[..., :63], rtol=1e-3, atol_scale=3e-3, name="embedding")   # sin/cos(512 x)
+    # Embedder (sin / cos of ndc * 2^k, k = 0..9): pinned in two steps instead of a chosen constant.
+    #  (1) the embedding FUNCTION: our 63 columns vs the oracle's embed() in float64 of OUR ndc.  The oracle's own
+    #      float32-vs-float64 spread on the fixture's points is 3.6e-8 (ndc * 2^k is exact in fp32); the device's
+    #      sincos of arguments up to 512 must stay within EMBED_FN_TOL of it;
+    #  (2) against the reference's columns the only other difference is the ndc INPUT: |d sin(2^k x)| <= 2^k |dx|.
+    EMBED_FN_TOL = 5e-7          # measured on MI355X / ROCm 7.2: 6.7e-8
+    own = M.embed(x86[..., :3].double().cpu())
+    fn_err = float((x86[..., :63].double().cpu() - own).abs().max())
+    print(f"[embedding] function error vs float64 of our own ndc: {fn_err:.3e}")
+    assert fn_err <= EMBED_FN_TOL, f"embedding function: {fn_err:.3e}"
+    d_ndc = (x86[..., :3].cpu() - want_x[..., :3]).abs()                                  # (..., 3)
+    octaves = ((2.0 ** torch.arange(10.0))[:, None] * d_ndc[..., None, :]).reshape(*d_ndc.shape[:-1], 30)   # k-major, component fastest
+    bound = torch.cat([d_ndc, octaves, octaves], -1) + EMBED_FN_TOL + 1e-7                  # x | sin 2^k x | cos 2^k x
+    err = (x86[..., :63].cpu() - want_x[..., :63]).abs()
+    print(f"[embedding] vs reference: max err {float(err.max()):.3e}, max bound {float(bound.max()):.3e}, max |d ndc| {float(d_ndc.max()):.3e}")
+    assert bool((err <= bound).all()), f"embedding: {float((err - bound).max()):.3e} over the input-sensitivity bound"
     assert_close(z[None], fx.t("cap/ray_marcher#0.1"), rtol=1e-5, atol_scale=1e-6, name="z")
     assert_close(raw, chunks(fx, "nerf"), name="raw", max_outlier_frac=1e-3)
     assert float(mask.min()) >= 0 and float(mask.max()) <= 1
@@ -151,6 +166,7 @@ def test_boost_mvsnerf_network(fx, bfx, tmp_path):
     for k in range(K):
         ref = torch.cat([bfx.t(f"cap/mask_viewport#{k * per_vol + c}").reshape(-1) for c in range(per_vol)]).reshape(N, Ns)
         diff = (masks[0, k] - ref).abs() > 1e-6
+        print(f"[boost_mvs flips] volume {k}: {int(diff.sum())} of {diff.numel()} samples")
         assert float(diff.float().mean()) < 3e-3, f"volume {k}: {int(diff.sum())} visibility flips"
         flipped |= diff.any(-1)
     for k in want:

@@ -190,9 +190,12 @@ def test_finetune_step_under_ddp_and_syncbn(enerf_fx):
 
 
 def test_graphed_train_step_equals_eager_steps(enerf_fx):
-    """train.GraphedTrainStep (forward + loss + backward replayed as one HIP graph, clip + Adam eager) against the
-    same number of eager train_step calls from the same start: training-mode batch norm (running statistics move),
-    new target tensors every step (copied into the captured buffers), 6 steps = 3 eager + 1 capture + 2 replays."""
+    """train.GraphedTrainStep (forward + loss + backward replayed as one HIP graph, clip + Adam eager) against eager
+    train_step calls in lockstep: before every step the eager twin takes over the graphed network's parameters,
+    batch-norm statistics and Adam state (two free-running Adam trajectories diverge by themselves: entries whose
+    gradient is rounding noise step +-lr either way), then both step on the same batch -- training-mode batch norm,
+    new target tensors every step (copied into the captured buffers), 6 steps = 3 eager + 1 capture + 2 more replays.
+    Loss, every gradient and the running statistics after the step must agree."""
     import copy
     from boostmvsnerfs_amd.config import set_cfg
     from boostmvsnerfs_amd.networks.enerf.network import Network
@@ -202,39 +205,37 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
     net_a.load_state_dict(enerf_fx.group("sd"), strict=True)
     net_a = net_a.to(DEV).train()
     net_b = copy.deepcopy(net_a).train()
+    start = {k: v.clone() for k, v in net_a.state_dict().items()}
     base = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in enerf_fx.batch().items()}
-    steps = []
-    for s in range(6):
-        b = dict(base)
-        for k, v in _targets({k: v for k, v in enerf_fx.batch().items()}, seed=s).items():
-            if k.startswith("rgb_"):
-                b[k] = v.to(DEV)
-        steps.append(b)
     wa, wb = NetworkWrapper(net_a), NetworkWrapper(net_b)
     oa, ob = make_optimizer(net_a), make_optimizer(net_b)
     graphed = GraphedTrainStep(wa, oa)
-    losses_a, losses_b = [], []
-    for b in steps:
-        loss, stats = graphed(dict(b))
-        losses_a.append(float(loss))
+    for s in range(6):
+        b = dict(base)
+        g = torch.Generator().manual_seed(s)
+        for i in range(2):
+            b[f"rgb_{i}"] = torch.rand(1, b[f"rays_{i}"].shape[1], 3, generator=g).to(DEV)
+        net_b.load_state_dict(copy.deepcopy(net_a.state_dict()))
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        loss_a, stats = graphed(dict(b))
         assert "psnr_1" in stats
-        loss, _ = train_step(wb, ob, dict(b))
-        losses_b.append(float(loss))
+        loss_b, _ = train_step(wb, ob, dict(b))
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, float(loss_a), float(loss_b))
+        ga = {k: p.grad for k, p in net_a.named_parameters()}
+        gmax = max(float(p.grad.abs().max()) for p in net_b.parameters())
+        for k, p in net_b.named_parameters():
+            # scatter kernels accumulate with atomics, so two runs of the SAME eager step differ by summation order;
+            # training-mode batch norm over the few voxels of the tiny fixture's deep levels amplifies that to 4e-3 of
+            # a tensor's rms (scripts/dev/r3_gradnoise.py: 4.1e-3 max in train mode, 1.4e-5 in eval mode): 5x that
+            err = (ga[k] - p.grad).abs()
+            tol = 2e-3 * p.grad.abs() + 2e-2 * float(p.grad.pow(2).mean().sqrt()) + 2e-6 * gmax
+            assert bool((err <= tol).all()), f"step {s} {k}: max err {float(err.max()):.3e}"
+        sa, sb = net_a.state_dict(), net_b.state_dict()
+        for k in sa:
+            if "running_" in k:
+                assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * float(sb[k].abs().max()) + 1e-7, (s, k)
+            elif "num_batches_tracked" in k:
+                assert torch.equal(sa[k], sb[k]), (s, k)
     assert graphed.stats["eager"] == 3 and graphed.stats["captures"] == 1 and graphed.stats["replays"] == 3
     assert graphed.stats["copies"] >= 2 * 2          # the two replays after the capture step got new target tensors
-    for la, lb in zip(losses_a, losses_b):
-        assert abs(la - lb) <= 1e-4 * abs(lb), (losses_a, losses_b)
-    # scatter kernels use atomics: the two runs differ by summation order only
-    sa, sb = net_a.state_dict(), net_b.state_dict()
-    lr = 5e-4
-    for k in sa:
-        if not sa[k].is_floating_point():
-            assert torch.equal(sa[k], sb[k]), k
-            continue
-        # (an entry whose gradient is rounding noise may step either way under Adam: a few such entries per tensor,
-        # bounded by 2 lr per step)
-        d = (sa[k] - sb[k]).abs()
-        tol = 0.5 * lr + 1e-4 * float(sb[k].abs().max())
-        assert float((d > tol).float().mean()) <= 0.02, f"{k}: {float((d > tol).float().mean()):.2%} differ, max {float(d.max()):.3e}"
-        assert float(d.max()) <= 2 * lr * len(steps) + tol, f"{k}: {float(d.max()):.3e}"
-    assert sum(float((sa[k] - enerf_fx.group('sd')[k].to(DEV)).abs().max()) > 0 for k in sa) > 100   # ... and they did train
+    assert sum(float((v - start[k]).abs().max()) > 0 for k, v in net_a.state_dict().items()) > 100   # ... and it did train
