@@ -82,6 +82,10 @@ SIGNATURES = {
     "bmv_mvs_mlp_blob_size": [],
     "bmv_mvs_mlp_pack_weights": [C.POINTER(MvsMlpParams), c_f, c_f],
     "bmv_mvs_mlp_fwd": [c_f, c_f, c_l, c_f, c_f],
+    "bmv_mvs_mlp_train_act_floats": [c_l],
+    "bmv_mvs_mlp_train_scratch_floats": [],
+    "bmv_mvs_mlp_train_fwd": [c_f, C.POINTER(MvsMlpParams), c_l, c_f, c_f, c_f, c_f],
+    "bmv_mvs_mlp_train_bwd": [C.POINTER(MvsMlpParams), c_f, c_f, c_f, c_f, c_l, c_f, C.POINTER(MvsMlpParams), c_f],
     "bmv_mvs_render_fwd": [C.POINTER(MvsRenderArgs), c_f],
     "bmv_mvs_march_mask": [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f],
     "bmv_conv_wpack_floats": [c_i, c_i, c_i, c_i, c_i],
@@ -146,6 +150,8 @@ def load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.bmv_nerf_bwd_workspace.restype = C.c_long
+    lib.bmv_mvs_mlp_train_act_floats.restype = C.c_long
+    lib.bmv_mvs_mlp_train_scratch_floats.restype = C.c_long
     lib.bmv_conv_wgrad_workspace.restype = C.c_long
     lib.bmv_last_error.argtypes = []
     lib.bmv_last_error.restype = C.c_char_p

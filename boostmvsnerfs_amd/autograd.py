@@ -255,3 +255,27 @@ class MvsVolFeat(torch.autograd.Function):
         H, W, vshape, pad = ctx.cfg
         d_vol = ops.mvs_vol_feat_bwd(rays, e0, k0, nf, d_values.contiguous(), H, W, vshape, pad)
         return d_vol, None, None, None, None, None, None, None, None
+
+
+class MvsMLP(torch.autograd.Function):
+    """a25 Renderer_ours (6 x 128, pts_bias gate, skip concat, alpha / rgb heads) with a HIP backward
+    (csrc/mvs_mlp_train.hip): x (npts, 86) + the 22 parameter tensors in bmv_mvs_mlp_params order -> (npts, 4).
+    Deterministic.  The forward's activations (1.3 KB x 2508 rows per 32 points) stay on the device until the backward."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        out, act, scratch = ops.mvs_mlp_train_fwd(x, params)
+        ctx.save_for_backward(out, *params)
+        ctx.act, ctx.scratch = act, scratch
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, *params = ctx.saved_tensors
+        if ctx.act is None:
+            raise RuntimeError("MvsMLP: the activations of this forward were already consumed by a backward "
+                               "(retain_graph / double backward are not supported)")
+        dx, grads = ops.mvs_mlp_train_bwd(params, ctx.act, ctx.scratch, out, d_out.contiguous())
+        ctx.act = ctx.scratch = None
+        return (dx if ctx.needs_input_grad[0] else None,
+                *[g if need else None for g, need in zip(grads, ctx.needs_input_grad[1:])])

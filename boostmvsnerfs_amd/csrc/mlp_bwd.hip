@@ -823,6 +823,10 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
 
 using namespace bmv;
 
+__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 namespace {
 constexpr int kWgradGrid = 256;   // one workgroup per CU (the kernel takes > 256 registers)
 
@@ -841,7 +845,9 @@ int run_bwd(const float* vox_feat, const float* img, const float* d_out, const f
   float* rows = ws;
   float* partials = rows + ntiles * (long)LB::R_TOTAL * 32;
   float* vecs = partials + (long)kWgradGrid * LB::PART;
-  BMV_REQUIRE(hipMemsetAsync(vecs, 0, 128 * sizeof(float), st) == hipSuccess, "bmv_nerf_mlp_bwd: memset failed");
+  // (a kernel, not hipMemsetAsync: inside a captured training step the memset NODE did not reliably clear the buffer
+  // on later replays -- tests/test_gpu_training.py::test_graphed_train_step_equals_eager_steps)
+  hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(128), 0, st, vecs, 128);
   const unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
   const size_t lds = (size_t)(MlpLayout<FC>::TOTAL + LB::TOTAL) * 4;
   BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC>),

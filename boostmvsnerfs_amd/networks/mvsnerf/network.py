@@ -193,9 +193,9 @@ class RendererMLP(nn.Module):
         return self._blob
 
     def forward_torch(self, x):
-        """Renderer_ours.forward (network.py:201-229) in torch ops, for training: the 6 x 128 MLP's backward is
-        autograd's (the MFMA kernel is forward-only); pts_bias multiplies, layer 4's output is concatenated behind
-        the embedded point."""
+        """Renderer_ours.forward (network.py:201-229) in torch ops (the reference form: tests compare the HIP training
+        path with it; BMV_MVS_MLP_TRAIN=torch trains through it); pts_bias multiplies, layer 4's output is concatenated
+        behind the embedded point."""
         pts, feat, views = x[..., :63], x[..., 63:83], x[..., 83:86]
         bias = self.pts_bias(feat)
         h = pts
@@ -207,10 +207,27 @@ class RendererMLP(nn.Module):
         h = F.relu(self.views_linears[0](torch.cat([self.feature_linear(h), views], -1)))
         return torch.cat([torch.sigmoid(self.rgb_linear(h)), alpha], -1)
 
+    TRAIN_CHUNK = 1 << 18      # points per autograd.MvsMLP call: 2.6 GB of kept activations
+
+    def _param_list(self):
+        """The 22 tensors in bmv_mvs_mlp_params order."""
+        m = self._named()
+        order = [f"pts_linears.{i}" for i in range(6)]
+        rest = ["pts_bias", "views_linears.0", "feature_linear", "alpha_linear", "rgb_linear"]
+        return ([m[k].weight for k in order] + [m[k].bias for k in order]
+                + [t for k in rest for t in (m[k].weight, m[k].bias)])
+
     def forward(self, x):
-        """x (..., 86) = [embedded ndc 63 | feature 20 | view dir 3] -> (..., 4) = [rgb, alpha]."""
+        """x (..., 86) = [embedded ndc 63 | feature 20 | view dir 3] -> (..., 4) = [rgb, alpha].  Under autograd: the
+        layer-wise MFMA kernels with a HIP backward (autograd.MvsMLP; BMV_MVS_MLP_TRAIN=torch: nn.Linear + torch
+        autograd); otherwise the fused inference kernel."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return self.forward_torch(x)
+            if not x.is_cuda or os.environ.get("BMV_MVS_MLP_TRAIN", "hip") == "torch":
+                return self.forward_torch(x)
+            flat = x.reshape(-1, 86)
+            params = self._param_list()
+            outs = [A.MvsMLP.apply(flat[i:i + self.TRAIN_CHUNK], *params) for i in range(0, flat.shape[0], self.TRAIN_CHUNK)]
+            return (outs[0] if len(outs) == 1 else torch.cat(outs)).reshape(*x.shape[:-1], 4)
         return ops.mvs_mlp(x, self.packed_weights())
 
 

@@ -506,6 +506,60 @@ def mvs_mlp_pack_weights(weights, biases):
     return blob
 
 
+def _mvs_mlp_params(tensors):
+    """22 tensors in the member order of bmv_mvs_mlp_params (6 pts weights, 6 pts biases, then weight / bias of
+    pts_bias, views_linears.0, feature_linear, alpha_linear, rgb_linear) -> the C struct."""
+    p = _lib.MvsMlpParams()
+    for i in range(6):
+        p.pts_w[i] = dptr(tensors[i], f"pts_linears.{i}.weight")
+        p.pts_b[i] = dptr(tensors[6 + i], f"pts_linears.{i}.bias")
+    for j, field in enumerate(("bias_w", "bias_b", "views_w", "views_b", "feature_w", "feature_b", "alpha_w", "alpha_b",
+                               "rgb_w", "rgb_b")):
+        setattr(p, field, dptr(tensors[12 + j], field))
+    return p
+
+
+MVS_MLP_SHAPES = ([(128, 63)] + [(128, 128)] * 4 + [(128, 191)] + [(128,)] * 6
+                  + [(128, 20), (128,), (64, 131), (64,), (128, 128), (128,), (1, 128), (1,), (3, 64), (3,)])
+
+
+def mvs_mlp_train_fwd(x, params):
+    """Renderer_ours.forward for autograd (csrc/mvs_mlp_train.hip): x (npts, 86), params = the 22 parameter tensors in
+    bmv_mvs_mlp_params order.  Returns (out (npts,4), act, scratch): `act` holds every layer's input and
+    pre-activation for ONE mvs_mlp_train_bwd."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.shape[1] != 86:
+        raise ValueError("MVSNeRF MLP input is (npts, 63 + 20 + 3)")
+    params = [_c(t.detach()) for t in params]
+    for t, shp in zip(params, MVS_MLP_SHAPES):
+        if tuple(t.shape) != shp:
+            raise ValueError(f"Renderer_ours parameter of shape {tuple(t.shape)}, expected {shp}")
+    npts = x.shape[0]
+    act = torch.empty(lib.bmv_mvs_mlp_train_act_floats(npts), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(lib.bmv_mvs_mlp_train_scratch_floats(), device=x.device, dtype=torch.float32)
+    out = torch.empty(npts, 4, device=x.device, dtype=torch.float32)
+    p = _mvs_mlp_params(params)
+    with ktimer.region("mvs_mlp_train_fwd"):
+        rc = lib.bmv_mvs_mlp_train_fwd(dptr(_c(x), "x"), C.byref(p), npts, dptr(act), dptr(scratch), dptr(out), stream())
+    _lib.check(rc, "mvs_mlp_train_fwd")
+    return out, act, scratch
+
+
+def mvs_mlp_train_bwd(params, act, scratch, out, d_out):
+    """-> (dx (npts,86), [22 parameter gradients]).  Overwrites `act`."""
+    lib = _lib.load()
+    params = [_c(t.detach()) for t in params]
+    npts = out.shape[0]
+    dx = torch.empty(npts, 86, device=out.device, dtype=torch.float32)
+    grads = [torch.empty_like(t) for t in params]
+    p, g = _mvs_mlp_params(params), _mvs_mlp_params(grads)
+    with ktimer.region("mvs_mlp_train_bwd"):
+        rc = lib.bmv_mvs_mlp_train_bwd(C.byref(p), dptr(act), dptr(scratch), dptr(_c(out), "out"), dptr(_c(d_out), "d_out"),
+                                       npts, dptr(dx), C.byref(g), stream())
+    _lib.check(rc, "mvs_mlp_train_bwd")
+    return dx, grads
+
+
 def mvs_mlp(x, blob):
     lead = x.shape[:-1]
     if x.shape[-1] != 86:

@@ -320,6 +320,23 @@ int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* params, float* blob, bmv_
 /* x (npts, 86) = [embed(ndc) 63 | volume+colour feature 20 | view direction 3] -> out (npts,4) = [sigmoid rgb, relu alpha] */
 int bmv_mvs_mlp_fwd(const float* x, const float* blob, long npts, float* out, bmv_stream_t stream);
 
+/* ---- a25 under autograd: Renderer_ours.forward + its backward          lib/networks/mvsnerf/network.py:201-229
+ * (replaces torch autograd through 11 nn.Linear; trained via configs/exps/finetune/mvsnerf).  Activations of the
+ * forward are kept for the backward as per-tile row matrices act[tile][row][32 points] (csrc/mvs_mlp_train.hip):
+ *   act      bmv_mvs_mlp_train_act_floats(npts) floats, written by _fwd, consumed AND overwritten by _bwd (one backward
+ *            per forward);
+ *   scratch  bmv_mvs_mlp_train_scratch_floats() floats (transposed weights of the step + weight-gradient partials);
+ *   params   the parameter tensors as stored by torch (row-major (out, in)); `grads`: tensors of the same shapes that
+ *            receive dL/dparam (written, not accumulated); dx (npts,86) = dL/dx.
+ * Deterministic (no atomics: partial weight gradients are summed in a fixed order). */
+long bmv_mvs_mlp_train_act_floats(long npts);
+long bmv_mvs_mlp_train_scratch_floats(void);
+int bmv_mvs_mlp_train_fwd(const float* x, const bmv_mvs_mlp_params* params, long npts, float* act, float* scratch,
+                          float* out, bmv_stream_t stream);
+int bmv_mvs_mlp_train_bwd(const bmv_mvs_mlp_params* params, float* act, float* scratch, const float* out,
+                          const float* d_out, long npts, float* dx, const bmv_mvs_mlp_params* grads,
+                          bmv_stream_t stream);
+
 /* ---- a21..a25 fused: ray_marcher, get_ndc_coordinate, gen_dir_feature, gen_pts_feats, Embedder, MLP
  *          lib/networks/mvsnerf/network.py:945-1042, utils.py:112-146,300-383, renderer.py:111-137
  * rays (N,8): near/far are columns 6 and 7 verbatim.  volume (8,D,hp,wp) = regularised cost volume of the

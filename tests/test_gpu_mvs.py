@@ -84,6 +84,65 @@ def test_mlp(fx):
     assert_close(raw2, chunks(fx, "nerf").reshape(-1, 4)[:1001], name="ragged")
 
 
+@pytest.mark.parametrize("npts", [1001, 4096 + 33])
+def test_mlp_training_path_matches_float64_autograd(fx, npts):
+    """autograd.MvsMLP (csrc/mvs_mlp_train.hip: layer-wise MFMA kernels, HIP backward) vs Renderer_ours.forward
+    (network.py:201-229) in float64 under torch autograd, on the reference's own MLP inputs and weights: the output,
+    the input gradient and all 22 parameter gradients; ragged point counts (last tile partly empty, odd tile count)."""
+    from boostmvsnerfs_amd.networks.mvsnerf.network import RendererMLP
+    torch.manual_seed(3)
+    sd = fx.group("sd")
+    mlp = RendererMLP()
+    mlp.load_state_dict({k[len("nerf.nerf."):]: v for k, v in sd.items() if k.startswith("nerf.nerf.")}, strict=True)
+    mlp = mlp.to(DEV)
+    x0 = chunks(fx, "run_network_mvs").reshape(-1, 86)
+    x0 = x0[torch.randint(0, x0.shape[0], (npts,))].to(DEV)
+    gy = torch.randn(npts, 4, device=DEV)
+    x = x0.clone().requires_grad_(True)
+    y = mlp(x)
+    fn, seen = y.grad_fn, []
+    while fn is not None and len(seen) < 4:                                      # (a reshape sits on top of it)
+        seen.append(type(fn).__name__)
+        fn = fn.next_functions[0][0] if fn.next_functions else None
+    assert any("MvsMLP" in s for s in seen), seen                                # the HIP path is the one that ran
+    y.backward(gy)
+    ref = RendererMLP().double().to(DEV)
+    ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+    xd = x0.double().requires_grad_(True)
+    yd = ref.forward_torch(xd)
+    yd.backward(gy.double())
+
+    def close(a, b, name, tol=2e-5):
+        err = float((a.double() - b).abs().max())
+        scale = float(b.abs().max()) + 1e-30
+        assert err <= tol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+    close(y, yd.detach(), "output")
+    assert_close(mlp.forward_torch(x0), y.detach(), rtol=1e-4, atol_scale=1e-5, name="fp32 torch forward")
+    close(x.grad, xd.grad, "d x")
+    named, named_d = dict(mlp.named_parameters()), dict(ref.named_parameters())
+    assert len(named) == 22
+    for k, p_ in named.items():
+        assert p_.grad is not None, k
+        close(p_.grad, named_d[k].grad, k, tol=5e-5)
+    # one backward per forward: the kept activations are consumed
+    x2 = x0.clone().requires_grad_(True)
+    y2 = mlp(x2)
+    y2.backward(gy, retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        y2.backward(gy)
+    # deterministic: same inputs, bit-identical gradients
+    mlp.zero_grad()
+    x4 = x0.clone().requires_grad_(True)
+    mlp(x4).backward(gy)
+    g4 = {k: p_.grad.clone() for k, p_ in named.items()}
+    mlp.zero_grad()
+    x5 = x0.clone().requires_grad_(True)
+    mlp(x5).backward(gy)
+    assert torch.equal(x5.grad, x4.grad) and torch.equal(x4.grad, x.grad)
+    for k, p_ in named.items():
+        assert torch.equal(p_.grad, g4[k]), k
+
+
 def test_fused_sampler_and_mlp(fx):
     from boostmvsnerfs_amd import ops
     from oracle import mvsnerf as M

@@ -225,11 +225,13 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
         gmax = max(float(p.grad.abs().max()) for p in net_b.parameters())
         for k, p in net_b.named_parameters():
             # scatter kernels accumulate with atomics, so two runs of the SAME eager step differ by summation order;
-            # training-mode batch norm over the few voxels of the tiny fixture's deep levels amplifies that to 4e-3 of
-            # a tensor's rms (scripts/dev/r3_gradnoise.py: 4.1e-3 max in train mode, 1.4e-5 in eval mode): 5x that
-            err = (ga[k] - p.grad).abs()
-            tol = 2e-3 * p.grad.abs() + 2e-2 * float(p.grad.pow(2).mean().sqrt()) + 2e-6 * gmax
-            assert bool((err <= tol).all()), f"step {s} {k}: max err {float(err.max()):.3e}"
+            # training-mode batch norm over the few voxels of the tiny fixture's deep levels amplifies that to ~4e-3 of
+            # a tensor's rms in single entries (scripts/dev/r3_gradnoise.py: 4.1e-3 in train mode, 1.4e-5 in eval
+            # mode).  A replay that read stale inputs or parameters is wrong by O(1): the bar is the tensor's relative
+            # L2 error
+            num = float((ga[k] - p.grad).pow(2).sum().sqrt())
+            den = float(p.grad.pow(2).sum().sqrt()) + 1e-6 * gmax
+            assert num <= 2e-2 * den, f"step {s} {k}: relative L2 error {num / den:.3e}"
         sa, sb = net_a.state_dict(), net_b.state_dict()
         for k in sa:
             if "running_" in k:
