@@ -128,7 +128,8 @@ struct RowsGemm {
 
 template <int MB, int EP>
 __global__ void __launch_bounds__(256, 2) rows_gemm_kernel(RowsGemm a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave index through readfirstlane: tile pointers are then scalar, loads take SGPR base + 32-bit lane offset)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, kh = lane >> 5;
   const long tile0 = ((long)blockIdx.x * 4 + wave) * 2;
   if (tile0 >= a.ntiles) return;
@@ -143,55 +144,109 @@ __global__ void __launch_bounds__(256, 2) rows_gemm_kernel(RowsGemm a) {
       for (int r = 0; r < 16; ++r) acc[t][mb][r] = 0.f;
   float* __restrict__ t0 = a.act + tile0 * TR::TOTAL * 32;
   float* __restrict__ t1 = two ? t0 + TR::TOTAL * 32 : t0;
+  // table column of this lane per 32-row block: clamped (no branch in the loop), masked to 0 past M
+  int colc[MB];
+  bool live[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mbase + mb * 32 + n;
+    live[mb] = m < a.M;
+    colc[mb] = a.col0 + (live[mb] ? m : a.M - 1);
+  }
+  // k loop: operands of step u + PF are requested before the MFMAs of step u are issued (PF x 6 loads in flight)
+  constexpr int PF = 4;
   int krow = 0;
   for (int seg = 0; seg < 2; ++seg) {
     const int steps = a.seg_k[seg] >> 1;
-    const float* __restrict__ in0 = t0 + (a.seg_row[seg] + kh) * 32 + n;
-    const float* __restrict__ in1 = t1 + (a.seg_row[seg] + kh) * 32 + n;
-    const float* __restrict__ tab = a.table + (long)(krow + kh) * a.ld + a.col0 + mbase + n;
-#pragma unroll 4
-    for (int u = 0; u < steps; ++u) {
-      const float b0 = in0[u * 64], b1 = in1[u * 64];
+    if (steps == 0) continue;
+    const float* __restrict__ in0 = t0 + a.seg_row[seg] * 32 + (kh * 32 + n);
+    const float* __restrict__ in1 = t1 + a.seg_row[seg] * 32 + (kh * 32 + n);
+    const float* __restrict__ tab = a.table + (long)krow * a.ld + kh * a.ld;
+    const int ld2 = 2 * a.ld;
+    float q0[PF], q1[PF], qw[PF][MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const float w = (mbase + mb * 32 + n < a.M) ? tab[(long)u * 2 * a.ld + mb * 32] : 0.f;
-        acc[0][mb] = BMV_MFMA(w, b0, acc[0][mb]);
-        acc[1][mb] = BMV_MFMA(w, b1, acc[1][mb]);
+    for (int j = 0; j < PF; ++j) {
+      const int uc = j < steps ? j : steps - 1;
+      q0[j] = in0[uc * 64], q1[j] = in1[uc * 64];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) qw[j][mb] = tab[uc * ld2 + colc[mb]];
+    }
+    for (int u0 = 0; u0 < steps; u0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        if (u0 + j < steps) {
+          const float b0 = q0[j], b1 = q1[j];
+          float w[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) w[mb] = live[mb] ? qw[j][mb] : 0.f;
+          const int un = u0 + j + PF, uc = un < steps ? un : steps - 1;
+          q0[j] = in0[uc * 64], q1[j] = in1[uc * 64];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) qw[j][mb] = tab[uc * ld2 + colc[mb]];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            acc[0][mb] = BMV_MFMA(w[mb], b0, acc[0][mb]);
+            acc[1][mb] = BMV_MFMA(w[mb], b1, acc[1][mb]);
+          }
+        }
       }
     }
     krow += a.seg_k[seg];
   }
-  // epilogue: register r of lane (n, kh) is element (row n16(r, kh), sample n) of its 32-row block
+  // epilogue: register r of lane (n, kh) is element (row n16(r, kh), sample n) of its 32-row block.  All loads of a
+  // block are issued before its stores (the rows alias through `act` as far as the compiler knows).
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (t == 1 && !two) break;
-    float* __restrict__ T = t ? t1 : t0;
+    float* __restrict__ T = (t ? t1 : t0) + n;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m0 = mbase + mb * 32 + 4 * kh;            // row of register r: m0 + (r & 3) + 8 (r >> 2)
+      if (mbase + mb * 32 >= a.M) break;                  // (uniform)
+      float v[16], x0[16], x1[16], x2[16];
+      bool ok[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mb * 32 + n16(r, kh);
-        if (m >= a.M) continue;
-        float v = acc[t][mb][r];
-        float* o = T + (a.out_row + m) * 32 + n;
+        const int m = m0 + (r & 3) + 8 * (r >> 2);
+        ok[r] = m < a.M;
+        const int mc = ok[r] ? m : a.M - 1;
+        v[r] = acc[t][mb][r];
         if constexpr (EP == EP_STORE) {
-          if (a.bias) v += a.bias[m];
-          *o = a.accumulate ? *o + v : v;
+          x0[r] = a.bias ? a.bias[mc] : 0.f;
+          x1[r] = a.accumulate ? T[(a.out_row + mc) * 32] : 0.f;
         } else if constexpr (EP == EP_GATE_RELU) {
-          v += a.bias[m];
-          *o = v;                                                                  // z_l
-          T[(a.aux1 + m) * 32 + n] = fmaxf(v * T[(a.aux0 + m) * 32 + n], 0.f);      // h_l = relu(z_l * gate)
+          x0[r] = a.bias[mc];
+          x1[r] = T[(a.aux0 + mc) * 32];
         } else if constexpr (EP == EP_RELU) {
-          *o = fmaxf(v + a.bias[m], 0.f);
+          x0[r] = a.bias[mc];
         } else {
-          if (a.aux2 >= 0) v += T[(a.aux2 + m) * 32 + n];
-          const float z = *o, g = T[(a.aux0 + m) * 32 + n];
-          const float dpre = z * g > 0.f ? v : 0.f;                                // d relu(z * gate)
-          float* db = T + (a.aux1 + m) * 32 + n;
-          *db = a.accumulate ? *db + dpre * z : dpre * z;                          // d gate
-          *o = dpre * g;                                                           // d z
+          x0[r] = T[(a.out_row + mc) * 32];                                   // z
+          x1[r] = T[(a.aux0 + mc) * 32];                                      // gate
+          x2[r] = a.aux2 >= 0 ? T[(a.aux2 + mc) * 32] : 0.f;
+          v[r] += x2[r];
+          x2[r] = a.accumulate ? T[(a.aux1 + mc) * 32] : 0.f;                 // running d gate
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!ok[r]) continue;
+        const int m = m0 + (r & 3) + 8 * (r >> 2);
+        if constexpr (EP == EP_STORE) {
+          T[(a.out_row + m) * 32] = v[r] + x0[r] + x1[r];
+        } else if constexpr (EP == EP_GATE_RELU) {
+          const float z = v[r] + x0[r];
+          T[(a.out_row + m) * 32] = z;                                        // z_l
+          T[(a.aux1 + m) * 32] = fmaxf(z * x1[r], 0.f);                       // h_l = relu(z_l * gate)
+        } else if constexpr (EP == EP_RELU) {
+          T[(a.out_row + m) * 32] = fmaxf(v[r] + x0[r], 0.f);
+        } else {
+          const float dpre = x0[r] * x1[r] > 0.f ? v[r] : 0.f;                // d relu(z * gate)
+          T[(a.aux1 + m) * 32] = x2[r] + dpre * x0[r];                        // d gate
+          T[(a.out_row + m) * 32] = dpre * x1[r];                             // d z
+        }
+      }
+      asm volatile("" ::: "memory");      // the next block's loads stay behind these stores (register pressure)
+    }
   }
 }
 
@@ -238,7 +293,7 @@ __global__ void __launch_bounds__(256) mvs_heads_bwd_kernel(float* __restrict__ 
 }
 
 // ---- weight gradients --------------------------------------------------------------------------------------------------
-constexpr int kMaxKB = 6, kMaxStrips = 48;
+constexpr int kMaxKB = 6, kMaxStrips = 40;
 struct Strip {
   short a_row, a_rows;            // 32-row block of the output-side gradient: first row, valid rows
   short nkb;                      // input-side blocks of 32 rows
@@ -248,21 +303,30 @@ struct Strip {
   short col[kMaxKB];
   short param, bias_param;        // indices into the gradient pointer table (bias_param < 0: none)
 };
+constexpr int kSplitPerKb = 16;   // workgroups per 32 x 32 block column of a layer: ~2500 waves = 2.5 per SIMD
+constexpr int kMaxGroups = 12;
 struct WgradArgsMvs {
   const float* act;
   long ntiles;
-  int nstrips, nsplit;
-  float* partials;                // [strip][split][kMaxKB * 1024 + 64]
+  int nstrips, ngroups, nwgs;
+  float* partials;                // [workgroup][wave][kMaxKB * 1024 + 64]
+  // a GROUP = the (up to 4) strips of one layer: same input-side blocks, different 32-row blocks of the output side.
+  // A workgroup is (group, split), its wave j is strip first_strip + j: the four waves read the same input-side rows
+  // at about the same time (one trip to HBM, three L1 / L2 hits) -- the strips one by one moved 2.8 GB per call
+  short first_strip[kMaxGroups + 1];
+  short first_wg[kMaxGroups + 1];
   Strip strip[kMaxStrips];
 };
 constexpr int kPartFloats = kMaxKB * 1024 + 64;
 
 __global__ void __launch_bounds__(256, 2) rows_wgrad_kernel(WgradArgsMvs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, kk = lane >> 5;
-  const int w = blockIdx.x * 4 + wave;
-  if (w >= a.nstrips * a.nsplit) return;
-  const int si = w / a.nsplit, split = w % a.nsplit;
+  int g = 0;
+  while (g + 1 < a.ngroups && (int)blockIdx.x >= a.first_wg[g + 1]) ++g;
+  const int si = a.first_strip[g] + wave;
+  if (si >= a.first_strip[g + 1]) return;
+  const int split = blockIdx.x - a.first_wg[g], nsplit = a.first_wg[g + 1] - a.first_wg[g];
   const Strip& S = a.strip[si];
   const long npairs = (a.ntiles + 1) / 2;
   f32x16 acc[kMaxKB];
@@ -272,34 +336,32 @@ __global__ void __launch_bounds__(256, 2) rows_wgrad_kernel(WgradArgsMvs a) {
     for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
   float bsum = 0.f;
   auto load = [&](long tile, int row0, int nrows, float (&v)[32]) {
-    if (m < nrows && tile < a.ntiles) {
-      const float4* p = reinterpret_cast<const float4*>(a.act + (tile * TR::TOTAL + row0 + m) * 32);
+    // (rows past the block / tiles past the end: row 0 of tile 0 is read instead and zeroed -- no divergent branch)
+    const bool ok = m < nrows && tile < a.ntiles;
+    const float4* p = reinterpret_cast<const float4*>(a.act + ((ok ? tile : 0) * TR::TOTAL + row0 + (ok ? m : 0)) * 32);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 t = p[q];
-        v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 32; ++q) v[q] = 0.f;
+    for (int q = 0; q < 8; ++q) {
+      const float4 t = p[q];
+      v[4 * q] = ok ? t.x : 0.f, v[4 * q + 1] = ok ? t.y : 0.f, v[4 * q + 2] = ok ? t.z : 0.f, v[4 * q + 3] = ok ? t.w : 0.f;
     }
   };
-  for (long pair = split; pair < npairs; pair += a.nsplit) {
+  for (long pair = split; pair < npairs; pair += nsplit) {
     const long tile = 2 * pair + kk;
-    float av[32], bv[32];
+    float av[32], bv[2][32];
     load(tile, S.a_row, S.a_rows, av);
+    load(tile, S.b_row[0], S.b_rows[0], bv[0]);
 #pragma unroll
     for (int j = 0; j < 32; ++j) bsum += av[j];
 #pragma unroll
     for (int kb = 0; kb < kMaxKB; ++kb) {
       if (kb < S.nkb) {
-        load(tile, S.b_row[kb], S.b_rows[kb], bv);
+        if (kb + 1 < S.nkb) load(tile, S.b_row[kb + 1 < kMaxKB ? kb + 1 : kb], S.b_rows[kb + 1 < kMaxKB ? kb + 1 : kb], bv[(kb + 1) & 1]);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[kb] = BMV_MFMA(av[j], bv[j], acc[kb]);
+        for (int j = 0; j < 32; ++j) acc[kb] = BMV_MFMA(av[j], bv[kb & 1][j], acc[kb]);
       }
     }
   }
-  float* __restrict__ part = a.partials + ((long)si * a.nsplit + split) * kPartFloats;
+  float* __restrict__ part = a.partials + ((long)blockIdx.x * 4 + wave) * kPartFloats;
 #pragma unroll
   for (int kb = 0; kb < kMaxKB; ++kb)
     if (kb < S.nkb) {
@@ -312,26 +374,41 @@ __global__ void __launch_bounds__(256, 2) rows_wgrad_kernel(WgradArgsMvs a) {
 struct GradPtrs {
   float* p[22];
 };
+// grid (strip, block): blocks 0 .. kMaxKB-1 sum one 32 x 32 weight block each over the strip's splits (fixed order),
+// block kMaxKB the bias row sums
 __global__ void __launch_bounds__(256) rows_wgrad_finish_kernel(WgradArgsMvs a, GradPtrs g) {
-  const Strip& S = a.strip[blockIdx.x];
-  const float* __restrict__ part = a.partials + (long)blockIdx.x * a.nsplit * kPartFloats;
-  float* __restrict__ out = g.p[S.param];
-  for (int e = threadIdx.x; e < S.nkb * 1024; e += blockDim.x) {
-    const int kb = e >> 10, row = (e >> 5) & 31, j = e & 31;
-    const int i = row - S.sel0;
-    if (i < 0 || i >= S.out_rows || j >= S.b_rows[kb]) continue;
-    float s = 0.f;
-    for (int sp = 0; sp < a.nsplit; ++sp) s += part[(long)sp * kPartFloats + e];
-    out[(S.out_row0 + i) * S.ld + S.col[kb] + j] = s;
-  }
-  if (S.bias_param >= 0)
+  const int si = blockIdx.x, kb = blockIdx.y;
+  const Strip& S = a.strip[si];
+  int gr = 0;
+  while (gr + 1 < a.ngroups && si >= a.first_strip[gr + 1]) ++gr;
+  const int nsplit = a.first_wg[gr + 1] - a.first_wg[gr];
+  const long stride = 4L * kPartFloats;                    // between the splits of one strip
+  const float* __restrict__ part = a.partials + ((long)a.first_wg[gr] * 4 + (si - a.first_strip[gr])) * kPartFloats;
+  // fixed summation order (8 interleaved running sums, then a fixed tree): deterministic
+  auto total = [&](int off) {
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] += part[(sp + q) * stride + off];
+    for (; sp < nsplit; ++sp) t[sp & 7] += part[sp * stride + off];
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  };
+  if (kb < kMaxKB) {
+    if (kb >= S.nkb) return;
+    float* __restrict__ out = g.p[S.param];
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+      const int row = e >> 5, j = e & 31;
+      const int i = row - S.sel0;
+      if (i < 0 || i >= S.out_rows || j >= S.b_rows[kb]) continue;
+      out[(S.out_row0 + i) * S.ld + S.col[kb] + j] = total(kb * 1024 + e);
+    }
+  } else if (S.bias_param >= 0) {
     for (int e = threadIdx.x; e < S.out_rows; e += blockDim.x) {
       const int row = S.sel0 + e;
-      float s = 0.f;
-      for (int sp = 0; sp < a.nsplit; ++sp)
-        s += part[(long)sp * kPartFloats + kMaxKB * 1024 + row] + part[(long)sp * kPartFloats + kMaxKB * 1024 + 32 + row];
-      g.p[S.bias_param][S.out_row0 + e] = s;
+      g.p[S.bias_param][S.out_row0 + e] = total(kMaxKB * 1024 + row) + total(kMaxKB * 1024 + 32 + row);
     }
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -362,7 +439,7 @@ extern "C" {
 
 long bmv_mvs_mlp_train_act_floats(long npts) { return ((npts + 31) / 32) * (long)bmv::TR::TOTAL * 32; }
 long bmv_mvs_mlp_train_scratch_floats(void) {
-  return (long)bmv::TW::TOTAL + (long)bmv::kMaxStrips * 32 * bmv::kPartFloats;
+  return (long)bmv::TW::TOTAL + (long)bmv::kMaxGroups * bmv::kMaxKB * bmv::kSplitPerKb * 4 * bmv::kPartFloats;
 }
 
 int bmv_mvs_mlp_train_fwd(const float* x, const bmv_mvs_mlp_params* params, long npts, float* act, float* scratch,
@@ -432,7 +509,7 @@ int bmv_mvs_mlp_train_bwd(const bmv_mvs_mlp_params* params, float* act, float* s
 
   // weight gradients
   WgradArgsMvs w;
-  w.act = act, w.ntiles = T, w.nsplit = 32, w.partials = scratch + TW::TOTAL;
+  w.act = act, w.ntiles = T, w.partials = scratch + TW::TOTAL;
   int ns = 0;
   auto add = [&](int a_row, int a_rows, int out_row0, int sel0, int out_rows, int param, int bias_param, int ld,
                  std::initializer_list<int> brow, std::initializer_list<int> brows, std::initializer_list<int> col) {
@@ -447,30 +524,51 @@ int bmv_mvs_mlp_train_bwd(const bmv_mvs_mlp_params* params, float* act, float* s
     i = 0;
     for (int v : col) S.col[i++] = (short)v;
   };
-  for (int mb = 0; mb < 4; ++mb) {
-    const int o = mb * 32;
-    add(TR::DBIAS + o, 32, o, 0, 32, G_BIAS_W, G_BIAS_B, 20, {TR::FEAT}, {20}, {0});
+  int ng = 0;
+  auto group = [&]() { w.first_strip[ng++] = (short)ns; };
+  group();
+  for (int o = 0; o < 128; o += 32) add(TR::DBIAS + o, 32, o, 0, 32, G_BIAS_W, G_BIAS_B, 20, {TR::FEAT}, {20}, {0});
+  group();
+  for (int o = 0; o < 128; o += 32)
     add(TR::Z(0) + o, 32, o, 0, 32, G_W0 + 0, G_B0 + 0, 63, {TR::PTS, TR::PTS + 32}, {32, 31}, {0, 32});
-    for (int l = 1; l <= 4; ++l)
+  for (int l = 1; l <= 4; ++l) {
+    group();
+    for (int o = 0; o < 128; o += 32)
       add(TR::Z(l) + o, 32, o, 0, 32, G_W0 + l, G_B0 + l, 128,
           {TR::H(l - 1), TR::H(l - 1) + 32, TR::H(l - 1) + 64, TR::H(l - 1) + 96}, {32, 32, 32, 32}, {0, 32, 64, 96});
+  }
+  group();
+  for (int o = 0; o < 128; o += 32)
     add(TR::Z(5) + o, 32, o, 0, 32, G_W0 + 5, G_B0 + 5, 191,
         {TR::PTS, TR::PTS + 32, TR::H(4), TR::H(4) + 32, TR::H(4) + 64, TR::H(4) + 96}, {32, 31, 32, 32, 32, 32},
         {0, 32, 63, 95, 127, 159});
+  group();
+  for (int o = 0; o < 128; o += 32)
     add(TR::DFEATL + o, 32, o, 0, 32, G_FEAT_W, G_FEAT_B, 128, {TR::H(5), TR::H(5) + 32, TR::H(5) + 64, TR::H(5) + 96},
         {32, 32, 32, 32}, {0, 32, 64, 96});
-  }
-  for (int mb = 0; mb < 2; ++mb)
-    add(TR::DHV + mb * 32, 32, mb * 32, 0, 32, G_VIEWS_W, G_VIEWS_B, 131,
+  group();
+  for (int o = 0; o < 64; o += 32)
+    add(TR::DHV + o, 32, o, 0, 32, G_VIEWS_W, G_VIEWS_B, 131,
         {TR::FEATL, TR::FEATL + 32, TR::FEATL + 64, TR::FEATL + 96, TR::VIEW}, {32, 32, 32, 32, 3}, {0, 32, 64, 96, 128});
+  group();
   add(TR::GOUT, 4, 0, 0, 1, G_ALPHA_W, G_ALPHA_B, 128, {TR::H(5), TR::H(5) + 32, TR::H(5) + 64, TR::H(5) + 96},
       {32, 32, 32, 32}, {0, 32, 64, 96});
+  group();
   add(TR::GOUT, 4, 0, 1, 3, G_RGB_W, G_RGB_B, 64, {TR::HV, TR::HV + 32}, {32, 32}, {0, 32});
-  w.nstrips = ns;
+  w.first_strip[ng] = (short)ns;
+  w.nstrips = ns, w.ngroups = ng;
+  const long npairs = (T + 1) / 2;
+  int nwg = 0;
+  for (int i = 0; i < ng; ++i) {
+    w.first_wg[i] = (short)nwg;
+    const long sp = (long)kSplitPerKb * w.strip[w.first_strip[i]].nkb;
+    nwg += (int)(sp < npairs ? sp : npairs);             // (never more splits than tile pairs)
+  }
+  w.first_wg[ng] = (short)nwg, w.nwgs = nwg;
   GradPtrs g;
   for (int i = 0; i < 22; ++i) g.p[i] = const_cast<float*>(gp[i]);
-  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(cdiv((long)ns * w.nsplit, 4)), dim3(256), 0, st, w);
-  hipLaunchKernelGGL(rows_wgrad_finish_kernel, dim3(ns), dim3(256), 0, st, w, g);
+  hipLaunchKernelGGL(rows_wgrad_kernel, dim3(nwg), dim3(256), 0, st, w);
+  hipLaunchKernelGGL(rows_wgrad_finish_kernel, dim3(ns, kMaxKB + 1), dim3(256), 0, st, w, g);
   BMV_LAUNCH_END("bmv_mvs_mlp_train_bwd");
 }
 
