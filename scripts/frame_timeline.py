@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """One steady-state frame of a rocprofv3 kernel trace, launch by launch: start offset, duration, gap to the previous
 end, workgroups, threads, LDS -- the view that shows which short launches leave the chip idle.
-    python scripts/frame_timeline.py <kernel_trace.csv> [--marker render_rays_kernel] [--frame -2]"""
+    python scripts/frame_timeline.py <kernel_trace.csv> [--marker render_pc_kernel,render_rays_kernel] [--frame -2]"""
 import argparse
 import csv
 
 ap = argparse.ArgumentParser()
 ap.add_argument("trace")
-ap.add_argument("--marker", default="render_rays_kernel")
+ap.add_argument("--marker", default="render_pc_kernel,render_rays_kernel",
+                help="comma-separated kernel-name fragments; the last launch of a frame matches one of them")
 ap.add_argument("--frame", type=int, default=-2)
 a = ap.parse_args()
 rows = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if any(m in r["Kernel_Name"] for m in a.marker.split(","))]
 lo, hi = marks[a.frame - 1] + 1, marks[a.frame] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 prev_end = t0
