@@ -68,7 +68,9 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
  * the layout, 1 = reference-layout direct gather (feat_layout 0), 2 = channel-last direct
  * gather, 3 = channel-last LDS-staged corner windows (round 1), 4 = channel-last LDS-staged exact windows
  * (sweep_win.hip: the default for C in {16, 32}), 5 = channel-last split-geometry gather; 40 + i = tuning variant i of
- * algo 4 (2..5 and 40+ need feat_layout 1). */
+ * algo 4; round 3 (measured experiments, parity-tested, not the default): 6 / 100 + i = persistent ring of LDS windows
+ * (sweep_ring.hip), 7 / 200 + i = zero-padded windows (sweep_zp.hip; BMV_SWEEP_ZP=1 makes it algo 0), 300 + i = the
+ * same with plane-uniform hypotheses detected from depth_values (2..7 and 40+ need feat_layout 1). */
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
                            bmv_stream_t stream);
