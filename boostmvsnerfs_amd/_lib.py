@@ -103,6 +103,7 @@ SIGNATURES = {
     "bmv_depth_regress_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_depth_values_cascade_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_sweep_variance_bwd_cl": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_nerf_bwd_blob_size": [c_i],
     "bmv_nerf_bwd_rows": [c_i, C.POINTER(C.c_int)],
     "bmv_nerf_pack_bwd_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],

@@ -6,6 +6,7 @@ Everything runs on torch's current stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -714,12 +715,27 @@ def depth_values_cascade_bwd(depth, std, near_far, d_dv):
     return d_depth, d_std
 
 
-def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad):
+def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad, algo=None):
+    """d variance -> (d feats (B,S,C,Hs,Ws), d depth_values or None).  algo None / "cl": for S = 3 and C in {16, 32} the
+    channel-last kernel (csrc/sweep_bwd_cl.hip: the gradient is accumulated channel-last with the channel on the lane
+    and handed back as a (B,S,C,Hs,Ws) VIEW of that buffer); "planar" (or BMV_SWEEP_BWD=planar): the LDS-window kernel
+    on the reference layout."""
     B, S, C_, Hs, Ws = feats.shape
     _, D, h, w = depth_values.shape
+    lib = _lib.load()
+    if algo is None:
+        algo = os.environ.get("BMV_SWEEP_BWD", "cl")
+    if algo == "cl" and S == 3 and C_ in (16, 32):
+        cl = feats.permute(0, 1, 3, 4, 2)
+        cl = cl if cl.is_contiguous() else nchw_to_nhwc(feats)
+        d_cl = torch.zeros(B, S, Hs, Ws, C_, device=feats.device, dtype=torch.float32)
+        d_dv = torch.empty_like(depth_values, memory_format=torch.contiguous_format) if want_depth_grad else None
+        _lib.check(lib.bmv_sweep_variance_bwd_cl(dptr(cl, "feats_cl"), dptr(_c(proj), "proj"),
+                                                 dptr(_c(depth_values), "depth_values"), dptr(_c(d_var), "d_var"), B, S, C_,
+                                                 Hs, Ws, D, h, w, dptr(d_cl), dptr(d_dv), stream()), "sweep_variance_bwd_cl")
+        return d_cl.permute(0, 1, 4, 2, 3), d_dv
     d_feats = torch.zeros_like(feats, memory_format=torch.contiguous_format)
     d_dv = torch.zeros_like(depth_values) if want_depth_grad else None
-    lib = _lib.load()
     _lib.check(lib.bmv_sweep_variance_bwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
                                           dptr(_c(depth_values), "depth_values"), dptr(_c(d_var), "d_var"), B, S, C_,
                                           Hs, Ws, D, h, w, dptr(d_feats), dptr(d_dv), stream()), "sweep_variance_bwd")

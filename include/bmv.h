@@ -227,6 +227,14 @@ int bmv_depth_values_cascade_bwd(const float* depth, const float* std, const flo
 int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_variance,
                            int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
                            float* d_depth_values, bmv_stream_t stream);
+/* The same gradient on CHANNEL-LAST tensors (round 3): feats_cl (B,S,Hs,Ws,C) in, d_feats_cl (B,S,Hs,Ws,C) accumulated
+ * (zero it first) with the channel on the lane -- >= 16 consecutive channels of a tap per atomic instruction run at
+ * 330 G lane-atomics/s against 116 G/s for a planar gradient and 203 G/s through an LDS window
+ * (scripts/ubench/atomic_rate.hip).  S = 3, C in {16, 32}.  d_depth_values (B,D,h,w) is WRITTEN (not accumulated) or
+ * NULL. */
+int bmv_sweep_variance_bwd_cl(const float* feats_cl, const float* proj, const float* depth_values,
+                              const float* d_variance, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                              float* d_feats_cl, float* d_depth_values, bmv_stream_t stream);
 
 /* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89), three launches on `stream`:
  *   1. the data path: the forward of every 32-sample tile is recomputed and back-propagated on the matrix cores;

@@ -1,9 +1,13 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3s
-timeout 300 python -m pytest tests/test_gpu_mvs.py tests/test_gpu_configs34.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | grep -v "^  File\|^Extension" | tail -12
-for aux in 2 0; do
-BMV_MVS_SWEEP_AUX=$aux timeout 600 python bench.py --workload mvsnerf_ours_224x352_128planes_k4 --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print('aux $aux value', round(d['value'],3), 'sweep', {k:(round(v,3) if isinstance(v,float) else v) for k,v in d['roofline'].items() if k in ('avg_us','frac')})"
-done
+set -u
+R=$(pwd); O=$R/gpurun_out/r3s; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_sb
+rocprofv3 --kernel-trace --stats -d /tmp/prof_sb --output-format csv -- python3 $R/scripts/bench_sweep_bwd.py > $O/prof_run.txt 2>&1
+T=$(ls /tmp/prof_sb/*/*kernel_trace.csv | head -1)
+python3 - <<PY
+import csv, collections
+rows=[r for r in csv.DictReader(open("$T")) if "sweep_bwd" in r["Kernel_Name"]]
+for r in rows:
+    print(r["Kernel_Name"][:60], r["Grid_Size_X"], (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+PY

@@ -135,3 +135,24 @@ def test_sweep_bwd(enerf_fx):
         (A.SweepVariance.apply(fg, P.to(DEV), dg) * g.to(DEV)).sum().backward()
         assert_close(fg.grad, f.grad, name=f"d_feats{lvl}", **GTOL)
         assert_close(dg.grad, d.grad, name=f"d_depth_values{lvl}", rtol=5e-3, atol_scale=5e-3)
+        # both kernels (default: channel-last gradient with the channel on the lane; "planar": LDS windows on the
+        # reference layout) against the oracle, called directly, with and without the depth gradient
+        from boostmvsnerfs_amd import ops
+        for algo in ("cl", "planar"):
+            for want in (True, False):
+                df, ddv = ops.sweep_variance_bwd(feats[lvl].to(DEV), P.to(DEV), dv.to(DEV), g.to(DEV), want, algo=algo)
+                assert_close(df, f.grad, name=f"d_feats{lvl} [{algo}]", **GTOL)
+                assert (ddv is None) == (not want)
+                if want:
+                    assert_close(ddv, d.grad, name=f"d_depth_values{lvl} [{algo}]", rtol=5e-3, atol_scale=5e-3)
+        assert not ops.sweep_variance_bwd(feats[lvl].to(DEV), P.to(DEV), dv.to(DEV), g.to(DEV), False)[0].is_contiguous()   # cl ran
+    # ragged: a voxel count that is not a multiple of the 64-voxel wave tile, rays leaving the source maps
+    P, dv = enerf_fx.t("cap/get_proj_mats#1"), enerf_fx.t("cap/get_depth_values#1.0")
+    dv2 = (dv[:, :3, :5, :7] * 1.7).contiguous()
+    g2 = torch.randn(1, feats[1].shape[2], 3, 5, 7)
+    f, d = leaf(feats[1]), leaf(dv2)
+    (O.variance_volume(f, P, d) * g2).sum().backward()
+    from boostmvsnerfs_amd import ops
+    df, ddv = ops.sweep_variance_bwd(feats[1].to(DEV), P.to(DEV), dv2.to(DEV), g2.to(DEV), True, algo="cl")
+    assert_close(df, f.grad, name="ragged d_feats", **GTOL)
+    assert_close(ddv, d.grad, name="ragged d_depth_values", rtol=5e-3, atol_scale=5e-3)
