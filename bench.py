@@ -456,6 +456,7 @@ def main():
         # the batch copied from pinned host memory each step, with the rays copied too / built on the device instead
         host = {k: v.cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
         ray_keys = [k for k in host if k.startswith("rays_")]
+        resident = {k: batch[k] for k in host}          # the tensor objects the forward's graph was captured on
 
         def from_host(device_rays):
             def fn():
@@ -473,11 +474,10 @@ def main():
             extra[name] = {"value": N / t_h / 1e6, "ms_per_step": t_h * 1e3,
                            "what": "run.py bracket incl. the host->device copy of the batch (PCIe), eager forward"
                                    + ("; rays built on the device (bmv_make_rays) instead of copied" if dr else "")}
-        for k, v in host.items():                       # leave the resident batch as the graphs captured it
-            if k not in batch:
-                batch[k] = torch.empty_like(v, device=dev)
-            batch[k].copy_(v)
-        torch.cuda.synchronize()
+        for k, v in host.items():                       # leave the resident batch as the graphs captured it: the SAME
+            batch[k] = resident[k]                      # tensor objects (the device-rays leg replaced batch['rays_i'] by
+            batch[k].copy_(v)                           # tensors built on the device, which a later capture would rebuild
+        torch.cuda.synchronize()                        # inside every frame: +15 us of make_rays per step)
 
     import gc
     gc.collect()
