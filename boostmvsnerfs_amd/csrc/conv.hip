@@ -549,6 +549,7 @@ struct FpnSmoothArgs {
   float* packed;        // (B, H, W, 12) lookup records of the fused renderer: [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0]
   int B, C, Cout, H, W;
   float slope;
+  int ntiles;           // tiles in all; the grid may be smaller (persistent form: a workgroup walks tiles gridDim.x apart)
 };
 
 template <int R>
@@ -561,7 +562,8 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
   __shared__ float cl[2][4][CN];
   const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
   const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY;
-  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  int bid = xcd_contiguous(tile, a.ntiles);
   const int tx = bid % ntx;
   bid /= ntx;
   const int ty = bid % nty;
@@ -674,12 +676,12 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
   const int x = x0 + (lane & 15);
   const int g = lane >> 4;
   const int co0 = 4 * (g & 1);
-  if (x >= a.W || co0 >= a.Cout) return;
+  const bool live = x < a.W && co0 < a.Cout;
   float bs[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bs[j] = a.bias[co0 + j];
+  for (int j = 0; j < 4; ++j) bs[j] = a.bias[live ? co0 + j : 0];
   const int ybase = y0 + rg * R;
-  if (a.packed) {
+  if (live && a.packed) {
     // one record per pixel, everything a bilinear tap of the renderer needs from this view: the wpack rows were
     // permuted on the host so that MFMA rows 0-3 are channels 0 2 4 6 and rows 4-7 channels 1 3 5 7 (the two lane
     // halves of the renderer's MLP take even / odd channels); the source colours ride along
@@ -705,8 +707,7 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
         c.x = cp[(size_t)hw + pix], c.y = 0.f;
       *reinterpret_cast<float2*>(rec + 8 + 2 * q) = c;
     }
-    return;
-  }
+  } else if (live) {
 #pragma unroll
   for (int r = 0; r < T::NACC; ++r) {
     const int y = ybase + 2 * r + (g >> 1);
@@ -719,6 +720,8 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
       if (co0 + j < a.Cout) a.out[o + (size_t)j * hw] = v;
     }
   }
+  }
+  }   // tile loop (the k loop above ends with a barrier: the next tile may overwrite LDS)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1382,13 +1385,20 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
   a.rgb = rgb, a.packed = packed_out;
   a.B = B, a.C = C, a.Cout = Cout, a.H = H, a.W = W, a.slope = act_slope;
   static const int rows = getenv("BMV_FPN_SMOOTH_R") ? atoi(getenv("BMV_FPN_SMOOTH_R")) : 8;
+  // BMV_FPN_SMOOTH_PERSIST=n: at most n workgroups per CU, each walking several tiles -- leaves registers for the short
+  // launches of the level-0 regulariser that run beside this kernel on the second stream
+  static const int persist = getenv("BMV_FPN_SMOOTH_PERSIST") ? atoi(getenv("BMV_FPN_SMOOTH_PERSIST")) : 0;
   hipStream_t st = as_stream(stream);
   if (rows == 4) {
     using T = ConvTile<1, 3, 1, 1, 4, 0, true>;
-    hipLaunchKernelGGL(fpn_smooth_kernel<4>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+    a.ntiles = cdiv(W, 16) * cdiv(H, T::TY) * B;
+    const int grid = persist > 0 ? min(a.ntiles, persist * 256) : a.ntiles;
+    hipLaunchKernelGGL(fpn_smooth_kernel<4>, dim3(grid), dim3(256), 0, st, a);
   } else {
     using T = ConvTile<1, 3, 1, 1, 8, 0, true>;
-    hipLaunchKernelGGL(fpn_smooth_kernel<8>, dim3(cdiv(W, 16) * cdiv(H, T::TY) * B), dim3(256), 0, st, a);
+    a.ntiles = cdiv(W, 16) * cdiv(H, T::TY) * B;
+    const int grid = persist > 0 ? min(a.ntiles, persist * 256) : a.ntiles;
+    hipLaunchKernelGGL(fpn_smooth_kernel<8>, dim3(grid), dim3(256), 0, st, a);
   }
   BMV_LAUNCH_END("fpn_smooth_fwd");
 }

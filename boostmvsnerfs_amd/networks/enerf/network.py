@@ -280,7 +280,7 @@ class Network(nn.Module):
         c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
         main = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))
         side = self._side_stream
         level0 = p2_cl.reshape(B, V, -1, H // 4, W // 4)
         if self.overlap_front == 2:
@@ -351,7 +351,7 @@ class Network(nn.Module):
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         st0 = None
         if self._side_stream is None and batch["src_inps"].is_cuda:
-            self._side_stream = torch.cuda.Stream()          # created outside any capture
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))   # created outside any capture
         self.feature_net.pack_lookup = self.wants_lookup_records() and engine_ok(self.feature_net, batch["src_inps"])
         self.set_volume_records(self.feature_net.pack_lookup)
         try:
