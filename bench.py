@@ -474,6 +474,21 @@ def main():
             extra[name] = {"value": N / t_h / 1e6, "ms_per_step": t_h * 1e3,
                            "what": "run.py bracket incl. the host->device copy of the batch (PCIe), eager forward"
                                    + ("; rays built on the device (bmv_make_rays) instead of copied" if dr else "")}
+        if args.graph and hasattr(net, "_autograph") and not args.all_kernel_events:
+            # ... and what an unchanged run.py loop gets: every frame a NEW set of device tensors (`batch[k].cuda()`,
+            # run.py:114-116) handed to net(batch), which copies them into its captured buffers and replays
+            meta = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
+
+            def run_py_frame():
+                fresh = dict(meta)
+                for k, v in host.items():
+                    fresh[k] = v.to(dev, non_blocking=True)
+                with torch.no_grad():
+                    return finish(net(fresh))
+            t_h = bracketed(run_py_frame, n_x)
+            extra["host_batch_sync"] = {"value": N / t_h / 1e6, "ms_per_step": t_h * 1e3,
+                                        "what": "run.py bracket incl. the host->device copy of the batch (PCIe) into NEW device "
+                                                "tensors every frame, net(batch) = copy into the captured buffers + graph replay"}
         for k, v in host.items():                       # leave the resident batch as the graphs captured it: the SAME
             batch[k] = resident[k]                      # tensor objects (the device-rays leg replaced batch['rays_i'] by
             batch[k].copy_(v)                           # tensors built on the device, which a later capture would rebuild

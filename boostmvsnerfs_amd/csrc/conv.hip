@@ -1148,6 +1148,8 @@ static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
         if (!IS3D && a.Cin <= 8) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
         static const int r3d = getenv("BMV_CONV_PAIR_ROWS") ? atoi(getenv("BMV_CONV_PAIR_ROWS")) : 0;   // tuning
         if (r3d == 4) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
+        // 5: half-height tiles only where the full-height grid is below 4 workgroups per CU (level 0's 640)
+        if (r3d == 5 && conv_blocks<KD, K, S, 1, RB, MB, true>(a) < 1024) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
         return launch_conv<KD, K, S, 1, RB, MB, true>(a, st);
       }
       return launch_conv<KD, K, S, 1, 2, MS, true>(a, st);
