@@ -135,7 +135,7 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     loss.backward()
     # K-volume path: a sample whose viewport test lands on the other side of the mask threshold than the oracle's
     # (the forward tests budget 0.2 % such flips, test_gpu_boost.py) shifts the weight-gradient SUMS it feeds; measured
-    # (scripts/grad_flake_probe.py): worst entry 0.96 x tolerance on nerf_1.color.0.weight, the same to ~1e-7 from run to
+    # (tests/tools/grad_flake_probe.py): worst entry 0.96 x tolerance on nerf_1.color.0.weight, the same to ~1e-7 from run to
     # run (the scatter kernels and two 1-wide head gradients add with float atomics: not bit-reproducible) --
     # so a change of MIOpen's convolution algorithm on a fresh box can tip single entries over.  Budget: 0.2 % of the
     # entries of a tensor, none beyond 3 x the tolerance.

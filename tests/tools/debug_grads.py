@@ -1,6 +1,6 @@
 import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from conftest import load_fixture, tiny_cfg
 from boostmvsnerfs_amd.config import set_cfg

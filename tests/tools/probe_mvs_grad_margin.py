@@ -1,5 +1,5 @@
 import sys, os, json, tempfile, torch
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
 from conftest import load_fixture
 import test_gpu_mvs as T
