@@ -339,6 +339,10 @@ def main():
             with torch.no_grad():
                 return finish(net(batch))           # the drop-in call: replays its own HIP graph from the 2nd call on
 
+        def step_plain():
+            with torch.no_grad():
+                return finish(net(batch))
+
         _eager_call = getattr(net, "_forward_checked", net)    # the same frame as ~42 eager launches (BMV_AUTOGRAPH=0)
 
         def eager_only_step():
@@ -371,6 +375,7 @@ def main():
     # as the GPU needs to run them).  The plane sweeps stay ordinary launches between the graphs so the HIP events
     # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
+    split_frame = None
     if not wl.get("train"):
         graphed_train = None
     eager_step = step
@@ -489,6 +494,26 @@ def main():
             extra["host_batch_sync"] = {"value": N / t_h / 1e6, "ms_per_step": t_h * 1e3,
                                         "what": "run.py bracket incl. the host->device copy of the batch (PCIe) into NEW device "
                                                 "tensors every frame, net(batch) = copy into the captured buffers + graph replay"}
+        if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
+                and all(hasattr(net, f"cost_reg_{i}") for i in range(cc.num))):
+            # EXPERIMENT, not the metric: the regularisers' first layers and heads (4 of the frame's 30 convolutions) on
+            # the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip; 2^-16 per product, fp32 accumulation)
+            for i in range(cc.num):
+                getattr(net, f"cost_reg_{i}").split_bf16 = True
+            try:
+                for _ in range(3):                      # eager, capture, first replay of the new configuration
+                    step_plain()
+                torch.cuda.synchronize()
+                t_s = bracketed(step_plain, max(n_x, 50))
+                with torch.no_grad():
+                    split_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
+                extra["split_bf16_first_last_layers"] = {
+                    "value": N / t_s / 1e6, "ms_per_step": t_s * 1e3,
+                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads as three bf16 MFMAs per product group "
+                            "(BMV_CONV_SPLIT=1); `parity_max_rel_split` below is its frame against the oracle's"}
+            finally:
+                for i in range(cc.num):
+                    getattr(net, f"cost_reg_{i}").split_bf16 = False
         for k, v in host.items():                       # leave the resident batch as the graphs captured it: the SAME
             batch[k] = resident[k]                      # tensor objects (the device-rays leg replaced batch['rays_i'] by
             batch[k].copy_(v)                           # tensors built on the device, which a later capture would rebuild
@@ -698,6 +723,14 @@ def main():
                 line["parity_max_rel"] = {"per_output": par, "max": max(par.values()) if par else None,
                                           "against": "oracle/enerf.py enerf_forward on the same weights and batch (the cpu_baseline frame)",
                                           "tolerance": 1e-3}
+                if split_frame is not None:       # the split-bf16 experiment's frame against the same oracle frame
+                    ps = {}
+                    for k, want in ref.items():
+                        if k in split_frame and torch.is_tensor(want):
+                            g = split_frame[k].reshape(want.shape)
+                            rms = float(want.pow(2).mean().sqrt())
+                            ps[k] = float(((g - want).abs() / (want.abs() + rms + 1e-30)).max())
+                    line["parity_max_rel_split"] = {"per_output": ps, "max": max(ps.values()) if ps else None}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -225,6 +225,9 @@ class _CostReg(nn.Module):
         self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
         self._packed = _Packed()
         self.volume_records = False   # engine path: emit the feature volume as the renderer's voxel records
+        # experiment (csrc/conv_split.hip, BMV_CONV_SPLIT=1 or set per module): first layer and heads on the bf16 matrix
+        # cores with split fp32 operands
+        self.split_bf16 = convnet.SPLIT_BF16
 
     def _apply(self, fn, *args, **kwargs):
         self._packed.invalidate()
@@ -243,12 +246,20 @@ class _CostReg(nn.Module):
             P["heads"] = convnet.pack_conv(heads, None)
             # the same layer with its output channels in the order of the renderer's volume records
             P["heads_rec"] = convnet.pack_conv(heads[list(convnet.VolumeRecords.ORDER)], None)
+            if True:                 # (39 KB per regulariser; used when self.split_bf16)
+                P["conv0_split"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn))
+                P["heads_split"] = convnet.pack_conv_split(heads, None)
+                P["heads_rec_split"] = convnet.pack_conv_split(heads[list(convnet.VolumeRecords.ORDER)], None)
             return P
         return self._packed.get(self, build)
 
     def _forward_engine(self, x):
         P = self.prepack()
-        s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
+        split = self.split_bf16 and x.shape[-1] % 4 == 0
+        if split:
+            s0 = convnet.conv3d_split_fwd(x, *P["conv0_split"], 8, relu=True)
+        else:
+            s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
         s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)
         s2 = convnet.conv_fwd(convnet.conv_fwd(s1, *P["conv3"], 32, 3, 3, 2, relu=True), *P["conv4"], 32, 3, 3, relu=True)
         y = s2
@@ -258,7 +269,12 @@ class _CostReg(nn.Module):
         y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
         y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
+            if split:
+                return convnet.conv3d_split_heads_records(y, *P["heads_rec_split"])
             return convnet.conv_heads_records(y, *P["heads_rec"])
+        if split:
+            heads = convnet.conv3d_split_fwd(y, *P["heads_split"], 9)
+            return heads[:, :8], heads[:, 8]
         heads = convnet.conv_fwd(y, *P["heads"], 9, 3, 3)
         return heads[:, :8], heads[:, 8]
 

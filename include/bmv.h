@@ -465,6 +465,18 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
                        const float* wpack, const float* bias, float* out, const float* rgb, float* packed_out, int B,
                        int Cf, int C, int Cout, int H, int W, float act_slope, bmv_stream_t stream);
 
+/* ---- EXPERIMENT (round 3, opt-in BMV_CONV_SPLIT=1): 3x3x3 stride-1 convolution on the BF16 matrix cores with split
+ * fp32 operands (hi + lo, three bf16 MFMAs per product group: <= 2^-16 relative per product, fp32 accumulation).
+ * ConvBnReLU3D of cost_reg_net.py:4-86 with Cin % 8 == 0 and Cout <= 16; in / out planar fp32 like bmv_conv_fwd.
+ * wsplit: bmv_conv3d_split_wsplit_ints(Cin) int32, [octet][step 7][part hi|lo][lane 64][4] (convnet.pack_conv_split). */
+int bmv_conv3d_split_wsplit_ints(int Cin);
+int bmv_conv3d_split_fwd(const float* in, const int* wsplit, const float* bias, float* out, int B, int Cin, int D, int H,
+                         int W, int Cout, float act_slope, bmv_stream_t stream);
+/* the 9-channel head convolution in that form, with bmv_conv_heads_fwd's outputs (volume records + depth logits; the
+ * weights packed in record order) */
+int bmv_conv3d_split_heads_fwd(const float* in, const int* wsplit, const float* bias, float* records_out, float* depth_out,
+                               int B, int Cin, int D, int H, int W, bmv_stream_t stream);
+
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,
  * tar_ixt (B,3,3) at full resolution, render scale (rows 0-1 of the intrinsics are multiplied by it, :28-31) and the
