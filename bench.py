@@ -498,8 +498,9 @@ def main():
                 and all(hasattr(net, f"cost_reg_{i}") for i in range(cc.num))):
             # EXPERIMENT, not the metric: the regularisers' first layers and heads (4 of the frame's 30 convolutions) on
             # the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip; 2^-16 per product, fp32 accumulation)
+            split_was = [getattr(net, f"cost_reg_{i}").split_bf16 for i in range(cc.num)]
             for i in range(cc.num):
-                getattr(net, f"cost_reg_{i}").split_bf16 = True
+                getattr(net, f"cost_reg_{i}").split_bf16 = 2
             try:
                 for _ in range(3):                      # eager, capture, first replay of the new configuration
                     step_plain()
@@ -509,11 +510,12 @@ def main():
                     split_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
                 extra["split_bf16_first_last_layers"] = {
                     "value": N / t_s / 1e6, "ms_per_step": t_s * 1e3,
-                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads as three bf16 MFMAs per product group "
-                            "(BMV_CONV_SPLIT=1); `parity_max_rel_split` below is its frame against the oracle's"}
+                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads as THREE bf16 MFMAs per product group "
+                            "(two-piece split, 2^-16 per product: BMV_CONV_SPLIT=2); `parity_max_rel_split` below is its "
+                            "frame against the oracle's"}
             finally:
                 for i in range(cc.num):
-                    getattr(net, f"cost_reg_{i}").split_bf16 = False
+                    getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
         for k, v in host.items():                       # leave the resident batch as the graphs captured it: the SAME
             batch[k] = resident[k]                      # tensor objects (the device-rays leg replaced batch['rays_i'] by
             batch[k].copy_(v)                           # tensors built on the device, which a later capture would rebuild

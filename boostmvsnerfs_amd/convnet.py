@@ -53,59 +53,68 @@ def pack_conv(weight, bias, stride=1, allow_pair=True):
     return wpack, b
 
 
-def pack_conv_split(weight, bias):
-    """EXPERIMENT (BMV_CONV_SPLIT=1, csrc/conv_split.hip): weight (Cout <= 16, Cin % 8 == 0, 3, 3, 3) -> the split-bf16 A
-    operands of bmv_conv3d_split_fwd, int32 [octet][step 7][part hi|lo][lane 64][4]: lane = 16 * (tap % 4) + cout, the 8
-    bf16 of a lane = the 8 channels of the octet at tap 4 * step + lane // 16; hi = upper 16 bits of the fp32 weight,
-    lo = bf16(w - hi) rounded to nearest even.  Returns (wsplit, bias16)."""
+def pack_conv_split(weight, bias, parts=3):
+    """weight (Cout <= 16, Cin % 8 == 0, 3, 3, 3) -> the split-bf16 A operands of bmv_conv3d_split_fwd (csrc/conv_split.hip),
+    int32 [octet][step 7][part][lane 64][4]: lane = 16 * (tap % 4) + cout, the 8 bf16 of a lane = the 8 channels of the
+    octet at tap 4 * step + lane // 16.  parts = 3: hi / mid / lo = the three 8-bit pieces of the fp32 mantissa (exact);
+    parts = 2: hi = upper 16 bits, lo = bf16(w - hi) rounded to nearest even.  Returns (wsplit, bias16, parts)."""
     Cout, Cin = weight.shape[:2]
-    assert weight.shape[2:] == (3, 3, 3) and Cin % 8 == 0 and Cout <= 16
+    assert weight.shape[2:] == (3, 3, 3) and Cin % 8 == 0 and Cout <= 16 and parts in (2, 3)
     dev = weight.device
     w = torch.zeros(16, Cin, 28, device=dev, dtype=torch.float32)
     w[:Cout, :, :27] = weight.detach().reshape(Cout, Cin, 27).float()
     w = w.view(16, Cin // 8, 8, 7, 4).permute(1, 3, 4, 0, 2).reshape(Cin // 8, 7, 64, 8).contiguous()   # (o, g, kk*16+m, c)
-    bits = w.view(torch.int32)
-    hi_bits = bits & -65536
-    lo16 = (w - hi_bits.view(torch.float32)).to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
-    hi16 = (hi_bits >> 16) & 0xFFFF
+    trunc = lambda t: (t.view(torch.int32) & -65536).view(torch.float32)
+    top16 = lambda t: (t.view(torch.int32) >> 16) & 0xFFFF
+    rne16 = lambda t: t.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+    pieces, r = [], w
+    for i in range(parts):
+        if i + 1 < parts:
+            h = trunc(r)
+            pieces.append(top16(h))
+            r = r - h
+        else:
+            pieces.append(rne16(r))
     pack = lambda t: t[..., 0::2] | (t[..., 1::2] << 16)
-    wsplit = torch.stack([pack(hi16), pack(lo16)], 2).contiguous()                                      # (o, g, 2, 64, 4)
+    wsplit = torch.stack([pack(t) for t in pieces], 2).contiguous()                                     # (o, g, P, 64, 4)
     b = torch.zeros(16, device=dev, dtype=torch.float32)
     if bias is not None:
         b[:Cout] = bias.detach().float()
-    return wsplit, b
+    return wsplit, b, parts
 
 
-def conv3d_split_fwd(x, wsplit, bias, Cout, relu=False, slope=None, out=None):
+def conv3d_split_fwd(x, wsplit, bias, parts, Cout, relu=False, slope=None, out=None):
     """x (B,Cin,D,H,W) -> act(conv3d(x, k=3, padding=1) + bias) on the split-bf16 path (see pack_conv_split)."""
     B, Cin, D, H, W = x.shape
     lib = _lib.load()
-    assert wsplit.numel() == lib.bmv_conv3d_split_wsplit_ints(Cin) and wsplit.dtype == torch.int32
+    assert wsplit.numel() == lib.bmv_conv3d_split_wsplit_ints(Cin, parts) and wsplit.dtype == torch.int32
     if out is None:
         out = torch.empty(B, Cout, D, H, W, device=x.device, dtype=torch.float32)
     x = x if x.is_contiguous() else x.contiguous()
-    with ktimer.region(f"conv_split[{Cin}->{Cout},{D}x{H}x{W}]"):
-        rc = lib.bmv_conv3d_split_fwd(dptr(x, "conv input"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out), B, Cin,
-                                      D, H, W, Cout, _slope(relu, slope), stream())
+    with ktimer.region(f"conv_split{parts}[{Cin}->{Cout},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv3d_split_fwd(dptr(x, "conv input"), dptr(wsplit, "wsplit", torch.int32), parts, dptr(bias, "bias"),
+                                      dptr(out), B, Cin, D, H, W, Cout, _slope(relu, slope), stream())
     _lib.check(rc, "conv3d_split_fwd")
     return out
 
 
-def conv3d_split_heads_records(x, wsplit, bias):
+def conv3d_split_heads_records(x, wsplit, bias, parts):
     """conv_heads_records on the split-bf16 path (weights packed with pack_conv_split in VolumeRecords.ORDER)."""
     B, Cin, D, H, W = x.shape
     rec = torch.empty(B, D, H, W, 8, device=x.device, dtype=torch.float32)
     dp = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
     x = x if x.is_contiguous() else x.contiguous()
     lib = _lib.load()
-    with ktimer.region(f"conv_split[{Cin}->9 records,{D}x{H}x{W}]"):
-        rc = lib.bmv_conv3d_split_heads_fwd(dptr(x, "conv input"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"),
+    with ktimer.region(f"conv_split{parts}[{Cin}->9 records,{D}x{H}x{W}]"):
+        rc = lib.bmv_conv3d_split_heads_fwd(dptr(x, "conv input"), dptr(wsplit, "wsplit", torch.int32), parts, dptr(bias, "bias"),
                                             dptr(rec), dptr(dp), B, Cin, D, H, W, stream())
     _lib.check(rc, "conv3d_split_heads_fwd")
     return VolumeRecords(rec), dp
 
 
-SPLIT_BF16 = os.environ.get("BMV_CONV_SPLIT", "0") == "1"
+# 0: fp32 MFMA engine; 3: three bf16 pieces per operand / six MFMAs per product group (fp32-equivalent); 2: two pieces /
+# three MFMAs (2^-16 per product: the opt-in experiment)
+SPLIT_BF16 = int(os.environ.get("BMV_CONV_SPLIT", "0"))
 
 
 _ZERO_BIAS = {}

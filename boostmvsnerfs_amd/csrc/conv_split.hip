@@ -32,7 +32,7 @@ struct ConvSplitArgs {
   float* depth_out;     // (B, D, H, W): heads form -- channels 0..7 -> one 32-byte record per voxel, channel 8 -> here
   int B, Cin, Cout, D, H, W;
   float slope;
-};
+};   // wsplit: [octet][step 7][part P][lane 64][4 dwords], P = 2 (hi, lo) or 3 (hi, mid, lo)
 
 constexpr int kTY = 8, kTX = 32, kIY = kTY + 2, kIX = kTX + 2, kPlane = kIY * kIX;   // 340 positions per input plane
 constexpr int kGX = (kTX + 8) / 4;                                                   // aligned 4-pixel groups per row: 10
@@ -51,10 +51,17 @@ __device__ __forceinline__ float trunc_bf16(float v) {
 }
 
 // TZ output planes per workgroup (input planes TZ + 2: the z halo is read (TZ + 2) / TZ times instead of 3 times)
-template <int TZ>
+// P parts per operand: 2 = hi + lo, products hh, hl, lh (2^-16 per product); 3 = hi + mid + lo (the 24 bits of an fp32
+// mantissa in three bf16 pieces: x is represented EXACTLY), products hh, hm, mh, hl, mm, lh -- what is dropped (ml, lm, ll)
+// is <= 3 x 2^-24 of the product, the size of an fp32 rounding
+// (Tried and dropped: 4 MFMA waves + 4 staging waves per workgroup with a double-buffered tile -- 88 / 108 us for the
+// level-1 first layer against 55 / 78: the kernel is bound by the latency of staging, and half the threads staging with
+// one workgroup per CU is worse than three whole workgroups taking turns.)
+template <int TZ, int P>
 __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
   constexpr int NPL = TZ + 2, kPos = NPL * kPlane, NG = NPL * kIY * kGX, NSLOT = (NG + 255) / 256, NQ = 4 * TZ;
-  __shared__ i32x4 hi[kPos], lo[kPos];
+  extern __shared__ i32x4 part_raw[];                      // [P][kPos]
+  auto part = [&](int q) { return part_raw + (long)q * kPos; };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kk = lane >> 4;
   const int ntx = (a.W + kTX - 1) / kTX, nty = (a.H + kTY - 1) / kTY;
@@ -84,6 +91,9 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
     pos0[i] = s < NG ? pz * kPlane + py * kIX + 4 * gi - 3 : -1000000;
   }
   const unsigned cstride = (unsigned)(vol * 4);
+  // (Tried and dropped: the next octet's loads kept in registers under the MFMAs -- 176-188 registers, two workgroups per
+  // CU instead of three: 75 us instead of 55 for the level-1 first layer.  Whole workgroups taking turns hide the
+  // staging latency better than a deeper pipeline inside one.)
   auto stage = [&](int oct) {
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
@@ -95,14 +105,21 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int px = ((tid + 256 * i) % kGX) * 4 + e - 3;
         if (px < 0 || px >= kIX || pos0[i] <= -1000000) continue;
-        i32x4 h, l;
+        i32x4 pc[P];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float v0 = v[2 * j][e], v1 = v[2 * j + 1][e];
-          h[j] = (int)pack_hi(v0, v1);
-          l[j] = (int)pack_lo(v0 - trunc_bf16(v0), v1 - trunc_bf16(v1));
+          pc[0][j] = (int)pack_hi(v0, v1);
+          const float r0 = v0 - trunc_bf16(v0), r1 = v1 - trunc_bf16(v1);
+          if constexpr (P == 2) {
+            pc[1][j] = (int)pack_lo(r0, r1);
+          } else {
+            pc[1][j] = (int)pack_hi(r0, r1);
+            pc[2][j] = (int)pack_lo(r0 - trunc_bf16(r0), r1 - trunc_bf16(r1));
+          }
         }
-        hi[pos0[i] + e] = h, lo[pos0[i] + e] = l;
+#pragma unroll
+        for (int q = 0; q < P; ++q) part(q)[pos0[i] + e] = pc[q];
       }
     }
   };
@@ -127,19 +144,30 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
   for (int oct = 0; oct < nocts; ++oct) {
     stage(oct);
     __syncthreads();
-    const i32x4* __restrict__ wo = wp + (long)oct * kSteps * 2 * 64;
-    i32x4 wh = wo[0], wl = wo[64];
+    const i32x4* __restrict__ wo = wp + (long)oct * kSteps * P * 64;
+    i32x4 wn[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) wn[q] = wo[q * 64];
 #pragma unroll
     for (int g = 0; g < kSteps; ++g) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), al = __builtin_bit_cast(bf16x8, wl);
-      if (g + 1 < kSteps) wh = wo[(g + 1) * 128], wl = wo[(g + 1) * 128 + 64];
+      bf16x8 aw[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) aw[q] = __builtin_bit_cast(bf16x8, wn[q]);
+      if (g + 1 < kSteps) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) wn[q] = wo[((g + 1) * P + q) * 64];
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int p = pbase[q] + tapoff[g];
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, hi[p]), bl = __builtin_bit_cast(bf16x8, lo[p]);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[q], 0, 0, 0);
+        bf16x8 bx[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) bx[r] = __builtin_bit_cast(bf16x8, part(r)[p]);
+        // smallest terms first
+#pragma unroll
+        for (int sum = P - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[i], bx[sum - i], acc[q], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -177,24 +205,24 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
 
 extern "C" {
 
-int bmv_conv3d_split_wsplit_ints(int Cin) { return (Cin / 8) * bmv::kSteps * 2 * 64 * 4; }
+int bmv_conv3d_split_wsplit_ints(int Cin, int parts) { return (Cin / 8) * bmv::kSteps * parts * 64 * 4; }
 
-static int conv3d_split_launch(const float* in, const int* wsplit, const float* bias, float* out, float* depth_out, int B,
-                               int Cin, int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream);
+static int conv3d_split_launch(const float* in, const int* wsplit, int parts, const float* bias, float* out, float* depth_out,
+                               int B, int Cin, int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream);
 
-int bmv_conv3d_split_fwd(const float* in, const int* wsplit, const float* bias, float* out, int B, int Cin, int D, int H,
-                         int W, int Cout, float act_slope, bmv_stream_t stream) {
-  return conv3d_split_launch(in, wsplit, bias, out, nullptr, B, Cin, D, H, W, Cout, act_slope, stream);
+int bmv_conv3d_split_fwd(const float* in, const int* wsplit, int parts, const float* bias, float* out, int B, int Cin, int D,
+                         int H, int W, int Cout, float act_slope, bmv_stream_t stream) {
+  return conv3d_split_launch(in, wsplit, parts, bias, out, nullptr, B, Cin, D, H, W, Cout, act_slope, stream);
 }
 
-int bmv_conv3d_split_heads_fwd(const float* in, const int* wsplit, const float* bias, float* records_out, float* depth_out,
-                               int B, int Cin, int D, int H, int W, bmv_stream_t stream) {
+int bmv_conv3d_split_heads_fwd(const float* in, const int* wsplit, int parts, const float* bias, float* records_out,
+                               float* depth_out, int B, int Cin, int D, int H, int W, bmv_stream_t stream) {
   BMV_REQUIRE(depth_out, "conv3d_split_heads: null pointer");
-  return conv3d_split_launch(in, wsplit, bias, records_out, depth_out, B, Cin, D, H, W, 9, 1.f, stream);
+  return conv3d_split_launch(in, wsplit, parts, bias, records_out, depth_out, B, Cin, D, H, W, 9, 1.f, stream);
 }
 
-static int conv3d_split_launch(const float* in, const int* wsplit, const float* bias, float* out, float* depth_out, int B,
-                               int Cin, int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream) {
+static int conv3d_split_launch(const float* in, const int* wsplit, int parts, const float* bias, float* out, float* depth_out,
+                               int B, int Cin, int D, int H, int W, int Cout, float act_slope, bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(in && wsplit && bias && out, "conv3d_split: null pointer");
   BMV_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_split: bad shape");
@@ -204,17 +232,23 @@ static int conv3d_split_launch(const float* in, const int* wsplit, const float* 
   a.in = in, a.wsplit = wsplit, a.bias = bias, a.out = out, a.depth_out = depth_out;
   a.B = B, a.Cin = Cin, a.Cout = Cout, a.D = D, a.H = H, a.W = W, a.slope = act_slope;
   BMV_REQUIRE(W % 4 == 0, "conv3d_split: W %% 4 == 0 (16-byte staging loads; W=%d)", W);
+  BMV_REQUIRE(parts == 2 || parts == 3, "conv3d_split: parts must be 2 or 3 (got %d)", parts);
   static const int tz = getenv("BMV_CONV_SPLIT_TZ") ? atoi(getenv("BMV_CONV_SPLIT_TZ")) : 2;
-  if (tz == 1) {
-    const dim3 grid(cdiv(W, kTX) * cdiv(H, kTY) * D, B);
-    hipLaunchKernelGGL(conv3d_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), a);
-  } else if (tz == 4) {
-    const dim3 grid(cdiv(W, kTX) * cdiv(H, kTY) * cdiv(D, 4), B);
-    hipLaunchKernelGGL(conv3d_split_kernel<4>, grid, dim3(256), 0, as_stream(stream), a);
-  } else {
-    const dim3 grid(cdiv(W, kTX) * cdiv(H, kTY) * cdiv(D, 2), B);
-    hipLaunchKernelGGL(conv3d_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), a);
-  }
+  hipStream_t st = as_stream(stream);
+#define BMV_SPLIT_LAUNCH(TZV, PV)                                                                                        \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)PV * (TZV + 2) * kPlane * sizeof(i32x4);                                           \
+    BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_split_kernel<TZV, PV>),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,                 \
+                "conv3d_split: cannot reserve %zu B of LDS", lds);                                                       \
+    const dim3 grid(cdiv(W, kTX) * cdiv(H, kTY) * cdiv(D, TZV), B);                                                      \
+    hipLaunchKernelGGL((conv3d_split_kernel<TZV, PV>), grid, dim3(256), lds, st, a);                               \
+  } while (0)
+  if (tz == 1 && parts == 2) BMV_SPLIT_LAUNCH(1, 2);
+  else if (tz == 1) BMV_SPLIT_LAUNCH(1, 3);
+  else if (parts == 2) BMV_SPLIT_LAUNCH(2, 2);
+  else BMV_SPLIT_LAUNCH(2, 3);
+#undef BMV_SPLIT_LAUNCH
   BMV_LAUNCH_END("bmv_conv3d_split_fwd");
 }
 

@@ -225,8 +225,8 @@ class _CostReg(nn.Module):
         self.feat_conv = nn.Sequential(Conv3d(8, 8, 3, padding=1, bias=False))
         self._packed = _Packed()
         self.volume_records = False   # engine path: emit the feature volume as the renderer's voxel records
-        # experiment (csrc/conv_split.hip, BMV_CONV_SPLIT=1 or set per module): first layer and heads on the bf16 matrix
-        # cores with split fp32 operands
+        # first layer and heads on the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip): 0 = fp32 MFMA
+        # engine, 3 = three pieces / six MFMAs (fp32-equivalent), 2 = two pieces / three MFMAs (2^-16 per product)
         self.split_bf16 = convnet.SPLIT_BF16
 
     def _apply(self, fn, *args, **kwargs):
@@ -246,18 +246,18 @@ class _CostReg(nn.Module):
             P["heads"] = convnet.pack_conv(heads, None)
             # the same layer with its output channels in the order of the renderer's volume records
             P["heads_rec"] = convnet.pack_conv(heads[list(convnet.VolumeRecords.ORDER)], None)
-            if True:                 # (39 KB per regulariser; used when self.split_bf16)
-                P["conv0_split"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn))
-                P["heads_split"] = convnet.pack_conv_split(heads, None)
-                P["heads_rec_split"] = convnet.pack_conv_split(heads[list(convnet.VolumeRecords.ORDER)], None)
+            for parts in (2, 3):     # (csrc/conv_split.hip; used when self.split_bf16 == parts; < 100 KB per regulariser)
+                P[f"conv0_split{parts}"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn), parts=parts)
+                P[f"heads_split{parts}"] = convnet.pack_conv_split(heads, None, parts=parts)
+                P[f"heads_rec_split{parts}"] = convnet.pack_conv_split(heads[list(convnet.VolumeRecords.ORDER)], None, parts=parts)
             return P
         return self._packed.get(self, build)
 
     def _forward_engine(self, x):
         P = self.prepack()
-        split = self.split_bf16 and x.shape[-1] % 4 == 0
+        split = int(self.split_bf16) if x.shape[-1] % 4 == 0 else 0
         if split:
-            s0 = convnet.conv3d_split_fwd(x, *P["conv0_split"], 8, relu=True)
+            s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
         else:
             s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
         s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)
@@ -270,10 +270,10 @@ class _CostReg(nn.Module):
         y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:
-                return convnet.conv3d_split_heads_records(y, *P["heads_rec_split"])
+                return convnet.conv3d_split_heads_records(y, *P[f"heads_rec_split{split}"])
             return convnet.conv_heads_records(y, *P["heads_rec"])
         if split:
-            heads = convnet.conv3d_split_fwd(y, *P["heads_split"], 9)
+            heads = convnet.conv3d_split_fwd(y, *P[f"heads_split{split}"], 9)
             return heads[:, :8], heads[:, 8]
         heads = convnet.conv_fwd(y, *P["heads"], 9, 3, 3)
         return heads[:, :8], heads[:, 8]

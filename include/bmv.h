@@ -465,17 +465,20 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
                        const float* wpack, const float* bias, float* out, const float* rgb, float* packed_out, int B,
                        int Cf, int C, int Cout, int H, int W, float act_slope, bmv_stream_t stream);
 
-/* ---- EXPERIMENT (round 3, opt-in BMV_CONV_SPLIT=1): 3x3x3 stride-1 convolution on the BF16 matrix cores with split
- * fp32 operands (hi + lo, three bf16 MFMAs per product group: <= 2^-16 relative per product, fp32 accumulation).
- * ConvBnReLU3D of cost_reg_net.py:4-86 with Cin % 8 == 0 and Cout <= 16; in / out planar fp32 like bmv_conv_fwd.
- * wsplit: bmv_conv3d_split_wsplit_ints(Cin) int32, [octet][step 7][part hi|lo][lane 64][4] (convnet.pack_conv_split). */
-int bmv_conv3d_split_wsplit_ints(int Cin);
-int bmv_conv3d_split_fwd(const float* in, const int* wsplit, const float* bias, float* out, int B, int Cin, int D, int H,
-                         int W, int Cout, float act_slope, bmv_stream_t stream);
+/* ---- 3x3x3 stride-1 convolution on the BF16 matrix cores with SPLIT fp32 operands (round 3, csrc/conv_split.hip).
+ * parts = 3: x = hi + mid + lo, the 24 mantissa bits of an fp32 number in three bf16 pieces (exact); a product is the six
+ *   bf16 MFMAs hh, hm, mh, hl, mm, lh with fp32 accumulation -- the dropped terms are <= 3 x 2^-24 of it, the size of an
+ *   fp32 rounding: fp32-equivalent results at 96 instead of 256 matrix-core cycles per 32 k-values.
+ * parts = 2: hi + lo, three MFMAs, <= 2^-16 per product (opt-in experiment BMV_CONV_SPLIT=2; 48 cycles).
+ * ConvBnReLU3D of cost_reg_net.py:4-86 with Cin % 8 == 0, Cout <= 16, W % 4 == 0; in / out planar fp32 like bmv_conv_fwd.
+ * wsplit: bmv_conv3d_split_wsplit_ints(Cin, parts) int32, [octet][step 7][part][lane 64][4] (convnet.pack_conv_split). */
+int bmv_conv3d_split_wsplit_ints(int Cin, int parts);
+int bmv_conv3d_split_fwd(const float* in, const int* wsplit, int parts, const float* bias, float* out, int B, int Cin, int D,
+                         int H, int W, int Cout, float act_slope, bmv_stream_t stream);
 /* the 9-channel head convolution in that form, with bmv_conv_heads_fwd's outputs (volume records + depth logits; the
  * weights packed in record order) */
-int bmv_conv3d_split_heads_fwd(const float* in, const int* wsplit, const float* bias, float* records_out, float* depth_out,
-                               int B, int Cin, int D, int H, int W, bmv_stream_t stream);
+int bmv_conv3d_split_heads_fwd(const float* in, const int* wsplit, int parts, const float* bias, float* records_out,
+                               float* depth_out, int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
 /* ==== section 8(f) rank 4: target rays on the device ======================================================
  * `build_rays`, full-image branch (lib/datasets/enerf_utils.py:25-31, 62-71): tar_ext (B,4,4) world->camera,

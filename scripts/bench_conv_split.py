@@ -34,14 +34,16 @@ def main():
         x = torch.randn(1, cin, *dhw, device=dev)
         w = torch.randn(cout, cin, 3, 3, 3, device=dev) / (27 * cin) ** 0.5
         b = torch.randn(cout, device=dev)
-        p32, ps = convnet.pack_conv(w, b), convnet.pack_conv_split(w, b)
+        p32 = convnet.pack_conv(w, b)
         o32 = torch.empty(1, cout, *dhw, device=dev)
-        os_ = torch.empty_like(o32)
         t32 = timeit(lambda: convnet.conv_fwd(x, *p32, cout, 3, 3, relu=True, out=o32))
-        ts = timeit(lambda: convnet.conv3d_split_fwd(x, *ps, cout, relu=True, out=os_))
-        flop = 2 * 27 * cin * cout * x[0, 0].numel()
-        print(f"{name:15s} {cin:2d}->{cout:2d} {dhw}: fp32 engine {t32:6.1f} us   split bf16 {ts:6.1f} us   "
-              f"({flop / ts / 1e6:.1f} TFLOP/s useful)   max |d| {float((o32 - os_).abs().max()):.2e}", flush=True)
+        line = f"{name:15s} {cin:2d}->{cout:2d} {dhw}: fp32 engine {t32:6.1f} us"
+        for parts in (3, 2):
+            ps = convnet.pack_conv_split(w, b, parts=parts)
+            os_ = torch.empty_like(o32)
+            ts = timeit(lambda: convnet.conv3d_split_fwd(x, *ps, cout, relu=True, out=os_))
+            line += f"   {parts}-piece split {ts:6.1f} us (max |d| {float((o32 - os_).abs().max()):.1e})"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -395,21 +395,24 @@ def test_conv2d_training_module(cin, cout, k, stride, bias, hw):
         _close(m.bias.grad.double(), bd.grad, 1e-4)
 
 
+@pytest.mark.parametrize("parts", [3, 2])
 @pytest.mark.parametrize("cin,cout,dhw", [(16, 8, (8, 40, 72)), (32, 8, (5, 19, 52)), (8, 9, (3, 16, 36)), (16, 16, (2, 8, 32))])
-def test_conv3d_split_bf16_experiment(cin, cout, dhw):
-    """csrc/conv_split.hip (opt-in BMV_CONV_SPLIT=1): 3x3x3 convolution on the bf16 matrix cores with split fp32
-    operands (hi*hi + hi*lo + lo*hi, fp32 accumulation) against float64; the bound is 2^-16 per product, the observed
-    error ~1e-6 of the output scale (the fp32 engine is held to 2e-5 by the tests above)."""
+def test_conv3d_split_bf16(cin, cout, dhw, parts):
+    """csrc/conv_split.hip: 3x3x3 convolution on the bf16 matrix cores with split fp32 operands, fp32 accumulation, against
+    float64.  parts = 3 (hi + mid + lo: the operand exactly; six MFMAs per product group) must be as close to float64 as
+    the fp32 engine is; parts = 2 (three MFMAs; the opt-in experiment) within 2^-16-class error."""
     from boostmvsnerfs_amd import convnet
     torch.manual_seed(4)
     x = torch.randn(2, cin, *dhw, device=DEV)
     w = torch.randn(cout, cin, 3, 3, 3, device=DEV) / (27 * cin) ** 0.5
     b = torch.randn(cout, device=DEV)
-    y = convnet.conv3d_split_fwd(x, *convnet.pack_conv_split(w, b), cout, relu=True)
+    y = convnet.conv3d_split_fwd(x, *convnet.pack_conv_split(w, b, parts=parts), cout, relu=True)
     yd = F.relu(F.conv3d(x.double(), w.double(), b.double(), 1, 1))
-    err = float((y.double() - yd).abs().max())
-    print(f"[conv_split] {cin}->{cout} {dhw}: max err {err:.3e} of scale {float(yd.abs().max()):.3e}")
-    assert err <= 2e-5 * float(yd.abs().max())
-    # against the fp32 engine on the same layer
     y32 = convnet.conv_fwd(x, *convnet.pack_conv(w, b), cout, 3, 3, relu=True)
-    assert float((y - y32).abs().max()) <= 2e-5 * float(yd.abs().max())
+    scale = float(yd.abs().max())
+    err, err32 = float((y.double() - yd).abs().max()), float((y32.double() - yd).abs().max())
+    print(f"[conv_split{parts}] {cin}->{cout} {dhw}: max err {err:.3e}, fp32 engine {err32:.3e}, scale {scale:.3e}")
+    if parts == 3:
+        assert err <= max(2.0 * err32, 1e-6 * scale)          # fp32-equivalent
+    else:
+        assert err <= 2e-5 * scale
