@@ -510,9 +510,9 @@ def main():
                     split_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
                 extra["split_bf16_first_last_layers"] = {
                     "value": N / t_s / 1e6, "ms_per_step": t_s * 1e3,
-                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads as THREE bf16 MFMAs per product group "
-                            "(two-piece split, 2^-16 per product: BMV_CONV_SPLIT=2); `parity_max_rel_split` below is its "
-                            "frame against the oracle's"}
+                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads ALL as THREE bf16 MFMAs per product group "
+                            "(two-piece split, 2^-16 per product: BMV_CONV_SPLIT=2); `parity_max_rel_split` below is its frame "
+                            "against the oracle's"}
             finally:
                 for i in range(cc.num):
                     getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]

@@ -112,9 +112,22 @@ def conv3d_split_heads_records(x, wsplit, bias, parts):
     return VolumeRecords(rec), dp
 
 
-# 0: fp32 MFMA engine; 3: three bf16 pieces per operand / six MFMAs per product group (fp32-equivalent); 2: two pieces /
-# three MFMAs (2^-16 per product: the opt-in experiment)
-SPLIT_BF16 = int(os.environ.get("BMV_CONV_SPLIT", "0"))
+# Which of the regularisers' first layers / heads run on the split-bf16 path (csrc/conv_split.hip); BMV_CONV_SPLIT:
+#   "0" (default): fp32 MFMA engine everywhere;
+#   "auto": THREE bf16 pieces per operand (fp32-equivalent: the operand exactly, six MFMAs per product group) for the
+#           heads and for a first layer with >= 32 input channels (stand-alone 77 -> 61, 52 -> 47, 30 -> 23 us; in the
+#           frame only -7 us of 881: the level-0 first layer runs beside FeatureNet's top-down path and is no faster
+#           there -- all 183 GPU tests pass unchanged with it, but it is not worth a default);
+#   "3" / "2": all four layers with three / two pieces (two = 2^-16 per product: the opt-in experiment, +7 % of the frame).
+_split_env = os.environ.get("BMV_CONV_SPLIT", "0")
+SPLIT_BF16 = _split_env if _split_env == "auto" else int(_split_env)
+
+
+def split_parts(policy, kind, cin):
+    """pieces to use for a layer (0 = fp32 engine); kind: "conv0" | "heads"."""
+    if policy == "auto":
+        return 3 if (kind == "heads" or cin >= 32) else 0
+    return int(policy)
 
 
 _ZERO_BIAS = {}

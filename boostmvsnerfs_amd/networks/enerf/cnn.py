@@ -226,7 +226,7 @@ class _CostReg(nn.Module):
         self._packed = _Packed()
         self.volume_records = False   # engine path: emit the feature volume as the renderer's voxel records
         # first layer and heads on the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip): 0 = fp32 MFMA
-        # engine, 3 = three pieces / six MFMAs (fp32-equivalent), 2 = two pieces / three MFMAs (2^-16 per product)
+        # engine (default), "auto" = three pieces (fp32-equivalent) where faster stand-alone, 3 / 2 = all with 3 / 2 pieces
         self.split_bf16 = convnet.SPLIT_BF16
 
     def _apply(self, fn, *args, **kwargs):
@@ -255,7 +255,8 @@ class _CostReg(nn.Module):
 
     def _forward_engine(self, x):
         P = self.prepack()
-        split = int(self.split_bf16) if x.shape[-1] % 4 == 0 else 0
+        ok4 = x.shape[-1] % 4 == 0
+        split = convnet.split_parts(self.split_bf16, "conv0", x.shape[1]) if ok4 else 0
         if split:
             s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
         else:
@@ -268,6 +269,7 @@ class _CostReg(nn.Module):
             y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2)
         y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
         y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
+        split = convnet.split_parts(self.split_bf16, "heads", 8) if ok4 else 0
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:
                 return convnet.conv3d_split_heads_records(y, *P[f"heads_rec_split{split}"])
