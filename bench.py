@@ -9,9 +9,18 @@ bracketed the way the reference's evaluate loop brackets it (run.py:113-129:
 synchronize -> t0 -> network(batch) -> synchronize, one step at a time).  A step is
 one forward over one synthetic batch already resident in HBM; EVERY timed step ends
 with a device synchronize, so `value` is the run.py number, not a pipelined one.
-The forward that is timed is the HIP-graph replay of the frame (`config.launch`);
-`value_extra` reports the same bracket around the eager `net(batch)` a drop-in
-run.py would call, and the un-synchronised (pipelined) replay rate.
+The forward that is timed is the drop-in call itself, `net(batch)`, which replays
+the HIP graph it captured of its own frame (autograph.AutoGraph; `config.launch`).
+`value_extra`: `sync_bracketed_eager` (the same bracket around the ~42 eager
+launches), `pipelined_replay` (no per-step synchronize), `value_cold` (the bracket
+started after 50 ms of idle, no spin-up), the PCIe-inclusive legs
+(`host_batch_sync*`: the batch copied from pinned host memory every frame -- eager,
+with the rays built on the device, and through `net(batch)` with new device tensors
+per frame as an unchanged run.py loop hands them over), and
+`split_bf16_first_last_layers` (an opt-in EXPERIMENT, not the metric: four
+convolutions on the bf16 matrix cores with split fp32 operands; its frame's
+distance to the oracle is `parity_max_rel_split`).  `parity_max_rel`: the frame the
+timed steps render against the oracle's frame of the `cpu_baseline` leg.
 
 N > 1 (one process per GPU, torch.distributed over RCCL): independent target
 views are sharded across ranks -- every rank renders its own target frame of the
