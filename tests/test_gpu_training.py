@@ -241,3 +241,40 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
     assert graphed.stats["eager"] == 3 and graphed.stats["captures"] == 1 and graphed.stats["replays"] == 3
     assert graphed.stats["copies"] >= 2 * 2          # the two replays after the capture step got new target tensors
     assert sum(float((v - start[k]).abs().max()) > 0 for k, v in net_a.state_dict().items()) > 100   # ... and it did train
+
+
+def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path):
+    """GraphedTrainStep on boost_enerf (config 5's path: K cost volumes, triplets from view_selection.json baked into the
+    captured launches, targets named in batch['meta'] part of the key): losses of the replayed steps against an eager twin
+    in lockstep, and a batch whose meta names another target is NOT served by the captured graph."""
+    import copy
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.boost_enerf.network import Network
+    from boostmvsnerfs_amd.train import GraphedTrainStep, NetworkWrapper, make_optimizer, train_step
+    cfg = tiny_cfg(boost_fx, "enerf_ours_ft")
+    cfg.enerf.cas_config.k_best = len(boost_fx.raw["extra/k_best"])
+    cfg.result_dir = str(tmp_path)
+    set_cfg(cfg)
+    k_best = [int(k) for k in boost_fx.raw["extra/k_best"]]
+    with open(tmp_path / "view_selection.json", "w") as f:
+        json.dump({"synthetic_0": k_best, "synthetic_1": k_best[::-1]}, f)
+    net_a = Network()
+    net_a.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net_a = net_a.to(DEV).train()
+    net_b = copy.deepcopy(net_a).train()
+    base = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _targets(boost_fx.batch(), seed=1).items()}
+    wa, wb = NetworkWrapper(net_a), NetworkWrapper(net_b)
+    oa, ob = make_optimizer(net_a), make_optimizer(net_b)
+    graphed = GraphedTrainStep(wa, oa)
+    for s in range(6):
+        net_b.load_state_dict(copy.deepcopy(net_a.state_dict()))
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        loss_a, _ = graphed(dict(base))
+        loss_b, _ = train_step(wb, ob, dict(base))
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, float(loss_a), float(loss_b))
+    assert graphed.stats == {"eager": 3, "captures": 1, "replays": 3, "copies": 0}
+    other = dict(base)
+    other["meta"] = dict(base["meta"], tar_view=[1])            # another target: other triplets -> its own key
+    assert graphed._key(other) != graphed._key(base)
+    graphed(other)
+    assert graphed.stats["eager"] == 4 and graphed.stats["replays"] == 3
