@@ -34,7 +34,6 @@ struct ConvSplitArgs {
   float slope;
 };   // wsplit: [octet][step 7][part P][lane 64][4 dwords], P = 2 (hi, lo) or 3 (hi, mid, lo)
 
-constexpr int kTY = 8, kIY = kTY + 2;   // output rows of a tile; input rows
 constexpr int kSteps = 7;                                                            // 28 tap slots
 
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {   // [bf16(a) | bf16(b) << 16] by truncation
@@ -57,10 +56,12 @@ __device__ __forceinline__ float trunc_bf16(float v) {
 // level-1 first layer against 55 / 78: the kernel is bound by the latency of staging, and half the threads staging with
 // one workgroup per CU is worse than three whole workgroups taking turns.)
 // TX = 32 or 16 output columns per tile (16: half the LDS per workgroup -> more workgroups taking turns per CU)
-template <int TZ, int P, int TX>
+// RW = 2 or 1 output rows per wave (tile height 8 or 4: smaller tiles, more workgroups per CU)
+template <int TZ, int P, int TX, int RW>
 __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
+  constexpr int kTY = 4 * RW, kIY = kTY + 2;
   constexpr int kTX = TX, kIX = kTX + 2, kPlane = kIY * kIX, kGX = (kTX + 8) / 4, XH = TX / 16;
-  constexpr int NPL = TZ + 2, kPos = NPL * kPlane, NG = NPL * kIY * kGX, NSLOT = (NG + 255) / 256, NQ = 2 * XH * TZ;
+  constexpr int NPL = TZ + 2, kPos = NPL * kPlane, NG = NPL * kIY * kGX, NSLOT = (NG + 255) / 256, NQ = RW * XH * TZ;
   extern __shared__ i32x4 part_raw[];                      // [P][kPos]
   auto part = [&](int q) { return part_raw + (long)q * kPos; };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
   int pbase[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
-    pbase[q] = (q / (2 * XH)) * kPlane + (2 * wave + ((q / XH) & 1)) * kIX + 16 * (q % XH) + n;
+    pbase[q] = (q / (RW * XH)) * kPlane + (RW * wave + ((q / XH) % RW)) * kIX + 16 * (q % XH) + n;
 
   f32x4 acc[NQ];
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) conv3d_split_kernel(ConvSplitArgs a) {
   // epilogue: accumulator j of lane (n, kk) = output channel 4 kk + j at x = n of its piece
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int z = z0 + q / (2 * XH), y = y0 + 2 * wave + ((q / XH) & 1), x = x0 + 16 * (q % XH) + n;
+    const int z = z0 + q / (RW * XH), y = y0 + RW * wave + ((q / XH) % RW), x = x0 + 16 * (q % XH) + n;
     if (z >= a.D || y >= a.H || x >= a.W) continue;
     if (a.depth_out) {   // heads: no activation (cost_reg_net.py:30-31, 80-81 end in plain convolutions)
       const long vox = ((long)b * a.D + z) * plane + (long)y * a.W + x;
@@ -237,25 +238,29 @@ static int conv3d_split_launch(const float* in, const int* wsplit, int parts, co
   BMV_REQUIRE(parts == 2 || parts == 3, "conv3d_split: parts must be 2 or 3 (got %d)", parts);
   static const int tz = getenv("BMV_CONV_SPLIT_TZ") ? atoi(getenv("BMV_CONV_SPLIT_TZ")) : 2;
   hipStream_t st = as_stream(stream);
-#define BMV_SPLIT_LAUNCH(TZV, PV, TXV)                                                                                   \
+#define BMV_SPLIT_LAUNCH(TZV, PV, TXV, RWV)                                                                              \
   do {                                                                                                                   \
-    const size_t lds = (size_t)PV * (TZV + 2) * kIY * (TXV + 2) * sizeof(i32x4);                                         \
-    BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_split_kernel<TZV, PV, TXV>),                    \
+    const size_t lds = (size_t)PV * (TZV + 2) * (4 * RWV + 2) * (TXV + 2) * sizeof(i32x4);                               \
+    BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_split_kernel<TZV, PV, TXV, RWV>),               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,                 \
                 "conv3d_split: cannot reserve %zu B of LDS", lds);                                                       \
-    const dim3 grid(cdiv(W, TXV) * cdiv(H, kTY) * cdiv(D, TZV), B);                                                      \
-    hipLaunchKernelGGL((conv3d_split_kernel<TZV, PV, TXV>), grid, dim3(256), lds, st, a);                                \
+    const dim3 grid(cdiv(W, TXV) * cdiv(H, 4 * RWV) * cdiv(D, TZV), B);                                                  \
+    hipLaunchKernelGGL((conv3d_split_kernel<TZV, PV, TXV, RWV>), grid, dim3(256), lds, st, a);                           \
+  } while (0)
+#define BMV_SPLIT_TX_RW(TZV, PV)                                  \
+  do {                                                            \
+    if (txv == 16 && rwv == 1) BMV_SPLIT_LAUNCH(TZV, PV, 16, 1);  \
+    else if (txv == 16) BMV_SPLIT_LAUNCH(TZV, PV, 16, 2);         \
+    else if (rwv == 1) BMV_SPLIT_LAUNCH(TZV, PV, 32, 1);          \
+    else BMV_SPLIT_LAUNCH(TZV, PV, 32, 2);                        \
   } while (0)
   static const int txv = getenv("BMV_CONV_SPLIT_TX") ? atoi(getenv("BMV_CONV_SPLIT_TX")) : 32;
-  if (txv == 16) {
-    if (tz == 1 && parts == 2) BMV_SPLIT_LAUNCH(1, 2, 16);
-    else if (tz == 1) BMV_SPLIT_LAUNCH(1, 3, 16);
-    else if (parts == 2) BMV_SPLIT_LAUNCH(2, 2, 16);
-    else BMV_SPLIT_LAUNCH(2, 3, 16);
-  } else if (tz == 1 && parts == 2) BMV_SPLIT_LAUNCH(1, 2, 32);
-  else if (tz == 1) BMV_SPLIT_LAUNCH(1, 3, 32);
-  else if (parts == 2) BMV_SPLIT_LAUNCH(2, 2, 32);
-  else BMV_SPLIT_LAUNCH(2, 3, 32);
+  static const int rwv = getenv("BMV_CONV_SPLIT_RW") ? atoi(getenv("BMV_CONV_SPLIT_RW")) : 1;
+  if (tz == 1 && parts == 2) BMV_SPLIT_TX_RW(1, 2);
+  else if (tz == 1) BMV_SPLIT_TX_RW(1, 3);
+  else if (parts == 2) BMV_SPLIT_TX_RW(2, 2);
+  else BMV_SPLIT_TX_RW(2, 3);
+#undef BMV_SPLIT_TX_RW
 #undef BMV_SPLIT_LAUNCH
   BMV_LAUNCH_END("bmv_conv3d_split_fwd");
 }
