@@ -1,21 +1,23 @@
-// EXPERIMENT (round 3, opt-in: BMV_CONV_SPLIT=1): a 3x3x3 stride-1 convolution on the BF16 matrix cores with SPLIT fp32
-// operands -- x = hi + lo with hi = the upper 16 bits of x (a bf16 value) and lo = bf16(x - hi); the product is
-// evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation ("bf16x3": relative error of a product <= 2^-16; the
-// dropped lo*lo term is 2^-16 of it).  tests/tools/probe_split_bf16.py emulates exactly this arithmetic in EVERY
-// convolution of the network on the CPU oracle: the whole frame moves by <= 1.3e-5 relative (the bar is 1e-3; the fp32
-// engine's own distance to the oracle is 5e-6).  Why: v_mfma_f32_16x16x32_bf16 retires 32 k-values in 16 cycles, the
-// fp32 form 4 in 32: three bf16 MFMAs replace eight fp32 ones (48 vs 256 cycles per 32 k-values), and the first /
-// last layers of the regularisers are MFMA-bound at 0.61-0.64 busy.  The reference on an NVIDIA GPU runs
-// these convolutions in TF32 (10-bit mantissas) by default; this is 2^6 tighter.
+// EXPERIMENT (round 3, opt-in: BMV_CONV_SPLIT=2|3|auto): a 3x3x3 stride-1 convolution on the BF16 matrix cores with SPLIT
+// fp32 operands.  Two pieces: x = hi + lo with hi = the upper 16 bits of x (a bf16 value) and lo = bf16(x - hi); a product
+// is hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error <= 2^-16; the dropped lo*lo term is 2^-16 of it).
+// Three pieces: hi + mid + lo = the 24 mantissa bits exactly; hh, hm, mh, hl, mm, lh (what is dropped is <= 3 x 2^-24 of
+// the product: fp32-equivalent).  tests/tools/probe_split_bf16.py emulates exactly this arithmetic in EVERY convolution
+// of the network on the CPU oracle: the whole frame moves by <= 1.3e-5 relative with two pieces and 1e-6 with three (the
+// bar is 1e-3; the fp32 engine's own distance to the oracle is 5e-6).  Why: v_mfma_f32_16x16x32_bf16 retires 32
+// k-values in 16 cycles, the fp32 form 4 in 32: three (six) bf16 MFMAs replace eight fp32 ones (48 / 96 vs 256 cycles per
+// 32 k-values), and the first / last layers of the regularisers are MFMA-bound at 0.61-0.64 busy.  The
+// reference on an NVIDIA GPU runs these convolutions in TF32 (10-bit mantissas) by default.
 //
 // Layout.  k = (tap, channel): the 8 k-values of a lane are the 8 channels of one OCTET at one tap, the four lane groups
-// (lane >> 4) are four consecutive taps -- so a B operand is ONE 16-byte LDS read per part (hi, lo) and lane, from
-// position-major planes hi[pos][8 x bf16], lo[pos][8 x bf16] (16-byte stride: conflict-free).  The split happens ONCE,
-// when a tile is staged (3 VALU per element), not per use (27 taps x output tiles).  A operand: the weights, split and
-// laid out on the host in exactly the lane order, two 16-byte loads per step.  Accumulators have the layout of the
-// fp32 16x16x4 form (row = 4 (lane >> 4) + j = output channel, column = lane & 15 = x), so epilogues carry over.
-// Tile: TZ x 8 x 32 outputs per workgroup of 4 waves (TZ planes x 2 rows x 2 half-rows per wave), input tile (TZ + 2) x
-// 10 x 34 positions per octet (43.5 KB at TZ = 2), staged with 16-byte loads of 4 consecutive pixels per channel.
+// (lane >> 4) are four consecutive taps -- so a B operand is ONE 16-byte LDS read per piece and lane, from position-major
+// planes piece[pos][8 x bf16] (16-byte stride: conflict-free).  The split happens ONCE, when a tile is staged, not per
+// use (27 taps x output tiles).  A operand: the weights, split and laid out on the host in exactly the lane order, one
+// 16-byte load per piece and step.  Accumulators have the layout of the fp32 16x16x4 form (row = 4 (lane >> 4) + j =
+// output channel, column = lane & 15 = x), so epilogues carry over.
+// Tile: TZ x (4 RW) x TX outputs per workgroup of 4 waves (default 2 x 4 x 32), input tile (TZ + 2) x (4 RW + 2) x (TX + 2)
+// positions per octet, staged with 16-byte loads of 4 consecutive pixels per channel.  The kernel is bound by the
+// latency of that staging, and small tiles -- many workgroups taking turns on a CU -- hide it best.
 #include "bmv_common.hpp"
 
 namespace bmv {
