@@ -7,7 +7,9 @@ Metric (BASELINE.json): rendered Mray/s (512x640 target, 3 source views, 64 dept
 planes) = rays rendered by the whole job per second of `Network.forward(batch)`,
 bracketed the way the reference's evaluate loop brackets it (run.py:113-129:
 synchronize -> t0 -> network(batch) -> synchronize, one step at a time).  A step is
-one forward over one synthetic batch already resident in HBM; EVERY timed step ends
+one forward over one synthetic batch already in HBM (other device tensors every step,
+as run.py hands them over; `value_extra.resident_batch` is the declared-resident
+opt-in that copies nothing); EVERY timed step ends
 with a device synchronize, so `value` is the run.py number, not a pipelined one.
 The forward that is timed is the drop-in call itself, `net(batch)`, which replays
 the HIP graph it captured of its own frame (autograph.AutoGraph; `config.launch`).
@@ -114,6 +116,9 @@ def parse():
                     help="1: let MIOpen search its convolution solvers (torch.backends.cudnn.benchmark).  Only the "
                          "training workloads still run convolutions on MIOpen (inference uses csrc/conv.hip), and "
                          "its search for the 3-D fp32 backward solvers takes > 15 min: off by default")
+    ap.add_argument("--stub-renderer", action="store_true",
+                    help="TEST ONLY (tests/test_bench_cli.py): CPU tensors, gloo, and a stub in place of the network, so that "
+                         "the launcher, the rendezvous, the exchange and the timing contract of `--gpus N` run without a GPU")
     args = ap.parse_args()
     if args.steps is None:
         w = WORKLOADS[args.workload]
@@ -144,6 +149,10 @@ def build(args, rank, dev):
     if mvs:   # a real depth interval in the near/far columns (the shipped loaders put pixel x, y there: quirk 9)
         batch_cpu["rays_0"][..., 6], batch_cpu["rays_0"][..., 7] = 2.2, 7.5
     torch.manual_seed(0)
+    if args.stub_renderer:
+        if wl["net"] != "enerf" or wl.get("train"):
+            raise SystemExit("--stub-renderer drives the ENeRF inference workloads only")
+        return cfg, wl, _StubRenderer(1), {}, batch_cpu, clone_batch(batch_cpu, dev), 1
     if wl["net"] == "enerf":
         from boostmvsnerfs_amd.networks.enerf.network import Network
         net = Network()
@@ -292,25 +301,71 @@ def make_exchange(shard, world, rank, N, dev, net, wl, k_best, level, pipelined=
     return finish, gather, vshard
 
 
+class _StubRenderer:
+    """--stub-renderer: what the timed step touches of a network -- the ray / volume shard attributes and a forward that
+    returns (rgb, depth) of the frame's shape computed from the batch's rays -- so that `bench.py --gpus N` runs end to
+    end on CPU + gloo (launcher, rendezvous, exchange, barriers, max-over-ranks timing, the JSON line)."""
+    ray_range = None
+    volume_ids = None
+    training = False
+
+    def __init__(self, level):
+        self.level = level
+
+    def __call__(self, batch):
+        rays = batch[f"rays_{self.level}"]
+        if self.ray_range is not None:
+            rays = rays[:, self.ray_range[0]:self.ray_range[1]]
+        return {f"rgb_level{self.level}": rays[..., :3] * 0.5, f"depth_level{self.level}": rays[..., 3].clone()}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves, the way the reference's
+    train_net.py expects to be started (train_net.py:144-149 reads RANK / LOCAL_RANK from torch.distributed's launcher).
+    Only `import torch` has happened in this process -- nothing has touched the GPU -- and the ranks are CHILD processes
+    (never an exec of this one); rank 0's JSON line passes through on stdout, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL between the ranks (see the task notes)
+    env.setdefault("OMP_NUM_THREADS", "1" if not args.stub_renderer else "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # training-mode convolutions run on MIOpen
+    stub = args.stub_renderer
     import torch.distributed as dist
+    if stub:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None       # (this process only: the stub run has no device to wait for)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        torch.backends.cudnn.benchmark = bool(args.miopen_find)   # training-mode convolutions run on MIOpen
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
 
     from boostmvsnerfs_amd import ktimer, sharding
+    if stub:
+        args.no_kernel_events, args.no_cpu_baseline, args.spinup_steps = True, True, min(args.spinup_steps, 2)
 
     cfg, wl, net, sd_cpu, batch_cpu, batch, level = build(args, rank, dev)
     cc = cfg.enerf.cas_config
@@ -344,19 +399,31 @@ def main():
                 return graphed_train(batch)
             return train_step(wrapper, optimizer, batch)
     else:
+        # What run.py times (run.py:113-123): every iteration hands `network(batch)` device tensors that are NOT the ones
+        # of the previous call (`batch[k] = batch[k].cuda()` in front of the bracket).  The timed steps walk a ring of
+        # three distinct device copies of the batch, created here, outside every bracket: `net(...)` sees other
+        # tensors on every call, copies them into its graph's private inputs and returns fresh outputs.
+        from boostmvsnerfs_amd.synthetic import clone_batch as _clone
+        ring = [batch] + [_clone(batch, dev) for _ in range(2)]
+        ring_pos = [0]
+
+        def feed():
+            ring_pos[0] = (ring_pos[0] + 1) % len(ring)
+            return ring[ring_pos[0]]
+
         def step():
             with torch.no_grad():
-                return finish(net(batch))           # the drop-in call: replays its own HIP graph from the 2nd call on
+                return finish(net(feed()))          # the drop-in call: replays its own HIP graph from the 2nd call on
 
         def step_plain():
             with torch.no_grad():
-                return finish(net(batch))
+                return finish(net(feed()))
 
         _eager_call = getattr(net, "_forward_checked", net)    # the same frame as ~42 eager launches (BMV_AUTOGRAPH=0)
 
         def eager_only_step():
             with torch.no_grad():
-                return finish(_eager_call(batch))
+                return finish(_eager_call(dict(feed())))
 
     # MIOpen's solver search writes its per-user find-db: rank 0 searches first with a collective-free forward,
     # the other ranks then hit the finished db instead of N processes searching (and locking the db) at once.
@@ -402,13 +469,13 @@ def main():
             sampled = {"n": 0, "every": 1, "evented": True}
             if args.no_kernel_events:
                 fg = None
-                replay = lambda: net(batch)   # noqa: E731  (Network.forward replays its own graph)
+                replay = lambda: net(feed())   # noqa: E731  (Network.forward replays its own graph)
             else:
                 # bracketed frames: the sweeps are ordinary launches between the graphs, their events bound to their
                 # own dispatch (hipExtLaunchKernelGGL: the kernel's begin and end); the renderer is bracketed by
                 # event-record nodes inside its graph.  --in-graph-sweeps keeps the frame one graph and brackets the
                 # sweeps with event-record nodes too (they then read ~2.5 us more).
-                fg = FrameGraph(net, batch, cut=None if args.in_graph_sweeps else "all", events=True)
+                fg = FrameGraph(net, _clone(batch, dev), cut=None if args.in_graph_sweeps else "all", events=True)
                 replay = fg.replay
                 if fg.events and args.event_every > 1:
                     # plain steps are the drop-in call itself, `net(batch)`: Network.forward replays the graph it
@@ -416,10 +483,19 @@ def main():
                     # bracketed capture instead (the measurement instrument)
                     sampled["every"] = args.event_every
 
+                    from boostmvsnerfs_amd import autograph as _ag
+                    fg_names = [k for k, v in fg.batch.items() if torch.is_tensor(v) and not getattr(v, "_bmv_built_rays", False)]
+
                     def replay():   # noqa: F811
                         sampled["evented"] = sampled["n"] % sampled["every"] == 0
                         sampled["n"] += 1
-                        return fg.replay() if sampled["evented"] else net(batch)
+                        b = feed()
+                        if not sampled["evented"]:
+                            return net(b)
+                        # the bracketed capture does what net(b) does: inputs copied in, frame replayed, outputs copied out
+                        if b is not fg.batch:
+                            _ag._copy_many([fg.batch[k] for k in fg_names], [b[k] for k in fg_names])
+                        return _ag.AutoGraph._fresh_outputs({}, fg.replay())
 
             def step():   # noqa: F811
                 with torch.no_grad():
@@ -427,7 +503,8 @@ def main():
             for _ in range(4):
                 step()
             ag = net._autograph.stats
-            graph_note = (f"net(batch) replaying its own HIP graph (autograph: {ag['captures']} capture(s), {ag['copies']} input copies)"
+            graph_note = (f"net(batch) on other device tensors every step (a ring of {len(ring)}), replaying its own HIP graph (autograph: "
+                          f"{ag['captures']} capture(s), {ag['copies']} input tensors copied in {ag['replays']} replays, outputs copied out)"
                           + ("" if fg is None else f"; every {sampled['every']}. step a bracketed capture instead: {len(fg.graphs)} graph(s)"
                              + (f" + {len(fg.sweeps)} eager plane sweep(s) with dispatch-bound events" if fg.sweeps else "")))
         except Exception as e:   # keep the eager path: the bench must still produce its line
@@ -465,23 +542,24 @@ def main():
             extra["pipelined_replay"] = {"value": N * (world if args.shard == "views" else 1) / t_pipe / 1e6, "ms_per_step": t_pipe * 1e3,
                                          "what": "graph replays issued back to back, one synchronize at the end (not the metric)"}
 
-    if not wl.get("train") and world == 1:
+    if not wl.get("train") and world == 1 and not stub:
         # the reference's loaders hand over HOST tensors (run.py:114-116 moves them every frame): the same bracket with
         # the batch copied from pinned host memory each step, with the rays copied too / built on the device instead
         host = {k: v.cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
         ray_keys = [k for k in host if k.startswith("rays_")]
-        resident = {k: batch[k] for k in host}          # the tensor objects the forward's graph was captured on
+        hb = _clone(batch, dev)                         # the legs' own working batch (they pop / refill its keys)
 
         def from_host(device_rays):
             def fn():
                 for k, v in host.items():
                     if device_rays and k in ray_keys:
-                        batch.pop(k, None)              # Network.ensure_rays rebuilds them from tar_ext / tar_ixt
+                        hb.pop(k, None)                 # Network.ensure_rays rebuilds them from tar_ext / tar_ixt
                     else:
-                        if k not in batch:
-                            batch[k] = torch.empty_like(v, device=dev)
-                        batch[k].copy_(v, non_blocking=True)
-                return eager_step()
+                        if k not in hb:
+                            hb[k] = torch.empty_like(v, device=dev)
+                        hb[k].copy_(v, non_blocking=True)
+                with torch.no_grad():
+                    return finish(_eager_call(hb))
             return fn
         for name, dr in (("host_batch_sync_eager", False), ("host_batch_device_rays_sync_eager", True)):
             t_h = bracketed(from_host(dr), n_x)
@@ -525,10 +603,27 @@ def main():
             finally:
                 for i in range(cc.num):
                     getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
-        for k, v in host.items():                       # leave the resident batch as the graphs captured it: the SAME
-            batch[k] = resident[k]                      # tensor objects (the device-rays leg replaced batch['rays_i'] by
-            batch[k].copy_(v)                           # tensors built on the device, which a later capture would rebuild
-        torch.cuda.synchronize()                        # inside every frame: +15 us of make_rays per step)
+        if args.graph and hasattr(net, "_autograph") and not args.all_kernel_events:
+            # the opt-in a serving loop with a resident batch can make (autograph.py): captured on the caller's own
+            # tensors, no input copies, the graph's static outputs handed out.  NOT `value`: run.py hands over other
+            # tensors every frame and keeps what it is given.
+            rb = _clone(batch, dev)
+            net.resident_inputs = net.alias_outputs = True
+            try:
+                def resident_step():
+                    with torch.no_grad():
+                        return finish(net(rb))
+                for _ in range(4):
+                    resident_step()
+                torch.cuda.synchronize()
+                t_r = bracketed(resident_step, max(n_x, 50))
+                extra["resident_batch"] = {"value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
+                                           "what": "same bracket, net.resident_inputs = net.alias_outputs = True: the graph "
+                                                   "captured on the caller's resident tensors, no copies in or out (rounds 1-3 "
+                                                   "reported this as `value`)"}
+            finally:
+                net.resident_inputs = net.alias_outputs = False
+        torch.cuda.synchronize()
 
     import gc
     gc.collect()
@@ -697,7 +792,7 @@ def main():
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if (args.shard == "views" or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not stub else "synthetic; STUB renderer on CPU + gloo (launcher test, not a measurement)",
             "config": {"workload": args.workload, "network": wl["net"], "H": H, "W": W, "src_views": wl["views"],
                        "volume_planes": list(cc.volume_planes) if "planes" in wl else None,
                        "num_samples": list(cc.num_samples), "render_if": list(cc.render_if),

@@ -10,12 +10,23 @@ unchanged `network(batch)` was host-bound (round 2: 323 Mray/s eager against 353
   volume shard of the network and, for the K-volume networks, the cost-volume triplets `view_selection.json` selects
   for the batch's targets;
 * the FIRST call with a key runs eagerly; the second captures (`framegraph.FrameGraph`, inside the caller's timing
-  bracket: the cost is charged to the iteration that triggers it) ON THE CALLER'S OWN TENSORS, later ones replay.  A
-  caller that keeps its batch resident pays nothing per frame; one that hands over new tensors every frame pays one
-  in-place device copy per tensor into the captured buffers (what evaluate.py's refresh did from outside);
-* outputs are the graph's static tensors: valid until the next forward of this network (the reference's evaluators
-  consume a frame before the next one is rendered); `BMV_AUTOGRAPH_CLONE=1` hands out copies instead;
-* training, CPU tensors, a forward that is itself being captured, and `BMV_AUTOGRAPH=0` take the eager path.
+  bracket: the cost is charged to the iteration that triggers it), later ones replay;
+* **forward never writes its inputs and never hands out memory it will overwrite** (the reference's forward does
+  neither): the graph is captured on PRIVATE copies of the batch's tensors, every call copies the caller's tensors into
+  them with one multi-tensor launch (23 MB at 512x640: what an unchanged run.py loop, which hands over new device
+  tensors every frame, needs anyway), and the outputs are copies of the graph's static outputs (8 MB).  Two opt-ins
+  trade that contract for the copies, attribute by attribute on the network:
+    - `net.resident_inputs = True`: the caller DECLARES its batch resident -- the graph is captured on the caller's own
+      tensors and a call with those very tensors copies nothing (in-place edits of them are picked up); a call with
+      other tensors of the same shapes is copied INTO THE DECLARED BATCH'S tensors, which is what the declaration
+      permits;
+    - `net.alias_outputs = True`: the returned tensors are the graph's static outputs, valid until the next forward of
+      this network (the reference's evaluators consume a frame before the next one is rendered);
+* training, CPU tensors, a batch tensor that requires grad (pose refinement: the outputs must carry an autograd graph),
+  a forward that is itself being captured, and `BMV_AUTOGRAPH=0` take the eager path.
+
+Not noticed: a parameter whose storage is swapped through `p.data = ...` (no version bump, no hook); call
+`net._autograph.invalidate()` after such an edit.  `load_state_dict` (also `assign=True`) and `.to()` invalidate.
 """
 from __future__ import annotations
 
@@ -27,7 +38,6 @@ import torch
 _version_of = attrgetter("_version")
 
 ENABLED = os.environ.get("BMV_AUTOGRAPH", "1") != "0"
-CLONE_OUTPUTS = os.environ.get("BMV_AUTOGRAPH_CLONE", "0") == "1"
 MAX_GRAPHS = int(os.environ.get("BMV_AUTOGRAPH_MAX", "4"))
 
 
@@ -35,16 +45,30 @@ def _built(v):
     return getattr(v, "_bmv_built_rays", False)
 
 
+def _copy_many(dsts, srcs):
+    """dst[i] <- src[i] on the current stream: one multi-tensor launch per dtype group."""
+    if not dsts:
+        return
+    groups = {}
+    for d, s in zip(dsts, srcs):
+        groups.setdefault((d.dtype, s.dtype), ([], []))
+        g = groups[(d.dtype, s.dtype)]
+        g[0].append(d)
+        g[1].append(s)
+    for d, s in groups.values():
+        torch._foreach_copy_(d, s)
+
+
 class AutoGraph:
     def __init__(self, net):
         """`net` provides `_forward_checked(batch) -> dict` (the eager forward) and `_autograph_key(batch)` (what else a
         captured frame is specialised to, e.g. the selected triplets; or None)."""
         self.net = net
-        self.entries = {}          # key -> {"fg", "static", "hits"}
+        self.entries = {}          # key -> {"fg", "static", "hits", ...}
         self.seen = {}             # key -> number of eager calls so far
         self._tensors = None
-        self._last = None          # ((ids of the batch's values, parameter version, shard, extra key), entry) of the last replay
-        self.epoch = 0             # bumped by Module._apply (.to() / .cuda() replace storage)
+        self._last = None          # resident inputs: ((ids of the batch's values, parameter version, shard, extra), entry)
+        self.epoch = 0             # bumped by Module._apply (.to() / .cuda() replace storage) and load_state_dict
         self.stats = {"eager": 0, "captures": 0, "replays": 0, "copies": 0}
 
     def eager_forward(self, batch):
@@ -69,8 +93,9 @@ class AutoGraph:
         self.seen.clear()
 
     def _param_version(self):
-        # in-place updates (optimiser steps, load_state_dict, manual edits) bump `_version`; storage moves go through
-        # Module._apply -> invalidate().  ~5 us for the 184 tensors of an ENeRF network (sum / map run in C)
+        # in-place updates (optimiser steps, manual edits) bump `_version`; storage moves and replaced Parameter objects
+        # go through Module._apply / load_state_dict -> invalidate(), which drops the cached list.  ~5 us for the 184
+        # tensors of an ENeRF network (sum / map run in C)
         if self._tensors is None:
             self._tensors = list(self.net.parameters()) + list(self.net.buffers())
         return self.epoch + sum(map(_version_of, self._tensors))
@@ -88,9 +113,16 @@ class AutoGraph:
     def usable(self, batch):
         if not ENABLED or self.net.training:
             return False
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+        probe = None
+        grad = torch.is_grad_enabled()
+        for v in batch.values():
+            if torch.is_tensor(v):
+                if probe is None:
+                    probe = v
+                if grad and v.requires_grad:
+                    return False               # the outputs must carry an autograd graph back to this tensor
+        if grad and any(p.requires_grad for p in self.net.parameters()):
             return False
-        probe = next((v for v in batch.values() if torch.is_tensor(v)), None)
         if probe is None or not probe.is_cuda:
             return False
         return not torch.cuda.is_current_stream_capturing()
@@ -99,18 +131,21 @@ class AutoGraph:
     def __call__(self, batch):
         version = self._param_version()
         extra = self.net._autograph_key(batch)
-        # fast path: the very tensor objects of the last replay (a resident batch) -> same key, nothing to copy
-        ident = (tuple(map(id, batch.values())), version, self._shard(), extra)
-        last = self._last
-        if last is not None and last[0] == ident:
-            e = last[1]
-        else:
-            key = (self._shapes(batch), ident[2], extra)
+        resident = bool(getattr(self.net, "resident_inputs", False))
+        ident = None
+        e = None
+        if resident:
+            # fast path: the very tensor objects of the last replay (the declared resident batch) -> nothing to copy
+            ident = (tuple(map(id, batch.values())), version, self._shard(), extra)
+            last = self._last
+            if last is not None and last[0] == ident:
+                e = last[1]
+        if e is None:
+            key = (self._shapes(batch), self._shard(), extra, resident)
             e = self.entries.get(key)
             if e is not None and e["version"] != version:
                 del self.entries[key]
                 e = None
-            copies = self.stats["copies"]
             if e is None:
                 n = self.seen.get(key, 0)
                 self.seen[key] = n + 1
@@ -119,30 +154,47 @@ class AutoGraph:
                         self.seen.clear()
                     self.stats["eager"] += 1
                     return self.eager_forward(batch)
-                e = self._capture(key, batch, version)
-            else:
-                self._refresh(e["static"], batch)
-            # these objects ARE the static inputs if nothing had to be copied: remember them for the fast path
-            self._last = (ident, e) if copies == self.stats["copies"] else None
+                e = self._capture(key, batch, version, resident)
+            copied = self._refresh(e, batch)
+            if resident:
+                # these objects ARE the static inputs if nothing had to be copied: remember them for the fast path
+                self._last = (ident, e) if not copied else None
         self.stats["replays"] += 1
         out = e["fg"].replay()
         e["hits"] += 1
         for k, v in e["added"].items():             # keys the eager forward adds to the batch (rays built on the device)
             batch[k] = v
-        if self._last is not None and e["added"] and len(ident[0]) != len(batch):
+        if resident and self._last is not None and e["added"] and len(ident[0]) != len(batch):
             self._last = ((tuple(map(id, batch.values())),) + ident[1:], e)       # (the batch just gained those keys)
-        if CLONE_OUTPUTS:
-            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
-        return dict(out)
+        if getattr(self.net, "alias_outputs", False):
+            return dict(out)
+        return self._fresh_outputs(e, out)
 
-    def _capture(self, key, batch, version):
+    @staticmethod
+    def _fresh_outputs(e, out):
+        names = e.get("out_names")
+        if names is None:
+            names = e["out_names"] = [k for k, v in out.items() if torch.is_tensor(v)]
+        srcs = [out[k] for k in names]
+        dsts = [torch.empty_like(s) for s in srcs]
+        _copy_many(dsts, srcs)
+        res = dict(out)
+        res.update(zip(names, dsts))
+        return res
+
+    def _capture(self, key, batch, version, resident):
         from .framegraph import FrameGraph
         if len(self.entries) >= MAX_GRAPHS:          # every graph owns a private memory pool: keep a few
             victim = min(self.entries, key=lambda k: self.entries[k]["hits"])
             del self.entries[victim]
-        # the caller's tensors ARE the static inputs (kept alive by this reference); python entries ('meta') are read
-        # at capture time only -- anything of theirs that changes the frame is part of the key
-        static = {k: v for k, v in batch.items() if not _built(v)}
+        # static inputs of the graph: private copies (default), or -- declared resident -- the caller's own tensors, kept
+        # alive by this reference.  Python entries ('meta') are read at capture time only: anything of theirs that
+        # changes the frame is part of the key
+        static = {}
+        for k, v in batch.items():
+            if _built(v):
+                continue
+            static[k] = v.clone() if (torch.is_tensor(v) and not resident) else v
         added = {}
 
         def run(b):
@@ -157,16 +209,24 @@ class AutoGraph:
         with torch.no_grad():
             fg = FrameGraph(run, static, cut=None)
         self.stats["captures"] += 1
-        e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added}
+        e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added, "resident": resident,
+             "names": [k for k, v in static.items() if torch.is_tensor(v)]}
         self.entries[key] = e
         return e
 
-    def _refresh(self, static, batch):
-        for k, v in batch.items():
-            if not torch.is_tensor(v) or _built(v):
+    def _refresh(self, e, batch):
+        """The caller's tensors into the graph's static inputs; returns the number of tensors copied."""
+        static = e["static"]
+        dsts, srcs = [], []
+        for k in e["names"]:
+            v = batch.get(k)
+            if v is None or not torch.is_tensor(v):
                 continue
-            s = static.get(k)
-            if s is None or s is v or (s.data_ptr() == v.data_ptr() and s.stride() == v.stride()):
-                continue
-            s.copy_(v)
-            self.stats["copies"] += 1
+            s = static[k]
+            if s is v or (s.data_ptr() == v.data_ptr() and s.stride() == v.stride()):
+                continue                               # (only possible when the capture ran on the caller's tensors)
+            dsts.append(s)
+            srcs.append(v)
+        _copy_many(dsts, srcs)
+        self.stats["copies"] += len(dsts)
+        return len(dsts)

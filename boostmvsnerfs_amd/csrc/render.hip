@@ -328,6 +328,9 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
         atomicAdd(&g_pc_spins[2 + (want & 1)], 1ull);
       }
 #endif
+      // compiler barrier: the plain LDS loads / stores of the mailbox that follow a successful poll must not be
+      // hoisted above it (the flag is volatile, the boxes are not)
+      asm volatile("" ::: "memory");
       return true;
     }
     __builtin_amdgcn_s_sleep(4);

@@ -55,9 +55,10 @@ def evaluate(network, batches, on_output=None, graph=None):
 
     The bracket is around `network(batch)` and nothing else.  The networks of this package replay a HIP graph of the
     frame from the second call with the same shapes on (autograph.AutoGraph, inside `forward`): the iteration that
-    triggers a capture pays for it inside its own bracket, batches that arrive as new tensors are copied into the
-    captured buffers inside the bracket too, and the outputs handed to `on_output` are then the graph's static
-    tensors (consume them before the next iteration).  graph=False times the eager launches instead
+    triggers a capture pays for it inside its own bracket, the batch's tensors are copied into the graph's private
+    input buffers inside the bracket too (one multi-tensor launch), and the outputs handed to `on_output` are fresh
+    tensors like the reference's (`network.alias_outputs = True` hands out the graph's static tensors instead: consume
+    them before the next iteration).  graph=False times the eager launches instead
     (`network._forward_checked`); `stats` reports how many iterations were eager / captures / replays."""
     network.eval()
     net_time, rays = [], 0

@@ -60,6 +60,12 @@ class Network(nn.Module):
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
         from ...autograph import AutoGraph
         object.__setattr__(self, "_autograph", AutoGraph(self))
+        # autograph opt-ins (autograph.py): the caller declares its batch resident / accepts outputs that the next
+        # forward overwrites.  Default: forward neither writes its inputs nor hands out memory it will reuse
+        self.resident_inputs = False
+        self.alias_outputs = False
+        # load_state_dict (assign=True replaces the Parameter objects) makes captured frames stale
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._autograph.invalidate())
         self._side_stream = None
 
     # ------------------------------------------------------------------ 2-D features

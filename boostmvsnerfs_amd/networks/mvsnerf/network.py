@@ -12,7 +12,8 @@ the volume and the three images, builds the 86-wide input and runs the 6x128 MLP
 the matrix cores -> compositing kernel.  The reference's 10-chunk Python loop
 (network.py:1010-1033) and its per-sample intermediates disappear.  Under autograd (training) the same
 kernels build the MLP inputs, the sweep and the volume lookup have HIP backward kernels (csrc/mvs.hip) and the
-6 x 128 MLP runs in torch ops.
+6 x 128 MLP runs on the layer-wise MFMA kernels with a HIP backward (csrc/mvs_mlp_train.hip, autograd.MvsMLP;
+BMV_MVS_MLP_TRAIN=torch keeps nn.Linear + torch autograd).
 """
 import os
 
@@ -308,7 +309,8 @@ class Network(nn.Module):
     def _render_volume_train(self, rays, st, want_mask, outs):
         """Differentiable form of render_volume: the render kernel only builds the MLP inputs (marching, NDC point,
         positional encoding, volume / colour lookups, visibility), the 8 volume channels get their gradient to the
-        regularised volume (autograd.MvsVolFeat), the MLP runs in torch ops."""
+        regularised volume (autograd.MvsVolFeat), the MLP runs through RendererMLP.forward (HIP forward + backward under
+        autograd: autograd.MvsMLP)."""
         if self.ray_range is not None or outs is not None:
             raise NotImplementedError("training renders every ray of batch['rays_0'] (no ray_range / preallocated outputs)")
         cc = cfg.enerf.cas_config
@@ -317,7 +319,7 @@ class Network(nn.Module):
         _, z, mask, x86 = ops.mvs_render(rays, st.volume.detach(), src_inps, src_exts, src_ixts, st.near_far, None,
                                          Ns=cc.num_samples[0], pad=PAD, want_mask=want_mask, want_inputs=True)
         vf = A.MvsVolFeat.apply(st.volume, x86[..., 63:71], rays, src_exts[0], src_ixts[0], st.near_far, H, W, PAD)
-        raw = self.nerf.nerf.forward_torch(torch.cat([x86[..., :63], vf, x86[..., 71:]], -1))
+        raw = self.nerf(torch.cat([x86[..., :63], vf, x86[..., 71:]], -1))
         if self.capture is not None:
             self.capture.update({"mlp_in": x86, "raw": raw, "cost_volume": st.cost_volume, "volume": st.volume})
         return raw, z, mask

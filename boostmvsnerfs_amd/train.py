@@ -136,7 +136,8 @@ class GraphedTrainStep:
     Every kernel of the training path goes to the current stream and nothing on it reads the device from the host, so the
     step captures unmodified.  A captured step is specialised to the shapes of the batch's tensors and -- for the
     K-volume networks -- to the targets named in batch['meta'] (the triplets view_selection.json picks for them are
-    baked into the launches); a batch with another key is captured separately (up to `max_graphs`), the first
+    baked into the launches; other networks' batches are keyed by shapes alone); a batch with another key is captured
+    separately (up to `max_graphs`, each replay binds ITS gradient tensors to `p.grad` before clip + Adam), the first
     `eager_steps` steps with a key run eagerly (allocator pools, packed weights, MIOpen's solver picks settle there).
     Batches that arrive as new tensors are copied into the captured buffers.  Parameters, batch-norm statistics and
     gradients are updated in place, so the graph always reads the current ones.  Not under DDP (the bucketed all-reduce
@@ -151,10 +152,14 @@ class GraphedTrainStep:
         self.stats = {"eager": 0, "captures": 0, "replays": 0, "copies": 0}
         self.disabled = isinstance(wrapper, nn.parallel.DistributedDataParallel)
 
-    @staticmethod
-    def _key(batch):
-        meta = batch.get("meta") or {}
-        targets = tuple(f"{s}_{v}" for s, v in zip(meta.get("scene", ()), meta.get("tar_view", ())))
+    def _key(self, batch):
+        # the targets named in batch['meta'] select cost-volume triplets that are baked into the captured launches -- of
+        # the K-volume networks only (view_selection_outputs); plain ENeRF batches of one shape share one graph
+        targets = ()
+        net = getattr(self.wrapper, "net", None)
+        if getattr(net, "view_selection_outputs", None) is not None:
+            meta = batch.get("meta") or {}
+            targets = tuple(f"{s}_{v}" for s, v in zip(meta.get("scene", ()), meta.get("tar_view", ())))
         shapes = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items())
                        if torch.is_tensor(v) and not getattr(v, "_bmv_built_rays", False))
         return shapes, targets
@@ -186,7 +191,12 @@ class GraphedTrainStep:
                 loss, stats = self._fwd_bwd(dict(static))
         finally:
             ktimer.enabled = was
-        e = {"graph": graph, "static": static, "loss": loss, "stats": stats, "hits": 0}
+        # the gradient tensors this graph writes (allocations of ITS pool).  Any other step -- an eager one, another key's
+        # graph -- rebinds p.grad (zero_grad(set_to_none=True)): every replay binds these back before clip + Adam read
+        # p.grad, and un-binds the parameters this graph leaves without a gradient
+        params = [p for p in self.wrapper.parameters()]
+        e = {"graph": graph, "static": static, "loss": loss, "stats": stats, "hits": 0,
+             "grads": [(p, p.grad) for p in params]}
         self.entries[key] = e
         self.stats["captures"] += 1
         return e
@@ -199,6 +209,8 @@ class GraphedTrainStep:
         e = self.entries.get(key)
         if e is None:
             n = self.seen.get(key, 0)
+            if len(self.seen) > 64:
+                self.seen.clear()
             self.seen[key] = n + 1
             if n < self.eager_steps:
                 self.stats["eager"] += 1
@@ -216,6 +228,8 @@ class GraphedTrainStep:
                     s.copy_(v)
                     self.stats["copies"] += 1
         e["graph"].replay()
+        for p, g in e["grads"]:
+            p.grad = g
         e["hits"] += 1
         self.stats["replays"] += 1
         self._finish()

@@ -52,3 +52,27 @@ def test_ktimer_is_inert_when_disabled():
         pass
     ktimer.collect()
     assert ktimer.summary() == {}
+
+
+def test_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1 (no torch.distributed.run in front): bench.py
+    starts its two ranks itself, they rendezvous (gloo here, RCCL on the GPU box), run warm-up + K timed steps with the
+    per-step exchange of the `views` sharding, and rank 0 prints ONE JSON line with n_gpus = 2.  --stub-renderer replaces
+    the network (the HIP path cannot run on CPU); everything else is bench.main()."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "enerf_256x320_3src_32planes", "--stub-renderer"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["unit"] == "Mray/s" and line["value"] > 0 and "STUB" in line["data"]
+    # whole-job aggregate: two frames per step
+    assert abs(line["value"] - 2 * 256 * 320 * 3 / (line["ms_per_step"] * 3 * 1e-3) / 1e6) < 1e-6 * line["value"] + 1e-9
+    assert line["config"]["shard"] == "views"

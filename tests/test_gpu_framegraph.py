@@ -162,33 +162,120 @@ def test_bound_events_on_the_sweeps_between_graphs():
         assert launches == 3 and 0.0 < min_ms <= mean_ms < 5.0, (name, launches, mean_ms)
 
 
-def test_forward_captures_itself():
-    """autograph.AutoGraph behind Network.forward: the drop-in call replays a HIP graph from the second call with the
-    same shapes on -- on the caller's own resident tensors (no copies), with in-place input changes picked up, new
-    tensors copied in, a parameter update re-capturing, and another shape falling back to an eager first call."""
+def _small_net():
     from boostmvsnerfs_amd.config import make_cfg, set_cfg
     from boostmvsnerfs_amd.networks.enerf.network import Network
-    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
     cfg = make_cfg("enerf_eval")
     cfg.enerf.cas_config.volume_planes = [16, 8]
     set_cfg(cfg)
     torch.manual_seed(0)
     net = Network().eval().to(DEV)
-    ag = net._autograph
 
     def eager(b):
         with torch.no_grad():
             return {k: v.clone() for k, v in net._forward_checked(dict(b)).items()}
+    return net, eager
+
+
+def test_forward_captures_itself():
+    """autograph.AutoGraph behind Network.forward: the drop-in call replays a HIP graph from the second call with the
+    same shapes on.  Default contract = the reference's forward: inputs are never written, outputs are fresh tensors
+    (captured on private copies of the batch); a parameter update re-captures, another shape falls back to an eager
+    first call, a batch tensor that requires grad keeps the call eager."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    ag = net._autograph
+
+    def snapshot(b):
+        return {k: v.clone() for k, v in b.items() if torch.is_tensor(v)}
+
+    def unchanged(b, snap):
+        return all(torch.equal(b[k], v) for k, v in snap.items())
 
     batch = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
-    want = eager(batch)
+    other = clone_batch(make_batch(128, 160, n_views=3, seed=1), DEV)
+    snap_a, snap_b = snapshot(batch), snapshot(other)
+    want, want_other = eager(batch), eager(other)
     with torch.no_grad():
-        outs = [{k: v.clone() for k, v in net(batch).items()} for _ in range(4)]
+        outs = [net(batch) for _ in range(4)]          # NOT cloned: every call must hand out its own tensors
     torch.cuda.synchronize()
-    assert ag.stats["eager"] == 1 and ag.stats["captures"] == 1 and ag.stats["replays"] == 3 and ag.stats["copies"] == 0
+    assert ag.stats["eager"] == 1 and ag.stats["captures"] == 1 and ag.stats["replays"] == 3 and ag.stats["copies"] > 0
     for o in outs:
         for k in want:
             assert torch.equal(o[k], want[k]), k
+    assert len({o["rgb_level1"].data_ptr() for o in outs}) == 4
+    # two batches of the same shapes, alternated twice (ADVICE r3: with the graph captured on the caller's tensors the
+    # second pass rendered the wrong frame and the first batch's tensors had been overwritten)
+    with torch.no_grad():
+        frames = [net(b) for b in (batch, other, batch, other)]
+    torch.cuda.synchronize()
+    assert ag.stats["captures"] == 1
+    for f, w in zip(frames, (want, want_other, want, want_other)):
+        for k in w:
+            assert torch.equal(f[k], w[k]), k
+    assert unchanged(batch, snap_a) and unchanged(other, snap_b)
+    assert not torch.equal(want_other["rgb_level1"], want["rgb_level1"])
+    # a parameter update invalidates the captured frame
+    with torch.no_grad():
+        next(net.nerf_1.parameters()).mul_(1.01)
+    want4 = eager(other)
+    with torch.no_grad():
+        got4 = net(other)
+    assert ag.stats["captures"] == 2
+    for k in want4:
+        assert torch.equal(got4[k], want4[k]), k
+    # load_state_dict invalidates too (assign=True replaces the Parameter objects the version check walks)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    first = next(iter(k for k in sd if k.startswith("nerf_1") and sd[k].is_floating_point()))
+    sd[first] = sd[first] * 1.01
+    net.load_state_dict(sd, assign=True)
+    want4b = eager(other)
+    assert not torch.equal(want4b["rgb_level1"], want4["rgb_level1"])
+    with torch.no_grad():
+        for _ in range(3):
+            got4b = net(other)
+    for k in want4b:
+        assert torch.equal(got4b[k], want4b[k]), k
+    # another size: first call eager
+    small = clone_batch(make_batch(64, 96, n_views=3, seed=0), DEV)
+    n_eager = ag.stats["eager"]
+    with torch.no_grad():
+        got5 = net(small)
+    assert ag.stats["eager"] == n_eager + 1
+    want5 = eager(small)
+    for k in want5:
+        assert torch.equal(got5[k], want5[k]), k
+    # a batch tensor that requires grad (pose refinement with frozen weights): eager, the output carries the graph
+    for p in net.parameters():
+        p.requires_grad_(False)
+    posed = dict(other)
+    posed["tar_ext"] = other["tar_ext"].clone().requires_grad_(True)
+    assert not ag.usable(posed) and ag.usable(other)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    # training / autograd never replays
+    net.train()
+    assert not ag.usable(batch)
+    net.eval()
+
+
+def test_forward_resident_opt_in():
+    """`net.resident_inputs = True` / `net.alias_outputs = True` (autograph.py): the caller declares its batch resident
+    -- captured on its own tensors, nothing copied per frame, in-place edits picked up; outputs are the graph's static
+    tensors."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    net.resident_inputs = True
+    net.alias_outputs = True
+    ag = net._autograph
+    batch = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    want = eager(batch)
+    with torch.no_grad():
+        outs = [net(batch) for _ in range(4)]
+        for k in want:
+            assert torch.equal(outs[-1][k], want[k]), k
+    assert ag.stats["eager"] == 1 and ag.stats["captures"] == 1 and ag.stats["replays"] == 3 and ag.stats["copies"] == 0
+    assert outs[-1]["rgb_level1"].data_ptr() == outs[-2]["rgb_level1"].data_ptr()
     # the caller moves the camera IN PLACE in its resident batch: the replay reads the same tensors
     batch["tar_ext"][..., 0, 3] += 0.05
     want2 = eager(batch)
@@ -198,7 +285,7 @@ def test_forward_captures_itself():
     assert not torch.equal(want2["rgb_level1"], want["rgb_level1"])
     for k in want2:
         assert torch.equal(got2[k], want2[k]), k
-    # a new batch (other tensors, same shapes): copied into the captured buffers, same graph
+    # a new batch (other tensors, same shapes): copied into the declared batch's tensors, same graph
     other = clone_batch(make_batch(128, 160, n_views=3, seed=1), DEV)
     want3 = eager(other)
     with torch.no_grad():
@@ -206,26 +293,3 @@ def test_forward_captures_itself():
     assert ag.stats["captures"] == 1 and ag.stats["copies"] > 0
     for k in want3:
         assert torch.equal(got3[k], want3[k]), k
-    # a parameter update invalidates the captured frame
-    with torch.no_grad():
-        net.nerf_1.lr0[0].weight.mul_(1.01) if hasattr(net.nerf_1, "lr0") else next(net.nerf_1.parameters()).mul_(1.01)
-    want4 = eager(other)
-    with torch.no_grad():
-        got4 = net(other)
-        got4 = {k: v.clone() for k, v in got4.items()}
-    assert ag.stats["captures"] == 2
-    for k in want4:
-        assert torch.equal(got4[k], want4[k]), k
-    # another size: first call eager
-    small = clone_batch(make_batch(64, 96, n_views=3, seed=0), DEV)
-    n_eager = ag.stats["eager"]
-    with torch.no_grad():
-        got5 = net(small)
-    assert ag.stats["eager"] == n_eager + 1 and ag.stats["captures"] == 2
-    want5 = eager(small)
-    for k in want5:
-        assert torch.equal(got5[k], want5[k]), k
-    # training / autograd never replays
-    net.train()
-    assert not ag.usable(batch)
-    net.eval()

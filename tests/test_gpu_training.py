@@ -226,7 +226,7 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
         for k, p in net_b.named_parameters():
             # scatter kernels accumulate with atomics, so two runs of the SAME eager step differ by summation order;
             # training-mode batch norm over the few voxels of the tiny fixture's deep levels amplifies that to ~4e-3 of
-            # a tensor's rms in single entries (scripts/dev/r3_gradnoise.py: 4.1e-3 in train mode, 1.4e-5 in eval
+            # a tensor's rms in single entries (measured in round 3: 4.1e-3 in train mode, 1.4e-5 in eval
             # mode).  A replay that read stale inputs or parameters is wrong by O(1): the bar is the tensor's relative
             # L2 error
             num = float((ga[k] - p.grad).pow(2).sum().sqrt())
@@ -278,3 +278,52 @@ def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path
     assert graphed._key(other) != graphed._key(base)
     graphed(other)
     assert graphed.stats["eager"] == 4 and graphed.stats["replays"] == 3
+
+
+def test_graphed_train_step_interleaved_keys(enerf_fx):
+    """with more than one key in play a replay of an OLDER graph wrote gradients that no p.grad referenced
+    any more (the newer capture / an eager step had rebound them), and clip + Adam stepped on stale ones.  Sequence:
+    A x4 (3 eager + capture), B x4 (another ray count: its own eager steps and capture), then A (replay), B (replay),
+    A (replay) -- each against an eager twin in lockstep: loss and every gradient."""
+    import copy
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.train import GraphedTrainStep, NetworkWrapper, make_optimizer, train_step
+    set_cfg(tiny_cfg(enerf_fx, "enerf_pretrain"))
+    net_a = Network()
+    net_a.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net_a = net_a.to(DEV).train()
+    net_b = copy.deepcopy(net_a).train()
+    base = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in enerf_fx.batch().items()}
+
+    def batch_of(kind, seed):
+        b = dict(base)
+        g = torch.Generator().manual_seed(seed)
+        for i in range(2):
+            n = b[f"rays_{i}"].shape[1]
+            if kind == "B":                          # another key: half the rays of every level
+                b[f"rays_{i}"] = b[f"rays_{i}"][:, : n // 2].contiguous()
+                n = n // 2
+            b[f"rgb_{i}"] = torch.rand(1, n, 3, generator=g).to(DEV)
+        return b
+    wa, wb = NetworkWrapper(net_a), NetworkWrapper(net_b)
+    oa, ob = make_optimizer(net_a), make_optimizer(net_b)
+    graphed = GraphedTrainStep(wa, oa)
+    order = ["A"] * 4 + ["B"] * 4 + ["A", "B", "A"]
+    for s, kind in enumerate(order):
+        b = batch_of(kind, s)
+        net_b.load_state_dict(copy.deepcopy(net_a.state_dict()))
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        loss_a, _ = graphed(dict(b))
+        loss_b, _ = train_step(wb, ob, dict(b))
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, kind, float(loss_a), float(loss_b))
+        ga = {k: p.grad for k, p in net_a.named_parameters()}
+        gmax = max(float(p.grad.abs().max()) for p in net_b.parameters() if p.grad is not None)
+        for k, p in net_b.named_parameters():
+            assert (ga[k] is None) == (p.grad is None), (s, kind, k)
+            if p.grad is None:
+                continue
+            num = float((ga[k] - p.grad).pow(2).sum().sqrt())
+            den = float(p.grad.pow(2).sum().sqrt()) + 1e-6 * gmax
+            assert num <= 2e-2 * den, f"step {s} ({kind}) {k}: relative L2 error {num / den:.3e}"
+    assert graphed.stats["captures"] == 2 and graphed.stats["replays"] == 3 + 2, graphed.stats
