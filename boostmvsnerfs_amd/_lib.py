@@ -59,6 +59,8 @@ SIGNATURES = {
     "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],
+    "bmv_sweep_variance_quad_fwd": [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],
+    "bmv_to_quad_planar": [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_sweep_variance_views_fwd": [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_nchw_to_nhwc": [c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_depth_regress_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
@@ -120,7 +122,7 @@ SIGNATURES = {
     "bmv_bn_chunks": [c_i, c_l],
     "bmv_bn_train_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f],
     "bmv_bn_train_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_fl, c_f, c_f, c_f, c_f, c_f],
-    "bmv_conv_top_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f],
+    "bmv_conv_top_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_i, c_f],
     "bmv_conv0_fused_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_fl, c_f],
     "bmv_conv_heads_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "bmv_fpn_smooth_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],

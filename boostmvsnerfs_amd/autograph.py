@@ -68,6 +68,7 @@ class AutoGraph:
         self.seen = {}             # key -> number of eager calls so far
         self._tensors = None
         self._last = None          # resident inputs: ((ids of the batch's values, parameter version, shard, extra), entry)
+        self._hot = None           # private copies: the entry of the last replay (fast path of _hot_call)
         self.epoch = 0             # bumped by Module._apply (.to() / .cuda() replace storage) and load_state_dict
         self.stats = {"eager": 0, "captures": 0, "replays": 0, "copies": 0}
 
@@ -89,6 +90,7 @@ class AutoGraph:
         self.epoch += 1
         self._tensors = None
         self._last = None
+        self._hot = None
         self.entries.clear()
         self.seen.clear()
 
@@ -128,10 +130,50 @@ class AutoGraph:
         return not torch.cuda.is_current_stream_capturing()
 
     # ------------------------------------------------------------------ call
+    def _hot_call(self, batch):
+        """The steady state of a loop that hands over other tensors every frame (run.py): the batch has the structure of
+        the last replayed private-copy entry -> the input copy goes to the GPU FIRST (it is harmless whatever the key
+        checks say: the static inputs are private), the host-side checks run under it."""
+        e = self._hot
+        st = e["static"]
+        srcs = []
+        n = 0
+        for v in batch.values():
+            if torch.is_tensor(v) and not _built(v):
+                n += 1
+        if n != len(e["names"]):
+            return None
+        for k in e["names"]:
+            v = batch.get(k)
+            s = st[k]
+            if v is None or v.shape != s.shape or v.dtype != s.dtype or v.device != s.device:
+                return None
+            srcs.append(v)
+        if e["one_dtype"]:
+            torch._foreach_copy_(e["dsts"], srcs)
+        else:
+            _copy_many(e["dsts"], srcs)
+        if (e["version"] != self._param_version() or e["shard"] != self._shard()
+                or e["extra"] != self.net._autograph_key(batch) or self.entries.get(e["key"]) is not e):
+            return None
+        self.stats["copies"] += len(srcs)
+        self.stats["replays"] += 1
+        out = e["fg"].replay()
+        e["hits"] += 1
+        for k, v in e["added"].items():
+            batch[k] = v
+        if getattr(self.net, "alias_outputs", False):
+            return dict(out)
+        return self._fresh_outputs(e, out)
+
     def __call__(self, batch):
+        resident = bool(getattr(self.net, "resident_inputs", False))
+        if not resident and self._hot is not None:
+            res = self._hot_call(batch)
+            if res is not None:
+                return res
         version = self._param_version()
         extra = self.net._autograph_key(batch)
-        resident = bool(getattr(self.net, "resident_inputs", False))
         ident = None
         e = None
         if resident:
@@ -156,6 +198,9 @@ class AutoGraph:
                     return self.eager_forward(batch)
                 e = self._capture(key, batch, version, resident)
             copied = self._refresh(e, batch)
+            if not resident:
+                e["key"], e["shard"], e["extra"] = key, key[1], extra
+                self._hot = e
             if resident:
                 # these objects ARE the static inputs if nothing had to be copied: remember them for the fast path
                 self._last = (ident, e) if not copied else None
@@ -209,8 +254,9 @@ class AutoGraph:
         with torch.no_grad():
             fg = FrameGraph(run, static, cut=None)
         self.stats["captures"] += 1
+        names = [k for k, v in static.items() if torch.is_tensor(v)]
         e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added, "resident": resident,
-             "names": [k for k, v in static.items() if torch.is_tensor(v)]}
+             "names": names, "dsts": [static[k] for k in names], "one_dtype": len({static[k].dtype for k in names}) == 1}
         self.entries[key] = e
         return e
 

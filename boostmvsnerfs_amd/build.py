@@ -15,10 +15,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbmv.so")
-SOURCES = ["sweep.hip", "sweep_tiled.hip", "sweep_lds.hip", "sweep_split.hip", "sweep_win.hip", "sweep_ring.hip", "sweep_zp.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
+SOURCES = ["sweep.hip", "sweep_tiled.hip", "sweep_lds.hip", "sweep_split.hip", "sweep_win.hip", "sweep_ring.hip", "sweep_zp.hip", "sweep_quad.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
 HEADERS = ["bmv_common.hpp", "sweep_util.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}    # per-file flags
+# hipcc's SLP vectoriser turns the blend into v_pk_fma_f32 with every weight held as a register PAIR: slower per FMA on
+# gfx950 (measured round 2) and 20 registers over the 5-waves-per-SIMD budget
+EXTRA_FLAGS["sweep_quad.hip"] = ["-fno-slp-vectorize"]
+if os.environ.get("BMV_QUAD_DEFS"):
+    EXTRA_FLAGS["sweep_quad.hip"] += os.environ["BMV_QUAD_DEFS"].split()
 if os.environ.get("BMV_RENDER_DEFS"):   # e.g. "-DBMV_RENDER_STAMPS" for scripts/stamps_render.py
     EXTRA_FLAGS["render.hip"] = os.environ["BMV_RENDER_DEFS"].split()
 if os.environ.get("BMV_CONV_DEFS"):   # e.g. "-DBMV_CONV_WPE_TUNED=0": the convolution kernels at the allocator's own occupancy

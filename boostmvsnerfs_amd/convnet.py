@@ -197,14 +197,20 @@ def convT3d_fwd(x, wpack, bias, Cout, relu=False, skip=None, out=None, slope=Non
 def fpn_topdown(fine, coarse, weight, bias, out=None):
     """bilinear_x2(coarse, align_corners=True) + conv1x1(fine, weight (C,Cf,1,1), bias) -> (B,C,H,W)."""
     B, Cf, H, W = fine.shape
-    C = coarse.shape[1]
-    assert coarse.shape == (B, C, H // 2, W // 2)
+    from .ops import QuadFeats
+    if isinstance(coarse, QuadFeats):          # quad-planar (B,C/4,h,w,4): the plane sweep's layout, read in place
+        C = coarse.shape[-3]
+        assert tuple(coarse.data.shape) == (B, C // 4, H // 2, W // 2, 4)
+        coarse_mem, cl = coarse.data, 3
+    else:
+        C = coarse.shape[1]
+        assert coarse.shape == (B, C, H // 2, W // 2)
+        # a (B,C,h,w) view of a channel-last (B,h,w,C) buffer is read in place
+        cl = int((not coarse.is_contiguous()) and coarse.permute(0, 2, 3, 1).is_contiguous())
+        coarse_mem = coarse.permute(0, 2, 3, 1) if cl else coarse.contiguous()
     if out is None:
         out = torch.empty(B, C, H, W, device=fine.device, dtype=torch.float32)
     w = weight.detach().reshape(C, Cf).contiguous()
-    # a (B,C,h,w) view of a channel-last (B,h,w,C) buffer is read in place (the coarsest FPN map exists only so)
-    cl = (not coarse.is_contiguous()) and coarse.permute(0, 2, 3, 1).is_contiguous()
-    coarse_mem = coarse.permute(0, 2, 3, 1) if cl else coarse.contiguous()
     lib = _lib.load()
     with ktimer.region(f"fpn_topdown[{Cf}->{C},{H}x{W}]"):
         rc = lib.bmv_fpn_topdown_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse_mem, "coarse"), dptr(w, "w"),
@@ -234,17 +240,18 @@ class LookupRecords:
         return self.t.shape
 
 
-def conv_top(x, wpack, bias, wpack_top, bias_top, relu=True):
-    """conv1x1(act(conv3x3(x (B,32,H,W)))) -> (B,H,W,32) channel-last: FeatureNet's conv2.1 + toplayer as one launch
-    (the 1x1 layer is a second stage of the 3x3 layer's workgroups).  Both packs from `pack_conv`."""
+def conv_top(x, wpack, bias, wpack_top, bias_top, relu=True, quad=False):
+    """conv1x1(act(conv3x3(x (B,32,H,W)))) -> (B,H,W,32) channel-last, or (B,8,H,W,4) quad-planar with `quad`:
+    FeatureNet's conv2.1 + toplayer as one launch (the 1x1 layer is a second stage of the 3x3 layer's workgroups).  Both
+    packs from `pack_conv`."""
     B, C, H, W = x.shape
     assert C == 32
-    out = torch.empty(B, H, W, 32, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, 8, H, W, 4) if quad else (B, H, W, 32), device=x.device, dtype=torch.float32)
     lib = _lib.load()
     with ktimer.region(f"conv_top[32->32->32,{H}x{W}]"):
         rc = lib.bmv_conv_top_fwd(dptr(x.contiguous(), "x"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                                   dptr(wpack_top, "wpack_top"), dptr(bias_top, "bias_top"), dptr(out), B, H, W,
-                                  _slope(relu, None), stream())
+                                  _slope(relu, None), 3 if quad else 1, stream())
     _lib.check(rc, "conv_top_fwd")
     return out
 
@@ -322,14 +329,17 @@ def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, 
 
 def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):
     """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
-    ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout))."""
+    ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout)), or -- channels_last="quad" -- quad-planar (B,Cout/4,[Do,]Ho,Wo,4)."""
     is3d = x.dim() == 5
     B, Cin = x.shape[:2]
     D = x.shape[2] if is3d else 1
     H, W = x.shape[-2:]
     p, pd = k // 2, kd // 2
     Do, Ho, Wo = (D + 2 * pd - kd) // stride + 1, (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
-    if channels_last:
+    quad = channels_last == "quad"          # (B, Cout/4, [Do,] Ho, Wo, 4): the plane sweep's source layout
+    if quad:
+        shape = (B, Cout // 4, Do, Ho, Wo, 4) if is3d else (B, Cout // 4, Ho, Wo, 4)
+    elif channels_last:
         shape = (B, Do, Ho, Wo, Cout) if is3d else (B, Ho, Wo, Cout)
     else:
         shape = (B, Cout, Do, Ho, Wo) if is3d else (B, Cout, Ho, Wo)
@@ -343,6 +353,6 @@ def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, chann
     with ktimer.region(f"conv[{Cin}->{Cout},k{kd}x{k}x{k},s{stride},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                               dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout, kd, k, stride,
-                              _slope(relu, slope), int(bool(channels_last)), stream())
+                              _slope(relu, slope), 3 if quad else int(bool(channels_last)), stream())
     _lib.check(rc, "conv_fwd")
     return out

@@ -45,7 +45,8 @@ struct ConvArgs {
   float* out;          // (B, Cout, Do, Ho, Wo) or channel-last (B, Do, Ho, Wo, Cout)
   int B, Cin, D, H, W, Cout, Do, Ho, Wo;
   float slope;  // activation: v > 0 ? v : slope * v  (1 = none, 0 = ReLU, 0.01 = InPlaceABN's leaky ReLU)
-  int channels_last;   // 0 planar, 1 channel-last, 2 = the renderer's volume records (bmv_conv_heads_fwd)
+  int channels_last;   // 0 planar, 1 channel-last, 2 = the renderer's volume records (bmv_conv_heads_fwd),
+                       // 3 = quad-planar (B, Cout/4, Do, Ho, Wo, 4): the plane sweep's source layout (csrc/sweep_quad.hip)
   float* out2;         // mode 2: channel 8 (the depth logits), planar (B, Do, Ho, Wo)
   const float* w2;     // second stage (TOP): packed 1x1 weights [2 tiles][8 chunks][4][16] and bias (32)
   const float* b2;
@@ -244,7 +245,10 @@ void conv_mfma_kernel(ConvArgs a) {
         const int y = y0 + row, oc = t2 * 16 + 4 * g;
         if (x < a.Wo && y < a.Ho) {
           f32x4 q = {o[0] + a.b2[oc], o[1] + a.b2[oc + 1], o[2] + a.b2[oc + 2], o[3] + a.b2[oc + 3]};
-          *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.Ho + y) * a.Wo + x) * 32 + oc) = q;
+          if (a.channels_last == 3)   // quad-planar: (B, 8, Ho, Wo, 4)
+            *reinterpret_cast<f32x4*>(a.out + ((((size_t)b * 8 + (oc >> 2)) * a.Ho + y) * a.Wo + x) * 4) = q;
+          else
+            *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.Ho + y) * a.Wo + x) * 32 + oc) = q;
         }
       }
     }
@@ -276,6 +280,12 @@ void conv_mfma_kernel(ConvArgs a) {
       } else {
         a.out2[vox] = v[0];
       }
+    } else if (a.channels_last == 3) {
+      // quad-planar (Cout % 4 == 0, no skip: checked by the launcher): 4 consecutive channels of a pixel = one 16-byte store,
+      // neighbouring lanes (x) write neighbouring records
+      const size_t o = (((((size_t)b * (a.Cout >> 2) + (co0 >> 2)) * a.Do + z) * a.Ho + y) * a.Wo + x) * 4;
+      f32x4 q = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(a.out + o) = q;
     } else if (a.channels_last) {
       const size_t o = ((((size_t)b * a.Do + z) * a.Ho + y) * a.Wo + x) * a.Cout + co0;
       if ((a.Cout & 3) == 0) {
@@ -462,7 +472,7 @@ template <int CF, bool COARSE_CL>
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE, 8))) void fpn_topdown_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int C, int H, int W) {
+                                                          float* __restrict__ out, int C, int H, int W, int quad) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
   if (x >= W || y >= H) return;
   const int Hc = H / 2, Wc = W / 2;
@@ -475,13 +485,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE
   if constexpr (COARSE_CL) {
     // coarse is (B, Hc, Wc, C), the channel-last map the plane sweep reads: a bilinear tap of FOUR channels is one
     // 16-byte load (C % 4 == 0, checked by the launcher); two quads in flight
+    // ... or quad-planar (B, C/4, Hc, Wc, 4) (`quad`): the same 16-byte taps, pixel stride 4 and quad stride Hc Wc 4
     const float* cp = coarse + (size_t)b * hwc * C;
-    const size_t o00 = (size_t)(ly.i0 * Wc + lx.i0) * C, o01 = (size_t)(ly.i0 * Wc + lx.i1) * C;
-    const size_t o10 = (size_t)(ly.i1 * Wc + lx.i0) * C, o11 = (size_t)(ly.i1 * Wc + lx.i1) * C;
+    const size_t ps = quad ? 4 : (size_t)C;                 // floats between neighbouring pixels
+    const size_t qs = quad ? hwc * 4 : 4;                   // floats between the channel quads of a pixel
+    const size_t o00 = (size_t)(ly.i0 * Wc + lx.i0) * ps, o01 = (size_t)(ly.i0 * Wc + lx.i1) * ps;
+    const size_t o10 = (size_t)(ly.i1 * Wc + lx.i0) * ps, o11 = (size_t)(ly.i1 * Wc + lx.i1) * ps;
     const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
     for (int c = 0; c < C; c += 4) {
-      const float4 t00 = *reinterpret_cast<const float4*>(cp + o00 + c), t01 = *reinterpret_cast<const float4*>(cp + o01 + c);
-      const float4 t10 = *reinterpret_cast<const float4*>(cp + o10 + c), t11 = *reinterpret_cast<const float4*>(cp + o11 + c);
+      const size_t co = (size_t)(c >> 2) * qs;
+      const float4 t00 = *reinterpret_cast<const float4*>(cp + o00 + co), t01 = *reinterpret_cast<const float4*>(cp + o01 + co);
+      const float4 t10 = *reinterpret_cast<const float4*>(cp + o10 + co), t11 = *reinterpret_cast<const float4*>(cp + o11 + co);
       float v[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -991,7 +1005,11 @@ void conv_splitk_kernel(ConvArgs a) {
     v[j] = sum[j] + a.bias[co0 + j];
     v[j] = fmaxf(v[j], 0.f) + a.slope * fminf(v[j], 0.f);
   }
-  if (a.channels_last) {
+  if (a.channels_last == 3) {
+    const size_t o = (((((size_t)b * (a.Cout >> 2) + (co0 >> 2)) * a.Do + z0) * a.Ho + y) * a.Wo + x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.out[o + j] = v[j];
+  } else if (a.channels_last) {
     const size_t o = ((((size_t)b * a.Do + z0) * a.Ho + y) * a.Wo + x) * a.Cout + co0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1255,7 +1273,9 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = Cout;
   const int p = k / 2, pd = kd / 2;
   a.Do = (D + 2 * pd - kd) / stride + 1, a.Ho = (H + 2 * p - k) / stride + 1, a.Wo = (W + 2 * p - k) / stride + 1;
-  a.slope = act_slope, a.channels_last = out_channels_last ? 1 : 0, a.out2 = nullptr;
+  BMV_REQUIRE(out_channels_last == 0 || out_channels_last == 1 || out_channels_last == 3, "conv: out layout %d", out_channels_last);
+  BMV_REQUIRE(out_channels_last != 3 || ((Cout & 3) == 0 && !skip), "conv: quad-planar output needs Cout %% 4 == 0 and no skip");
+  a.slope = act_slope, a.channels_last = out_channels_last, a.out2 = nullptr;
   hipStream_t st = as_stream(stream);
   if (kd == 1 && k == 3 && stride == 1)
     dispatch_conv<1, 3, 1, 8, 2, false>(a, st);
@@ -1320,30 +1340,33 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   BMV_REQUIRE(!coarse_channels_last || C % 4 == 0, "fpn_topdown: a channel-last coarse map needs C %% 4 == 0 (C=%d)", C);
   dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
   hipStream_t st = as_stream(stream);
+  const int quad = coarse_channels_last == 3;   // 0 planar, 1 channel-last, 3 quad-planar
   if (Cf == 8 && !coarse_channels_last)
-    hipLaunchKernelGGL((fpn_topdown_kernel<8, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
   else if (Cf == 16 && !coarse_channels_last)
-    hipLaunchKernelGGL((fpn_topdown_kernel<16, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
   else if (Cf == 8)
-    hipLaunchKernelGGL((fpn_topdown_kernel<8, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
   else if (Cf == 16)
-    hipLaunchKernelGGL((fpn_topdown_kernel<16, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W);
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");
 }
 
 int bmv_conv_top_fwd(const float* in, const float* wpack, const float* bias, const float* wpack_top,
-                     const float* bias_top, float* out, int B, int H, int W, float act_slope, bmv_stream_t stream) {
+                     const float* bias_top, float* out, int B, int H, int W, float act_slope, int out_layout,
+                     bmv_stream_t stream) {
   using namespace bmv;
   BMV_REQUIRE(in && wpack && bias && wpack_top && bias_top && out, "conv_top: null pointer");
+  BMV_REQUIRE(out_layout == 1 || out_layout == 3, "conv_top: out layout %d (1 channel-last, 3 quad-planar)", out_layout);
   BMV_REQUIRE(B > 0 && H > 0 && W > 0, "conv_top: bad shape");
   BMV_REQUIRE((size_t)32 * H * W < (1u << 29), "conv_top: one batch item must stay below 2 GiB");
   ConvArgs a;
   a.in = in, a.wpack = wpack, a.bias = bias, a.skip = nullptr, a.out = out, a.out2 = nullptr;
   a.w2 = wpack_top, a.b2 = bias_top;
   a.B = B, a.Cin = 32, a.D = 1, a.H = H, a.W = W, a.Cout = 32, a.Do = 1, a.Ho = H, a.Wo = W;
-  a.slope = act_slope, a.channels_last = 1;
+  a.slope = act_slope, a.channels_last = out_layout;
   using T = ConvTile<1, 3, 1, 2, 4, 0, false>;
   dim3 grid(cdiv(W, 16) * cdiv(H, T::TY) * B, 1);
   hipLaunchKernelGGL((conv_mfma_kernel<1, 3, 1, 2, 4, 0, false, true>), grid, dim3(256), 0, as_stream(stream), a);

@@ -85,6 +85,8 @@ class Network(enerf_network.Network):
     @staticmethod
     def _pick_feats(f, bi, ids):
         """f[bi, ids] that keeps a channel-last feature buffer channel-last (the sweep reads it without a transpose)."""
+        if isinstance(f, ops.QuadFeats):           # quad-planar (the inference sweep's layout): gathered as it is
+            return ops.QuadFeats(f.data[bi, ids].contiguous())
         cl = f.permute(0, 1, 3, 4, 2)
         if not f.is_contiguous() and cl.is_contiguous():
             return cl[bi, ids].permute(0, 1, 4, 2, 3)
@@ -251,7 +253,8 @@ class Network(enerf_network.Network):
             f_i = feats[f"level_{i}"]
             variance = torch.empty(K, f_i.shape[2], D, h, w, device=dev)
             for k in ks:
-                ops.sweep_variance_views(f_i, sel32[k], proj[k:k + 1], cur.depth_values[k:k + 1], out=variance[k:k + 1])
+                ops.sweep_variance_views(f_i, sel32[k], proj[k:k + 1], cur.depth_values[k:k + 1], out=variance[k:k + 1],
+                                         plane_uniform=st is None)
             cur.feature_volume, depth_prob = getattr(self, f"cost_reg_{i}")(variance)
             cur.depth, cur.std = ops.depth_regress(depth_prob, cur.depth_values, cc.depth_inv[i])
             st = cur
@@ -339,8 +342,9 @@ class Network(enerf_network.Network):
         # views out of the all-views tensors by index -- no gathered copies of images / feature maps per volume
         # (those copies were 15 % of a K = 4 frame); only the 4x4 / 3x3 camera matrices are gathered, once per volume.
         by_index = (self.by_index and not train and all(cc.render_scale[i] == 1.0 for i in range(cc.num) if cc.render_if[i])
-                    and all(not feats[f"level_{i}"].is_contiguous()
-                            and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous() for i in range(cc.num)))
+                    and all(isinstance(feats[f"level_{i}"], ops.QuadFeats)
+                            or (not feats[f"level_{i}"].is_contiguous()
+                                and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous()) for i in range(cc.num)))
         if by_index:
             # (B,K,3) -> K tensors (B,3); in range by construction: rows of combinations(range(N), 3) picked by the
             # triplet numbers validated above, so no device read is spent on ops.check_view_ids

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import autograd as A
-from ... import convnet
+from ... import convnet, ops
 from .conv_train import Conv2d, Conv3d, ConvTranspose3d, _Conv3dFn   # engine forward / data gradients, MFMA weight gradients
 
 
@@ -129,6 +129,7 @@ class FeatureNet(nn.Module):
         self.smooth0 = Conv2d(32, 8, 3, padding=1)
         self._packed = _Packed()
         self.pack_lookup = False     # engine path: emit the full-resolution map as the renderer's lookup records
+        self.quad_out = True         # engine path: the two maps the plane sweeps read come out quad-planar (ops.QuadFeats)
 
     @staticmethod
     def _top_down(coarse, lateral):
@@ -164,11 +165,13 @@ class FeatureNet(nn.Module):
         c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
         # the coarsest map is written once, channel-last (the level-0 sweep's layout); the top-down step reads it so
+        quad = self.quad_out      # the plane sweep's quad-planar layout (inference default) or channel-last
         if FUSE_TOP:      # conv2.1 + toplayer: the 1x1 layer is a second stage of the 3x3 layer's workgroups
-            p2 = convnet.conv_top(c2, *P["conv2.1"], *P["toplayer"]).permute(0, 3, 1, 2)
+            p2 = convnet.conv_top(c2, *P["conv2.1"], *P["toplayer"], quad=quad)
         else:
             c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
-            p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last=True).permute(0, 3, 1, 2)
+            p2 = convnet.conv_fwd(c2, *P["toplayer"], 32, 1, 1, channels_last="quad" if quad else True)
+        p2 = ops.QuadFeats(p2) if quad else p2.permute(0, 3, 1, 2)
         return c0, c1, p2, p2
 
     def engine_top_down(self, c0, c1, p2, rgb=None):
@@ -177,7 +180,7 @@ class FeatureNet(nn.Module):
         (convnet.LookupRecords: feature channels + colours of a pixel in one 48-byte record)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
-        f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last=True)
+        f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last="quad" if self.quad_out else True)
         if rgb is not None:
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
         elif FUSE_FPN_SMOOTH:
@@ -186,11 +189,12 @@ class FeatureNet(nn.Module):
         else:
             p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
             f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
-        return f1.permute(0, 3, 1, 2), f0
+        return (ops.QuadFeats(f1) if self.quad_out else f1.permute(0, 3, 1, 2)), f0
 
     def _forward_engine(self, x):
-        """Same graph, one launch per conv block.  The two maps the plane sweeps read come out channel-last
-        (returned as (N,C,H,W) views of (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
+        """Same graph, one launch per conv block.  The two maps the plane sweeps read come out quad-planar
+        (ops.QuadFeats: `.to_nchw()` gives the planar tensor); with `quad_out = False` channel-last ((N,C,H,W) views of
+        (N,H,W,C) buffers: `.contiguous()` gives the planar tensor)."""
         c0, c1, p2, p2_cl = self.engine_bottom_up(x)
         f1, f0 = self.engine_top_down(c0, c1, p2, rgb=x if self.pack_lookup else None)
         return p2_cl, f1, f0

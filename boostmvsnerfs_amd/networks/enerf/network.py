@@ -24,6 +24,11 @@ from .cnn import CostRegNet, FeatureNet, MinCostRegNet, engine_ok
 from .nerf import NeRF
 
 
+def _views(t, B, V, h, w):
+    """(B V, C, h, w) feature maps -> (B, V, C, h, w); ops.QuadFeats (the sweep's layout) keep their wrapper."""
+    return t.reshape_views(B, V) if isinstance(t, ops.QuadFeats) else t.reshape(B, V, -1, h, w)
+
+
 class LevelState:
     """What one cascade level hands to the next (and to the renderer)."""
     __slots__ = ("depth", "std", "near_far", "feature_volume", "depth_values", "keep")
@@ -73,9 +78,10 @@ class Network(nn.Module):
         """(B,V,3,H,W) -> {'level_0': 32ch @ 1/4, 'level_1': 16ch @ 1/2, 'level_2': 8ch @ 1}
         (lib/networks/enerf/network.py:58-67)."""
         B, V, C, H, W = x.shape
+        self.feature_net.quad_out = self.sweep_algo == 0 or self.sweep_algo >= 500
         coarse, mid, fine = self.feature_net(x.reshape(B * V, C, H, W))
-        return {"level_0": coarse.reshape(B, V, -1, H // 4, W // 4),
-                "level_1": mid.reshape(B, V, -1, H // 2, W // 2),
+        return {"level_0": _views(coarse, B, V, H // 4, W // 4),
+                "level_1": _views(mid, B, V, H // 2, W // 2),
                 "level_2": fine.reshape_views(B, V) if isinstance(fine, convnet.LookupRecords) else fine.reshape(B, V, -1, H, W)}
 
     def set_volume_records(self, on):
@@ -142,12 +148,13 @@ class Network(nn.Module):
                 st.depth_values, st.near_far = ops.depth_values_cascade(prev.depth, prev.std, prev.near_far, h, w, D)
         proj = pre["proj"][i] if pre is not None else ops.proj_mats(
             src_exts, src_ixts, batch["tar_ext"], batch["tar_ixt"], cc.im_feat_scale[i], cc.volume_scale[i])
+        uniform = prev is None or prev.depth is None     # level 0: one hypothesis per plane (enerf/utils.py:104-111)
         if train:
             variance = A.SweepVariance.apply(feats_i, proj, st.depth_values, self.sweep_algo)
         elif view_ids is not None:
-            variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values)
+            variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values, plane_uniform=uniform)
         else:
-            variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo)
+            variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo, plane_uniform=uniform)
         if fork_after_sweep is not None:
             fork_after_sweep.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(fork_after_sweep):
@@ -221,6 +228,8 @@ class Network(nn.Module):
     def render_level(self, i, st, im_feat, views, batch, mode=0, outs=None, view_ids=None):
         """rays -> pixels (mode 0) or raw MLP outputs + depths + visibility (mode 1)
         (network.py:24-55, boost_enerf/network.py:123-161).  `view_ids`: see level_front (needs render_scale 1)."""
+        if isinstance(im_feat, ops.QuadFeats):     # a cascade level rendered from a map the sweep also reads (level 0 /
+            im_feat = im_feat.to_nchw()            # level 1 image features): the renderer takes the planar tensor
         cc = cfg.enerf.cas_config
         src_inps, src_exts, src_ixts = views
         H, W = src_inps.shape[-2:]
@@ -283,12 +292,13 @@ class Network(nn.Module):
         B, V, C, H, W = x.shape
         fn = self.feature_net
         self._pre = self.camera_only(views, batch) if self.frame_setup else None
+        fn.quad_out = self.sweep_algo == 0 or self.sweep_algo >= 500
         c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
         main = torch.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))
         side = self._side_stream
-        level0 = p2_cl.reshape(B, V, -1, H // 4, W // 4)
+        level0 = _views(p2_cl, B, V, H // 4, W // 4)
         if self.overlap_front == 2:
             st0 = self.level_front(0, level0, views, batch, None, fork_after_sweep=side, pre=self._pre)
         else:
@@ -304,7 +314,7 @@ class Network(nn.Module):
                     t = t.t
                 if t is not None:
                     t.record_stream(main)
-        feats = {"level_0": level0, "level_1": f1.reshape(B, V, -1, H // 2, W // 2),
+        feats = {"level_0": level0, "level_1": _views(f1, B, V, H // 2, W // 2),
                  "level_2": f0.reshape_views(B, V) if isinstance(f0, convnet.LookupRecords) else f0.reshape(B, V, -1, H, W)}
         return feats, st0
 

@@ -121,19 +121,129 @@ def nchw_to_nhwc(x):
     return out
 
 
+class QuadFeats:
+    """Source feature maps in the plane sweep's QUAD-PLANAR layout (csrc/sweep_quad.hip): `data` is (N, C/4, H, W, 4) or
+    (B, V, C/4, H, W, 4) contiguous -- a record of 4 channels = 16 bytes.  Written directly by the convolution engine in
+    inference (convnet.conv_fwd(..., channels_last="quad")); `to_quad_planar` converts planar / channel-last maps.
+    `shape` is the LOGICAL planar shape, `to_nchw()` the planar tensor (a copy)."""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        if data.dim() not in (5, 6) or data.shape[-1] != 4 or not data.is_contiguous():
+            raise ValueError("QuadFeats wants a contiguous (..., C/4, H, W, 4) tensor")
+        self.data = data
+
+    @property
+    def shape(self):            # the logical (N, C, H, W) / (B, V, C, H, W)
+        *lead, Q, H, W, _ = self.data.shape
+        return torch.Size((*lead, Q * 4, H, W))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    def dim(self):
+        return self.data.dim() - 1
+
+    def reshape_views(self, B, V):
+        """(B V, C/4, H, W, 4) -> the (B, V, ...) form the sweep takes."""
+        return QuadFeats(self.data.reshape(B, V, *self.data.shape[-4:]))
+
+    def contiguous(self):       # (what `.contiguous()` on the earlier channel-last views gave: the planar tensor)
+        return self.to_nchw()
+
+    def to_nchw(self):
+        *lead, Q, H, W, _ = self.data.shape
+        n = len(lead)
+        return self.data.permute(*range(n), n, n + 3, n + 1, n + 2).reshape(*lead, Q * 4, H, W)
+
+
+def to_quad_planar(x, channels_last=False):
+    """(..., C, H, W) planar -- or (..., H, W, C) with channels_last=True -- -> (..., C/4, H, W, 4), C % 4 == 0."""
+    if channels_last:
+        H, W, C_ = x.shape[-3:]
+    else:
+        C_, H, W = x.shape[-3:]
+    n = x.numel() // (C_ * H * W)
+    out = torch.empty(*x.shape[:-3], C_ // 4, H, W, 4, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"to_quad_planar[C={C_},{H}x{W}]"):
+        rc = lib.bmv_to_quad_planar(dptr(_c(x), "x"), int(bool(channels_last)), n, C_, H, W, dptr(out), stream())
+    _lib.check(rc, "to_quad_planar")
+    return out
+
+
+def _plane_uniform(depth_values, plane_uniform):
+    """dv_plane_uniform of include/bmv.h from the hypotheses' shape: (B,D) -> 1; (B,D,h,w) -> 0, or 2 when the caller
+    vouches that the planes are constant (cascade level 0: `plane_uniform=True`)."""
+    if depth_values.dim() == 2:
+        return 1
+    return 2 if plane_uniform else 0
+
+
+def sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plane_uniform=False, variant=-1, out=None,
+                        flags=0):
+    """Plane sweep on quad-planar features (QuadFeats or its (B,V,C/4,Hs,Ws,4) tensor).  `view_ids` (B,S) int32 picks the
+    S views of proj from the V views of feats; None: V == S."""
+    if sweep_hook is not None:
+        r = sweep_hook(_sweep_variance_quad, (feats, proj, depth_values),
+                       dict(view_ids=view_ids, hw=hw, plane_uniform=plane_uniform, variant=variant, out=out, flags=flags))
+        if r is not None:
+            return r
+    return _sweep_variance_quad(feats, proj, depth_values, view_ids, hw, plane_uniform, variant, out, flags)
+
+
+def _sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plane_uniform=False, variant=-1, out=None,
+                         flags=0):
+    data = feats.data if isinstance(feats, QuadFeats) else feats
+    if data.dim() != 6:
+        raise ValueError("the quad-planar sweep takes (B, V, C/4, Hs, Ws, 4) features (QuadFeats.reshape_views)")
+    B, V, Q, Hs, Ws, _ = data.shape
+    C_ = Q * 4
+    S = proj.shape[1]
+    if depth_values.dim() == 2:
+        D = depth_values.shape[1]
+        h, w = hw
+    else:
+        _, D, h, w = depth_values.shape
+    if view_ids is not None:
+        if view_ids.dtype != torch.int32 or tuple(view_ids.shape) != (B, S):
+            raise ValueError("view_ids must be int32 (B,S)")
+        check_view_ids(view_ids, V)
+    elif V != S:
+        raise ValueError(f"{V} source views but {S} projection matrices (pass view_ids to pick)")
+    if out is None:
+        out = torch.empty(B, C_, D, h, w, device=data.device, dtype=torch.float32)
+    lib = _lib.load()
+    with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]", bind=True):
+        rc = lib.bmv_sweep_variance_quad_fwd(dptr(data, "feats_quad"), dptr(_c(view_ids), "view_ids", torch.int32) if view_ids is not None else None,
+                                             V, dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
+                                             _plane_uniform(depth_values, plane_uniform), B, S, C_,
+                                             Hs, Ws, D, h, w, dptr(out), int(variant), int(flags), stream())
+    _lib.check(rc, "sweep_variance_quad")
+    return out
+
+
 sweep_hook = None     # framegraph.FrameGraph: hook(impl, args, kwargs) lets a graph capture step around one sweep launch
 
 
-def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
-    """feats: (B,S,C,Hs,Ws) in the reference layout, or channel-last (B,S,Hs,Ws,C) when
-    channels_last=True.  With channels_last=None (default) a reference-layout input with C in
-    {16, 32} is first put into the channel-last layout (one transpose kernel) and the fast
-    channel-last sweep runs; algo=1 forces the reference-layout direct-gather kernel."""
+def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False):
+    """feats: QuadFeats (the inference layout: csrc/sweep_quad.hip), or (B,S,C,Hs,Ws) in the reference layout, or
+    channel-last (B,S,Hs,Ws,C) when channels_last=True.  With channels_last=None (default) a reference-layout input
+    with C in {16, 32} is first put into the channel-last layout (one transpose kernel) and the windowed channel-last
+    sweep runs; algo=1 forces the reference-layout direct-gather kernel; algo 500 + i / 600 + i: the quad-planar kernel
+    (tuning variant i; 600: hypotheses declared plane-uniform) after a layout conversion.  `plane_uniform`: the caller
+    vouches that every plane of depth_values is constant (cascade level 0)."""
     if sweep_hook is not None:
-        r = sweep_hook(_sweep_variance, (feats, proj, depth_values), dict(algo=algo, out=out, channels_last=channels_last))
+        r = sweep_hook(_sweep_variance, (feats, proj, depth_values),
+                       dict(algo=algo, out=out, channels_last=channels_last, plane_uniform=plane_uniform))
         if r is not None:
             return r
-    return _sweep_variance(feats, proj, depth_values, algo, out, channels_last)
+    return _sweep_variance(feats, proj, depth_values, algo, out, channels_last, plane_uniform)
 
 
 def mark_view_ids(view_ids, n_all):
@@ -159,18 +269,20 @@ def check_view_ids(view_ids, n_all):
     return mark_view_ids(view_ids, n_all)
 
 
-def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
-    """Plane sweep over the S views `view_ids` (B,S) int32 picked from feats_all = ALL source views: a
-    (B,n_all,C,Hs,Ws) view of a channel-last (B,n_all,Hs,Ws,C) buffer (what FeatureNet's engine path returns).
-    No gathered copy of the feature maps is made."""
+def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False):
+    """Plane sweep over the S views `view_ids` (B,S) int32 picked from feats_all = ALL source views: QuadFeats (what
+    FeatureNet's engine path returns in inference), or a (B,n_all,C,Hs,Ws) view of a channel-last (B,n_all,Hs,Ws,C)
+    buffer.  No gathered copy of the feature maps is made."""
     if sweep_hook is not None:
-        r = sweep_hook(_sweep_variance_views, (feats_all, view_ids, proj, depth_values), dict(out=out))
+        r = sweep_hook(_sweep_variance_views, (feats_all, view_ids, proj, depth_values), dict(out=out, plane_uniform=plane_uniform))
         if r is not None:
             return r
-    return _sweep_variance_views(feats_all, view_ids, proj, depth_values, out)
+    return _sweep_variance_views(feats_all, view_ids, proj, depth_values, out, plane_uniform)
 
 
-def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
+def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False):
+    if isinstance(feats_all, QuadFeats):
+        return _sweep_variance_quad(feats_all, proj, depth_values, view_ids, None, plane_uniform, -1, out)
     cl = feats_all.permute(0, 1, 3, 4, 2) if feats_all.dim() == 5 else None
     if cl is None or not cl.is_contiguous():
         raise ValueError("sweep_variance_views needs a (B,n_all,C,Hs,Ws) view of channel-last feature maps")
@@ -191,7 +303,23 @@ def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None):
     return out
 
 
-def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None):
+def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False):
+    if isinstance(feats, QuadFeats) and not (algo == 0 or algo >= 500):
+        feats, channels_last = feats.to_nchw(), None     # another kernel was asked for by id: back to the planar layout
+    if isinstance(feats, QuadFeats) or algo >= 500:      # quad-planar kernel (500 + i: tuning variant i; 600 + i: the same
+        variant = -1                                     # with the hypotheses declared plane-uniform)
+        pu = bool(plane_uniform)
+        if algo >= 600:
+            variant, pu = algo - 600, True
+        elif algo >= 500:
+            variant = algo - 500
+        if not isinstance(feats, QuadFeats):
+            if channels_last is None and feats.dim() == 5 and not feats.is_contiguous():
+                cl = feats.permute(0, 1, 3, 4, 2)
+                if cl.is_contiguous():
+                    feats, channels_last = cl, True
+            feats = QuadFeats(to_quad_planar(feats, channels_last=bool(channels_last)))
+        return _sweep_variance_quad(feats, proj, depth_values, None, None, pu, variant, out)
     if channels_last is None and feats.dim() == 5 and not feats.is_contiguous() and algo != 1:
         cl = feats.permute(0, 1, 3, 4, 2)
         if cl.is_contiguous():        # (B,S,C,Hs,Ws) view of a channel-last buffer (the conv engine writes it so)

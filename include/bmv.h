@@ -80,6 +80,21 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
 int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, int n_all, const float* proj,
                                  const float* depth_values, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
                                  float* variance, bmv_stream_t stream);
+/* ---- a3+a4 on QUAD-PLANAR features with union windows in LDS (round 4, csrc/sweep_quad.hip): the inference sweep.
+ * Same function as bmv_sweep_variance_fwd (lib/networks/enerf/utils.py:57-95, :324-351) on another source layout:
+ * feats_quad (B, n_views, C/4, Hs, Ws, 4) -- a record of 4 channels = 16 bytes (written directly by the convolution
+ * engine, out_layout 3 of bmv_conv_fwd; bmv_to_quad_planar converts planar or channel-last maps)
+ * -> variance (B,C,D,h,w) planar, as bmv_sweep_variance_fwd writes it.
+ * dv_plane_uniform: 0 = depth_values (B,D,h,w); 1 = (B,D) one hypothesis per plane (cascade level 0); 2 = (B,D,h,w)
+ * whose planes are constant ([b,d,0,0] is read).  view_ids (B,S) int32 or NULL: views picked from the n_all views of
+ * feats_quad (n_all ignored when NULL: feats_quad holds exactly S views per item).  variant: -1 = by the source / volume
+ * scale; 0.. = tuning table of sweep_quad.hip.  flags: 0 (tuning ablations: 1 no fill, 2 no blend, 4 no store).
+ * S in 2..4, C % 4 == 0, C <= 64. */
+int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, int n_all, const float* proj,
+                                const float* depth_values, int dv_plane_uniform, int B, int S, int C, int Hs, int Ws,
+                                int D, int h, int w, float* variance, int variant, int flags, bmv_stream_t stream);
+/* in (n,C,H,W) planar (channels_last 0) or (n,H,W,C) (channels_last 1) -> out (n,C/4,H,W,4), C % 4 == 0 */
+int bmv_to_quad_planar(const float* in, int channels_last, int n, int C, int H, int W, float* out, bmv_stream_t stream);
 /* (n,C,H,W) -> (n,H,W,C), C % 4 == 0: puts the 2-D features into the sweep's channel-last layout */
 int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, bmv_stream_t stream);
 
@@ -413,6 +428,8 @@ int bmv_conv_wpack_floats(int Cin, int Cout, int kd, int k, int stride);
  * convolution run as a convolution).  for_transpose_kernel != 0: the blob of bmv_conv3d_transpose_fwd (never paired). */
 int bmv_conv_pack_weights(const float* weight, int Cin, int Cout, int kd, int k, int stride, int transposed, int flip,
                           int for_transpose_kernel, float* wpack, bmv_stream_t stream);
+/* out_channels_last: 0 = out planar (B,Cout,Do,Ho,Wo); 1 = channel-last (B,Do,Ho,Wo,Cout); 3 = quad-planar
+ * (B,Cout/4,Do,Ho,Wo,4), the plane sweep's source layout (bmv_sweep_variance_quad_fwd; Cout % 4 == 0, no skip). */
 int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                  int D, int H, int W, int Cout, int kd, int k, int stride, float act_slope, int out_channels_last,
                  bmv_stream_t stream);
@@ -426,7 +443,8 @@ int bmv_conv3d_transpose_fwd(const float* in, const float* wpack, const float* b
 
 /* FPN top-down step (feature_net.py:24-36 `_upsample_add` + lat1 / lat0):
  * out (B,C,H,W) = bilinear_x2(coarse (B,C,H/2,W/2), align_corners=True) + conv1x1(fine (B,Cf,H,W); w (C,Cf)) + bias;
- * coarse_channels_last: coarse is (B,H/2,W/2,C) (the coarsest map is kept only in the sweep's layout) */
+ * coarse_channels_last: 0 = coarse planar; 1 = (B,H/2,W/2,C); 3 = quad-planar (B,C/4,H/2,W/2,4) (the coarsest map
+ * is kept only in the plane sweep's layout) */
 int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, const float* bias, float* out, int B,
                         int Cf, int C, int H, int W, int coarse_channels_last, bmv_stream_t stream);
 
@@ -439,11 +457,13 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
                        int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
-/* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last =
+/* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
+ * or (B,8,H,W,4) quad-planar (out_layout 3) =
  * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights
  * layout for (32, 32, k = 3 | 1, stride 1).  The 3x3 layer's output is finished in LDS by the same workgroup. */
 int bmv_conv_top_fwd(const float* in, const float* wpack, const float* bias, const float* wpack_top,
-                     const float* bias_top, float* out, int B, int H, int W, float act_slope, bmv_stream_t stream);
+                     const float* bias_top, float* out, int B, int H, int W, float act_slope, int out_layout,
+                     bmv_stream_t stream);
 
 /* FeatureNet's first block as one launch (feature_net.py:8-10: ConvBnReLU(3,8) + ConvBnReLU(8,Cout<=8), eval-mode batch
  * norm folded): out (B,Cout,H,W) = act1(conv3x3(act0(conv3x3(in (B,3,H,W); w0 (8,3,3,3)) + b0); wpack) + bias); the

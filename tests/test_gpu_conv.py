@@ -192,10 +192,21 @@ def test_feature_net_engine_matches_torch_modules(monkeypatch):
         got = net(x)
         monkeypatch.setenv("BMV_CNN", "torch")
         want = net(x)
-    assert not got[0].is_contiguous() and got[0].permute(0, 2, 3, 1).is_contiguous()      # sweep layout
+    from boostmvsnerfs_amd.ops import QuadFeats
+    assert isinstance(got[0], QuadFeats) and isinstance(got[1], QuadFeats)                  # the sweep's layout
     for g_, w_ in zip(got, want):
         assert g_.shape == w_.shape
+        _close(g_.contiguous(), w_)
+    # ... and the channel-last form (training / other sweep kernels): (N,C,H,W) views of (N,H,W,C) buffers
+    monkeypatch.delenv("BMV_CNN")
+    net.quad_out = False
+    with torch.no_grad():
+        got_cl = net(x)
+    net.quad_out = True
+    assert not got_cl[0].is_contiguous() and got_cl[0].permute(0, 2, 3, 1).is_contiguous()
+    for g_, w_ in zip(got_cl, want):
         _close(g_, w_)
+    monkeypatch.setenv("BMV_CNN", "torch")
     # a parameter update invalidates the packed weights
     monkeypatch.delenv("BMV_CNN")
     with torch.no_grad():

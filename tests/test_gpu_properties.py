@@ -90,10 +90,10 @@ def test_views_by_index_equals_gathered_views_full_size(full):
         picked = (batch["all_src_inps"][bi, ids], exts, ixts)
         by_index = (batch["all_src_inps"], exts, ixts)
         f1 = feats["level_1"]
-        assert not f1.is_contiguous() and f1.permute(0, 1, 3, 4, 2).is_contiguous()
+        assert isinstance(f1, ops.QuadFeats)                 # the inference sweep's layout, all N views
         st_a = st_b = None
         for i in range(cc.num):
-            fa = feats[f"level_{i}"].permute(0, 1, 3, 4, 2)[bi, ids].permute(0, 1, 4, 2, 3)
+            fa = ops.QuadFeats(feats[f"level_{i}"].data[bi, ids].contiguous())      # gathered copies of the 3 views
             st_a = net.level_front(i, fa, picked, batch, st_a)
             st_b = net.level_front(i, feats[f"level_{i}"], by_index, batch, st_b, view_ids=ids32)
             assert torch.equal(st_a.depth, st_b.depth) and torch.equal(st_a.feature_volume, st_b.feature_volume)
