@@ -133,6 +133,11 @@ SIGNATURES = {
     "bmv_bind_next_launch": [C.c_void_p, C.c_void_p],
     "bmv_launch_events_pending": [],
     "bmv_version": [],
+    "bmv_tuning_set": [C.c_char_p, c_i],
+    "bmv_tuning_clear": [C.c_char_p],
+    "bmv_tuning_get": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "bmv_tuning_name": [c_i],          # returns const char*
+    "bmv_tuning_doc": [c_i],           # returns const char*
 }
 
 
@@ -161,8 +166,42 @@ def load():
     lib.bmv_conv_wgrad_workspace.restype = C.c_long
     lib.bmv_last_error.argtypes = []
     lib.bmv_last_error.restype = C.c_char_p
+    lib.bmv_tuning_name.restype = C.c_char_p
+    lib.bmv_tuning_doc.restype = C.c_char_p
     _lib = lib
+    # the launchers' tuning switches are explicit library state (include/bmv.h); environment variables of the same names
+    # are applied HERE, once, in the open -- the C side never reads the environment
+    for name in tuning_names():
+        if name in os.environ:
+            set_tuning(name, int(os.environ[name], 0))
     return lib
+
+
+def tuning_names():
+    lib = load()
+    names, i = [], 0
+    while True:
+        n = lib.bmv_tuning_name(i)
+        if n is None:
+            return names
+        names.append(n.decode())
+        i += 1
+
+
+def set_tuning(name, value):
+    """Set (value = int) or clear (value = None) a launcher tuning switch (include/bmv.h: bmv_tuning_set)."""
+    lib = load()
+    if value is None:
+        check(lib.bmv_tuning_clear(name.encode()), "tuning_clear")
+    else:
+        check(lib.bmv_tuning_set(name.encode(), int(value)), "tuning_set")
+
+
+def get_tuning(name):
+    """The switch's value, or None when it is not set."""
+    v, is_set = C.c_int(0), C.c_int(0)
+    check(load().bmv_tuning_get(name.encode(), C.byref(v), C.byref(is_set)), "tuning_get")
+    return v.value if is_set.value else None
 
 
 def check(rc, what=""):

@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbmv.so")
-SOURCES = ["sweep.hip", "sweep_tiled.hip", "sweep_lds.hip", "sweep_split.hip", "sweep_win.hip", "sweep_ring.hip", "sweep_zp.hip", "sweep_quad.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
+SOURCES = ["sweep.hip", "sweep_win.hip", "sweep_quad.hip", "tuning.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
 HEADERS = ["bmv_common.hpp", "sweep_util.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}    # per-file flags
@@ -28,14 +28,10 @@ if os.environ.get("BMV_RENDER_DEFS"):   # e.g. "-DBMV_RENDER_STAMPS" for scripts
     EXTRA_FLAGS["render.hip"] = os.environ["BMV_RENDER_DEFS"].split()
 if os.environ.get("BMV_CONV_DEFS"):   # e.g. "-DBMV_CONV_WPE_TUNED=0": the convolution kernels at the allocator's own occupancy
     EXTRA_FLAGS["conv.hip"] = os.environ["BMV_CONV_DEFS"].split()
-if os.environ.get("BMV_RING_DEFS"):   # tuning builds of the ring-pipelined sweep
-    EXTRA_FLAGS["sweep_ring.hip"] = os.environ["BMV_RING_DEFS"].split()
 if os.environ.get("BMV_BWD_DEFS"):   # ablation builds of the scatter kernels (scripts/bench_sweep_bwd.py)
     EXTRA_FLAGS["backward.hip"] = os.environ["BMV_BWD_DEFS"].split()
 if os.environ.get("BMV_MVS_DEFS"):
     EXTRA_FLAGS["mvs.hip"] = os.environ["BMV_MVS_DEFS"].split()
-if os.environ.get("BMV_ZP_DEFS"):
-    EXTRA_FLAGS["sweep_zp.hip"] = os.environ["BMV_ZP_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

@@ -16,6 +16,8 @@
 namespace bmv {
 
 void set_error(const char* fmt, ...);
+// explicit tuning switch of the launchers (csrc/tuning.hip; include/bmv.h bmv_tuning_set): its value, or dflt when unset
+int tuning(const char* name, int dflt);
 
 // Events the NEXT sweep launch of this thread binds to its own dispatch (bmv_bind_next_launch, csrc/timing.hip):
 // hipExtLaunchKernelGGL start / stop events read the kernel's begin and end, a hipEventRecord pair around a launch reads
@@ -43,6 +45,13 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop);
     }                                                                               \
     return BMV_OK;                                                                  \
   } while (0)
+
+// consecutive workgroup ids go round-robin over the 8 XCDs: XCD x runs workgroups x, x + 8, ...  Gives each XCD a
+// CONTIGUOUS run of the n work items (per + (x < rem) of them)
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int x = bid & 7, per = n >> 3, rem = n & 7;
+  return x * per + min(x, rem) + (bid >> 3);
+}
 
 static inline hipStream_t as_stream(bmv_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }

@@ -32,10 +32,6 @@ namespace bmv {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
-  const int x = bid & 7, per = n >> 3, rem = n & 7;      // XCD x runs workgroups x, x+8, ...: per + (x < rem) of them
-  return x * per + min(x, rem) + (bid >> 3);
-}
 
 struct ConvArgs {
   const float* in;     // (B, Cin, D, H, W)
@@ -48,6 +44,8 @@ struct ConvArgs {
   int channels_last;   // 0 planar, 1 channel-last, 2 = the renderer's volume records (bmv_conv_heads_fwd),
                        // 3 = quad-planar (B, Cout/4, Do, Ho, Wo, 4): the plane sweep's source layout (csrc/sweep_quad.hip)
   float* out2;         // mode 2: channel 8 (the depth logits), planar (B, Do, Ho, Wo)
+  int band_map = 0;    // 1: the tile rows are cut into 8 bands, workgroup id % 8 = band (the plane sweep's XCD bands: the
+                       // map it reads is then produced in the L2 it is read from); 0: XCD-contiguous runs of tiles
   const float* w2;     // second stage (TOP): packed 1x1 weights [2 tiles][8 chunks][4][16] and bias (32)
   const float* b2;
 };
@@ -104,13 +102,22 @@ void conv_mfma_kernel(ConvArgs a) {
   const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + T::TY - 1) / T::TY, ntz = (a.Do + T::TZ - 1) / T::TZ;
   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles so that the
   // halo rows / planes neighbouring tiles share are served by one L2
-  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int tx = bid % ntx;
-  bid /= ntx;
-  const int ty = bid % nty;
-  bid /= nty;
-  const int tz = bid % ntz;
-  const int b = bid / ntz;
+  int tx, ty, tz, b;
+  if (a.band_map) {
+    // ... or, for a map the plane sweep reads next (quad-planar output): XCD k = rows band k of EVERY batch item, the
+    // bands of csrc/sweep_quad.hip (blockIdx.x % 8 there too)
+    const int band = blockIdx.x & 7, per = (nty + 7) >> 3;
+    int j = blockIdx.x >> 3;
+    tx = j % ntx, j /= ntx;
+    ty = band * per + j % per, j /= per;
+    tz = j % ntz, b = j / ntz;
+    if (ty >= nty) return;   // whole workgroup, before any barrier
+  } else {
+    int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    tx = bid % ntx, bid /= ntx;
+    ty = bid % nty, bid /= nty;
+    tz = bid % ntz, b = bid / ntz;
+  }
   const int x0 = tx * 16, y0 = ty * T::TY, z0 = tz * T::TZ;
   const int ix0 = x0 * S - K / 2, iy0 = y0 * S - K / 2, iz0 = z0 * S - KD / 2;
   const int plane = a.D * a.H * a.W;
@@ -1143,12 +1150,13 @@ template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
+  if (a.band_map) grid.x = 8u * cdiv(a.Wo, 16) * cdiv(cdiv(a.Ho, T::TY), 8) * cdiv(a.Do, T::TZ) * a.B;
   hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR>), grid, dim3(256), 0, st, a);
 }
 
 constexpr unsigned kEnoughBlocks = 512;  // 2 per CU
 static bool splitk_enabled() {
-  static const bool v = !(getenv("BMV_CONV_SPLITK") && atoi(getenv("BMV_CONV_SPLITK")) == 0);
+  const bool v = bmv::tuning("BMV_CONV_SPLITK", 1) != 0;
   return v;
 }
 
@@ -1164,7 +1172,7 @@ static void dispatch_conv(const ConvArgs& a, hipStream_t st) {
         // measured inside the frame (bench.py, graph replay): 4 rows per wave win for the 3 -> 8 / 8 -> 8 full-resolution
         // 2-D layers (more resident blocks), 8 rows for 32-channel inputs and the volumes (fewer halo loads)
         if (!IS3D && a.Cin <= 8) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
-        static const int r3d = getenv("BMV_CONV_PAIR_ROWS") ? atoi(getenv("BMV_CONV_PAIR_ROWS")) : 0;   // tuning
+        const int r3d = bmv::tuning("BMV_CONV_PAIR_ROWS", 0);   // tuning
         if (r3d == 4) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
         // 5: half-height tiles only where the full-height grid is below 4 workgroups per CU (level 0's 640)
         if (r3d == 5 && conv_blocks<KD, K, S, 1, RB, MB, true>(a) < 1024) return launch_conv<KD, K, S, 1, 4, MB, true>(a, st);
@@ -1276,6 +1284,7 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   BMV_REQUIRE(out_channels_last == 0 || out_channels_last == 1 || out_channels_last == 3, "conv: out layout %d", out_channels_last);
   BMV_REQUIRE(out_channels_last != 3 || ((Cout & 3) == 0 && !skip), "conv: quad-planar output needs Cout %% 4 == 0 and no skip");
   a.slope = act_slope, a.channels_last = out_channels_last, a.out2 = nullptr;
+  a.band_map = out_channels_last == 3 && kd == 1;
   hipStream_t st = as_stream(stream);
   if (kd == 1 && k == 3 && stride == 1)
     dispatch_conv<1, 3, 1, 8, 2, false>(a, st);
@@ -1366,9 +1375,9 @@ int bmv_conv_top_fwd(const float* in, const float* wpack, const float* bias, con
   a.in = in, a.wpack = wpack, a.bias = bias, a.skip = nullptr, a.out = out, a.out2 = nullptr;
   a.w2 = wpack_top, a.b2 = bias_top;
   a.B = B, a.Cin = 32, a.D = 1, a.H = H, a.W = W, a.Cout = 32, a.Do = 1, a.Ho = H, a.Wo = W;
-  a.slope = act_slope, a.channels_last = out_layout;
+  a.slope = act_slope, a.channels_last = out_layout, a.band_map = out_layout == 3;
   using T = ConvTile<1, 3, 1, 2, 4, 0, false>;
-  dim3 grid(cdiv(W, 16) * cdiv(H, T::TY) * B, 1);
+  dim3 grid(a.band_map ? 8u * cdiv(W, 16) * cdiv(cdiv(H, T::TY), 8) * B : cdiv(W, 16) * cdiv(H, T::TY) * B, 1);
   hipLaunchKernelGGL((conv_mfma_kernel<1, 3, 1, 2, 4, 0, false, true>), grid, dim3(256), 0, as_stream(stream), a);
   BMV_LAUNCH_END("conv_top_fwd");
 }
@@ -1382,7 +1391,7 @@ int bmv_conv0_fused_fwd(const float* in, const float* w0, const float* b0, const
   Conv0Args a;
   a.in = in, a.w0 = w0, a.b0 = b0, a.wpack = wpack, a.bias = bias, a.out = out;
   a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.slope0 = slope0, a.slope1 = slope1;
-  static const int rows = getenv("BMV_CONV0_R") ? atoi(getenv("BMV_CONV0_R")) : 4;
+  const int rows = bmv::tuning("BMV_CONV0_R", 4);
   hipStream_t st = as_stream(stream);
   if (rows == 8) {
     using T = ConvTile<1, 3, 1, 1, 8, 0, true>;
@@ -1409,10 +1418,10 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
   a.fine = fine, a.coarse = coarse, a.wlat = w_lat, a.blat = b_lat, a.wpack = wpack, a.bias = bias, a.out = out;
   a.rgb = rgb, a.packed = packed_out;
   a.B = B, a.C = C, a.Cout = Cout, a.H = H, a.W = W, a.slope = act_slope;
-  static const int rows = getenv("BMV_FPN_SMOOTH_R") ? atoi(getenv("BMV_FPN_SMOOTH_R")) : 8;
+  const int rows = bmv::tuning("BMV_FPN_SMOOTH_R", 8);
   // BMV_FPN_SMOOTH_PERSIST=n: at most n workgroups per CU, each walking several tiles -- leaves registers for the short
   // launches of the level-0 regulariser that run beside this kernel on the second stream
-  static const int persist = getenv("BMV_FPN_SMOOTH_PERSIST") ? atoi(getenv("BMV_FPN_SMOOTH_PERSIST")) : 0;
+  const int persist = bmv::tuning("BMV_FPN_SMOOTH_PERSIST", 0);
   hipStream_t st = as_stream(stream);
   if (rows == 4) {
     using T = ConvTile<1, 3, 1, 1, 4, 0, true>;

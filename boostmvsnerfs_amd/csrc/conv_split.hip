@@ -238,7 +238,7 @@ static int conv3d_split_launch(const float* in, const int* wsplit, int parts, co
   a.B = B, a.Cin = Cin, a.Cout = Cout, a.D = D, a.H = H, a.W = W, a.slope = act_slope;
   BMV_REQUIRE(W % 4 == 0, "conv3d_split: W %% 4 == 0 (16-byte staging loads; W=%d)", W);
   BMV_REQUIRE(parts == 2 || parts == 3, "conv3d_split: parts must be 2 or 3 (got %d)", parts);
-  static const int tz = getenv("BMV_CONV_SPLIT_TZ") ? atoi(getenv("BMV_CONV_SPLIT_TZ")) : 2;
+  const int tz = bmv::tuning("BMV_CONV_SPLIT_TZ", 2);
   hipStream_t st = as_stream(stream);
 #define BMV_SPLIT_LAUNCH(TZV, PV, TXV, RWV)                                                                              \
   do {                                                                                                                   \
@@ -256,8 +256,8 @@ static int conv3d_split_launch(const float* in, const int* wsplit, int parts, co
     else if (rwv == 1) BMV_SPLIT_LAUNCH(TZV, PV, 32, 1);          \
     else BMV_SPLIT_LAUNCH(TZV, PV, 32, 2);                        \
   } while (0)
-  static const int txv = getenv("BMV_CONV_SPLIT_TX") ? atoi(getenv("BMV_CONV_SPLIT_TX")) : 32;
-  static const int rwv = getenv("BMV_CONV_SPLIT_RW") ? atoi(getenv("BMV_CONV_SPLIT_RW")) : 1;
+  const int txv = bmv::tuning("BMV_CONV_SPLIT_TX", 32);
+  const int rwv = bmv::tuning("BMV_CONV_SPLIT_RW", 1);
   if (tz == 1 && parts == 2) BMV_SPLIT_TX_RW(1, 2);
   else if (tz == 1) BMV_SPLIT_TX_RW(1, 3);
   else if (parts == 2) BMV_SPLIT_TX_RW(2, 2);

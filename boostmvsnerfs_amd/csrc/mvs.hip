@@ -941,7 +941,7 @@ int bmv_mvs_sweep_cl_fwd(const float* imgs, const float* feats_cl, const float* 
     return BMV_ERR_UNSUPPORTED;
   }
   // BMV_MVS_SWEEP_AUX: cache-policy bits of the stores (2 = nt); + 256 = stores staged through LDS as whole channel rows
-  static const int aux = getenv("BMV_MVS_SWEEP_AUX") ? atoi(getenv("BMV_MVS_SWEEP_AUX")) : 0x102;
+  const int aux = bmv::tuning("BMV_MVS_SWEEP_AUX", 0x102);
   const dim3 grid(cdiv(4 * nvox, 256), B);
 #define BMV_MVS_CL(A)                                                                                            \
   hipLaunchKernelGGL((mvs_sweep_cl_kernel<3, A>), grid, dim3(256), 0, as_stream(stream), imgs, feats_cl, proj, \

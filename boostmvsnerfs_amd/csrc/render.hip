@@ -650,7 +650,7 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
 
 // workgroups of the fused renderer: 2 are resident per CU (launch bounds), tiles are walked grid-stride
 static unsigned render_grid() {
-  static const unsigned v = getenv("BMV_RENDER_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_GRID")) : 256u * BMV_RENDER_WPS;   // every workgroup is resident from the start
+  const unsigned v = (unsigned)bmv::tuning("BMV_RENDER_GRID", (int)(256u * BMV_RENDER_WPS));   // every workgroup is resident from the start
   return v;
 }
 
@@ -670,13 +670,13 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   if (a->ray_begin == a->ray_end) return BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
   // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
-  static const bool use_pc = !(getenv("BMV_RENDER_PC") && atoi(getenv("BMV_RENDER_PC")) == 0);
+  const bool use_pc = bmv::tuning("BMV_RENDER_PC", 1) != 0;
 #define RENDER_CASE_PC(NSV)                                                                                          \
   if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0) {            \
     size_t lds = MlpLayout<8>::TOTAL * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * kPcBox * 64 * 4;           \
     BMV_REQUIRE(set_lds(render_pc_kernel<NSV, false>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");        \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
-    static const unsigned pc_grid = getenv("BMV_RENDER_PC_GRID") ? (unsigned)atoi(getenv("BMV_RENDER_PC_GRID")) : 256u; \
+    const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u)); \
     unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;                                        \
     hipLaunchKernelGGL((render_pc_kernel<NSV, false>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,      \
                        as_stream(stream), *a);                                                                      \

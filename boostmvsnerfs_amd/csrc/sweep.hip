@@ -158,7 +158,8 @@ __global__ void depth_values_cascade_kernel(const float* __restrict__ depth, con
                                             const float* __restrict__ near_far, int h0, int w0, int h, int w,
                                             int D, float* __restrict__ dv, float* __restrict__ nf_out) {
   int b = blockIdx.y;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD x writes a contiguous eighth of the pixels = the rows band the plane sweep's workgroups of that XCD read
+  int i = xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   int hw = h * w;
   if (i >= hw) return;
   int y = i / w, x = i - y * w;
@@ -449,40 +450,9 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
   BMV_LAUNCH_END("bmv_homo_warp_fwd");
 }
 
-int bmv_sweep_nhwc_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                          int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
-int bmv_sweep_lds_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                         int D, int h, int w, float* out, int shape, hipStream_t stream);
-int bmv_sweep_split_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
-                           int D, int h, int w, float* out, const int* view_ids, int n_all, hipStream_t stream);
 int bmv_sweep_win_launch(const float* feats, const float* proj, const float* dv, int B, int S, int C, int Hs, int Ws,
                          int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
                          hipStream_t stream);
-int bmv_sweep_ring_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B, int S,
-                          int C, int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all,
-                          int variant, hipStream_t stream);
-int bmv_sweep_zp_launch(const float* feats, const float* proj, const float* dv, int dv_plane_uniform, int B, int S, int C,
-                        int Hs, int Ws, int D, int h, int w, float* out, const int* view_ids, int n_all, int variant,
-                        hipStream_t stream);
-// split-geometry kernel (sweep_split.hip) by default: 26.9 / 27.4 us vs 31.4 / 29.0 us (level 0 / 1, config 2);
-// BMV_SWEEP_SPLIT=0 selects the all-quad-layout kernel of sweep_tiled.hip
-// windowed kernel (sweep_win.hip) first unless BMV_SWEEP_WIN=0
-static bool prefer_win() {
-  static const bool v = !(getenv("BMV_SWEEP_WIN") && atoi(getenv("BMV_SWEEP_WIN")) == 0);
-  return v;
-}
-// zero-padded windows (sweep_zp.hip, round 3) instead of the windowed kernel of round 2: BMV_SWEEP_ZP=1.  Stand-alone
-// (back-to-back launches on resident inputs) it is 3-8 % faster (27 % fewer vector instructions); inside the frame, where
-// the source maps come from cold caches, the two read the same 22-24 us, so the default stays the kernel whose rounding
-// the training-path gradient fixtures were recorded with.
-static bool prefer_zp() {
-  static const bool v = getenv("BMV_SWEEP_ZP") && atoi(getenv("BMV_SWEEP_ZP")) == 1;
-  return v;
-}
-static bool prefer_split() {
-  static const bool v = !(getenv("BMV_SWEEP_SPLIT") && atoi(getenv("BMV_SWEEP_SPLIT")) == 0);
-  return v;
-}
 
 int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, int n_all, const float* proj,
                                  const float* depth_values, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
@@ -490,19 +460,8 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
   BMV_REQUIRE(feats_all && view_ids && proj && depth_values && variance, "bmv_sweep_variance_views_fwd: null pointer");
   BMV_REQUIRE(B > 0 && S > 0 && n_all >= S && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_views_fwd: bad shape");
-  int rc = BMV_ERR_UNSUPPORTED;
-  if (prefer_zp())
-    rc = bmv_sweep_zp_launch(feats_all, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
-                             as_stream(stream));
-  if (rc == BMV_ERR_UNSUPPORTED && prefer_win())
-    rc = bmv_sweep_win_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
-                              as_stream(stream));
-  if (rc == BMV_ERR_UNSUPPORTED && prefer_split())
-    rc = bmv_sweep_split_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
-                                as_stream(stream));
-  if (rc == BMV_ERR_UNSUPPORTED)
-    rc = bmv_sweep_nhwc_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all,
-                               as_stream(stream));
+  const int rc = bmv_sweep_win_launch(feats_all, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, view_ids, n_all, -1,
+                                      as_stream(stream));
   if (rc == BMV_ERR_UNSUPPORTED)
     set_error("bmv_sweep_variance_views_fwd: needs channel-last features with C in {16, 32} and 2..4 views (C=%d, S=%d)", C,
               S);
@@ -516,58 +475,16 @@ int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* d
   BMV_REQUIRE(B > 0 && S > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0,
               "bmv_sweep_variance_fwd: bad shape");
   BMV_REQUIRE(feat_layout == 0 || feat_layout == 1, "bmv_sweep_variance_fwd: feat_layout=%d", feat_layout);
-  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) ||
-                  ((algo == 2 || algo == 3 || algo == 4 || algo == 5 || algo == 6 || algo == 7 || (algo >= 40 && algo < 400)) && feat_layout == 1),
+  BMV_REQUIRE(algo == 0 || (algo == 1 && feat_layout == 0) || ((algo == 4 || (algo >= 40 && algo < 100)) && feat_layout == 1),
               "bmv_sweep_variance_fwd: algo=%d with feat_layout=%d", algo, feat_layout);
   size_t nvox = (size_t)D * h * w;
   if (feat_layout == 1) {
-    int rc = BMV_ERR_UNSUPPORTED;
-    // Measured on MI355X (scripts/bench_sweep.py, config 2 level 1): gather 29 us, LDS-staged 37-52 us.
-    // The staged kernel is kept selectable (algo 3) but is not the default.
-    if (algo == 3) {  // LDS-staged windows: tile shape by source / volume scale
-      float scale = (float)Ws / (float)w;
-      int shape = scale <= 1.25f ? 0 : scale <= 2.5f ? 1 : -1;
-      if (shape >= 0)
-        rc = bmv_sweep_lds_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, shape,
-                                  as_stream(stream));
-      if (rc != BMV_ERR_UNSUPPORTED || algo == 3) {
-        if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: LDS sweep does not cover this shape");
-        return rc;
-      }
-    }
-    rc = BMV_ERR_UNSUPPORTED;
-    if (algo == 7 || algo >= 200) {   // zero-padded LDS windows (sweep_zp.hip); 300 + i: planes known to be constant
-      rc = bmv_sweep_zp_launch(feats, proj, depth_values, algo >= 300 ? 2 : 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                               algo >= 300 ? algo - 300 : algo >= 200 ? algo - 200 : -1, as_stream(stream));
-      if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: zero-padded sweep does not cover this shape / variant");
-      return rc;
-    }
-    if (algo == 6 || algo >= 100) {   // persistent ring of LDS windows (sweep_ring.hip)
-      rc = bmv_sweep_ring_launch(feats, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                 algo >= 100 ? algo - 100 : -1, as_stream(stream));
-      if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: ring sweep does not cover this shape / variant");
-      return rc;
-    }
-    if (algo == 0 && prefer_zp()) {
-      rc = bmv_sweep_zp_launch(feats, proj, depth_values, 0, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0, -1,
-                               as_stream(stream));
-      if (rc != BMV_ERR_UNSUPPORTED) return rc;
-    }
-    if (algo == 4 || algo >= 40 || (algo == 0 && prefer_win())) {   // LDS-staged exact windows (sweep_win.hip)
-      rc = bmv_sweep_win_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                algo >= 40 ? algo - 40 : -1, as_stream(stream));
-      if (rc != BMV_ERR_UNSUPPORTED || algo != 0) {
-        if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: windowed sweep does not cover this shape / variant");
-        return rc;
-      }
-    }
-    if (prefer_split() || algo == 5)
-      rc = bmv_sweep_split_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                  as_stream(stream));
-    if (rc == BMV_ERR_UNSUPPORTED)   // (source maps beyond the split kernel's 28-bit tap offsets, or BMV_SWEEP_SPLIT=0)
-      rc = bmv_sweep_nhwc_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
-                                 as_stream(stream));
-    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_fwd: channel-last sweep needs C in {16, 32}, got %d", C);
+    // channel-last: LDS-staged exact windows (sweep_win.hip); 40 + i = its tuning variant i
+    const int rc = bmv_sweep_win_launch(feats, proj, depth_values, B, S, C, Hs, Ws, D, h, w, variance, nullptr, 0,
+                                        algo >= 40 ? algo - 40 : -1, as_stream(stream));
+    if (rc == BMV_ERR_UNSUPPORTED)
+      set_error("bmv_sweep_variance_fwd: the channel-last sweep needs C in {16, 32}, 2..4 views and a known variant "
+                "(C=%d, S=%d, algo=%d); use feat_layout 0 or the quad-planar entry point", C, S, algo);
     return rc;
   }
   dim3 block(256);

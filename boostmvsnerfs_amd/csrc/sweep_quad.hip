@@ -111,6 +111,7 @@ struct QuadArgs {
   int dv_ps, dv_rs, dv_cs;
   long long dv_bs;
   int flags;                                  // tuning: 1 no fill, 2 no blend, 4 no store
+  int qsplit;                                 // the C/4 channel quads of a tile are shared by qsplit workgroups
 };
 
 // PU: plane-uniform hypotheses (one depth per plane)
@@ -128,13 +129,14 @@ sweep_quad_kernel(const QuadArgs a) {
   // whose L2 holds that band's source rows
   const int b = blockIdx.z;
   const int band = blockIdx.x & 7;
-  const int pgrp = blockIdx.x >> 3;
+  const int pgrp = (int)(blockIdx.x >> 3) / a.qsplit, qpart = (int)(blockIdx.x >> 3) - pgrp * a.qsplit;
   const int j = a.tiles_x_magic ? (int)__umulhi((unsigned)blockIdx.y, (unsigned)a.tiles_x_magic) : (int)blockIdx.y;
   const int tx = blockIdx.y - j * a.tiles_x;
   const int ty = band * a.tyb + j;
   if (ty * TYH >= a.h) return;  // whole workgroup, before any barrier
   const int Hs = a.Hs, Ws = a.Ws, D = a.D, h = a.h, w = a.w;
-  const int NQ = a.C >> 2;
+  const int NQ = a.C >> 2;                               // channel quads of the source maps
+  const int q_begin = qpart * (NQ / a.qsplit), q_end = q_begin + NQ / a.qsplit;   // ... this workgroup's
   const unsigned qstride = (unsigned)(Hs * Ws) * 16u;   // bytes between the channel quads of a view
   const size_t hw = (size_t)h * w;
 
@@ -293,7 +295,7 @@ sweep_quad_kernel(const QuadArgs a) {
     vbase[s] = (unsigned)(a.view_ids ? a.view_ids[b * S + s] : s) * (unsigned)NQ * qstride;
 
   // the first windows are on their way before the tap geometry is computed
-  issue_fill(0);
+  issue_fill(q_begin);
 
   // ---- 5. tap geometry of this lane's PG planes (under the fill), kept across the quads: one LDS byte offset (window
   // base included) + 3 weights per (plane, view)
@@ -375,10 +377,10 @@ sweep_quad_kernel(const QuadArgs a) {
   // two copies of the quad loop: the common one (every view staged) carries none of the gather path's live values
   auto run_quads = [&](auto fast_tag) {
   constexpr bool FAST = decltype(fast_tag)::value;
-  for (int q = 0; q < NQ; ++q) {
+  for (int q = q_begin; q < q_end; ++q) {
     // fills of quad q landed in this wave's pieces: everything older than the last 4 stores of quad q - 1
     // (a raw s_barrier: __syncthreads() carries a workgroup-scope fence that would wait for the stores as well)
-    if (q == 0)
+    if (q == q_begin)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // ... and in every wave's
@@ -478,7 +480,7 @@ sweep_quad_kernel(const QuadArgs a) {
         if (pl + 1 < PG) store_plane(pl);
       }
     }
-    if (q + 1 < NQ) {
+    if (q + 1 < q_end) {
       barrier_lds();       // every wave is done with the windows (its LDS reads have returned)
       issue_fill(q + 1);
     }
@@ -491,6 +493,17 @@ sweep_quad_kernel(const QuadArgs a) {
     run_quads(std::true_type{});
   else
     run_quads(std::false_type{});
+}
+
+// (n, C, H, W) -> (n, H, W, C), C % 4 == 0: one thread per pixel, C coalesced plane reads, then C contiguous floats out
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int HW, float* __restrict__ dst) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HW) return;
+  const float* s = src + (size_t)n * C * HW + i;
+  float4* d = reinterpret_cast<float4*>(dst + ((size_t)n * HW + i) * C);
+  for (int c = 0; c < C; c += 4)
+    d[c >> 2] = make_float4(s[(size_t)c * HW], s[(size_t)(c + 1) * HW], s[(size_t)(c + 2) * HW], s[(size_t)(c + 3) * HW]);
 }
 
 // (n, H, W, C) channel-last -> (n, C/4, H, W, 4) quad-planar
@@ -518,6 +531,7 @@ namespace {
 
 struct QuVariant {
   int txw, tyh, dp, pg, wpe, cap;   // tile, planes across waves x per lane, waves per SIMD budgeted, records per view window
+  int qsplit = 1;                   // workgroups sharing the channel quads of a tile (more, shorter workgroups)
 };
 // tuning table (algo 500 + i); cap = LDS records (16 bytes) per view ON AVERAGE, multiples of 64: the S windows share cap x S
 const QuVariant kQu[] = {
@@ -534,6 +548,10 @@ const QuVariant kQu[] = {
     {32, 2, 4, 1, 5, 640},    // 10: level 0 with whole-line rows
     {32, 8, 1, 1, 6, 512},    // 11
     {32, 2, 4, 2, 5, 640},    // 12
+    {32, 2, 4, 1, 6, 512},    // 13: level 0, one plane per lane, 6 workgroups per CU = one round
+    {16, 4, 4, 2, 5, 640, 2}, // 14: level 0, 16 x 4 tiles, the 8 quads over two workgroups: 1280 = one round
+    {32, 2, 4, 2, 5, 640, 2}, // 15
+    {32, 8, 1, 2, 5, 640, 2}, // 16: level 1 with the quads split (2560 workgroups)
 };
 constexpr int kNumQu = sizeof(kQu) / sizeof(kQu[0]);
 
@@ -568,7 +586,7 @@ int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
     }
     allowed = lds;
   }
-  dim3 grid(8u * (unsigned)a.pgroups, (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
+  dim3 grid(8u * (unsigned)(a.pgroups * a.qsplit), (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
   const LaunchEvents ev = take_launch_events();
   if (ev.start)   // bench.py's roofline bracket: events bound to this dispatch (bmv_bind_next_launch)
     hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev.start, ev.stop, 0, a);
@@ -626,7 +644,10 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)(((unsigned long long)1 << 32) / (unsigned)a.tiles_x) + 1u;
   if (a.tiles_x * a.tyb >= 65536 || 8 * a.pgroups >= 65536) return BMV_ERR_UNSUPPORTED;
   a.dv_ps = g.dv_ps, a.dv_rs = g.dv_rs, a.dv_cs = g.dv_cs, a.dv_bs = g.dv_bs;
-  a.flags = flags;
+  a.flags = flags & 0xffff;
+  if ((flags >> 16) & 0xff) a.budget = (flags >> 16) & 0xff;   // tests: an LDS budget below the windows -> gather fallback
+  a.qsplit = ((C >> 2) % v.qsplit) == 0 ? v.qsplit : 1;
+  if (8 * a.pgroups * a.qsplit >= 65536) return BMV_ERR_UNSUPPORTED;
   const bool pu = dv_plane_uniform != 0;
   int rc = BMV_ERR_UNSUPPORTED;
 #define V(TXW, TYH, DP, PG, WPE) \
@@ -644,10 +665,18 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   V(32, 2, 4, 1, 5)
   V(32, 8, 1, 1, 6)
   V(32, 2, 4, 2, 5)
+  V(32, 2, 4, 1, 6)
 #undef V
   if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_quad_fwd: variant %d not instantiated", variant);
   if (rc != BMV_OK) return rc;
   BMV_LAUNCH_END("bmv_sweep_variance_quad_fwd");
+}
+
+int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, bmv_stream_t stream) {
+  BMV_REQUIRE(src && dst, "bmv_nchw_to_nhwc: null pointer");
+  BMV_REQUIRE(n > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "bmv_nchw_to_nhwc: bad shape (C must be a multiple of 4)");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv((long)H * W, 256), n), dim3(256), 0, as_stream(stream), src, C, H * W, dst);
+  BMV_LAUNCH_END("bmv_nchw_to_nhwc");
 }
 
 int bmv_to_quad_planar(const float* in, int channels_last, int n, int C, int H, int W, float* out, bmv_stream_t stream) {

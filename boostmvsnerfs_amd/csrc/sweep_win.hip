@@ -593,8 +593,7 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   }
   if (variant >= kNumVariants) return BMV_ERR_UNSUPPORTED;
   Variant v = kVariants[variant];
-  if (const char* e = getenv("BMV_SWEEP_WIN_CAP")) {
-    int c = atoi(e);
+  if (int c = tuning("BMV_SWEEP_WIN_CAP", 0)) {
     if (c >= 16) v.cap = (c + 15) & ~15;
   }
   WinArgs a;
@@ -610,13 +609,13 @@ extern "C" int bmv_sweep_win_launch(const float* feats, const float* proj, const
   // 16 x 4 x 8, S = 3), so that the prologue and the tap geometry are not done twice.  Measured: 27.6 -> 27.1 us
   // stand-alone, no difference in the frame -- those phases already hide under the fills -- so two workgroups stay
   // the default.
-  if (C == 32 && S == 3 && v.txw == 16 && v.tyh == 4 && v.dp == 8 && getenv("BMV_SWEEP_WIN_NH") && atoi(getenv("BMV_SWEEP_WIN_NH")) == 2)
+  if (C == 32 && S == 3 && v.txw == 16 && v.tyh == 4 && v.dp == 8 && tuning("BMV_SWEEP_WIN_NH", 0) == 2)
     a.nh = 2, a.chalves = 1;
   a.cap = v.cap;
   a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)(((unsigned long long)1 << 32) / (unsigned)a.tiles_x) + 1u;
   if (a.tiles_x * a.tyb >= 65536) return BMV_ERR_UNSUPPORTED;
   a.flags = 0;
-  if (const char* e = getenv("BMV_SWEEP_WIN_FLAGS")) a.flags = atoi(e);
+  a.flags = tuning("BMV_SWEEP_WIN_FLAGS", a.flags);
   int rc = BMV_ERR_UNSUPPORTED;
 #define V(TXW, TYH, DP, NB) \
   if (v.txw == TXW && v.tyh == TYH && v.dp == DP && v.nb == NB) rc = launch_s<TXW, TYH, DP, NB>(a, B, S, stream);

@@ -180,7 +180,6 @@ class FeatureNet(nn.Module):
         (convnet.LookupRecords: feature channels + colours of a pixel in one 48-byte record)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
-        f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last="quad" if self.quad_out else True)
         if rgb is not None:
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
         elif FUSE_FPN_SMOOTH:
@@ -189,6 +188,9 @@ class FeatureNet(nn.Module):
         else:
             p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
             f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
+        # the level-1 sweep's source map LAST: it then sits in the L2s (rows band k in XCD k's, conv.hip's band map) when
+        # that sweep starts instead of being pushed out by the 23 MB the full-resolution map writes
+        f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last="quad" if self.quad_out else True)
         return (ops.QuadFeats(f1) if self.quad_out else f1.permute(0, 3, 1, 2)), f0
 
     def _forward_engine(self, x):

@@ -188,7 +188,7 @@ def _plane_uniform(depth_values, plane_uniform):
 def sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plane_uniform=False, variant=-1, out=None,
                         flags=0):
     """Plane sweep on quad-planar features (QuadFeats or its (B,V,C/4,Hs,Ws,4) tensor).  `view_ids` (B,S) int32 picks the
-    S views of proj from the V views of feats; None: V == S."""
+    S views of proj from the V views of feats; None: V == S.  flags: include/bmv.h (bits 16-23: LDS budget in KB)."""
     if sweep_hook is not None:
         r = sweep_hook(_sweep_variance_quad, (feats, proj, depth_values),
                        dict(view_ids=view_ids, hw=hw, plane_uniform=plane_uniform, variant=variant, out=out, flags=flags))

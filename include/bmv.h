@@ -65,12 +65,10 @@ int bmv_homo_warp_fwd(const float* src_feat, const float* proj, const float* dep
  * -> variance (B,C,D,h,w) = sum_s(x^2)/S - (sum_s(x)/S)^2, never materialising the
  * S warped volumes.  feat_layout: 0 = feats is (B,S,C,Hs,Ws) as the reference holds it,
  * 1 = channel-last (B,S,Hs,Ws,C) (bmv_nchw_to_nhwc converts).  algo: 0 = best kernel for
- * the layout, 1 = reference-layout direct gather (feat_layout 0), 2 = channel-last direct
- * gather, 3 = channel-last LDS-staged corner windows (round 1), 4 = channel-last LDS-staged exact windows
- * (sweep_win.hip: the default for C in {16, 32}), 5 = channel-last split-geometry gather; 40 + i = tuning variant i of
- * algo 4; round 3 (measured experiments, parity-tested, not the default): 6 / 100 + i = persistent ring of LDS windows
- * (sweep_ring.hip), 7 / 200 + i = zero-padded windows (sweep_zp.hip; BMV_SWEEP_ZP=1 makes it algo 0), 300 + i = the
- * same with plane-uniform hypotheses detected from depth_values (2..7 and 40+ need feat_layout 1). */
+ * the layout, 1 = reference-layout direct gather (feat_layout 0); feat_layout 1: 0 / 4 = LDS-staged exact windows
+ * (sweep_win.hip; C in {16, 32}, 2..4 views: the training forward), 40 + i = its tuning variant i.  The inference
+ * networks run bmv_sweep_variance_quad_fwd (below) instead.  (The round-1..3 experiments -- channel-last gather, corner
+ * windows, split geometry, ring of windows, zero-padded windows -- were removed in round 4: all superseded.) */
 int bmv_sweep_variance_fwd(const float* feats, const float* proj, const float* depth_values, int B, int S, int C,
                            int Hs, int Ws, int D, int h, int w, float* variance, int feat_layout, int algo,
                            bmv_stream_t stream);
@@ -88,7 +86,8 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
  * dv_plane_uniform: 0 = depth_values (B,D,h,w); 1 = (B,D) one hypothesis per plane (cascade level 0); 2 = (B,D,h,w)
  * whose planes are constant ([b,d,0,0] is read).  view_ids (B,S) int32 or NULL: views picked from the n_all views of
  * feats_quad (n_all ignored when NULL: feats_quad holds exactly S views per item).  variant: -1 = by the source / volume
- * scale; 0.. = tuning table of sweep_quad.hip.  flags: 0 (tuning ablations: 1 no fill, 2 no blend, 4 no store).
+ * scale; 0.. = tuning table of sweep_quad.hip.  flags: 0; tuning ablations: 1 no fill, 2 no blend, 4 no store; bits 16-23:
+ * LDS budget in 1-KB pieces for the S windows together (tests: small budgets force the global-gather fallback).
  * S in 2..4, C % 4 == 0, C <= 64. */
 int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, int n_all, const float* proj,
                                 const float* depth_values, int dv_plane_uniform, int B, int S, int C, int Hs, int Ws,
@@ -519,6 +518,17 @@ int bmv_event_create(bmv_event_t* ev);
 int bmv_event_destroy(bmv_event_t ev);
 int bmv_event_record(bmv_event_t ev, bmv_stream_t stream);
 int bmv_event_elapsed_us(bmv_event_t start, bmv_event_t end, float* us);
+/* ==== tuning switches of the launchers: explicit library state, never the process environment =================
+ * A switch changes WHICH kernel / tile shape a launcher picks, never what is computed.  bmv_tuning_name(i) /
+ * bmv_tuning_doc(i) list them (NULL past the end); a switch that is not set has the launcher's default.  May be set,
+ * changed and cleared at any time from any thread (the next launch sees it).  Host frameworks that want environment
+ * variables apply them through these calls (boostmvsnerfs_amd/_lib.py does, once, at load). */
+int bmv_tuning_set(const char* name, int value);
+int bmv_tuning_clear(const char* name);
+int bmv_tuning_get(const char* name, int* value, int* is_set);
+const char* bmv_tuning_name(int i);
+const char* bmv_tuning_doc(int i);
+
 /* Bind `start` / `stop` to the NEXT plane-sweep launch of this thread (bmv_sweep_variance_fwd /
  * bmv_sweep_variance_views_fwd, windowed kernel): the launch goes through hipExtLaunchKernelGGL and the events read the
  * kernel's own begin and end (a record pair around a launch reads ~2.5 us more; scripts/ubench/ext_events.hip).  Not

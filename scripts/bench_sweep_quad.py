@@ -20,6 +20,8 @@ ap.add_argument("--variants", default="")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--cold", action="store_true")
+ap.add_argument("--evict-mb", type=int, default=0, help="MB written between timed launches (32: the L2s turn over, the "
+                "Infinity Cache keeps the source maps; 512 = --cold: everything comes from HBM)")
 ap.add_argument("--size", default="512x640")
 a = ap.parse_args()
 H, W = (int(v) for v in a.size.split("x"))
@@ -36,7 +38,8 @@ with torch.no_grad():
     net._forward_checked(dict(batch))
 ops.sweep_hook = None
 torch.cuda.synchronize()
-scratch = torch.empty(128 << 20, device="cuda") if a.cold else None
+mb = 512 if a.cold else a.evict_mb
+scratch = torch.empty(mb << 18, device="cuda") if mb else None
 
 
 def timed(fn, name):
@@ -69,7 +72,7 @@ for lvl, (feats, proj, dv) in enumerate(calls):
     t = timed(lambda: ops._sweep_variance(cl, proj, dv, algo=4, channels_last=True), "win")
     for k, (avg, mn) in t.items():
         print(f"level {lvl}  windowed (algo 4)        {k}: avg {avg:6.2f} us  min {mn:6.2f}  -> {nbytes / avg / 1e3 / 8000:.3f} of 8 TB/s")
-    variants = [int(v) for v in a.variants.split(",")] if a.variants else ([1, 4, 6, 10, 12] if Ws > 1.5 * w else [0, 3, 7, 5, 11])
+    variants = [int(v) for v in a.variants.split(",")] if a.variants else ([1, 4, 10, 12, 13, 14, 15] if Ws > 1.5 * w else [0, 3, 5, 11, 16])
     for v in variants:
         try:
             got = ops._sweep_variance_quad(quad, proj, dv, plane_uniform=pu, variant=v)

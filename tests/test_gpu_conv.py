@@ -122,10 +122,12 @@ def test_fpn_smooth_fused_equals_the_two_launches(H, W, rows, monkeypatch):
     want = F.conv2d(p0, ws, bs, padding=1)
     wp, bp = convnet.pack_conv(ws, bs)
     two = convnet.conv_fwd(convnet.fpn_topdown(fine, coarse, wl, bl), wp, bp, 8, 1, 3)
-    import os
-    if rows != int(os.environ.get("BMV_FPN_SMOOTH_R", "8")):
-        pytest.skip("the tile height is read once per process (BMV_FPN_SMOOTH_R): run the suite with it set to cover this case")
-    got = convnet.fpn_smooth(fine, coarse, wl, bl, wp, bp, 8)
+    from boostmvsnerfs_amd import _lib
+    _lib.set_tuning("BMV_FPN_SMOOTH_R", rows)       # (explicit library state since round 4: changeable per call)
+    try:
+        got = convnet.fpn_smooth(fine, coarse, wl, bl, wp, bp, 8)
+    finally:
+        _lib.set_tuning("BMV_FPN_SMOOTH_R", None)
     _close(got, want)
     assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
 

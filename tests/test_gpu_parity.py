@@ -302,21 +302,25 @@ def test_sweep_extreme_coordinates(ops):
     assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0
     # channel-last kernels (16 channels): the windowed kernel sees an EMPTY tap box for every view
     feats16 = torch.randn(1, 3, 16, 16, 20, device=DEV)
-    for algo in (4, 5, 2, 6, 101, 7, 201, 302):
+    for algo in (4, 41) + QUAD_ALGOS + QUAD_PU_ALGOS:
         var = ops.sweep_variance(feats16, proj, dv, algo=algo)
         assert torch.isfinite(var).all() and float(var.abs().max()) == 0.0, algo
 
 
-RING_ALGOS = tuple(range(100, 111))     # csrc/sweep_ring.hip: the persistent ring-of-windows sweep, tuning variants
-ZP_ALGOS = tuple(range(200, 213))       # csrc/sweep_zp.hip: zero-padded windows, tuning variants
-ZP_PU_ALGOS = tuple(range(300, 313))    # ... told that every plane of the hypotheses is constant (cascade level 0)
+QUAD_ALGOS = tuple(range(500, 517))     # csrc/sweep_quad.hip: quad-planar features, union windows; tuning variants
+QUAD_PU_ALGOS = tuple(range(600, 617))  # ... told that every plane of the hypotheses is constant (cascade level 0)
+
+
+def _quad(ops, feats, channels_last=False):
+    return ops.QuadFeats(ops.to_quad_planar(feats, channels_last=channels_last))
 
 
 @pytest.mark.parametrize("level", [0, 1])
 def test_sweep_kernels_agree_at_scale(ops, level):
-    """All sweep kernels (reference-layout gather, channel-last gather, LDS-staged windows) against the
-    CPU oracle on BASELINE config-1 shapes (256x320), including a wide-baseline view whose epipolar
-    slide leaves the LDS window (global fallback path) and hypotheses that put a view behind the camera."""
+    """All sweep kernels (reference-layout gather, windowed channel-last, quad-planar union windows: every tuning variant)
+    against the CPU oracle on BASELINE config-1 shapes (256x320), including a wide-baseline view whose epipolar slide
+    leaves the LDS windows (global fallback path), LDS budgets below the windows, plane-uniform hypotheses in both
+    forms and views picked by index."""
     from boostmvsnerfs_amd.synthetic import make_batch
     from oracle import enerf as O
     H, W = 256, 320
@@ -333,43 +337,33 @@ def test_sweep_kernels_agree_at_scale(ops, level):
         dv = (3.0 + 2.0 * torch.rand(1, 1, h, w) + torch.linspace(-1.5, 1.5, cfgl["D"]).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
     fd, Pd, dvd = feats.to(DEV), P.to(DEV), dv.to(DEV)
-    for algo in (1, 2, 3, 4, 5, 6, 7, 0) + tuple(range(40, 60)) + RING_ALGOS + ZP_ALGOS + (ZP_PU_ALGOS if level == 0 else ()):
-        if algo == 3 and level == 0:
-            with pytest.raises(RuntimeError, match="LDS sweep does not cover"):
-                ops.sweep_variance(fd, Pd, dvd, algo=3)      # 2x source scale stays on the gather kernel
-            continue
+    for algo in (1, 4, 0) + tuple(range(40, 60)) + QUAD_ALGOS + (QUAD_PU_ALGOS if level == 0 else ()):
         got = ops.sweep_variance(fd, Pd, dvd, algo=algo)
         assert_close(got, want, name=f"level {level} algo {algo}")
     # windowed kernel with an LDS budget far below the tap boxes: clipped windows + the global fallback per wave
-    import os
-    os.environ["BMV_SWEEP_WIN_CAP"] = "48"
+    from boostmvsnerfs_amd import _lib
+    _lib.set_tuning("BMV_SWEEP_WIN_CAP", 48)
     try:
         for algo in (4, 41, 49):
             assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} algo {algo} cap 48")
     finally:
-        del os.environ["BMV_SWEEP_WIN_CAP"]
-    # zero-padded windows with an LDS budget below the tap boxes: whole views gathered from global memory
-    for cap in ("48", "256"):
-        os.environ["BMV_SWEEP_ZP_CAP"] = cap
-        try:
-            for algo in (7, 201, 202) + ((302,) if level == 0 else ()):
-                assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} zp algo {algo} cap {cap}")
-        finally:
-            del os.environ["BMV_SWEEP_ZP_CAP"]
-    # ring kernel with slots far below the tap boxes: every view of every unit takes the global-gather path
-    os.environ["BMV_SWEEP_RING_CAP"] = "48"
-    try:
-        for algo in (6, 101, 102):
-            assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} ring algo {algo} cap 48")
-    finally:
-        del os.environ["BMV_SWEEP_RING_CAP"]
-    # ... and with slots that hold SOME of the boxes (staged and gathered views in one unit)
-    os.environ["BMV_SWEEP_RING_CAP"] = "256"
-    try:
-        for algo in (100, 102):
-            assert_close(ops.sweep_variance(fd, Pd, dvd, algo=algo), want, name=f"level {level} ring algo {algo} cap 256")
-    finally:
-        del os.environ["BMV_SWEEP_RING_CAP"]
+        _lib.set_tuning("BMV_SWEEP_WIN_CAP", None)
+    # quad-planar kernel with LDS budgets below the union windows: 1 KB = no view fits (every view gathered from global
+    # memory), 6 / 12 KB = some views staged, the rest gathered, in one workgroup
+    q = _quad(ops, fd)
+    for variant in (0, 12, 3, 14):
+        for budget in (1, 6, 12):
+            got = ops.sweep_variance_quad(q, Pd, dvd, variant=variant, flags=budget << 16)
+            assert_close(got, want, name=f"level {level} quad variant {variant} budget {budget} KB")
+    if level == 0:     # hypotheses handed over as (B, D): one per plane (dv_plane_uniform 1)
+        got = ops.sweep_variance_quad(q, Pd, dvd[:, :, 0, 0].contiguous(), hw=(h, w))
+        assert_close(got, want, name="level 0 quad, (B, D) hypotheses")
+    # views picked by index from a larger set (the K-volume networks)
+    extra = torch.randn(1, 2, cfgl["C"], Hs, Ws, device=DEV)
+    allv = torch.cat([extra[:, :1], fd[:, 2:3], fd[:, 0:1], extra[:, 1:], fd[:, 1:2]], 1)      # views 2, 4, 1 are ours
+    ids = torch.tensor([[2, 4, 1]], device=DEV, dtype=torch.int32)
+    got = ops.sweep_variance_views(_quad(ops, allv), ids, Pd, dvd, plane_uniform=level == 0)
+    assert_close(got, want, name=f"level {level} quad, views by index")
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 16, 37, 53, 5, 19, 45), (2, 4, 32, 40, 24, 7, 21, 13), (1, 3, 16, 9, 7, 3, 33, 70),
@@ -389,9 +383,42 @@ def test_sweep_windowed_ragged_shapes(ops, shape):
                                     [0.0, 0.0, 1.0, 0.05 * s]])
     dv = (2.0 + torch.rand(B, 1, h, w) + torch.linspace(0.0, 3.0, D).view(1, -1, 1, 1)).contiguous()
     want = O.variance_volume(feats, P, dv)
-    for algo in (4, 40, 42, 46, 49, 51, 57, 59, 5, 6, 7) + RING_ALGOS + ZP_ALGOS:
+    for algo in (4, 40, 42, 46, 49, 51, 57, 59) + QUAD_ALGOS:
         got = ops.sweep_variance(feats.to(DEV), P.to(DEV), dv.to(DEV), algo=algo)
         assert_close(got, want, name=f"shape {shape} algo {algo}")
+
+
+@pytest.mark.parametrize("C,S", [(4, 2), (8, 3), (12, 4), (64, 2)])
+def test_sweep_quad_channel_counts(ops, C, S):
+    """The quad-planar kernel takes any C % 4 == 0 up to 64 and 2..4 views (the windowed kernel: 16 / 32 channels only)."""
+    from oracle import enerf as O
+    B, Hs, Ws, D, h, w = 1, 40, 56, 6, 20, 28
+    torch.manual_seed(C * S)
+    feats = torch.randn(B, S, C, Hs, Ws)
+    P = torch.zeros(B, S, 3, 4)
+    for s_ in range(S):
+        P[0, s_] = torch.tensor([[2.0, 0.03 * s_, 0.2 * s_, 3.0 * (s_ - 1)], [-0.02 * s_, 2.0, 0.1, 2.0 * (1 - s_)], [0.0, 0.0, 1.0, 0.04 * s_]])
+    dv = (2.0 + torch.rand(B, 1, h, w) + torch.linspace(0.0, 2.0, D).view(1, -1, 1, 1)).contiguous()
+    want = O.variance_volume(feats, P, dv)
+    for variant in (-1, 0, 1, 3, 12, 14):
+        got = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=variant)
+        assert_close(got, want, name=f"C {C} S {S} variant {variant}")
+    with pytest.raises(RuntimeError, match="not covered"):
+        ops.sweep_variance_quad(torch.zeros(1, 5, 1, 8, 8, 4, device=DEV), torch.zeros(1, 5, 3, 4, device=DEV), dv.to(DEV))
+
+
+def test_tuning_switches_are_library_state():
+    """include/bmv.h bmv_tuning_*: explicit, listable, changeable at any time; unknown names are errors."""
+    from boostmvsnerfs_amd import _lib
+    names = _lib.tuning_names()
+    assert "BMV_RENDER_PC" in names and "BMV_SWEEP_WIN_CAP" in names and len(names) >= 10
+    assert _lib.get_tuning("BMV_CONV0_R") is None
+    _lib.set_tuning("BMV_CONV0_R", 8)
+    assert _lib.get_tuning("BMV_CONV0_R") == 8
+    _lib.set_tuning("BMV_CONV0_R", None)
+    assert _lib.get_tuning("BMV_CONV0_R") is None
+    with pytest.raises(RuntimeError, match="unknown switch"):
+        _lib.set_tuning("BMV_NO_SUCH_SWITCH", 1)
 
 
 def test_make_rays_matches_reference_rays():
