@@ -46,7 +46,10 @@ def _built(v):
 
 
 def _copy_many(dsts, srcs):
-    """dst[i] <- src[i] on the current stream: one multi-tensor launch per dtype group."""
+    """dst[i] <- src[i] on the current stream: one multi-tensor launch per dtype group.  (Measured against it in round 4
+    and dropped: an own single-launch copy kernel through ctypes -- +34 us per frame where this costs +22, the host
+    side of the call is what counts -- and the two copies as nodes of the frame's graph re-targeted per replay with
+    hipGraphExecKernelNodeSetParams -- +66 us: an updated executable graph is re-prepared at its next launch.)"""
     if not dsts:
         return
     groups = {}
@@ -141,7 +144,7 @@ class AutoGraph:
         for v in batch.values():
             if torch.is_tensor(v) and not _built(v):
                 n += 1
-        if n != len(e["names"]):
+        if n != e["n_tensors"]:
             return None
         for k in e["names"]:
             v = batch.get(k)
@@ -149,10 +152,7 @@ class AutoGraph:
             if v is None or v.shape != s.shape or v.dtype != s.dtype or v.device != s.device:
                 return None
             srcs.append(v)
-        if e["one_dtype"]:
-            torch._foreach_copy_(e["dsts"], srcs)
-        else:
-            _copy_many(e["dsts"], srcs)
+        _copy_many(e["dsts"], srcs)
         if (e["version"] != self._param_version() or e["shard"] != self._shard()
                 or e["extra"] != self.net._autograph_key(batch) or self.entries.get(e["key"]) is not e):
             return None
@@ -235,11 +235,16 @@ class AutoGraph:
         # static inputs of the graph: private copies (default), or -- declared resident -- the caller's own tensors, kept
         # alive by this reference.  Python entries ('meta') are read at capture time only: anything of theirs that
         # changes the frame is part of the key
+        reads = getattr(self.net, "_autograph_inputs", lambda b: None)(batch)     # None: every tensor of the batch
         static = {}
         for k, v in batch.items():
             if _built(v):
                 continue
-            static[k] = v.clone() if (torch.is_tensor(v) and not resident) else v
+            if torch.is_tensor(v) and not resident:
+                # tensors the frame does not read stay the caller's (never copied, never written)
+                static[k] = v.clone() if (reads is None or k in reads) else v
+            else:
+                static[k] = v
         added = {}
 
         def run(b):
@@ -254,9 +259,10 @@ class AutoGraph:
         with torch.no_grad():
             fg = FrameGraph(run, static, cut=None)
         self.stats["captures"] += 1
-        names = [k for k, v in static.items() if torch.is_tensor(v)]
+        names = [k for k, v in static.items() if torch.is_tensor(v) and (resident or reads is None or k in reads)]
         e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added, "resident": resident,
-             "names": names, "dsts": [static[k] for k in names], "one_dtype": len({static[k].dtype for k in names}) == 1}
+             "names": names, "dsts": [static[k] for k in names], "one_dtype": len({static[k].dtype for k in names}) == 1,
+             "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v))}
         self.entries[key] = e
         return e
 

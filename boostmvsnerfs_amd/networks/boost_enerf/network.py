@@ -291,6 +291,11 @@ class Network(enerf_network.Network):
         finally:
             self.set_volume_records(False)
 
+    def _autograph_inputs(self, batch):
+        cc = cfg.enerf.cas_config
+        return {"all_src_inps", "all_src_exts", "all_src_ixts", "tar_ext", "tar_ixt", "near_far"} | {
+            f"rays_{i}" for i in range(cc.num) if cc.render_if[i]}
+
     def _autograph_key(self, batch):
         """A captured K-volume frame is specialised to the cost-volume triplets view_selection.json selects for the
         batch's targets (they are baked into the graph as device constants) and to the capture hook of the tests."""

@@ -349,6 +349,13 @@ class Network(nn.Module):
         finally:
             self.set_volume_records(False)       # the modules go back to planar outputs for any other caller
 
+    def _autograph_inputs(self, batch):
+        """The batch tensors an inference frame of THIS network reads (autograph copies only these into its captured
+        inputs; `all_src_*`, the unrendered levels' rays, targets and masks ride along in a loader's batch unread)."""
+        cc = cfg.enerf.cas_config
+        return {"src_inps", "src_exts", "src_ixts", "tar_ext", "tar_ixt", "near_far"} | {
+            f"rays_{i}" for i in range(cc.num) if cc.render_if[i]}
+
     def _autograph_key(self, batch):
         """What a captured frame is specialised to besides shapes and parameters: the execution switches of this module
         (tests and tuning scripts flip them between calls)."""

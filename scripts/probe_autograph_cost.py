@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Where the 'other tensors every frame' contract of Network.forward costs time (autograph.py): the run.py bracket around
+net(batch) with the graph captured on private copies / the caller's tensors, outputs copied out / aliased."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from boostmvsnerfs_amd.config import make_cfg, set_cfg
+from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+set_cfg(make_cfg("enerf_eval"))
+torch.manual_seed(0)
+from boostmvsnerfs_amd.networks.enerf.network import Network
+net = Network().eval().cuda()
+base = clone_batch(make_batch(512, 640), "cuda")
+ring = [clone_batch(base, "cuda") for _ in range(3)]
+
+
+def bracket(fn, n=200):
+    ts = []
+    for i in range(n + 20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(i)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[20:])
+    return ts[len(ts) // 2] * 1e6, sum(ts) / len(ts) * 1e6
+
+
+for res, alias in ((True, True), (False, True), (True, False), (False, False)):
+    net.resident_inputs, net.alias_outputs = res, alias
+    net._autograph.invalidate()
+    with torch.no_grad():
+        f = (lambda i: net(ring[0])) if res else (lambda i: net(ring[i % 3]))
+        for i in range(5):
+            f(i)
+        med, mean = bracket(f)
+    print(f"resident_inputs={res!s:5} alias_outputs={alias!s:5}: median {med:7.1f} us  mean {mean:7.1f} us   {net._autograph.stats}")
+# the pieces on their own
+net.resident_inputs = net.alias_outputs = False
+e = net._autograph._hot
+srcs = [ring[1][k] for k in e["names"]]
+med, _ = bracket(lambda i: torch._foreach_copy_(e["dsts"], srcs))
+print(f"foreach copy of the {len(srcs)} inputs ({sum(t.numel() * 4 for t in srcs) / 1e6:.1f} MB): {med:.1f} us (host + device, bracketed)")
+outs = [v for v in e["fg"].out.values() if torch.is_tensor(v)]
+def co(i):
+    d = [torch.empty_like(s) for s in outs]
+    torch._foreach_copy_(d, outs)
+med, _ = bracket(co)
+print(f"fresh outputs ({len(outs)} tensors, {sum(t.numel() * 4 for t in outs) / 1e6:.1f} MB): {med:.1f} us")
+med, _ = bracket(lambda i: e["fg"].replay())
+print(f"graph replay alone: {med:.1f} us")
+t0 = time.perf_counter()
+for _ in range(1000):
+    net._autograph._param_version()
+print(f"param version check: {(time.perf_counter() - t0) * 1e3:.1f} us")
+for k in e["names"]:
+    print("   ", k, tuple(e["static"][k].shape))
