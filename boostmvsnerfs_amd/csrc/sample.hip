@@ -209,6 +209,104 @@ __global__ void blend_kernel(const float* __restrict__ raws, const float* __rest
   depth[(size_t)b * N + n] = dsum;
 }
 
+// a16 with lane = SAMPLE (round 4; the kernel above is kept for sample counts that are not a power of two).  A ray's Ns
+// samples sit on Ns consecutive lanes (Ns <= 64: 64 / Ns rays per wave) or on the 64 lanes in NC = Ns / 64 register
+// chunks: every load is a coalesced run (16 bytes per lane for the raw outputs), each mask / depth is read ONCE, the
+// transmittance is a segmented prefix product across lanes (log2 steps of shuffles), the per-ray sums and the softmax
+// are xor butterflies inside the ray's aligned lane group, and the weights are written once.  The per-ray arithmetic
+// does not depend on which rays share the wave (ray shards stay bit-identical to the full frame).
+// Measured (config 4: K = 4, N = 78 848, Ns = 128, 970 MB): 2 825 us (0.04 of HBM) for the thread-per-ray loop above.
+template <int NC, int KMAX>
+__global__ void __launch_bounds__(256) blend_wave_kernel(const float* __restrict__ raws, const float* __restrict__ masks,
+                                                         const float* __restrict__ zv, int K, int N, int Ns, int normalise,
+                                                         float* __restrict__ rgb, float* __restrict__ depth,
+                                                         float* __restrict__ weights) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
+  const int G = NC > 1 ? 64 : Ns;             // lanes of a ray (a power of two)
+  const int s0 = lane & (G - 1);
+  const int n = wave * (64 / G) + lane / G;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;            // (idle lanes mirror the last ray: loads in bounds, no stores)
+  const size_t kstride = (size_t)N * Ns;
+  const size_t ray = ((size_t)b * K * N + nc) * Ns;
+  const float4* R = reinterpret_cast<const float4*>(raws) + ray;
+  const float* M = masks + ray;
+  const float* Z = zv + ray;
+  const float invK = 1.f / (float)K;
+  float alpha[NC], c0[NC], c1[NC], c2[NC], zm[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int s = s0 + 64 * c;
+    float mk[KMAX];
+    float msum = 0.f, zs = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        mk[k] = M[k * kstride + s];
+        msum += mk[k];
+        zs += Z[k * kstride + s];
+      }
+    float a = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        float m = mk[k];
+        if (normalise) m = msum > 0.f ? m / msum : invK;
+        const float4 q = R[k * kstride + s];
+        const float am = (1.f - expf(-q.w)) * m;   // alpha_k m_k
+        a += am;
+        q0 += am * q.x, q1 += am * q.y, q2 += am * q.z;
+      }
+    alpha[c] = a, c0[c] = q0, c1[c] = q1, c2[c] = q2, zm[c] = zs * invK;
+  }
+  // transmittance T_s = prod_{j < s} (1 - alpha_j) (no epsilon: enerf/utils.py:648): inclusive product scan in the lane
+  // group, shifted by one, carried across the register chunks
+  float T[NC], carry = 1.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float p = 1.f - alpha[c];
+    for (int off = 1; off < G; off <<= 1) {
+      const float t = __shfl_up(p, off);
+      if (s0 >= off) p *= t;
+    }
+    float ex = __shfl_up(p, 1);
+    if (s0 == 0) ex = 1.f;
+    T[c] = carry * ex;
+    carry *= __shfl(p, lane | (G - 1));
+  }
+  float w[NC], r0 = 0.f, r1 = 0.f, r2 = 0.f, wmax = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    w[c] = alpha[c] * T[c];
+    r0 += T[c] * c0[c], r1 += T[c] * c1[c], r2 += T[c] * c2[c];
+    wmax = fmaxf(wmax, w[c]);
+  }
+  for (int off = G >> 1; off > 0; off >>= 1) {
+    r0 += __shfl_xor(r0, off), r1 += __shfl_xor(r1, off), r2 += __shfl_xor(r2, off);
+    wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+  }
+  float e[NC], den = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) e[c] = expf(w[c] - wmax), den += e[c];
+  for (int off = G >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off);
+  float dsum = 0.f;
+  float* W = weights + ((size_t)b * N + nc) * Ns;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float sm = e[c] / den;
+    dsum += sm * zm[c];
+    if (live) W[s0 + 64 * c] = sm;
+  }
+  for (int off = G >> 1; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+  if (live && s0 == 0) {
+    float* o = rgb + ((size_t)b * N + n) * 3;
+    o[0] = r0, o[1] = r1, o[2] = r2;
+    depth[(size_t)b * N + n] = dsum;
+  }
+}
+
 }  // namespace bmv
 
 using namespace bmv;
@@ -301,6 +399,21 @@ int bmv_blend_fwd(const float* raws, const float* masks, const float* z_vals, in
   BMV_REQUIRE(raws && masks && z_vals && rgb && depth && weights, "bmv_blend_fwd: null pointer");
   BMV_REQUIRE(B > 0 && K > 0 && N >= 0 && Ns > 0, "bmv_blend_fwd: bad shape");
   if (N == 0) return BMV_OK;
+  if ((Ns & (Ns - 1)) == 0 && Ns <= 256 && K <= 8) {   // lane = sample (power-of-two sample counts: every shipped config)
+    const int G = Ns < 64 ? Ns : 64;
+    const long waves = ((long)N * G + 63) / 64;
+    dim3 grid(cdiv(waves, 4), B), block(256);
+#define BW(NC, KM) hipLaunchKernelGGL((blend_wave_kernel<NC, KM>), grid, block, 0, as_stream(stream), raws, masks, z_vals, K, N, Ns, normalise, rgb, depth, weights)
+    if (Ns <= 64) {
+      if (K <= 4) BW(1, 4); else BW(1, 8);
+    } else if (Ns == 128) {
+      if (K <= 4) BW(2, 4); else BW(2, 8);
+    } else {
+      if (K <= 4) BW(4, 4); else BW(4, 8);
+    }
+#undef BW
+    BMV_LAUNCH_END("bmv_blend_fwd");
+  }
   hipLaunchKernelGGL(blend_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), raws, masks, z_vals, K, N,
                      Ns, normalise, rgb, depth, weights);
   BMV_LAUNCH_END("bmv_blend_fwd");

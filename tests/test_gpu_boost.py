@@ -95,11 +95,16 @@ def test_boost_forward_matches_reference(enerf_fx, boost_fx, tmp_path, path):
     assert b["src_inps"].shape[1] == 3          # batch['src_*'] now hold the last triplet, as in the reference
 
 
-def test_blend_kernel(boost_fx):
+@pytest.mark.parametrize("K,N,Ns", [(3, 257, 4), (4, 1000, 128), (1, 65, 1), (6, 33, 2), (4, 130, 8), (2, 77, 32),
+                                    (4, 19, 64), (3, 21, 256), (3, 50, 3), (9, 40, 16)])
+def test_blend_kernel(boost_fx, K, N, Ns):
+    """bmv_blend_fwd (a16 + the mask normalisation of merge_mlp_outputs) against the oracle: the lane = sample kernel
+    (power-of-two sample counts, K <= 8: one ray on 1..64 lanes or in 2 / 4 register chunks) and the thread-per-ray
+    kernel it falls back to (Ns = 3, K = 9)."""
     from boostmvsnerfs_amd import ops
     from oracle import enerf as O
-    torch.manual_seed(1)
-    B, K, N, Ns = 2, 3, 257, 4
+    torch.manual_seed(K * 1000 + Ns)
+    B = 2
     raws = torch.rand(B, K, N, Ns, 4)
     masks = (torch.randint(0, 4, (B, K, N, Ns)).float() / 3)
     masks[:, :, :7] = 0                       # samples no volume sees -> 1/K fallback
@@ -111,6 +116,11 @@ def test_blend_kernel(boost_fx):
     assert_close(weights, want["weights"], name="weights")
     rgb2, _, _ = ops.blend(raws.to(DEV), O.normalise_masks(masks).to(DEV), z.to(DEV), normalise=False)
     assert_close(rgb2, want["rgb"], name="rgb (pre-normalised)")
+    # a ray's result does not depend on which rays share its launch (ray shards == the full frame, bit for bit)
+    lo = N // 3
+    rgb3, depth3, w3 = ops.blend(raws[:, :, lo:].contiguous().to(DEV), masks[:, :, lo:].contiguous().to(DEV),
+                                 z[:, :, lo:].contiguous().to(DEV), normalise=True)
+    assert torch.equal(rgb3, rgb[:, lo:]) and torch.equal(depth3, depth[:, lo:]) and torch.equal(w3, weights[:, lo:])
 
 
 def test_missing_view_selection_is_loud(boost_fx, tmp_path):
