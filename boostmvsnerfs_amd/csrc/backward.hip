@@ -855,14 +855,22 @@ int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* d
                            float* d_depth_values, bmv_stream_t stream) {
   BMV_REQUIRE(feats && proj && depth_values && d_variance && d_feats, "bmv_sweep_variance_bwd: null pointer");
   BMV_REQUIRE(B > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "bmv_sweep_variance_bwd: bad shape");
-  if (S != 3 || C % 8 != 0) {
-    set_error("bmv_sweep_variance_bwd: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
+  if (S < 2 || S > 4 || C % 8 != 0) {
+    set_error("bmv_sweep_variance_bwd: built for 2..4 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
     return BMV_ERR_UNSUPPORTED;
   }
   const int tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
-  hipLaunchKernelGGL((sweep_bwd_kernel<8, 3>), dim3(tiles_x * tiles_y * D, C / 8, B), dim3(256), 0, as_stream(stream),
-                     feats, proj, depth_values, d_variance, C, Hs, Ws, D, h, w, tiles_x, tiles_y, d_feats,
-                     d_depth_values);
+  const dim3 grid(tiles_x * tiles_y * D, C / 8, B);
+#define SB(SV)                                                                                                       \
+  hipLaunchKernelGGL((sweep_bwd_kernel<8, SV>), grid, dim3(256), 0, as_stream(stream), feats, proj, depth_values, d_variance, \
+                     C, Hs, Ws, D, h, w, tiles_x, tiles_y, d_feats, d_depth_values)
+  if (S == 3)
+    SB(3);
+  else if (S == 2)
+    SB(2);      // ENeRF pre-training draws 2 / 3 / 4 source views (dtu_pretrain.yaml:22-23)
+  else
+    SB(4);
+#undef SB
   BMV_LAUNCH_END("bmv_sweep_variance_bwd");
 }
 

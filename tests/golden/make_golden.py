@@ -396,7 +396,7 @@ if __name__ == "__main__":
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "cfg_dump", name])
     elif which == "cfg_dump":
         gen_cfg_dump(sys.argv[2])
-    elif which != "enerf_grads":
+    elif which not in ("enerf_grads", "enerf_views"):
         {"enerf": gen_enerf, "boost_enerf": gen_boost_enerf, "mvsnerf": gen_mvsnerf,
          "boost_mvsnerf": gen_boost_mvsnerf, "rays": gen_rays, "adam_step": gen_adam_step}[which]()
 
@@ -427,5 +427,44 @@ def gen_enerf_grads():
     print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
 
 
+def gen_enerf_views():
+    """ENeRF with 2 and 4 source views (the reference's Agg / NeRF are view-count agnostic and its pre-training draws 2 / 3 / 4
+    views: configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23, 75-76): output dict (eval, no grad) and the parameter
+    gradients of the fine-tune loss, with the weights of enerf_tiny.npz (same seed, same perturbation)."""
+    from boostmvsnerfs_amd.synthetic import make_batch
+    cfg = load_reference("configs/exps/evaluate/enerf/free_eval.yaml")
+    from lib.networks.enerf import network
+    cfg.enerf.cas_config.volume_planes = list(TINY_PLANES)
+    cfg.enerf.cas_config.render_if = [True, True]
+    for S in (2, 4):
+        torch.manual_seed(0)
+        net = perturb_(network.Network().eval())
+        batch = make_batch(TINY_H, TINY_W, n_views=S, seed=0)
+        blob = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v) and not k.startswith("all_"):
+                blob["in/" + k] = v.clone().numpy()
+        with torch.no_grad():
+            out = net({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        for k, v in out.items():
+            blob["out/" + k] = v.numpy()
+        g = torch.Generator().manual_seed(0)
+        targets = {i: torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=g) for i in range(2)}
+        out = net(batch)
+        w = [0.1, 1.0]
+        loss = sum(w[i] * ((out[f"rgb_level{i}"] - targets[i]) ** 2).mean() for i in range(2))
+        loss.backward()
+        blob["extra/loss"] = np.asarray(float(loss))
+        for i in range(2):
+            blob[f"in/rgb_{i}"] = targets[i].numpy()
+        for k, p in net.named_parameters():
+            blob["grad/" + k] = p.grad.numpy()
+        path = os.path.join(HERE, f"enerf_tiny_views{S}.npz")
+        np.savez_compressed(path, **blob)
+        print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB", len(blob), "arrays")
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "enerf_grads":
     gen_enerf_grads()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "enerf_views":
+    gen_enerf_views()

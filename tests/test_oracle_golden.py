@@ -145,3 +145,24 @@ def test_view_selection(enerf_fx, boost_fx):
     for i in (0, 4, 9):
         m = O.triplet_visibility(sd, b, cfg, trip[i])["mask_level1"]
         assert_close(m, boost_fx.t(f"cap/sel/calc_mask#{i}.mask_level1"), rtol=1e-4, atol_scale=1e-5, name=f"vis{i}")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("S", [2, 4])
+def test_enerf_forward_with_2_and_4_source_views(enerf_fx, S):
+    """The reference's Agg / NeRF are view-count agnostic and ENeRF pre-training draws 2 / 3 / 4 source views
+    (configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23): the oracle against the reference's own output dicts
+    (tests/golden/enerf_tiny_views{2,4}.npz, `make_golden.py enerf_views`; weights = enerf_tiny's)."""
+    from conftest import load_fixture
+    vfx = load_fixture(f"enerf_tiny_views{S}")
+    cfg = tiny_cfg(enerf_fx)
+    cfg.enerf.cas_config.render_if = [True, True]
+    b = vfx.batch()
+    assert b["src_inps"].shape[1] == S
+    out = O.enerf_forward(enerf_fx.group("sd"), b, cfg)
+    want = vfx.group("out")
+    assert set(want) <= set(out)
+    for k, v in want.items():
+        assert_close(out[k], v, name=f"S={S} {k}")
