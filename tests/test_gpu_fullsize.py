@@ -39,6 +39,10 @@ def _perturb(net, seed=1):
 
 # (H, W, volume_planes): BASELINE configs[0] (the reference's CPU-runnable case) and configs[1] (the metric's)
 FULL = {"config1_256x320": (256, 320, [32, 8]), "config2_512x640": (512, 640, [64, 8])}
+# entries of an output allowed outside the project bar at full size.  Measured on MI355X / ROCm 7.2 (round 4, the prints of
+# this test): 0 for every output of both configs, eager and replayed; the ceiling is that plus a few entries for a ray on a
+# mode switch under another evaluation order -- rounds 2-3 allowed 1e-4 of the entries (98 of the 512x640 rgb)
+OUTLIER_CEILING = 6
 
 
 @pytest.mark.parametrize("name", list(FULL))
@@ -69,10 +73,13 @@ def test_whole_frame_matches_oracle(name):
     torch.cuda.synchronize()
     for label, got in (("eager", eager), ("graph replay", replay)):
         for k in want:
-            # the project bar: |d| <= 1e-3 |want| + 1e-3 rms(want); a handful of rays sit on a depth-distribution
-            # mode switch of the 40x-sharpened logits (argmax-like softmax), where one ulp of the volume moves the ray's
-            # sample range: budget 1e-4 of the entries, counted by assert_close
-            assert_close(got[k], want[k], name=f"{name} {label} {k}", max_outlier_frac=1e-4)
+            # the project bar: |d| <= 1e-3 |want| + 1e-3 rms(want).  A ray can sit on a depth-distribution mode switch of
+            # the 40x-sharpened logits (argmax-like softmax), where one ulp of the volume moves its sample range; such
+            # entries are COUNTED and held to a ceiling pinned to the measurement (OUTLIER_CEILING), not to a fraction
+            g, w = got[k].detach().float().cpu(), want[k]
+            bad = int(((g - w).abs() > 1e-3 * w.abs() + 1e-3 * float(w.pow(2).mean().sqrt())).sum())
+            print(f"[whole frame] {name} {label} {k}: {bad} of {w.numel()} entries outside the bar")
+            assert bad <= OUTLIER_CEILING, f"{name} {label} {k}: {bad} entries outside the bar (ceiling {OUTLIER_CEILING})"
         mse = float(((got["rgb_level1"].cpu() - want["rgb_level1"]) ** 2).mean())
         assert mse < 1e-8, f"{name} {label}: mse between renders {mse:.3e}"
     # the replay is the same arithmetic as the eager call
@@ -154,3 +161,96 @@ def test_mvsnerf_modules_match_reference():
         vol = net.cost_reg_2(fx.t("cap/build_volume_costvar_img#0", DEV))
         vol = vol[0] if isinstance(vol, (tuple, list)) else vol
         assert_close(vol, fx.t("cap/cost_reg_2#0"), rtol=1e-3, atol_scale=1e-4, name="mvsnerf cost_reg_2")
+
+
+# ------------------------------------------------------------------ BASELINE configs[2], [3] at size vs the oracle
+def _flip_aware(out, want, masks, ref_masks, keys, tag, flip_ceiling, outlier_frac=0.0):
+    """The viewport test of a14 is a step function: samples whose visibility differs from the oracle's are COUNTED (ceiling
+    pinned to the measurement on MI355X), rays without such a sample are held to the project bar, the others may move."""
+    diff = (masks.cpu() - ref_masks).abs() > 1e-6          # (1, K, n, Ns)
+    per_volume = diff.sum((0, 2, 3)).tolist()
+    print(f"[{tag}] visibility flips per volume: {per_volume} of {diff[0, 0].numel()} samples")
+    assert max(per_volume) <= flip_ceiling, f"{tag}: {per_volume} visibility flips (ceiling {flip_ceiling})"
+    flipped = diff.any(-1).any(1)[0]                       # (n,) rays with a flipped sample in any volume
+    for k in keys:
+        g, w = out[k].detach().float().cpu(), want[k]
+        bad = ((g - w).abs() > 1e-3 * w.abs() + 1e-3 * float(w.pow(2).mean().sqrt()))
+        print(f"[{tag}] {k}: {int(bad.sum())} of {bad.numel()} entries outside the bar ({int(flipped.sum())} rays carry a flipped sample)")
+        if g.dim() >= 2 and g.shape[1] == flipped.shape[0]:
+            assert_close(g[:, ~flipped], w[:, ~flipped], name=f"{tag} {k}", max_outlier_frac=outlier_frac)
+        else:
+            assert_close(g, w, name=f"{tag} {k}", max_outlier_frac=outlier_frac)
+
+
+def test_config3_full_size_matches_oracle_on_a_ray_subset(tmp_path):
+    """BASELINE configs[2]: enerf_ours at 480x736, N = 6 source views, K = 4 cost volumes, planes [64, 8]
+    (lib/networks/boost_enerf/network.py:172-237).  The front end (FeatureNet on 6 views, 4 x 2 cost volumes and
+    regularisers) is run IN FULL by the oracle; the per-ray part on every 8th ray -- the sample bench.py's cpu_baseline
+    leg times (~7 s of host time).  Flip-aware: see _flip_aware."""
+    import json
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.boost_enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    from oracle import enerf as O      # the checker
+    cfg = make_cfg("enerf_ours_eval")
+    cfg.enerf.cas_config.volume_planes = [64, 8]
+    cfg.enerf.cas_config.k_best = 4
+    cfg.result_dir = str(tmp_path)
+    set_cfg(cfg)
+    sel = [0, 7, 13, 19]
+    with open(tmp_path / "view_selection.json", "w") as f:
+        json.dump({"synthetic_0": sel}, f)
+    torch.manual_seed(0)
+    net = _perturb(Network().eval())
+    batch = make_batch(480, 736, n_views=6, seed=0)
+    for i in range(cfg.enerf.cas_config.num):
+        batch[f"rays_{i}"] = batch[f"rays_{i}"][:, ::8].contiguous()
+    cap = {}
+    with torch.no_grad():
+        want = O.boost_enerf_forward({k: v.clone() for k, v in net.state_dict().items()}, clone_batch(batch), cfg, sel, capture=cap)
+    net = net.to(DEV)
+    net.capture = {}
+    with torch.no_grad():
+        out = net(clone_batch(batch, DEV))
+    torch.cuda.synchronize()
+    assert out["rgb_level1"].shape == (1, 480 * 736 // 8, 3)
+    # measured on MI355X / ROCm 7.2 (this test's print): see the ceilings below
+    # measured on MI355X / ROCm 7.2 (this test's prints): 0 flips in every volume, 0 entries outside the bar
+    _flip_aware(out, want, net.capture["level1"][2], cap["masks_1"], ("rgb_level1", "depth_level1"), "config 3", flip_ceiling=2)
+    for k in ("depth_mvs_level1", "std_level1"):
+        assert_close(out[k], want[k], name=f"config 3 {k}")
+
+
+def test_config4_full_size_matches_oracle_on_a_ray_subset(tmp_path):
+    """BASELINE configs[3]: mvsnerf_ours at 224x352, 128 depth planes AND 128 samples per ray, K = 4
+    (lib/networks/boost_mvsnerf/network.py:160-211): the K padded cost volumes and regularisers in full, every 64th ray
+    through the sampler, the 6 x 128 MLP (157 k points) and the fusion."""
+    import json
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.boost_mvsnerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    from oracle import mvsnerf as M    # the checker
+    cfg = make_cfg("mvsnerf_ours_eval")
+    cfg.enerf.cas_config.num_samples = [128]
+    cfg.enerf.cas_config.k_best = 4
+    cfg.result_dir = str(tmp_path)
+    set_cfg(cfg)
+    sel = [0, 7, 13, 19]
+    with open(tmp_path / "view_selection.json", "w") as f:
+        json.dump({"synthetic_0": sel}, f)
+    torch.manual_seed(0)
+    net = _perturb(Network().eval())
+    batch = make_batch(224, 352, n_views=6, seed=0, depth_ranges=True, render_scales=(1.0,))
+    batch["rays_0"][..., 6], batch["rays_0"][..., 7] = 2.2, 7.5      # a real depth interval (the loaders' quirk 9 puts x, y there)
+    batch["rays_0"] = batch["rays_0"][:, ::64].contiguous()
+    cap = {}
+    with torch.no_grad():
+        want = M.boost_mvsnerf_forward({k: v.clone() for k, v in net.state_dict().items()}, clone_batch(batch), cfg, sel, capture=cap)
+    net = net.to(DEV)
+    net.capture = {}
+    with torch.no_grad():
+        out = net(clone_batch(batch, DEV))
+    torch.cuda.synchronize()
+    assert out["rgb_level0"].shape == (1, 224 * 352 // 64, 3)
+    # measured: 0 flips of 157 696 samples per volume, 0 entries outside the bar
+    _flip_aware(out, want, net.capture["masks"], cap["masks"], ("rgb_level0", "depth_level0"), "config 4", flip_ceiling=2)
