@@ -484,7 +484,9 @@ def main():
                     sampled["every"] = args.event_every
 
                     from boostmvsnerfs_amd import autograph as _ag
-                    fg_names = [k for k, v in fg.batch.items() if torch.is_tensor(v) and not getattr(v, "_bmv_built_rays", False)]
+                    reads = net._autograph_inputs(batch) if hasattr(net, "_autograph_inputs") else None
+                    fg_names = [k for k, v in fg.batch.items() if torch.is_tensor(v) and not getattr(v, "_bmv_built_rays", False)
+                                and (reads is None or k in reads)]      # (the K-volume forward REPLACES batch['src_*']: quirk 8)
 
                     def replay():   # noqa: F811
                         sampled["evented"] = sampled["n"] % sampled["every"] == 0
@@ -545,7 +547,8 @@ def main():
     if not wl.get("train") and world == 1 and not stub:
         # the reference's loaders hand over HOST tensors (run.py:114-116 moves them every frame): the same bracket with
         # the batch copied from pinned host memory each step, with the rays copied too / built on the device instead
-        host = {k: v.cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
+        reads_h = net._autograph_inputs(batch) if hasattr(net, "_autograph_inputs") else None
+        host = {k: v.cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v) and (reads_h is None or k in reads_h)}
         ray_keys = [k for k in host if k.startswith("rays_")]
         hb = _clone(batch, dev)                         # the legs' own working batch (they pop / refill its keys)
 
@@ -555,7 +558,7 @@ def main():
                     if device_rays and k in ray_keys:
                         hb.pop(k, None)                 # Network.ensure_rays rebuilds them from tar_ext / tar_ixt
                     else:
-                        if k not in hb:
+                        if k not in hb or hb[k].shape != v.shape:      # (the K-volume forwards replace batch['src_*'])
                             hb[k] = torch.empty_like(v, device=dev)
                         hb[k].copy_(v, non_blocking=True)
                 with torch.no_grad():

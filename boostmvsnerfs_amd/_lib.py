@@ -133,6 +133,8 @@ SIGNATURES = {
     "bmv_bind_next_launch": [C.c_void_p, C.c_void_p],
     "bmv_launch_events_pending": [],
     "bmv_version": [],
+    "bmv_render_pc_check": [c_i],
+    "bmv_debug_render_pc_inject": [c_i],
     "bmv_tuning_set": [C.c_char_p, c_i],
     "bmv_tuning_clear": [C.c_char_p],
     "bmv_tuning_get": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],

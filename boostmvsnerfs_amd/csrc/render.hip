@@ -319,6 +319,12 @@ constexpr int kPcMlp = 8, kPcGather = BMV_RENDER_PC_GATHER, kPcBox = 36;   // wa
 #ifdef BMV_RENDER_PC_COUNT
 __device__ unsigned long long g_pc_spins[4];   // tuning: polls that found the flag not ready / waits, per role
 #endif
+// A wave that gives up on a mailbox flag (a lost wake-up: a protocol error, or a wedged partner) ends its tile with
+// unwritten / NaN pixels; it also COUNTS here, and bmv_render_pc_check (include/bmv.h) turns a non-zero count into an
+// error with a message.  g_pc_inject (bmv_debug_render_pc_inject, tests): the gather role of workgroup 0 withholds one
+// wake-up.
+__device__ unsigned g_pc_faults;
+__device__ int g_pc_inject;
 __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
   for (int it = 0; it < BMV_RENDER_PC_SPIN; ++it) {
     if (*flag == want) {
@@ -335,6 +341,7 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
     }
     __builtin_amdgcn_s_sleep(4);
   }
+  atomicAdd(&g_pc_faults, 1u);
   return false;
 }
 
@@ -489,7 +496,7 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
         box[35 * 64] = vis, box[35 * 64 + 32] = vis;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (job && s == 0) *flag = seq + 1;
+      if (job && s == 0 && !(g_pc_inject && blockIdx.x == 0 && blockIdx.y == 0 && p == 0)) *flag = seq + 1;
     }
     return;
   }
@@ -588,6 +595,29 @@ static int set_lds(K kernel, size_t bytes) {
 using namespace bmv;
 
 extern "C" {
+
+// lost wake-ups of the producer / consumer renderer since the last reset: synchronises the device.  0 -> BMV_OK;
+// otherwise BMV_ERR_LAUNCH with the count in bmv_last_error (the frames rendered since then hold unwritten pixels)
+int bmv_render_pc_check(int reset) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pc_faults), sizeof(n)) != hipSuccess) {
+    set_error("bmv_render_pc_check: cannot read the fault counter: %s", hipGetErrorString(hipGetLastError()));
+    return BMV_ERR_LAUNCH;
+  }
+  if (reset && n) {
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_faults), &zero, sizeof(zero));
+  }
+  if (n) {
+    set_error("render_pc_kernel: %u lane(s) gave up waiting for a mailbox flag (lost wake-up): the frames rendered since "
+              "the last check hold unwritten pixels", n);
+    return BMV_ERR_LAUNCH;
+  }
+  return BMV_OK;
+}
+int bmv_debug_render_pc_inject(int on) {   // tests: withhold one wake-up in workgroup 0
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pc_inject), &on, sizeof(on)) == hipSuccess ? BMV_OK : BMV_ERR_LAUNCH;
+}
 
 #ifdef BMV_RENDER_PC_COUNT
 int bmv_debug_fetch_pc_spins(unsigned long long* dst) {

@@ -518,6 +518,13 @@ int bmv_event_create(bmv_event_t* ev);
 int bmv_event_destroy(bmv_event_t ev);
 int bmv_event_record(bmv_event_t ev, bmv_stream_t stream);
 int bmv_event_elapsed_us(bmv_event_t start, bmv_event_t end, float* us);
+/* The producer / consumer renderer (bmv_render_rays_fwd with lookup records) hands tiles between its waves through LDS
+ * mailboxes with BOUNDED waits: a wave that gives up (a lost wake-up) leaves its pixels unwritten and counts.
+ * bmv_render_pc_check synchronises the device and returns BMV_ERR_LAUNCH (count in bmv_last_error) if any wave gave up
+ * since the last reset; bmv_debug_render_pc_inject(1) makes workgroup 0 withhold one wake-up (tests). */
+int bmv_render_pc_check(int reset);
+int bmv_debug_render_pc_inject(int on);
+
 /* ==== tuning switches of the launchers: explicit library state, never the process environment =================
  * A switch changes WHICH kernel / tile shape a launcher picks, never what is computed.  bmv_tuning_name(i) /
  * bmv_tuning_doc(i) list them (NULL past the end); a switch that is not set has the launcher's default.  May be set,

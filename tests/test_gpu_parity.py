@@ -519,3 +519,38 @@ def test_path_selection_follows_what_can_receive_a_gradient(ops, enerf_fx):
     part = net(enerf_fx.batch(DEV))["rgb_level1"]                # differentiable path, same ray slice
     assert part.requires_grad and part.shape[1] == N - N // 3
     assert_close(part, want[:, N // 3:], name="train path, ray_range")
+
+
+def test_render_pc_lost_wakeup_surfaces_as_an_error(enerf_fx):
+    """The producer / consumer renderer's waits are bounded: a wave that never sees its mailbox flag gives up (its pixels
+    stay unwritten) instead of hanging the GPU -- and that MUST NOT stay silent: the waves count, bmv_render_pc_check
+    reports the count through bmv_last_error.  bmv_debug_render_pc_inject withholds one wake-up in workgroup 0."""
+    from boostmvsnerfs_amd import _lib
+    lib = _lib.load()
+    net = _network(enerf_fx)
+    b = enerf_fx.batch(DEV)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in net._forward_checked(dict(b)).items()}
+    torch.cuda.synchronize()
+    assert lib.bmv_render_pc_check(1) == 0                      # a clean frame: no wave gave up
+    assert lib.bmv_debug_render_pc_inject(1) == 0
+    try:
+        with torch.no_grad():
+            net._forward_checked(dict(b))
+        torch.cuda.synchronize()
+        rc = lib.bmv_render_pc_check(1)
+        msg = lib.bmv_last_error().decode()
+        assert rc != 0 and "lost wake-up" in msg and "gave up" in msg, (rc, msg)
+        with pytest.raises(RuntimeError, match="lost wake-up"):
+            lib.bmv_debug_render_pc_inject(1)
+            with torch.no_grad():
+                net._forward_checked(dict(b))
+            _lib.check(lib.bmv_render_pc_check(1), "render_pc_check")
+    finally:
+        assert lib.bmv_debug_render_pc_inject(0) == 0
+    with torch.no_grad():
+        got = net._forward_checked(dict(b))
+    torch.cuda.synchronize()
+    assert lib.bmv_render_pc_check(1) == 0
+    for k in want:
+        assert torch.equal(got[k], want[k]), k

@@ -139,6 +139,13 @@ def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
     # run (the scatter kernels and two 1-wide head gradients add with float atomics: not bit-reproducible) --
     # so a change of MIOpen's convolution algorithm on a fresh box can tip single entries over.  Budget: 0.2 % of the
     # entries of a tensor, none beyond 3 x the tolerance.
+    # fp64 arbitration (round 4, tests/tools/grad_fp64_arbitration.py --gpu, in units of this tolerance): the fp32 ORACLE
+    # itself is 1.78 / 1.46 / 1.06 from the oracle run in fp64 on nerf_1.color.{0.weight, 2.weight, 0.bias} on the GPU box's
+    # host (0.03 on the build container's: a sample on the visibility threshold falls on the other side), the HIP path
+    # equals the fp32 oracle there to 0.002; on the tensors where HIP and the fp32 oracle differ most
+    # (cost_reg_0.conv9.0.weight: 0.90) HIP is 0.81 and the fp32 oracle 0.36 from fp64 -- weight gradients are fp32 sums
+    # over 1e5 voxels in another order than ATen's; no entry of any of the 115 tensors is outside the fp64 truth's bar
+    # except where the fp32 oracle is too.  The margin is the conditioning of fp32 sums, not an error of a kernel.
     _check_grads(net, want, float(loss), loss_c, outliers=2e-3)
     # one optimiser step (trainer.py:44-63): parameters must move, loss must be finite
     opt = make_optimizer(net)
