@@ -58,6 +58,8 @@ class Network(enerf_network.Network):
         self.capture = None
         self._sel_cache = {}
         self._streams = []
+        self._setup_stream = None      # camera-only work of a frame, under FeatureNet
+        self._cam_pre = None
         self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
         # the K cost volumes as one batch through the regularisers instead of K chains on K streams (round 3; opt-in:
         # measured 3.29 ms against 3.15 ms per 480x736 K = 4 frame -- the frame is 4 x 0.7 ms of render launches, and
@@ -185,6 +187,7 @@ class Network(enerf_network.Network):
             getattr(self, f"cost_reg_{i}").prepack()
             if cc.render_if[i]:
                 getattr(self, f"nerf_{i}").packed_weights()
+        pre = getattr(self, "_cam_pre", None)      # per volume: projection matrices + level-0 hypotheses (_forward_boost)
         first = {}
         for j, k in enumerate(ks):
             s = self._streams[j]
@@ -194,7 +197,8 @@ class Network(enerf_network.Network):
                 views = (batch["all_src_inps"], *cams[k])
                 st = None
                 for i in range(cc.num):
-                    st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid)
+                    st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid,
+                                          pre=pre[k] if pre is not None else None)
                     if cc.render_if[i]:
                         self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch, mode=1,
                                           outs=tuple(t[:, j] for t in stacks[i]), view_ids=vid)
@@ -331,6 +335,30 @@ class Network(enerf_network.Network):
             if len(self._sel_cache) > 64:
                 self._sel_cache.clear()
             self._sel_cache[key] = sel
+        # what the K chains need from the cameras alone -- the K triplets' camera matrices, K x S projection matrices per
+        # cascade level and level 0's hypotheses -- on a side stream UNDER FeatureNet: one gather per camera tensor and
+        # ONE launch (ops.frame_setup, the triplets as batch items) instead of 2 K + K latency-bound launches and ~20 index
+        # kernels inside the chains.  (The same launch in front of the fork on the main stream was measured slower in round 3:
+        # its single-thread fp64 inversions are pure latency there.)
+        cam = None
+        if (B == 1 and self.frame_setup and self.by_index and dev.type == "cuda" and not self.wants_grad()
+                and (self.parallel_volumes or self.volume_ids is not None) and not self.batched_volumes):
+            main = torch.cuda.current_stream()
+            if self._setup_stream is None:
+                self._setup_stream = torch.cuda.Stream()
+            su = self._setup_stream
+            su.wait_stream(main)
+            with torch.cuda.stream(su):
+                H, W = batch["all_src_inps"].shape[-2:]
+                ext_all, ixt_all = batch["all_src_exts"][0][sel[0]], batch["all_src_ixts"][0][sel[0]]    # (K,S,4,4), (K,S,3,3)
+                proj, (dv0, nf0) = ops.frame_setup(
+                    ext_all, ixt_all, batch["tar_ext"].expand(K, -1, -1), batch["tar_ixt"].expand(K, -1, -1),
+                    [cc.im_feat_scale[i] for i in range(cc.num)], [cc.volume_scale[i] for i in range(cc.num)],
+                    batch["near_far"].expand(K, -1), cc.volume_planes[0], int(H * cc.volume_scale[0]),
+                    int(W * cc.volume_scale[0]), cc.depth_inv[0])
+            cam = {"ext": ext_all, "ixt": ixt_all, "stream": su,
+                   "pre": [{"proj": [p[k:k + 1] for p in proj], "dv0": (dv0[k:k + 1], nf0[k:k + 1])} for k in range(K)],
+                   "keep": (*proj, dv0, nf0)}
         # all N views once; inference: the full-resolution map as the fused renderer's lookup records
         self.feature_net.pack_lookup = (self.wants_lookup_records()
                                         and enerf_network.engine_ok(self.feature_net, batch["all_src_inps"]))
@@ -339,6 +367,11 @@ class Network(enerf_network.Network):
             feats = self.forward_feat(batch["all_src_inps"])
         finally:
             self.feature_net.pack_lookup = False
+        if cam is not None:
+            torch.cuda.current_stream().wait_stream(cam["stream"])      # (long done: FeatureNet took 100x its time)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (cam["ext"], cam["ixt"], *cam["keep"]):
+                    t.record_stream(torch.cuda.current_stream())
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K
         ret = {}
@@ -354,7 +387,16 @@ class Network(enerf_network.Network):
             # (B,K,3) -> K tensors (B,3); in range by construction: rows of combinations(range(N), 3) picked by the
             # triplet numbers validated above, so no device read is spent on ops.check_view_ids
             sel32 = [ops.mark_view_ids(sel[:, k].to(torch.int32).contiguous(), N) for k in range(K)]
-            cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
+            if cam is not None:
+                cams = [(cam["ext"][k:k + 1], cam["ixt"][k:k + 1]) for k in range(K)]
+                self._cam_pre = cam["pre"]
+            elif B == 1:   # one gather for the K triplets' cameras: (K,S,4,4) / (K,S,3,3), volume k = a view of row k
+                ext_all, ixt_all = batch["all_src_exts"][0][sel[0]], batch["all_src_ixts"][0][sel[0]]
+                cams = [(ext_all[k:k + 1], ixt_all[k:k + 1]) for k in range(K)]
+                self._cam_pre = None
+            else:
+                self._cam_pre = None
+                cams = [(batch["all_src_exts"][bi, sel[:, k]], batch["all_src_ixts"][bi, sel[:, k]]) for k in range(K)]
             if self.batched_volumes and self.volume_ids is None and B == 1:
                 return self._forward_batched(batch, feats, sel, sel32, cams, K)
             if (self.parallel_volumes or self.volume_ids is not None) and B == 1:

@@ -5,6 +5,7 @@ Everything runs on torch's current stream.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 
@@ -14,8 +15,20 @@ from . import _lib, ktimer
 from ._lib import dptr, stream
 
 
+_TEMPS = collections.deque(maxlen=32)
+
+
 def _c(t):
-    return t if t.is_contiguous() else t.contiguous()
+    """`t`, contiguous.  A copy made here must outlive the LAUNCH it is made for: `dptr(_c(x))` drops the last
+    reference as soon as the address is taken, and the caching allocator hands the very block to the next `_c` copy
+    of the same call -- whose copy kernel then overwrites the first argument before the launch reads it (round 4:
+    expanded target cameras of the K-triplet frame_setup; two non-contiguous arguments in one call is all it takes).
+    The last 32 copies are therefore kept referenced (no entry point takes that many tensors)."""
+    if t.is_contiguous():
+        return t
+    t = t.contiguous()
+    _TEMPS.append(t)
+    return t
 
 
 def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):

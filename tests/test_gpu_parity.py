@@ -32,6 +32,19 @@ def test_proj_mats(ops, enerf_fx):
         assert_close(P, enerf_fx.t(f"cap/get_proj_mats#{lvl}"), rtol=1e-4, atol_scale=1e-5, name=f"proj{lvl}")
 
 
+def test_non_contiguous_arguments_outlive_the_launch(ops, enerf_fx):
+    """Several non-contiguous arguments in ONE call: each gets a contiguous copy, and every copy must still be intact
+    when the kernel runs (the allocator used to hand the first copy's block to the second one)."""
+    b = enerf_fx.batch(DEV)
+    K = 3
+    ext, ixt = b["src_exts"].expand(K, -1, -1, -1), b["src_ixts"].expand(K, -1, -1, -1)
+    want = ops.proj_mats(b["src_exts"], b["src_ixts"], b["tar_ext"], b["tar_ixt"], 0.25, 0.125)
+    for _ in range(3):
+        got = ops.proj_mats(ext, ixt, b["tar_ext"].expand(K, -1, -1), b["tar_ixt"].expand(K, -1, -1), 0.25, 0.125)
+        for k in range(K):
+            assert torch.equal(got[k], want[0])
+
+
 def test_depth_values(ops, enerf_fx):
     b = enerf_fx.batch(DEV)
     c = tiny_cfg(enerf_fx).enerf.cas_config
