@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--pipelined", action="store_true",
                     help="do not synchronize after every timed step (the un-bracketed replay rate; NOT the run.py metric)")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="graph replay: the frame with event brackets is replayed on every Nth timed step, the same "
                          "frame captured without them on the others (six event records cost a 1 ms frame ~3 %%); 1 = "
                          "brackets on every step")
@@ -506,7 +506,8 @@ def main():
                 step()
             ag = net._autograph.stats
             graph_note = (f"net(batch) on other device tensors every step (a ring of {len(ring)}), replaying its own HIP graph (autograph: "
-                          f"{ag['captures']} capture(s), {ag['copies']} input tensors copied in {ag['replays']} replays, outputs copied out)"
+                          f"{ag['captures']} capture(s); in {ag['replays']} replays {ag.get('deferred', 0)} large inputs / outputs read and written "
+                          f"in place through the frame's pointer table, {ag['copies']} small input tensors copied)"
                           + ("" if fg is None else f"; every {sampled['every']}. step a bracketed capture instead: {len(fg.graphs)} graph(s)"
                              + (f" + {len(fg.sweeps)} eager plane sweep(s) with dispatch-bound events" if fg.sweeps else "")))
         except Exception as e:   # keep the eager path: the bench must still produce its line

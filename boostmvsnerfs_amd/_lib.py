@@ -132,6 +132,12 @@ SIGNATURES = {
     "bmv_event_elapsed_us": [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)],
     "bmv_bind_next_launch": [C.c_void_p, C.c_void_p],
     "bmv_launch_events_pending": [],
+    "bmv_defer_pointer": [C.c_void_p, C.c_void_p, c_i],
+    "bmv_deferred_pending": [],
+    "bmv_ptr_table_set": [C.c_void_p, c_i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), c_f],
+    "bmv_frame_feed": [C.c_void_p, c_i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), c_i, C.POINTER(C.c_void_p),
+                       C.POINTER(C.c_void_p), C.POINTER(C.c_int), c_f],
+    "bmv_copy_to_slot": [c_f, C.c_void_p, c_i, c_l, c_f],
     "bmv_version": [],
     "bmv_render_pc_check": [c_i],
     "bmv_debug_render_pc_inject": [c_i],
@@ -206,7 +212,16 @@ def get_tuning(name):
     return v.value if is_set.value else None
 
 
+# Tensors whose addresses were taken for the launch being assembled.  `dptr(x.contiguous())` drops the last reference
+# to the copy as soon as the address is taken, and the caching allocator hands the very block to the NEXT argument's
+# copy of the same call -- whose copy kernel then overwrites the first argument before the launch reads it (round 4:
+# two non-contiguous arguments in one call are all it takes).  Every tensor handed to dptr() is therefore kept
+# referenced until the launch has been enqueued: check() -- called after every entry point -- lets go.
+_held = []
+
+
 def check(rc, what=""):
+    _held.clear()
     if rc != 0:
         msg = load().bmv_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libbmv {what} failed (code {rc}): {msg}")
@@ -225,6 +240,7 @@ def dptr(t, name="tensor", dtype=torch.float32):
                            "there is no CPU fallback")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
+    _held.append(t)
     return C.c_void_p(t.data_ptr())
 
 

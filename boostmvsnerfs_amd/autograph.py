@@ -13,9 +13,15 @@ unchanged `network(batch)` was host-bound (round 2: 323 Mray/s eager against 353
   bracket: the cost is charged to the iteration that triggers it), later ones replay;
 * **forward never writes its inputs and never hands out memory it will overwrite** (the reference's forward does
   neither): the graph is captured on PRIVATE copies of the batch's tensors, every call copies the caller's tensors into
-  them with one multi-tensor launch (23 MB at 512x640: what an unchanged run.py loop, which hands over new device
-  tensors every frame, needs anyway), and the outputs are copies of the graph's static outputs (8 MB).  Two opt-ins
-  trade that contract for the copies, attribute by attribute on the network:
+  them with one multi-tensor launch, and the outputs are copies of the graph's static outputs.  The LARGE tensors do
+  not move at all: the kernels that read the images and the rays, and the renderer that writes rgb / depth / weights,
+  take those pointers from a device table when they RUN (`ops.PtrTable`, include/bmv.h `bmv_defer_pointer`); a call
+  points the table at the caller's tensors and at freshly allocated outputs (one 1-workgroup launch) instead of
+  copying 22 MB in and 8 MB out.  Which inputs may be deferred is the network's statement
+  (`_autograph_deferrable`); whether the captured frame really reads them ONLY through the table is CHECKED at capture
+  time: a second replay with the private copies and the static outputs poisoned and the table pointing elsewhere must
+  reproduce the first one bit for bit, else the entry falls back to copies.  Two opt-ins
+  trade the contract for the remaining copies, attribute by attribute on the network:
     - `net.resident_inputs = True`: the caller DECLARES its batch resident -- the graph is captured on the caller's own
       tensors and a call with those very tensors copies nothing (in-place edits of them are picked up); a call with
       other tensors of the same shapes is copied INTO THE DECLARED BATCH'S tensors, which is what the declaration
@@ -33,11 +39,16 @@ from __future__ import annotations
 import os
 from operator import attrgetter
 
+import ctypes as C
+
 import torch
+
+from . import _lib, ops
 
 _version_of = attrgetter("_version")
 
 ENABLED = os.environ.get("BMV_AUTOGRAPH", "1") != "0"
+DEFER = os.environ.get("BMV_AUTOGRAPH_DEFER", "1") != "0"    # large inputs / outputs through a pointer table (no copies)
 MAX_GRAPHS = int(os.environ.get("BMV_AUTOGRAPH_MAX", "4"))
 
 
@@ -135,36 +146,137 @@ class AutoGraph:
     # ------------------------------------------------------------------ call
     def _hot_call(self, batch):
         """The steady state of a loop that hands over other tensors every frame (run.py): the batch has the structure of
-        the last replayed private-copy entry -> the input copy goes to the GPU FIRST (it is harmless whatever the key
-        checks say: the static inputs are private), the host-side checks run under it."""
+        the last replayed private-copy entry -> the input copy / the pointer table go to the GPU FIRST (harmless
+        whatever the key checks say: the static inputs and the table are private), the host-side checks run under it."""
         e = self._hot
         st = e["static"]
-        srcs = []
         n = 0
         for v in batch.values():
             if torch.is_tensor(v) and not _built(v):
                 n += 1
         if n != e["n_tensors"]:
             return None
-        for k in e["names"]:
+        for k in e["all_names"]:
             v = batch.get(k)
             s = st[k]
             if v is None or v.shape != s.shape or v.dtype != s.dtype or v.device != s.device:
                 return None
-            srcs.append(v)
-        _copy_many(e["dsts"], srcs)
+        fresh = self._feed(e, batch)
         if (e["version"] != self._param_version() or e["shard"] != self._shard()
                 or e["extra"] != self.net._autograph_key(batch) or self.entries.get(e["key"]) is not e):
             return None
-        self.stats["copies"] += len(srcs)
         self.stats["replays"] += 1
         out = e["fg"].replay()
         e["hits"] += 1
         for k, v in e["added"].items():
             batch[k] = v
+        return self._results(e, out, fresh)
+
+    @staticmethod
+    def _next_outputs(e):
+        """The NEXT call's output tensors, allocated while the GPU runs this frame: they have to exist before the next
+        replay is launched (their addresses go into the table), and five allocations in front of the launch are ~20 us
+        of host time on the critical path of a synchronized loop."""
+        d = e.get("defer")
+        if d is not None and d["feed"] is not None:
+            e["next_out"] = [torch.empty_like(sbuf) for _, _, sbuf in d["out"]]
+
+    # ------------------------------------------------------------------ inputs in, outputs out
+    def _feed(self, e, batch):
+        """This call's tensors into the captured frame: the deferred inputs (and the outputs' destinations) as pointers
+        into the table, the small ones copied into the static inputs -- one launch (bmv_frame_feed) when the entry has
+        a table, else one multi-tensor copy.  Returns the fresh output tensors by output name."""
+        static = e["static"]
+        d = e.get("defer")
+        f = d["feed"] if d is not None else None
+        if f is not None:
+            values, src = f["values"], f["src"]
+            i = 0
+            for k, _ in d["in"]:
+                v = batch[k]
+                if not v.is_contiguous():                   # rare: through the private copy after all
+                    static[k].copy_(v)
+                    v = static[k]
+                    self.stats["copies"] += 1
+                values[i] = v.data_ptr()
+                i += 1
+            fresh = {}
+            alias = getattr(self.net, "alias_outputs", False)
+            ready = e.pop("next_out", None)
+            for j, (k, _, sbuf) in enumerate(d["out"]):
+                t = sbuf if alias else (ready[j] if ready is not None else torch.empty_like(sbuf))
+                fresh[k] = t
+                values[i] = t.data_ptr()
+                i += 1
+            ok = True
+            for j, k in enumerate(e["names"]):
+                v = batch[k]
+                if not v.is_contiguous():
+                    ok = False
+                    break
+                src[j] = v.data_ptr()
+            if ok:
+                rc = f["fn"](f["table"], f["n"], f["slots"], values, f["m"], src, f["dst"], f["cnt"], _lib.stream())
+                if rc:
+                    _lib.check(rc, "frame_feed")
+                self.stats["copies"] += f["m"]
+                self.stats["deferred"] = self.stats.get("deferred", 0) + f["n"]
+                return fresh
+            _copy_many(e["dsts"], [batch[k] for k in e["names"]])
+            d["tb"].set(list(f["slots"])[:f["n"]], [values[q] for q in range(f["n"])])
+            self.stats["copies"] += len(e["names"])
+            return fresh
+        dsts, srcs = [], []
+        for k in e["names"]:
+            v = batch.get(k)
+            if v is None or not torch.is_tensor(v):
+                continue
+            s = static[k]
+            if s is v or (s.data_ptr() == v.data_ptr() and s.stride() == v.stride()):
+                continue                               # (only possible when the capture ran on the caller's tensors)
+            dsts.append(s)
+            srcs.append(v)
+        _copy_many(dsts, srcs)
+        self.stats["copies"] += len(dsts)
+        if d is None:
+            return None
+        slots, ptrs = [], []
+        for k, slot in d["in"]:
+            v = batch[k]
+            if not v.is_contiguous():
+                static[k].copy_(v)
+                v = static[k]
+                self.stats["copies"] += 1
+            slots.append(slot)
+            ptrs.append(v.data_ptr())
+        fresh = {}
+        alias = getattr(self.net, "alias_outputs", False)
+        for k, slot, sbuf in d["out"]:
+            t = sbuf if alias else torch.empty_like(sbuf)
+            fresh[k] = t
+            slots.append(slot)
+            ptrs.append(t.data_ptr())
+        d["tb"].set(slots, ptrs)
+        self.stats["deferred"] = self.stats.get("deferred", 0) + len(slots)
+        return fresh
+
+    def _results(self, e, out, fresh):
         if getattr(self.net, "alias_outputs", False):
             return dict(out)
-        return self._fresh_outputs(e, out)
+        if fresh:
+            self._next_outputs(e)
+        names = e.get("out_names")
+        if names is None:
+            skip = set(fresh) if fresh else ()
+            names = e["out_names"] = [k for k, v in out.items() if torch.is_tensor(v) and k not in skip]
+        srcs = [out[k] for k in names]
+        dsts = [torch.empty_like(s) for s in srcs]
+        _copy_many(dsts, srcs)
+        res = dict(out)
+        res.update(zip(names, dsts))
+        if fresh:
+            res.update(fresh)
+        return res
 
     def __call__(self, batch):
         resident = bool(getattr(self.net, "resident_inputs", False))
@@ -197,13 +309,17 @@ class AutoGraph:
                     self.stats["eager"] += 1
                     return self.eager_forward(batch)
                 e = self._capture(key, batch, version, resident)
-            copied = self._refresh(e, batch)
+            before = self.stats["copies"]
+            fresh = self._feed(e, batch)
+            copied = self.stats["copies"] - before
             if not resident:
                 e["key"], e["shard"], e["extra"] = key, key[1], extra
                 self._hot = e
             if resident:
                 # these objects ARE the static inputs if nothing had to be copied: remember them for the fast path
                 self._last = (ident, e) if not copied else None
+        else:
+            fresh = None
         self.stats["replays"] += 1
         out = e["fg"].replay()
         e["hits"] += 1
@@ -211,9 +327,7 @@ class AutoGraph:
             batch[k] = v
         if resident and self._last is not None and e["added"] and len(ident[0]) != len(batch):
             self._last = ((tuple(map(id, batch.values())),) + ident[1:], e)       # (the batch just gained those keys)
-        if getattr(self.net, "alias_outputs", False):
-            return dict(out)
-        return self._fresh_outputs(e, out)
+        return self._results(e, out, fresh)
 
     @staticmethod
     def _fresh_outputs(e, out):
@@ -255,30 +369,101 @@ class AutoGraph:
             for k, v in bb.items():
                 if k not in b:
                     added[k] = v
+            tb_ = ops.defer_table
+            if tb_ is not None and torch.cuda.is_current_stream_capturing():
+                # the outputs no kernel writes through the table (small maps produced by torch ops) are copied to their
+                # table entries by nodes of the frame's own graph: nothing is left to copy after a replay
+                for k, v in out.items():
+                    if (torch.is_tensor(v) and v.dtype == torch.float32 and v.is_contiguous()
+                            and v.data_ptr() not in tb_.outputs and tb_.n < tb_.SLOTS):
+                        slot = tb_._slot()
+                        tb_.outputs[v.data_ptr()] = (slot, v)
+                        ops.copy_to_slot(v, tb_, slot)
             return out
-        with torch.no_grad():
-            fg = FrameGraph(run, static, cut=None)
+        # the large inputs the network says its kernels can read through a pointer table (ops.PtrTable): registered
+        # BEFORE the capture so that the wrappers defer them while the frame is captured
+        tb = None
+        want = () if (resident or not DEFER) else getattr(self.net, "_autograph_deferrable", lambda b: ())(batch)
+        def_in = []
+        if want:
+            probe = next(v for v in static.values() if torch.is_tensor(v))
+            tb = ops.PtrTable(probe.device)
+            for k in want:
+                v = static.get(k)
+                if torch.is_tensor(v) and (reads is None or k in reads) and v.is_contiguous():
+                    def_in.append((k, tb.add_input(v)))
+        prev = ops.defer_table
+        ops.defer_table = tb
+        try:
+            with torch.no_grad():
+                fg = FrameGraph(run, static, cut=None)
+        finally:
+            ops.defer_table = prev
         self.stats["captures"] += 1
-        names = [k for k, v in static.items() if torch.is_tensor(v) and (resident or reads is None or k in reads)]
+        all_names = [k for k, v in static.items() if torch.is_tensor(v) and (resident or reads is None or k in reads)]
         e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added, "resident": resident,
-             "names": names, "dsts": [static[k] for k in names], "one_dtype": len({static[k].dtype for k in names}) == 1,
-             "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v))}
+             "all_names": all_names, "names": all_names, "dsts": [static[k] for k in all_names],
+             "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v)), "defer": None}
+        if tb is not None:
+            e["tb"] = tb        # the graph reads the table's memory on every replay, deferral adopted or not: keep it alive
+            self._adopt_table(e, tb, def_in)
         self.entries[key] = e
         return e
 
-    def _refresh(self, e, batch):
-        """The caller's tensors into the graph's static inputs; returns the number of tensors copied."""
-        static = e["static"]
-        dsts, srcs = [], []
-        for k in e["names"]:
-            v = batch.get(k)
-            if v is None or not torch.is_tensor(v):
-                continue
-            s = static[k]
-            if s is v or (s.data_ptr() == v.data_ptr() and s.stride() == v.stride()):
-                continue                               # (only possible when the capture ran on the caller's tensors)
-            dsts.append(s)
-            srcs.append(v)
-        _copy_many(dsts, srcs)
-        self.stats["copies"] += len(dsts)
-        return len(dsts)
+    def _adopt_table(self, e, tb, def_in):
+        """After the capture: which registered inputs some launch really deferred, which static outputs the renderer
+        registered; the table initialised to the static tensors themselves; then the CHECK that the captured frame
+        reads / writes them only through the table -- a replay with the private copies and static outputs poisoned and
+        the table pointing at other memory must reproduce the first replay bit for bit.  Else: copies, as before."""
+        fg, static = e["fg"], e["static"]
+        def_in = [(k, slot) for k, slot in def_in if slot in tb.taken]
+        out = fg.out
+        def_out = []
+        slots, ptrs = [], []
+        for k, slot in def_in:
+            slots.append(slot), ptrs.append(static[k].data_ptr())
+        for ptr, (slot, t) in tb.outputs.items():
+            slots.append(slot), ptrs.append(ptr)              # (every slot always points somewhere valid)
+            for name, v in out.items():
+                if torch.is_tensor(v) and v.data_ptr() == ptr and v.numel() == t.numel() and v.is_contiguous():
+                    def_out.append((name, slot, v))
+                    break
+        if not slots:
+            return
+        tb.set(slots, ptrs)
+        if not def_in and not def_out:
+            return
+        ref = {k: v.clone() for k, v in fg.replay().items() if torch.is_tensor(v)}
+        alt_in = {k: static[k].clone() for k, _ in def_in}
+        alt_out = {k: torch.empty_like(v) for k, _, v in def_out}
+        for k, _ in def_in:
+            static[k].fill_(float("nan")) if static[k].is_floating_point() else static[k].zero_()
+        for _, _, v in def_out:
+            v.fill_(float("nan")) if v.is_floating_point() else v.zero_()
+        tb.set([s for _, s in def_in] + [s for _, s, _ in def_out],
+               [alt_in[k].data_ptr() for k, _ in def_in] + [alt_out[k].data_ptr() for k, _, _ in def_out])
+        got = dict(fg.replay())
+        got.update(alt_out)
+        ok = all(torch.equal(got[k], v) for k, v in ref.items())
+        torch.cuda.current_stream().synchronize()
+        # (back to the static tensors either way: the table never points at memory of this function)
+        for k, _ in def_in:
+            static[k].copy_(alt_in[k])
+        tb.set(slots, ptrs)
+        self.stats["defer_checks"] = self.stats.get("defer_checks", 0) + 1
+        if not ok:
+            self.stats["defer_rejected"] = self.stats.get("defer_rejected", 0) + 1
+            return
+        gone = {k for k, _ in def_in}
+        e["names"] = [k for k in e["all_names"] if k not in gone]
+        e["dsts"] = [static[k] for k in e["names"]]
+        d = e["defer"] = {"tb": tb, "in": def_in, "out": def_out, "feed": None}
+        # table entries + the remaining (small) inputs in ONE launch (bmv_frame_feed), arguments prebuilt
+        small = [static[k] for k in e["names"]]
+        if len(small) <= 8 and all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= 65536 for t in small):
+            n, m = len(def_in) + len(def_out), len(small)
+            d["feed"] = {"n": n, "m": m, "slots": (C.c_int * max(n, 1))(*([s for _, s in def_in] + [s for _, s, _ in def_out])),
+                         "values": (C.c_void_p * max(n, 1))(), "src": (C.c_void_p * max(m, 1))(),
+                         "dst": (C.c_void_p * max(m, 1))(*[t.data_ptr() for t in small]),
+                         "cnt": (C.c_int * max(m, 1))(*[t.numel() for t in small]), "fn": _lib.load().bmv_frame_feed,
+                         "table": C.c_void_p(tb.t.data_ptr())}

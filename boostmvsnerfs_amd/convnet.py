@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import _lib, ktimer
+from . import _lib, ktimer, ops
 from ._lib import dptr, stream
 
 
@@ -264,8 +264,11 @@ def conv0_fused(x, w0, b0, wpack, bias, Cout, out=None):
     if out is None:
         out = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
     lib = _lib.load()
+    x = x.contiguous()
+    if ops.defer_table is not None:
+        ops.defer_input(x)
     with ktimer.region(f"conv0_fused[3->8->{Cout},{H}x{W}]"):
-        rc = lib.bmv_conv0_fused_fwd(dptr(x.contiguous(), "x"), dptr(w0, "w0"), dptr(b0, "b0"), dptr(wpack, "wpack"),
+        rc = lib.bmv_conv0_fused_fwd(dptr(x, "x"), dptr(w0, "w0"), dptr(b0, "b0"), dptr(wpack, "wpack"),
                                      dptr(bias, "bias"), dptr(out), B, Cout, H, W, 0.0, 0.0, stream())
     _lib.check(rc, "conv0_fused_fwd")
     return out
@@ -317,11 +320,15 @@ def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, 
         packed = torch.empty(B, H, W, 12, device=fine.device, dtype=torch.float32)
     elif out is None:
         out = torch.empty(B, Cout, H, W, device=fine.device, dtype=torch.float32)
+    if packed is not None:
+        rgb = rgb.contiguous()
+        if ops.defer_table is not None:
+            ops.defer_input(rgb)
     with ktimer.region(f"fpn_smooth[{Cf}+{C}->{Cout},{H}x{W}]"):
         rc = lib.bmv_fpn_smooth_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"), dptr(w, "w_lat"),
                                     dptr(lat_bias.detach().contiguous(), "b_lat"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                                     None if packed is not None else dptr(out),
-                                    dptr(rgb.contiguous(), "rgb") if packed is not None else None,
+                                    dptr(rgb, "rgb") if packed is not None else None,
                                     dptr(packed) if packed is not None else None, B, Cf, C, Cout, H, W, 1.0, stream())
     _lib.check(rc, "fpn_smooth_fwd")
     return LookupRecords(packed) if packed is not None else out

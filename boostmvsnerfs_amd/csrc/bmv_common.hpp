@@ -28,6 +28,20 @@ struct LaunchEvents {
 LaunchEvents take_launch_events();
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 
+// Deferred pointers (bmv_defer_pointer, csrc/timing.hip): "argument `ptr` of the NEXT launch is to be read from
+// table[slot] when the kernel RUNS".  A launcher that supports it for an argument asks deferred_for(); BMV_LAUNCH_END
+// fails the call if a registered deferral was not taken (the entry point does not read that argument through a table).
+struct DeferredPtr {
+  const void* const* table = nullptr;
+  int slot = -1;
+};
+DeferredPtr deferred_for(const void* ptr);
+int deferred_finish();   // number of registered deferrals no launcher took; clears the list
+template <typename T>
+__device__ __forceinline__ T* deferred_load(const void* const* table, int slot, T* direct) {
+  return (table && slot >= 0) ? static_cast<T*>(const_cast<void*>(table[slot])) : direct;
+}
+
 #define BMV_REQUIRE(cond, ...)                  \
   do {                                          \
     if (!(cond)) {                              \
@@ -42,6 +56,10 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop);
     if (e_ != hipSuccess) {                                                         \
       ::bmv::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
       return BMV_ERR_LAUNCH;                                                        \
+    }                                                                               \
+    if (::bmv::deferred_finish()) {                                                 \
+      ::bmv::set_error("%s: a pointer registered with bmv_defer_pointer is not an argument this entry point reads through a table", name); \
+      return BMV_ERR_UNSUPPORTED;                                                   \
     }                                                                               \
     return BMV_OK;                                                                  \
   } while (0)

@@ -571,6 +571,8 @@ struct FpnSmoothArgs {
   int B, C, Cout, H, W;
   float slope;
   int ntiles;           // tiles in all; the grid may be smaller (persistent form: a workgroup walks tiles gridDim.x apart)
+  const void* const* table;   // deferred `rgb` (bmv_defer_pointer)
+  int rgb_slot;
 };
 
 template <int R>
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(256) void fpn_smooth_kernel(FpnSmoothArgs a) {
     // permuted on the host so that MFMA rows 0-3 are channels 0 2 4 6 and rows 4-7 channels 1 3 5 7 (the two lane
     // halves of the renderer's MLP take even / odd channels); the source colours ride along
     const int q = g & 1;
-    const float* cp = a.rgb + (size_t)b * 3 * hw;
+    const float* cp = deferred_load(a.table, a.rgb_slot, a.rgb) + (size_t)b * 3 * hw;
 #pragma unroll
     for (int r = 0; r < T::NACC; ++r) {
       const int y = ybase + 2 * r + (g >> 1);
@@ -762,6 +764,8 @@ struct Conv0Args {
   float* out;           // (B, Cout, H, W)
   int B, Cout, H, W;
   float slope0, slope1;
+  const void* const* table;   // deferred `in` (bmv_defer_pointer): read from table[in_slot] when the kernel runs
+  int in_slot;
 };
 
 template <int R>
@@ -782,7 +786,8 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
   const int ix0 = x0 - 1, iy0 = y0 - 1;          // origin of the intermediate tile (second layer's halo)
   const int hw = a.H * a.W;
 
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (size_t)b * 3 * hw), 0,
+  const float* in = deferred_load(a.table, a.in_slot, a.in);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)b * 3 * hw), 0,
                                                                   (int)(4u * (unsigned)(3 * hw)), 0x00020000);
 #pragma unroll
   for (int j = 0; j < NIN; ++j) {
@@ -1391,6 +1396,8 @@ int bmv_conv0_fused_fwd(const float* in, const float* w0, const float* b0, const
   Conv0Args a;
   a.in = in, a.w0 = w0, a.b0 = b0, a.wpack = wpack, a.bias = bias, a.out = out;
   a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.slope0 = slope0, a.slope1 = slope1;
+  const DeferredPtr din = deferred_for(in);
+  a.table = din.table, a.in_slot = din.slot;
   const int rows = bmv::tuning("BMV_CONV0_R", 4);
   hipStream_t st = as_stream(stream);
   if (rows == 8) {
@@ -1418,6 +1425,8 @@ int bmv_fpn_smooth_fwd(const float* fine, const float* coarse, const float* w_la
   a.fine = fine, a.coarse = coarse, a.wlat = w_lat, a.blat = b_lat, a.wpack = wpack, a.bias = bias, a.out = out;
   a.rgb = rgb, a.packed = packed_out;
   a.B = B, a.C = C, a.Cout = Cout, a.H = H, a.W = W, a.slope = act_slope;
+  const DeferredPtr drgb = rgb ? deferred_for(rgb) : DeferredPtr{};
+  a.table = drgb.table, a.rgb_slot = drgb.slot;
   const int rows = bmv::tuning("BMV_FPN_SMOOTH_R", 8);
   // BMV_FPN_SMOOTH_PERSIST=n: at most n workgroups per CU, each walking several tiles -- leaves registers for the short
   // launches of the level-0 regulariser that run beside this kernel on the second stream

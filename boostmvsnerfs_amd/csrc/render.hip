@@ -64,11 +64,28 @@ __device__ float g_stamps[512 * 4 * 8];
 #endif
 
 // PK: 0 = planar lookups, 1 = image lookups from 48-byte records, 3 = image and volume lookups from records
+// the public argument block + the deferred pointers of this launch (bmv_defer_pointer: rays and the three outputs may be
+// read from a device table when the kernel runs -- a captured frame then renders the caller's rays into the caller's
+// tensors without copies)
+struct RenderArgsDev : bmv_render_args {
+  const void* const* table;
+  int s_rays, s_out0, s_out1, s_out2;
+};
+__device__ __forceinline__ void resolve_deferred(RenderArgsDev& a) {
+  if (a.table) {
+    a.rays = deferred_load(a.table, a.s_rays, a.rays);
+    a.out0 = deferred_load(a.table, a.s_out0, a.out0);
+    a.out1 = deferred_load(a.table, a.s_out1, a.out1);
+    a.out2 = deferred_load(a.table, a.s_out2, a.out2);
+  }
+}
+
 template <int FEAT_CH, int NS, bool INV, int PK = 0>
 #ifndef BMV_RENDER_WPS
 #define BMV_RENDER_WPS 2   // workgroups (= waves per SIMD) resident per CU
 #endif
-__global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(bmv_render_args a) {
+__global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(RenderArgsDev a) {
+  resolve_deferred(a);
   using L = MlpLayout<FEAT_CH>;
   static_assert(32 % NS == 0, "samples per ray must divide 32");
   constexpr int RAYS_PER_TILE = 32 / NS;
@@ -346,7 +363,8 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
 }
 
 template <int NS, bool INV>
-__global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(bmv_render_args a) {
+__global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(RenderArgsDev a) {
+  resolve_deferred(a);
   constexpr int FEAT_CH = 8;
   using L = MlpLayout<FEAT_CH>;
   static_assert(32 % NS == 0, "samples per ray must divide 32");
@@ -697,8 +715,18 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
               "bmv_render_rays_fwd: ray range [%d,%d) outside [0,%d)", a->ray_begin, a->ray_end, a->N);
   BMV_REQUIRE(a->mode == 0 || a->mode == 1, "bmv_render_rays_fwd: mode=%d", a->mode);
   BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
-  if (a->ray_begin == a->ray_end) return BMV_OK;
+  if (a->ray_begin == a->ray_end) return deferred_finish() ? BMV_ERR_UNSUPPORTED : BMV_OK;
   int nrays = a->ray_end - a->ray_begin;
+  RenderArgsDev dev;
+  static_cast<bmv_render_args&>(dev) = *a;
+  {
+    const DeferredPtr dr = deferred_for(a->rays), d0 = deferred_for(a->out0), d1 = deferred_for(a->out1), d2 = deferred_for(a->out2);
+    dev.table = dr.table ? dr.table : d0.table ? d0.table : d1.table ? d1.table : d2.table;
+    BMV_REQUIRE((!dr.table || dr.table == dev.table) && (!d0.table || d0.table == dev.table) &&
+                    (!d1.table || d1.table == dev.table) && (!d2.table || d2.table == dev.table),
+                "bmv_render_rays_fwd: the deferred pointers of one launch must share one table");
+    dev.s_rays = dr.slot, dev.s_out0 = d0.slot, dev.s_out1 = d1.slot, dev.s_out2 = d2.slot;
+  }
   // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
   const bool use_pc = bmv::tuning("BMV_RENDER_PC", 1) != 0;
 #define RENDER_CASE_PC(NSV)                                                                                          \
@@ -709,7 +737,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
     const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u)); \
     unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;                                        \
     hipLaunchKernelGGL((render_pc_kernel<NSV, false>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,      \
-                       as_stream(stream), *a);                                                                      \
+                       as_stream(stream), dev);                                                                      \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
   RENDER_CASE_PC(2)
@@ -723,7 +751,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
     BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, PKV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
-    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, PKV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, PKV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
   RENDER_CASE_PK(8, 2, false, 1)
@@ -744,7 +772,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
     BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");   \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
-    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), *a); \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
   RENDER_CASE(8, 2, false)

@@ -15,6 +15,67 @@ LaunchEvents take_launch_events() {
   return e;
 }
 void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_launch_events.start = start, g_launch_events.stop = stop; }
+
+namespace {
+struct DeferredEntry {
+  const void* ptr;
+  DeferredPtr d;
+  bool taken;
+};
+constexpr int kMaxDeferred = 8;
+thread_local DeferredEntry g_deferred[kMaxDeferred];
+thread_local int g_ndeferred = 0;
+}  // namespace
+
+DeferredPtr deferred_for(const void* ptr) {
+  for (int i = 0; i < g_ndeferred; ++i)
+    if (g_deferred[i].ptr == ptr) {
+      g_deferred[i].taken = true;
+      return g_deferred[i].d;
+    }
+  return DeferredPtr{};
+}
+int deferred_finish() {
+  int left = 0;
+  for (int i = 0; i < g_ndeferred; ++i) left += g_deferred[i].taken ? 0 : 1;
+  g_ndeferred = 0;
+  return left;
+}
+
+struct PtrTableSet {
+  int n;
+  int slot[16];
+  const void* value[16];
+};
+__global__ void ptr_table_set_kernel(const void** table, PtrTableSet s) {
+  const int i = threadIdx.x;
+  if (i < s.n) table[s.slot[i]] = s.value[i];
+}
+// one launch in front of a replayed frame: the table entries of this frame AND the frame's small inputs (cameras,
+// near / far: a few dozen floats each) copied into the captured buffers -- under run.py's per-frame synchronize every
+// launch in front of the graph costs ~10-15 us of latency whatever it moves
+struct FrameFeed {
+  int n_ptr, n_copy;
+  int slot[16];
+  const void* value[16];
+  const float* src[8];
+  float* dst[8];
+  int count[8];
+};
+__global__ void __launch_bounds__(256) frame_feed_kernel(const void** table, FrameFeed f) {
+  const int t = threadIdx.x;
+  if (t < f.n_ptr) table[f.slot[t]] = f.value[t];
+  for (int c = 0; c < f.n_copy; ++c)
+    for (int j = t; j < f.count[c]; j += 256) f.dst[c][j] = f.src[c][j];
+}
+// src (captured buffer) -> the tensor table[slot] points at when the kernel runs: the frame's small outputs, as a node of
+// the frame's own graph
+__global__ void __launch_bounds__(256) copy_to_slot_kernel(const float* __restrict__ src, const void* const* table, int slot,
+                                                           size_t n) {
+  float* dst = static_cast<float*>(const_cast<void*>(table[slot]));
+  if (dst == src) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 }  // namespace bmv
 
 using namespace bmv;
@@ -25,6 +86,56 @@ int bmv_bind_next_launch(bmv_event_t start, bmv_event_t stop) {
   BMV_REQUIRE((start == nullptr) == (stop == nullptr), "bmv_bind_next_launch: one event without the other");
   set_launch_events(reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop));
   return BMV_OK;
+}
+
+int bmv_defer_pointer(const void* ptr, const void* const* table, int slot) {
+  BMV_REQUIRE(ptr && table && slot >= 0, "bmv_defer_pointer: null pointer / negative slot");
+  BMV_REQUIRE(g_ndeferred < kMaxDeferred, "bmv_defer_pointer: more than %d deferrals pending", kMaxDeferred);
+  g_deferred[g_ndeferred++] = DeferredEntry{ptr, DeferredPtr{table, slot}, false};
+  return BMV_OK;
+}
+
+int bmv_deferred_pending(void) { return deferred_finish(); }
+
+int bmv_ptr_table_set(void* table, int n, const int* slots, const void* const* values, bmv_stream_t stream) {
+  BMV_REQUIRE(table && slots && values, "bmv_ptr_table_set: null pointer");
+  BMV_REQUIRE(n > 0 && n <= 16, "bmv_ptr_table_set: 1..16 entries per call (n=%d)", n);
+  PtrTableSet s;
+  s.n = n;
+  for (int i = 0; i < n; ++i) {
+    BMV_REQUIRE(slots[i] >= 0, "bmv_ptr_table_set: negative slot");
+    s.slot[i] = slots[i], s.value[i] = values[i];
+  }
+  hipLaunchKernelGGL(ptr_table_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), static_cast<const void**>(table), s);
+  BMV_LAUNCH_END("bmv_ptr_table_set");
+}
+
+int bmv_frame_feed(void* table, int n_ptr, const int* slots, const void* const* values, int n_copy,
+                   const float* const* src, float* const* dst, const int* counts, bmv_stream_t stream) {
+  BMV_REQUIRE(n_ptr >= 0 && n_ptr <= 16 && n_copy >= 0 && n_copy <= 8 && n_ptr + n_copy > 0,
+              "bmv_frame_feed: up to 16 table entries and 8 small copies (n_ptr=%d, n_copy=%d)", n_ptr, n_copy);
+  BMV_REQUIRE((n_ptr == 0 || (table && slots && values)) && (n_copy == 0 || (src && dst && counts)),
+              "bmv_frame_feed: null pointer");
+  FrameFeed f;
+  f.n_ptr = n_ptr, f.n_copy = n_copy;
+  for (int i = 0; i < n_ptr; ++i) {
+    BMV_REQUIRE(slots[i] >= 0, "bmv_frame_feed: negative slot");
+    f.slot[i] = slots[i], f.value[i] = values[i];
+  }
+  for (int i = 0; i < n_copy; ++i) {
+    BMV_REQUIRE(src[i] && dst[i] && counts[i] >= 0 && counts[i] <= 65536,
+                "bmv_frame_feed: small copies only (<= 65536 floats each; entry %d has %d)", i, counts[i]);
+    f.src[i] = src[i], f.dst[i] = dst[i], f.count[i] = counts[i];
+  }
+  hipLaunchKernelGGL(frame_feed_kernel, dim3(1), dim3(256), 0, as_stream(stream), static_cast<const void**>(table), f);
+  BMV_LAUNCH_END("bmv_frame_feed");
+}
+
+int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long n, bmv_stream_t stream) {
+  BMV_REQUIRE(src && table && slot >= 0 && n > 0, "bmv_copy_to_slot: bad arguments");
+  const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(copy_to_slot_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, table, slot, (size_t)n);
+  BMV_LAUNCH_END("bmv_copy_to_slot");
 }
 
 int bmv_launch_events_pending(void) {   // 1: the events of bmv_bind_next_launch were not taken by a launch (and are dropped)

@@ -58,8 +58,8 @@ class Network(enerf_network.Network):
         self.capture = None
         self._sel_cache = {}
         self._streams = []
-        self._setup_stream = None      # camera-only work of a frame, under FeatureNet
         self._cam_pre = None
+        self.side_setup = os.environ.get("BMV_BOOST_SIDE_SETUP", "1") == "1"
         self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
         # the K cost volumes as one batch through the regularisers instead of K chains on K streams (round 3; opt-in:
         # measured 3.29 ms against 3.15 ms per 480x736 K = 4 frame -- the frame is 4 x 0.7 ms of render launches, and
@@ -300,6 +300,10 @@ class Network(enerf_network.Network):
         return {"all_src_inps", "all_src_exts", "all_src_ixts", "tar_ext", "tar_ixt", "near_far"} | {
             f"rays_{i}" for i in range(cc.num) if cc.render_if[i]}
 
+    def _autograph_deferrable(self, batch):
+        cc = cfg.enerf.cas_config
+        return ("all_src_inps",) + tuple(f"rays_{i}" for i in range(cc.num) if cc.render_if[i])
+
     def _autograph_key(self, batch):
         """A captured K-volume frame is specialised to the cost-volume triplets view_selection.json selects for the
         batch's targets (they are baked into the graph as device constants) and to the capture hook of the tests."""
@@ -341,12 +345,15 @@ class Network(enerf_network.Network):
         # kernels inside the chains.  (The same launch in front of the fork on the main stream was measured slower in round 3:
         # its single-thread fp64 inversions are pure latency there.)
         cam = None
-        if (B == 1 and self.frame_setup and self.by_index and dev.type == "cuda" and not self.wants_grad()
+        if (B == 1 and self.frame_setup and self.side_setup and self.by_index and dev.type == "cuda" and not self.wants_grad()
                 and (self.parallel_volumes or self.volume_ids is not None) and not self.batched_volumes):
             main = torch.cuda.current_stream()
-            if self._setup_stream is None:
-                self._setup_stream = torch.cuda.Stream()
-            su = self._setup_stream
+            # (on the first volume's own stream, whose chain simply continues behind it.  A separate stream for this
+            # one launch crashed hipGraphLaunch on ROCm 7.2 when the process had captured other graphs before --
+            # tests/test_gpu_framegraph.py in file order)
+            while len(self._streams) < K:
+                self._streams.append(torch.cuda.Stream())
+            su = self._streams[0]
             su.wait_stream(main)
             with torch.cuda.stream(su):
                 H, W = batch["all_src_inps"].shape[-2:]
@@ -368,10 +375,11 @@ class Network(enerf_network.Network):
         finally:
             self.feature_net.pack_lookup = False
         if cam is not None:
-            torch.cuda.current_stream().wait_stream(cam["stream"])      # (long done: FeatureNet took 100x its time)
-            if not torch.cuda.is_current_stream_capturing():
-                for t in (cam["ext"], cam["ixt"], *cam["keep"]):
-                    t.record_stream(torch.cuda.current_stream())
+            # (long done: FeatureNet took 100x its time.  The tensors allocated on the side stream are read on the main
+            # and the volume streams and released when this function returns; the side stream's next allocation comes
+            # after its wait for the main stream of the NEXT frame, which has joined every volume stream by then: no
+            # record_stream needed)
+            torch.cuda.current_stream().wait_stream(cam["stream"])
         bi = torch.arange(B, device=dev)[:, None]
         states = [None] * K
         ret = {}
@@ -400,7 +408,10 @@ class Network(enerf_network.Network):
             if self.batched_volumes and self.volume_ids is None and B == 1:
                 return self._forward_batched(batch, feats, sel, sel32, cams, K)
             if (self.parallel_volumes or self.volume_ids is not None) and B == 1:
-                return self._forward_parallel(batch, feats, sel, sel32, cams, K)
+                try:
+                    return self._forward_parallel(batch, feats, sel, sel32, cams, K)
+                finally:
+                    self._cam_pre = None      # (tensors of this frame / this capture's pool: not kept across calls)
         if self.volume_ids is not None:
             raise NotImplementedError("volume_ids (multi-GPU volume sharding) needs the inference path with views by index, B = 1")
         for i in range(cc.num):

@@ -364,6 +364,13 @@ class Network(nn.Module):
         return {"src_inps", "src_exts", "src_ixts", "tar_ext", "tar_ixt", "near_far"} | {
             f"rays_{i}" for i in range(cc.num) if cc.render_if[i]}
 
+    def _autograph_deferrable(self, batch):
+        """The large inputs whose consumers can read them through a pointer table when the frame is replayed
+        (ops.PtrTable): the images (conv0_fused, the lookup records' colours in fpn_smooth) and the rendered levels'
+        rays (the fused renderer).  A statement of intent -- autograph verifies it on the captured frame."""
+        cc = cfg.enerf.cas_config
+        return ("src_inps",) + tuple(f"rays_{i}" for i in range(cc.num) if cc.render_if[i])
+
     def _autograph_key(self, batch):
         """What a captured frame is specialised to besides shapes and parameters: the execution switches of this module
         (tests and tuning scripts flip them between calls)."""

@@ -5,7 +5,6 @@ Everything runs on torch's current stream.
 """
 from __future__ import annotations
 
-import collections
 import ctypes as C
 import os
 
@@ -15,20 +14,10 @@ from . import _lib, ktimer
 from ._lib import dptr, stream
 
 
-_TEMPS = collections.deque(maxlen=32)
-
-
 def _c(t):
-    """`t`, contiguous.  A copy made here must outlive the LAUNCH it is made for: `dptr(_c(x))` drops the last
-    reference as soon as the address is taken, and the caching allocator hands the very block to the next `_c` copy
-    of the same call -- whose copy kernel then overwrites the first argument before the launch reads it (round 4:
-    expanded target cameras of the K-triplet frame_setup; two non-contiguous arguments in one call is all it takes).
-    The last 32 copies are therefore kept referenced (no entry point takes that many tensors)."""
-    if t.is_contiguous():
-        return t
-    t = t.contiguous()
-    _TEMPS.append(t)
-    return t
+    """`t`, contiguous.  (A copy made here outlives the launch it is made for: `_lib.dptr` keeps every tensor it is
+    given referenced until `_lib.check` -- see there.)"""
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def proj_mats(src_exts, src_ixts, tar_ext, tar_ixt, src_scale, tar_scale):
@@ -572,10 +561,92 @@ def render_rays(rays, depth, std, near_far, volume, im_feat, rgb_src, src_exts, 
     else:
         a.view_ids, a.n_all = None, 0
     lib = _lib.load()
+    if defer_table is not None:
+        defer_input(held[0])
+        if mode == 0:
+            for o in (o0, o1, o2):
+                defer_output(o, fresh=outs is None)
     with ktimer.region(f"render_rays[feat={feat_ch},Ns={Ns},mode={mode}]"):
         rc = lib.bmv_render_rays_fwd(C.byref(a), stream())
     _lib.check(rc, "render_rays")
     return o0, o1, o2
+
+
+# ======================================================================= deferred pointers (autograph)
+class PtrTable:
+    """A device table of pointers that a CAPTURED frame reads its large inputs and writes its large outputs through
+    (include/bmv.h, bmv_defer_pointer): the graph bakes the table's address in, `set()` points the entries at this
+    frame's tensors before a replay -- no copy into captured input buffers, none out of captured output buffers.
+    Inputs are registered by autograph (`add_input(static clone)`); outputs register themselves while the frame is
+    captured (`render_rays` for buffers it allocates).  Only while `ops.defer_table` is set AND the current stream is
+    capturing do the wrappers defer anything."""
+    SLOTS = 16
+
+    def __init__(self, device):
+        self.t = torch.zeros(self.SLOTS, dtype=torch.int64, device=device)
+        self.inputs = {}          # data_ptr of the static tensor -> slot
+        self.outputs = {}         # data_ptr of the static output -> (slot, tensor)
+        self.n = 0
+        self.taken = set()        # slots a launch actually deferred (an input nobody deferred keeps its copy)
+
+    def _slot(self):
+        if self.n >= self.SLOTS:
+            raise RuntimeError("PtrTable: out of slots")
+        self.n += 1
+        return self.n - 1
+
+    def add_input(self, t):
+        slot = self._slot()
+        self.inputs[t.data_ptr()] = slot
+        return slot
+
+    def set(self, slots, ptrs):
+        n = len(slots)
+        if n == 0:
+            return
+        _lib.check(_lib.load().bmv_ptr_table_set(self.t.data_ptr(), n, (C.c_int * n)(*slots), (C.c_void_p * n)(*ptrs),
+                                                 stream()), "ptr_table_set")
+
+
+def copy_to_slot(t, table, slot):
+    """`t` (contiguous fp32) -> the tensor `table[slot]` points at when the kernel runs (bmv_copy_to_slot)."""
+    _lib.check(_lib.load().bmv_copy_to_slot(dptr(t, "copy_to_slot"), table.t.data_ptr(), int(slot), t.numel(), stream()),
+               "copy_to_slot")
+
+
+defer_table = None      # the PtrTable of the capture in progress (autograph sets it around FrameGraph's capture)
+
+
+def _deferring():
+    return defer_table is not None and torch.cuda.is_current_stream_capturing()
+
+
+def defer_input(t):
+    """Call right before the launch that reads `t` (contiguous): if `t` is a registered static input of the frame being
+    captured, that launch reads it through the table."""
+    if defer_table is None or not torch.cuda.is_current_stream_capturing():
+        return
+    slot = defer_table.inputs.get(t.data_ptr())
+    if slot is not None:
+        rc = _lib.load().bmv_defer_pointer(t.data_ptr(), defer_table.t.data_ptr(), slot)
+        if rc:                      # (not through check() on success: it would let go of the launch's held tensors)
+            _lib.check(rc, "defer_pointer")
+        defer_table.taken.add(slot)
+
+
+def defer_output(t, fresh):
+    """... the launch that WRITES `t`: buffers a wrapper allocated itself (`fresh`) are registered on their first
+    launch, later launches into the same buffer (ray chunks) defer it again."""
+    if defer_table is None or not torch.cuda.is_current_stream_capturing():
+        return
+    ent = defer_table.outputs.get(t.data_ptr())
+    if ent is None:
+        if not fresh:
+            return
+        ent = defer_table.outputs[t.data_ptr()] = (defer_table._slot(), t)
+    rc = _lib.load().bmv_defer_pointer(t.data_ptr(), defer_table.t.data_ptr(), ent[0])
+    if rc:
+        _lib.check(rc, "defer_pointer")
 
 
 # ======================================================================= MVSNeRF backbone

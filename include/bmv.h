@@ -543,6 +543,29 @@ const char* bmv_tuning_doc(int i);
 int bmv_bind_next_launch(bmv_event_t start, bmv_event_t stop);
 int bmv_launch_events_pending(void);
 
+/* ---- deferred pointers: a captured frame (HIP graph) that reads the caller's tensors and writes the caller's outputs
+ * A graph bakes its kernels' arguments in.  run.py hands Network.forward OTHER device tensors every frame
+ * (run.py:113-123: `batch[k] = batch[k].cuda()`), so a replayed frame had to copy them into its captured buffers and
+ * its results out again (31 MB per 512x640 frame).  Instead: bmv_defer_pointer(ptr, table, slot) says that the argument
+ * of the NEXT launch of this thread whose value is `ptr` is to be read from the DEVICE table entry table[slot] when
+ * the kernel RUNS; bmv_ptr_table_set() (a 1-workgroup launch, outside the graph) points the entries at this frame's
+ * tensors before the replay.  Arguments that can be deferred: `in` of bmv_conv0_fused_fwd, `rgb` of
+ * bmv_fpn_smooth_fwd, `rays` / `out0` / `out1` / `out2` of bmv_render_rays_fwd (the deferrals of one launch share one
+ * table).  A registered deferral the next launch does not take fails that call with BMV_ERR_UNSUPPORTED (never a
+ * silently baked pointer); bmv_deferred_pending() returns the number of untaken deferrals and drops them. */
+int bmv_defer_pointer(const void* ptr, const void* const* table, int slot);
+int bmv_deferred_pending(void);
+/* table[slots[i]] = values[i], i < n <= 16, on `stream` */
+int bmv_ptr_table_set(void* table, int n, const int* slots, const void* const* values, bmv_stream_t stream);
+/* The same plus up to 8 SMALL device-to-device copies dst[i][0..counts[i]) = src[i][...] (<= 65536 floats each: the
+ * cameras and near / far of a frame into the captured buffers) in ONE 1-workgroup launch: under run.py's per-frame
+ * synchronize every launch in front of the replayed graph costs 10-15 us of latency whatever it moves. */
+int bmv_frame_feed(void* table, int n_ptr, const int* slots, const void* const* values, int n_copy,
+                   const float* const* src, float* const* dst, const int* counts, bmv_stream_t stream);
+/* n floats from `src` to the tensor table[slot] points at WHEN THE KERNEL RUNS (a frame's small outputs, as a node of
+ * the frame's own graph: nothing is left to copy after the replay); no-op when the entry points at `src` itself. */
+int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long n, bmv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

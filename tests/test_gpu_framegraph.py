@@ -204,6 +204,15 @@ def test_forward_captures_itself():
         for k in want:
             assert torch.equal(o[k], want[k]), k
     assert len({o["rgb_level1"].data_ptr() for o in outs}) == 4
+    # the images and the rays are READ IN PLACE and the renderer WRITES the returned tensors (pointer table,
+    # autograph._adopt_table): checked once at capture, nothing rejected, no copy of those tensors
+    assert ag.stats.get("defer_checks") == 1 and "defer_rejected" not in ag.stats and ag.stats.get("deferred", 0) > 0
+    d = ag._hot["defer"]
+    assert {k for k, _ in d["in"]} == {"src_inps", "rays_1"}
+    # ... rgb / depth / weights written by the renderer, the small maps copied by nodes of the frame's own graph
+    assert {k for k, _, _ in d["out"]} == {"rgb_level1", "depth_level1", "weights_level1", "depth_mvs_level1", "std_level1"}
+    assert "src_inps" not in ag._hot["names"] and "tar_ext" in ag._hot["names"]
+    assert d["feed"] is not None and d["feed"]["m"] == len(ag._hot["names"])      # one launch in front of the replay
     # two batches of the same shapes, alternated twice (with the graph captured on the caller's tensors the
     # second pass rendered the wrong frame and the first batch's tensors had been overwritten)
     with torch.no_grad():
@@ -257,6 +266,47 @@ def test_forward_captures_itself():
     net.train()
     assert not ag.usable(batch)
     net.eval()
+
+
+def test_deferral_is_rejected_when_a_kernel_reads_the_captured_copy():
+    """With the renderer's lookup records off, the fused renderer reads the source colours straight from `src_inps`
+    (a baked pointer): the capture-time check must notice that the frame does not read the images through the table
+    alone and keep the copies -- and the frames must still be right."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    net.lookup_records = False
+    ag = net._autograph
+    a = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    b = clone_batch(make_batch(128, 160, n_views=3, seed=1), DEV)
+    want_a, want_b = eager(a), eager(b)
+    with torch.no_grad():
+        frames = [net(x) for x in (a, a, b, a, b)]
+    torch.cuda.synchronize()
+    assert ag.stats["captures"] == 1 and ag.stats.get("defer_checks") == 1 and ag.stats.get("defer_rejected") == 1
+    assert ag._hot["defer"] is None and "src_inps" in ag._hot["names"]
+    for f, w in zip(frames, (want_a, want_a, want_b, want_a, want_b)):
+        for k in w:
+            assert torch.equal(f[k], w[k]), k
+
+
+def test_deferred_pointer_nobody_takes_fails_the_launch():
+    """include/bmv.h: a pointer registered with bmv_defer_pointer that the next launch does not read through a table
+    fails that call (never a silently baked pointer)."""
+    from boostmvsnerfs_amd import _lib, ops
+    lib = _lib.load()
+    table = torch.zeros(16, dtype=torch.int64, device=DEV)
+    x = torch.rand(1, 2, device=DEV)
+    assert lib.bmv_defer_pointer(x.data_ptr(), table.data_ptr(), 0) == 0
+    with pytest.raises(RuntimeError, match="bmv_defer_pointer"):
+        ops.depth_values_uniform(x, 4, 8, 8, True)
+    assert lib.bmv_deferred_pending() == 0          # ... and the registration is gone
+    ops.depth_values_uniform(x, 4, 8, 8, True)
+    # the table setter
+    vals = [x.data_ptr(), table.data_ptr()]
+    tb = ops.PtrTable(torch.device(DEV))
+    tb.set([3, 5], vals)
+    torch.cuda.synchronize()
+    assert tb.t[3].item() == vals[0] and tb.t[5].item() == vals[1] and tb.t[0].item() == 0
 
 
 def test_forward_resident_opt_in():
