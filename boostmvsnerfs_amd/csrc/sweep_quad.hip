@@ -399,15 +399,21 @@ sweep_quad_kernel(const QuadArgs a) {
       V[pl].z = fmaf(fS, acc2.z, -(acc.z * acc.z)), V[pl].w = fmaf(fS, acc2.w, -(acc.w * acc.w));
     };
     auto blend4 = [&](float4& acc, float4& acc2, const float4& t00, const float4& t01, const float4& t10, const float4& t11,
-                      const float* wt) {
+                      const float* wt, bool first = false) {
       const float a00 = wt[0], a01 = wt[1], a10 = wt[2], a11 = W4 ? wt[NWT - 1] : ((inv_s - a00) - a01) - a10;
       float4 v;
       v.x = t00.x * a00 + t01.x * a01 + t10.x * a10 + t11.x * a11;
       v.y = t00.y * a00 + t01.y * a01 + t10.y * a10 + t11.y * a11;
       v.z = t00.z * a00 + t01.z * a01 + t10.z * a10 + t11.z * a11;
       v.w = t00.w * a00 + t01.w * a01 + t10.w * a10 + t11.w * a11;
-      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
-      acc2.x += v.x * v.x, acc2.y += v.y * v.y, acc2.z += v.z * v.z, acc2.w += v.w * v.w;
+      if (first) {   // (known after unrolling: the first view of a plane assigns -- `0 + v` is not folded without
+                     // -fno-signed-zeros, 8 of the 164 vector instructions per quad, and the kernel is bound by them)
+        acc = v;
+        acc2.x = v.x * v.x, acc2.y = v.y * v.y, acc2.z = v.z * v.z, acc2.w = v.w * v.w;
+      } else {
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        acc2.x += v.x * v.x, acc2.y += v.y * v.y, acc2.z += v.z * v.z, acc2.w += v.w * v.w;
+      }
     };
     if (a.flags & 2) {
 #pragma unroll
@@ -436,11 +442,10 @@ sweep_quad_kernel(const QuadArgs a) {
           n00 = lds4(win, a0), n01 = lds4(win, a0 + 16u), n10 = lds4(win, a1), n11 = lds4(win, a1 + 16u);
         }
         BMV_QUAD_SB;
-        blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv]);
+        blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv], sv == 0);
         if (sv == S - 1) {
           finish(pl, acc, acc2);
           if (pl + 1 < PG) store_plane(pl);   // (only the LAST plane's stores wait for the next fill to be issued)
-          acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
         }
         BMV_QUAD_SB;
         if (u + 1 < NU) t00 = n00, t01 = n01, t10 = n10, t11 = n11;
@@ -451,11 +456,10 @@ sweep_quad_kernel(const QuadArgs a) {
         const int pl = u / S, sv = u % S;
         const unsigned a0 = tadr[pl][sv], a1 = a0 + (unsigned)wc[sv] * 16u;
         const float4 t00 = lds4(win, a0), t01 = lds4(win, a0 + 16u), t10 = lds4(win, a1), t11 = lds4(win, a1 + 16u);
-        blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv]);
+        blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv], sv == 0);
         if (sv == S - 1) {
           finish(pl, acc, acc2);
           if (pl + 1 < PG) store_plane(pl);   // (only the LAST plane's stores wait for the next fill to be issued)
-          acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
         }
         BMV_QUAD_SB;   // one unit's taps in flight (the other waves of the SIMD cover the latency)
       }

@@ -21,9 +21,9 @@ run() {  # name workload marker markers-per-step steps warmup extra...
 WL=${*:-"c2 c1 c3 c4 c5"}
 for w in $WL; do
   case $w in
-    c2) run ${PFX}_config2_enerf512x640 enerf_512x640_3src_64planes "$RM" 1 20 5 ;;
-    c1) run ${PFX}_config1_enerf256x320 enerf_256x320_3src_32planes "$RM" 1 10 3 ;;
-    c3) run ${PFX}_config3_enerf_ours480x736_k4 enerf_ours_480x736_6src_k4 "blend_wave_kernel" 1 8 3 ;;
+    c2) run ${PFX}_config2_enerf512x640 enerf_512x640_3src_64planes "$RM" 1 200 5 ;;
+    c1) run ${PFX}_config1_enerf256x320 enerf_256x320_3src_32planes "$RM" 1 100 3 ;;
+    c3) run ${PFX}_config3_enerf_ours480x736_k4 enerf_ours_480x736_6src_k4 "blend_wave_kernel" 1 60 3 ;;
     c4) run ${PFX}_config4_mvsnerf_ours_128planes_k4 mvsnerf_ours_224x352_128planes_k4 "blend_wave_kernel" 1 4 2 ;;
     c5) run ${PFX}_config5_enerf_ours_ft480x736_k4 enerf_ours_ft_480x736_6src_k4 "blend_bwd_kernel" 2 6 4 ;;
     ft) run ${PFX}_enerf_ft512x640 enerf_ft_512x640_3src "nerf_mlp_bwd_kernel<8>" 1 16 6 ;;

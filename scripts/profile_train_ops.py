@@ -37,9 +37,11 @@ def main():
         train_step(wrapper, opt, batch)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by=a.sort, row_limit=a.rows, max_name_column_width=60))
-    ev = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::clone", "aten::contiguous")]
-    ev.sort(key=lambda e: -e.count)
-    for e in ev[:25]:
+    ev = [e for e in prof.key_averages(group_by_input_shape=True)
+          if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::add_", "aten::add", "aten::fill_", "aten::zero_",
+                       "aten::index", "aten::cat", "aten::mul", "aten::sum")]
+    ev.sort(key=lambda e: -e.self_device_time_total)
+    for e in ev[:45]:
         print(e.key, e.count, e.input_shapes, f"{e.self_device_time_total:.0f}us")
 
 
