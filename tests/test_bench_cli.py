@@ -27,7 +27,7 @@ def test_driver_flags_and_defaults():
     b = _bench()
     a = _parse(b, ["--gpus", "1", "--steps", "20", "--warmup", "5"])
     assert (a.gpus, a.steps, a.warmup) == (1, 20, 5) and a.workload == b.HEADLINE
-    assert a.spinup_steps == 100 and a.event_every == 4 and not a.pipelined and a.shard == "views"
+    assert a.spinup_steps == 100 and a.event_every == 10 and not a.pipelined and a.shard == "views"
     # no flags: N = 1; the ms-scale inference workloads average over many steps, the others over 30
     assert _parse(b, []).steps == 400 and _parse(b, []).gpus == 1
     assert _parse(b, ["--workload", "enerf_ours_480x736_6src_k4"]).steps == 400
