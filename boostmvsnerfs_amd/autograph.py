@@ -179,7 +179,8 @@ class AutoGraph:
         of host time on the critical path of a synchronized loop."""
         d = e.get("defer")
         if d is not None and d["feed"] is not None:
-            e["next_out"] = [torch.empty_like(sbuf) for _, _, sbuf in d["out"]]
+            # (allocated on the stream this frame runs on: the next call uses them only if it runs there too)
+            e["next_out"] = (_lib.stream().value, [torch.empty_like(sbuf) for _, _, sbuf in d["out"]])
 
     # ------------------------------------------------------------------ inputs in, outputs out
     def _feed(self, e, batch):
@@ -203,6 +204,8 @@ class AutoGraph:
             fresh = {}
             alias = getattr(self.net, "alias_outputs", False)
             ready = e.pop("next_out", None)
+            if ready is not None:
+                ready = ready[1] if ready[0] == _lib.stream().value else None
             for j, (k, _, sbuf) in enumerate(d["out"]):
                 t = sbuf if alias else (ready[j] if ready is not None else torch.empty_like(sbuf))
                 fresh[k] = t
