@@ -1,1 +1,2 @@
-bash scripts/run_timeline.sh gpurun_out/r4w_tl > gpurun_out/r4w_tl.log 2>&1
+mkdir -p gpurun_out/r4w
+timeout 120 ./scripts/ubench/grid_barrier > gpurun_out/r4w/grid_barrier.txt 2>&1
