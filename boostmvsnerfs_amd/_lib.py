@@ -138,6 +138,7 @@ SIGNATURES = {
     "bmv_frame_feed": [C.c_void_p, c_i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), c_i, C.POINTER(C.c_void_p),
                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), c_f],
     "bmv_copy_to_slot": [c_f, C.c_void_p, c_i, c_l, c_f],
+    "bmv_copy_to_slots": [c_i, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long), c_f],
     "bmv_version": [],
     "bmv_render_pc_check": [c_i],
     "bmv_debug_render_pc_inject": [c_i],

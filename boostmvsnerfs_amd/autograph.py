@@ -376,12 +376,8 @@ class AutoGraph:
             if tb_ is not None and torch.cuda.is_current_stream_capturing():
                 # the outputs no kernel writes through the table (small maps produced by torch ops) are copied to their
                 # table entries by nodes of the frame's own graph: nothing is left to copy after a replay
-                for k, v in out.items():
-                    if (torch.is_tensor(v) and v.dtype == torch.float32 and v.is_contiguous()
-                            and v.data_ptr() not in tb_.outputs and tb_.n < tb_.SLOTS):
-                        slot = tb_._slot()
-                        tb_.outputs[v.data_ptr()] = (slot, v)
-                        ops.copy_to_slot(v, tb_, slot)
+                # (one launch for all of them; a network may have placed them earlier: ops.defer_small_outputs)
+                ops.defer_small_outputs([v for v in out.values() if torch.is_tensor(v)])
             return out
         # the large inputs the network says its kernels can read through a pointer table (ops.PtrTable): registered
         # BEFORE the capture so that the wrappers defer them while the frame is captured

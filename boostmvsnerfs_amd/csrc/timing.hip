@@ -76,6 +76,21 @@ __global__ void __launch_bounds__(256) copy_to_slot_kernel(const float* __restri
   if (dst == src) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+// ... several of them in one launch (a frame's small outputs: one node at the end of the graph instead of one each)
+struct SlotCopies {
+  int n;
+  const float* src[8];
+  int slot[8];
+  unsigned count[8];
+};
+__global__ void __launch_bounds__(256) copy_to_slots_kernel(const void* const* table, SlotCopies c) {
+  for (int k = 0; k < c.n; ++k) {
+    float* dst = static_cast<float*>(const_cast<void*>(table[c.slot[k]]));
+    const float* src = c.src[k];
+    if (dst == src) continue;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < c.count[k]; i += gridDim.x * 256) dst[i] = src[i];
+  }
+}
 }  // namespace bmv
 
 using namespace bmv;
@@ -136,6 +151,22 @@ int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long 
   const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(copy_to_slot_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, table, slot, (size_t)n);
   BMV_LAUNCH_END("bmv_copy_to_slot");
+}
+
+int bmv_copy_to_slots(int n, const float* const* src, const void* const* table, const int* slots, const long* counts,
+                      bmv_stream_t stream) {
+  BMV_REQUIRE(n > 0 && n <= 8 && src && table && slots && counts, "bmv_copy_to_slots: 1..8 copies (n=%d)", n);
+  SlotCopies c;
+  c.n = n;
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    BMV_REQUIRE(src[i] && slots[i] >= 0 && counts[i] > 0 && counts[i] < (1l << 31), "bmv_copy_to_slots: bad entry %d", i);
+    c.src[i] = src[i], c.slot[i] = slots[i], c.count[i] = (unsigned)counts[i];
+    most = counts[i] > most ? counts[i] : most;
+  }
+  const unsigned grid = (unsigned)((most + 255) / 256 < 2048 ? (most + 255) / 256 : 2048);
+  hipLaunchKernelGGL(copy_to_slots_kernel, dim3(grid), dim3(256), 0, as_stream(stream), table, c);
+  BMV_LAUNCH_END("bmv_copy_to_slots");
 }
 
 int bmv_launch_events_pending(void) {   // 1: the events of bmv_bind_next_launch were not taken by a launch (and are dropped)

@@ -614,6 +614,33 @@ def copy_to_slot(t, table, slot):
                "copy_to_slot")
 
 
+def copy_to_slots(tensors, table, slots):
+    """... up to 8 of them in one launch (bmv_copy_to_slots)."""
+    n = len(tensors)
+    _lib.check(_lib.load().bmv_copy_to_slots(n, (C.c_void_p * n)(*[dptr(t, "copy_to_slots").value for t in tensors]),
+                                             table.t.data_ptr(), (C.c_int * n)(*[int(s) for s in slots]),
+                                             (C.c_long * n)(*[t.numel() for t in tensors]), stream()), "copy_to_slots")
+
+
+def defer_small_outputs(tensors):
+    """Outputs of the frame being captured that no kernel writes through the table (small maps): copied to their
+    table entries by ONE node of the frame's graph; autograph calls this at the end of the captured frame.  (Tried: the
+    network placing it on its side stream under the renderer -- the fork / join around the persistent renderer cost
+    more than the 4.5 us of the copy: fresh-tensor frame +8 us.)"""
+    tb = defer_table
+    if tb is None or not torch.cuda.is_current_stream_capturing():
+        return
+    todo = []
+    for t in tensors:
+        if (t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() not in tb.outputs and tb.n < tb.SLOTS
+                and len(todo) < 8):
+            slot = tb._slot()
+            tb.outputs[t.data_ptr()] = (slot, t)
+            todo.append((t, slot))
+    if todo:
+        copy_to_slots([t for t, _ in todo], tb, [s for _, s in todo])
+
+
 defer_table = None      # the PtrTable of the capture in progress (autograph sets it around FrameGraph's capture)
 
 

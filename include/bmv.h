@@ -565,6 +565,9 @@ int bmv_frame_feed(void* table, int n_ptr, const int* slots, const void* const* 
 /* n floats from `src` to the tensor table[slot] points at WHEN THE KERNEL RUNS (a frame's small outputs, as a node of
  * the frame's own graph: nothing is left to copy after the replay); no-op when the entry points at `src` itself. */
 int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long n, bmv_stream_t stream);
+/* ... up to 8 such copies in one launch: counts[i] floats from src[i] to the tensor table[slots[i]] points at */
+int bmv_copy_to_slots(int n, const float* const* src, const void* const* table, const int* slots, const long* counts,
+                      bmv_stream_t stream);
 
 #ifdef __cplusplus
 }
