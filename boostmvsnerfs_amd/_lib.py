@@ -137,6 +137,8 @@ SIGNATURES = {
     "bmv_ptr_table_set": [C.c_void_p, c_i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), c_f],
     "bmv_frame_feed": [C.c_void_p, c_i, C.POINTER(C.c_int), C.POINTER(C.c_void_p), c_i, C.POINTER(C.c_void_p),
                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), c_f],
+    "bmv_frame_feed_ring": [C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_f],
+    "bmv_frame_feed_msg_bytes": [],
     "bmv_copy_to_slot": [c_f, C.c_void_p, c_i, c_l, c_f],
     "bmv_copy_to_slots": [c_i, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long), c_f],
     "bmv_version": [],

@@ -49,6 +49,7 @@ _version_of = attrgetter("_version")
 
 ENABLED = os.environ.get("BMV_AUTOGRAPH", "1") != "0"
 DEFER = os.environ.get("BMV_AUTOGRAPH_DEFER", "1") != "0"    # large inputs / outputs through a pointer table (no copies)
+RING = os.environ.get("BMV_AUTOGRAPH_RING", "1") != "0"      # ... fed by the frame's own first node from a host ring (no launch)
 MAX_GRAPHS = int(os.environ.get("BMV_AUTOGRAPH_MAX", "4"))
 
 
@@ -190,6 +191,46 @@ class AutoGraph:
         static = e["static"]
         d = e.get("defer")
         f = d["feed"] if d is not None else None
+        if f is not None and f["ring"] is not None:
+            # no launch at all: this replay's message into the host ring the frame's first node reads
+            ring = f["ring"]
+            values, srcs = [], []
+            for k, _ in d["in"]:
+                v = batch[k]
+                if not v.is_contiguous():                   # rare: through the private copy after all
+                    static[k].copy_(v)
+                    v = static[k]
+                    self.stats["copies"] += 1
+                values.append(v.data_ptr())
+            fresh = {}
+            alias = getattr(self.net, "alias_outputs", False)
+            ready = e.pop("next_out", None)
+            if ready is not None:
+                ready = ready[1] if ready[0] == _lib.stream().value else None
+            for j, (k, _, sbuf) in enumerate(d["out"]):
+                t = sbuf if alias else (ready[j] if ready is not None else torch.empty_like(sbuf))
+                fresh[k] = t
+                values.append(t.data_ptr())
+            ok = True
+            for k in e["names"]:
+                v = batch[k]
+                if not v.is_contiguous():
+                    ok = False
+                    break
+                srcs.append(v.data_ptr())
+            if ok:
+                if ring.fast is None:
+                    ring.prepare_fast(*f["ring_args"])
+                ring.post_fast(values, srcs)
+                self.stats["copies"] += f["m"]
+            else:
+                _copy_many(e["dsts"], [batch[k] for k in e["names"]])
+                ring.post(f["ring_args"][0], values)
+                self.stats["copies"] += len(e["names"])
+            self.stats["deferred"] = self.stats.get("deferred", 0) + f["n"]
+            return fresh
+        if e.get("ring") is not None:
+            e["ring"].post()            # (the frame's first node reads one message per replay, deferral adopted or not)
         if f is not None:
             values, src = f["values"], f["src"]
             i = 0
@@ -368,6 +409,9 @@ class AutoGraph:
             # forward may ADD keys to the batch (rays built on the device from the target camera): every call gets a
             # fresh shallow copy, so that such tensors are rebuilt inside the captured frame instead of being baked in
             bb = dict(b)
+            tb0 = ops.defer_table
+            if tb0 is not None and tb0.ring is not None and torch.cuda.is_current_stream_capturing():
+                tb0.ring.node(tb0)          # first node of the frame: this replay's table entries and small inputs
             out = self.eager_forward(bb)
             for k, v in bb.items():
                 if k not in b:
@@ -387,6 +431,8 @@ class AutoGraph:
         if want:
             probe = next(v for v in static.values() if torch.is_tensor(v))
             tb = ops.PtrTable(probe.device)
+            if RING:
+                tb.ring = ops.FeedRing(probe.device)
             for k in want:
                 v = static.get(k)
                 if torch.is_tensor(v) and (reads is None or k in reads) and v.is_contiguous():
@@ -405,6 +451,7 @@ class AutoGraph:
              "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v)), "defer": None}
         if tb is not None:
             e["tb"] = tb        # the graph reads the table's memory on every replay, deferral adopted or not: keep it alive
+            e["ring"] = tb.ring # ... and its first node reads one ring message per replay: every replay posts one
             self._adopt_table(e, tb, def_in)
         self.entries[key] = e
         return e
@@ -432,6 +479,9 @@ class AutoGraph:
         tb.set(slots, ptrs)
         if not def_in and not def_out:
             return
+        ring = tb.ring
+        if ring is not None:
+            ring.post()                       # (nothing to change: the table points at the static tensors)
         ref = {k: v.clone() for k, v in fg.replay().items() if torch.is_tensor(v)}
         alt_in = {k: static[k].clone() for k, _ in def_in}
         alt_out = {k: torch.empty_like(v) for k, _, v in def_out}
@@ -439,12 +489,18 @@ class AutoGraph:
             static[k].fill_(float("nan")) if static[k].is_floating_point() else static[k].zero_()
         for _, _, v in def_out:
             v.fill_(float("nan")) if v.is_floating_point() else v.zero_()
-        tb.set([s for _, s in def_in] + [s for _, s, _ in def_out],
-               [alt_in[k].data_ptr() for k, _ in def_in] + [alt_out[k].data_ptr() for k, _, _ in def_out])
+        alt_slots = [s for _, s in def_in] + [s for _, s, _ in def_out]
+        alt_ptrs = [alt_in[k].data_ptr() for k, _ in def_in] + [alt_out[k].data_ptr() for k, _, _ in def_out]
+        if ring is not None:
+            ring.post(alt_slots, alt_ptrs)    # (the check goes through the ring too)
+        else:
+            tb.set(alt_slots, alt_ptrs)
         got = dict(fg.replay())
         got.update(alt_out)
         ok = all(torch.equal(got[k], v) for k, v in ref.items())
         torch.cuda.current_stream().synchronize()
+        if ring is not None and ring.faults():
+            ok = False
         # (back to the static tensors either way: the table never points at memory of this function)
         for k, _ in def_in:
             static[k].copy_(alt_in[k])
@@ -465,4 +521,6 @@ class AutoGraph:
                          "values": (C.c_void_p * max(n, 1))(), "src": (C.c_void_p * max(m, 1))(),
                          "dst": (C.c_void_p * max(m, 1))(*[t.data_ptr() for t in small]),
                          "cnt": (C.c_int * max(m, 1))(*[t.numel() for t in small]), "fn": _lib.load().bmv_frame_feed,
-                         "table": C.c_void_p(tb.t.data_ptr())}
+                         "table": C.c_void_p(tb.t.data_ptr()), "ring": ring,
+                         "ring_args": ([s for _, s in def_in] + [s for _, s, _ in def_out], [t.data_ptr() for t in small],
+                                       [t.numel() for t in small])}

@@ -68,6 +68,36 @@ __global__ void __launch_bounds__(256) frame_feed_kernel(const void** table, Fra
   for (int c = 0; c < f.n_copy; ++c)
     for (int j = t; j < f.count[c]; j += 256) f.dst[c][j] = f.src[c][j];
 }
+// The same work as the FIRST NODE of the frame's graph, its arguments read from a ring of messages in pinned HOST memory:
+// the host writes message number n (plain stores) and replays the graph -- no launch in front of the replay at all.
+// `state[0]` counts the replays on the device (the host counts its posts; up to R frames may be in flight), a message
+// whose sequence number is not the replay's number raises state[1] (bmv_frame_feed_ring_faults).
+struct FrameFeedMsg {
+  unsigned seq;
+  int n_ptr, n_copy, pad;
+  int slot[16];
+  const void* value[16];
+  const float* src[8];
+  float* dst[8];
+  int count[8];
+};
+static_assert(sizeof(FrameFeedMsg) == 368, "layout shared with boostmvsnerfs_amd/ops.py FeedRing");
+__global__ void __launch_bounds__(256) frame_feed_ring_kernel(const void** table, const FrameFeedMsg* ring, unsigned* state,
+                                                              int R) {
+  __shared__ FrameFeedMsg m;
+  const int t = threadIdx.x;
+  const unsigned n = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const volatile unsigned* g = reinterpret_cast<const volatile unsigned*>(ring + (n % (unsigned)R));
+  if (t < (int)(sizeof(FrameFeedMsg) / 4)) reinterpret_cast<unsigned*>(&m)[t] = g[t];
+  __syncthreads();
+  if (t == 0 && m.seq != n) atomicAdd(&state[1], 1u);
+  if (t < m.n_ptr && t < 16) table[m.slot[t]] = m.value[t];
+  const int nc = m.n_copy < 8 ? m.n_copy : 8;
+  for (int c = 0; c < nc; ++c)
+    for (int j = t; j < m.count[c]; j += 256) m.dst[c][j] = m.src[c][j];
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&state[0], n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // src (captured buffer) -> the tensor table[slot] points at when the kernel runs: the frame's small outputs, as a node of
 // the frame's own graph
 __global__ void __launch_bounds__(256) copy_to_slot_kernel(const float* __restrict__ src, const void* const* table, int slot,
@@ -145,6 +175,14 @@ int bmv_frame_feed(void* table, int n_ptr, const int* slots, const void* const* 
   hipLaunchKernelGGL(frame_feed_kernel, dim3(1), dim3(256), 0, as_stream(stream), static_cast<const void**>(table), f);
   BMV_LAUNCH_END("bmv_frame_feed");
 }
+
+int bmv_frame_feed_ring(void* table, const void* ring, unsigned* state, int R, bmv_stream_t stream) {
+  BMV_REQUIRE(table && ring && state && R > 0, "bmv_frame_feed_ring: bad arguments");
+  hipLaunchKernelGGL(frame_feed_ring_kernel, dim3(1), dim3(256), 0, as_stream(stream), static_cast<const void**>(table),
+                     static_cast<const FrameFeedMsg*>(ring), state, R);
+  BMV_LAUNCH_END("bmv_frame_feed_ring");
+}
+int bmv_frame_feed_msg_bytes(void) { return (int)sizeof(FrameFeedMsg); }
 
 int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long n, bmv_stream_t stream) {
   BMV_REQUIRE(src && table && slot >= 0 && n > 0, "bmv_copy_to_slot: bad arguments");

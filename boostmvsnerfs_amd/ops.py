@@ -588,6 +588,7 @@ class PtrTable:
         self.outputs = {}         # data_ptr of the static output -> (slot, tensor)
         self.n = 0
         self.taken = set()        # slots a launch actually deferred (an input nobody deferred keeps its copy)
+        self.ring = None          # FeedRing, when the frame's first node reads its arguments from the host ring
 
     def _slot(self):
         if self.n >= self.SLOTS:
@@ -606,6 +607,70 @@ class PtrTable:
             return
         _lib.check(_lib.load().bmv_ptr_table_set(self.t.data_ptr(), n, (C.c_int * n)(*slots), (C.c_void_p * n)(*ptrs),
                                                  stream()), "ptr_table_set")
+
+
+class FeedRing:
+    """The arguments of a captured frame's first node (bmv_frame_feed_ring): R messages in pinned host memory.  The host
+    writes message number `posted` (plain stores through a numpy view) and replays the graph; the node's n-th
+    execution reads message n.  EVERY replay of a graph that contains the node must be preceded by exactly one post."""
+    R = 64
+    DT = [("seq", "<u4"), ("n_ptr", "<i4"), ("n_copy", "<i4"), ("pad", "<i4"), ("slot", "<i4", 16), ("value", "<u8", 16),
+          ("src", "<u8", 8), ("dst", "<u8", 8), ("count", "<i4", 8)]
+
+    def __init__(self, device):
+        import numpy as np
+        dt = np.dtype(self.DT)
+        assert dt.itemsize == _lib.load().bmv_frame_feed_msg_bytes()
+        self.host = torch.zeros(self.R * dt.itemsize, dtype=torch.uint8).pin_memory()
+        self.msgs = self.host.numpy().view(dt)
+        self.state = torch.zeros(2, dtype=torch.int32, device=device)     # [executions of the node, sequence faults]
+        self.posted = 0
+        self.fast = None
+
+    def node(self, table):
+        """The node itself, on the current stream (autograph issues it first thing in the captured frame)."""
+        _lib.check(_lib.load().bmv_frame_feed_ring(table.t.data_ptr(), self.host.data_ptr(), self.state.data_ptr(), self.R,
+                                                   stream()), "frame_feed_ring")
+
+    def post(self, slots=(), values=(), srcs=(), dsts=(), counts=()):
+        m = self.msgs[self.posted % self.R]
+        n, c = len(slots), len(srcs)
+        m["seq"], m["n_ptr"], m["n_copy"] = self.posted & 0xffffffff, n, c
+        if n:
+            m["slot"][:n] = slots
+            m["value"][:n] = values
+        if c:
+            m["src"][:c] = srcs
+            m["dst"][:c] = dsts
+            m["count"][:c] = counts
+        self.posted += 1
+        self.fast = None          # (the constant fields of the fast path are no longer in every slot)
+
+    def prepare_fast(self, slots, dsts, counts):
+        """The steady state posts the same slots / destinations / counts every time: written into all R messages
+        once, a post then stores the sequence number, the table values and the copy sources only."""
+        n, c = len(slots), len(dsts)
+        for m in self.msgs:
+            m["n_ptr"], m["n_copy"] = n, c
+            if n:
+                m["slot"][:n] = slots
+            if c:
+                m["dst"][:c] = dsts
+                m["count"][:c] = counts
+        self.fast = (n, c)
+
+    def post_fast(self, values, srcs):
+        m = self.msgs[self.posted % self.R]
+        n, c = self.fast
+        m["seq"] = self.posted & 0xffffffff
+        if n:
+            m["value"][:n] = values
+        if c:
+            m["src"][:c] = srcs
+        self.posted += 1
+
+    def faults(self):
+        return int(self.state[1].item())
 
 
 def copy_to_slot(t, table, slot):

@@ -562,6 +562,13 @@ int bmv_ptr_table_set(void* table, int n, const int* slots, const void* const* v
  * synchronize every launch in front of the replayed graph costs 10-15 us of latency whatever it moves. */
 int bmv_frame_feed(void* table, int n_ptr, const int* slots, const void* const* values, int n_copy,
                    const float* const* src, float* const* dst, const int* counts, bmv_stream_t stream);
+/* bmv_frame_feed as the FIRST NODE of the frame's graph: its arguments come from a ring of R messages in pinned (host
+ * coherent) memory that the host fills with plain stores before each replay -- no launch in front of the replay.
+ * Message n (bmv_frame_feed_msg_bytes() bytes: {u32 seq = n; i32 n_ptr, n_copy, pad; i32 slot[16]; void* value[16];
+ * float* src[8]; float* dst[8]; i32 count[8]}) is read by the n-th execution of the node (state[0], device memory,
+ * counts them; up to R frames may be in flight); a message whose seq is not the execution's number raises state[1]. */
+int bmv_frame_feed_ring(void* table, const void* ring, unsigned* state, int R, bmv_stream_t stream);
+int bmv_frame_feed_msg_bytes(void);
 /* n floats from `src` to the tensor table[slot] points at WHEN THE KERNEL RUNS (a frame's small outputs, as a node of
  * the frame's own graph: nothing is left to copy after the replay); no-op when the entry points at `src` itself. */
 int bmv_copy_to_slot(const float* src, const void* const* table, int slot, long n, bmv_stream_t stream);

@@ -212,7 +212,11 @@ def test_forward_captures_itself():
     # ... rgb / depth / weights written by the renderer, the small maps copied by nodes of the frame's own graph
     assert {k for k, _, _ in d["out"]} == {"rgb_level1", "depth_level1", "weights_level1", "depth_mvs_level1", "std_level1"}
     assert "src_inps" not in ag._hot["names"] and "tar_ext" in ag._hot["names"]
-    assert d["feed"] is not None and d["feed"]["m"] == len(ag._hot["names"])      # one launch in front of the replay
+    assert d["feed"] is not None and d["feed"]["m"] == len(ag._hot["names"])
+    # ... and no launch in front of the replay: the frame's first node reads this call's message from a host ring; every
+    # replay found the message with its own sequence number
+    ring = ag._hot["ring"]
+    assert ring is not None and ring.faults() == 0 and int(ring.state[0].item()) == ring.posted > 3
     # two batches of the same shapes, alternated twice (with the graph captured on the caller's tensors the
     # second pass rendered the wrong frame and the first batch's tensors had been overwritten)
     with torch.no_grad():
@@ -224,6 +228,15 @@ def test_forward_captures_itself():
             assert torch.equal(f[k], w[k]), k
     assert unchanged(batch, snap_a) and unchanged(other, snap_b)
     assert not torch.equal(want_other["rgb_level1"], want["rgb_level1"])
+    assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
+    # more frames than the ring has slots
+    with torch.no_grad():
+        for i in range(ring.R + 5):
+            f = net(other if i % 2 else batch)
+    torch.cuda.synchronize()
+    assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
+    for k in want:
+        assert torch.equal(f[k], want[k]), k
     # a parameter update invalidates the captured frame
     with torch.no_grad():
         next(net.nerf_1.parameters()).mul_(1.01)
