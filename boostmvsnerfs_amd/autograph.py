@@ -168,6 +168,8 @@ class AutoGraph:
             return None
         self.stats["replays"] += 1
         out = e["fg"].replay()
+        if e.get("ring") is not None:
+            e["ring"].replayed()
         e["hits"] += 1
         for k, v in e["added"].items():
             batch[k] = v
@@ -366,6 +368,8 @@ class AutoGraph:
             fresh = None
         self.stats["replays"] += 1
         out = e["fg"].replay()
+        if e.get("ring") is not None:
+            e["ring"].replayed()
         e["hits"] += 1
         for k, v in e["added"].items():             # keys the eager forward adds to the batch (rays built on the device)
             batch[k] = v
@@ -483,6 +487,8 @@ class AutoGraph:
         if ring is not None:
             ring.post()                       # (nothing to change: the table points at the static tensors)
         ref = {k: v.clone() for k, v in fg.replay().items() if torch.is_tensor(v)}
+        if ring is not None:
+            ring.replayed()
         alt_in = {k: static[k].clone() for k, _ in def_in}
         alt_out = {k: torch.empty_like(v) for k, _, v in def_out}
         for k, _ in def_in:
@@ -496,6 +502,8 @@ class AutoGraph:
         else:
             tb.set(alt_slots, alt_ptrs)
         got = dict(fg.replay())
+        if ring is not None:
+            ring.replayed()
         got.update(alt_out)
         ok = all(torch.equal(got[k], v) for k, v in ref.items())
         torch.cuda.current_stream().synchronize()

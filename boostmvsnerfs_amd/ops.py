@@ -626,6 +626,27 @@ class FeedRing:
         self.state = torch.zeros(2, dtype=torch.int32, device=device)     # [executions of the node, sequence faults]
         self.posted = 0
         self.fast = None
+        self.events = {}          # block number -> event recorded behind the last replay of that block of R / 2 messages
+
+    # A caller that does not synchronise per frame can run ahead of the GPU by more frames than the ring has slots (a
+    # graph launch only queues): slot n % R must not be rewritten before replay n - R has read it.  Every R / 2
+    # replays an event is recorded; the first post of a block waits for the event of the block before the last.
+    def _reserve(self):
+        n, half = self.posted, self.R // 2
+        if n % half == 0 and n >= self.R:
+            ev = self.events.pop(n // half - 2, None)
+            if ev is not None:
+                ev.synchronize()
+            else:                 # (a replay nobody reported: be safe)
+                torch.cuda.current_stream().synchronize()
+
+    def replayed(self):
+        """Call after the replay that followed a post."""
+        n, half = self.posted - 1, self.R // 2
+        if n % half == half - 1:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[n // half] = ev
 
     def node(self, table):
         """The node itself, on the current stream (autograph issues it first thing in the captured frame)."""
@@ -633,6 +654,7 @@ class FeedRing:
                                                    stream()), "frame_feed_ring")
 
     def post(self, slots=(), values=(), srcs=(), dsts=(), counts=()):
+        self._reserve()
         m = self.msgs[self.posted % self.R]
         n, c = len(slots), len(srcs)
         m["seq"], m["n_ptr"], m["n_copy"] = self.posted & 0xffffffff, n, c
@@ -660,6 +682,7 @@ class FeedRing:
         self.fast = (n, c)
 
     def post_fast(self, values, srcs):
+        self._reserve()
         m = self.msgs[self.posted % self.R]
         n, c = self.fast
         m["seq"] = self.posted & 0xffffffff

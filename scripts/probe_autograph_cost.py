@@ -48,7 +48,7 @@ def co(i):
 med, _ = bracket(co)
 print(f"fresh outputs ({len(outs)} tensors, {sum(t.numel() * 4 for t in outs) / 1e6:.1f} MB): {med:.1f} us")
 ring = e.get("ring")      # (the frame's first node reads one host-ring message per replay)
-med, _ = bracket(lambda i: (ring.post() if ring is not None else None, e["fg"].replay()))
+med, _ = bracket(lambda i: (ring.post() if ring is not None else None, e["fg"].replay(), ring.replayed() if ring is not None else None))
 print(f"graph replay alone: {med:.1f} us")
 t0 = time.perf_counter()
 for _ in range(1000):

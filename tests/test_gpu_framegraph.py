@@ -229,9 +229,10 @@ def test_forward_captures_itself():
     assert unchanged(batch, snap_a) and unchanged(other, snap_b)
     assert not torch.equal(want_other["rgb_level1"], want["rgb_level1"])
     assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
-    # more frames than the ring has slots
+    # more frames than the ring has slots, WITHOUT a synchronize per frame (the host runs ahead of the GPU: a slot must
+    # not be rewritten before the replay that reads it has run -- FeedRing._reserve)
     with torch.no_grad():
-        for i in range(ring.R + 5):
+        for i in range(3 * ring.R + 5):
             f = net(other if i % 2 else batch)
     torch.cuda.synchronize()
     assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
