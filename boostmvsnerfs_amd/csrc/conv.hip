@@ -479,8 +479,12 @@ template <int CF, bool COARSE_CL>
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE, 8))) void fpn_topdown_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int C, int H, int W, int quad) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+                                                          float* __restrict__ out, int C, int H, int W, int quad, int csplit) {
+  // csplit: the C output channels of a pixel are shared by csplit workgroups (grid.z = B x csplit): more waves in flight
+  // for a kernel whose waves otherwise sit in a chain of 8 dependent load -> FMA -> store rounds
+  const int part = blockIdx.z % csplit, b = blockIdx.z / csplit;
+  const int c_begin = part * (C / csplit), c_end = c_begin + C / csplit;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= W || y >= H) return;
   const int Hc = H / 2, Wc = W / 2;
   const size_t hw = (size_t)H * W, hwc = (size_t)Hc * Wc;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE
     const size_t o00 = (size_t)(ly.i0 * Wc + lx.i0) * ps, o01 = (size_t)(ly.i0 * Wc + lx.i1) * ps;
     const size_t o10 = (size_t)(ly.i1 * Wc + lx.i0) * ps, o11 = (size_t)(ly.i1 * Wc + lx.i1) * ps;
     const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
-    for (int c = 0; c < C; c += 4) {
+    for (int c = c_begin; c < c_end; c += 4) {
       const size_t co = (size_t)(c >> 2) * qs;
       const float4 t00 = *reinterpret_cast<const float4*>(cp + o00 + co), t01 = *reinterpret_cast<const float4*>(cp + o01 + co);
       const float4 t10 = *reinterpret_cast<const float4*>(cp + o10 + co), t11 = *reinterpret_cast<const float4*>(cp + o11 + co);
@@ -521,8 +525,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE
     // planar coarse: four channels per iteration, their 16 taps issued before the first is consumed
     const int i00 = ly.i0 * Wc + lx.i0, i01 = ly.i0 * Wc + lx.i1, i10 = ly.i1 * Wc + lx.i0, i11 = ly.i1 * Wc + lx.i1;
     const float* cp = coarse + (size_t)b * C * hwc;
-    int c = 0;
-    for (; c + 4 <= C; c += 4) {
+    int c = c_begin;
+    for (; c + 4 <= c_end; c += 4) {
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BMV_FPN_WPE
         op[(size_t)(c + j) * hw] = v;
       }
     }
-    for (; c < C; ++c) {
+    for (; c < c_end; ++c) {
       float v = bias[c];
 #pragma unroll
       for (int i = 0; i < CF; ++i) v = fmaf(w[c * CF + i], f[i], v);
@@ -1352,17 +1356,19 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
   BMV_REQUIRE(fine && coarse && w && bias && out, "fpn_topdown: null pointer");
   BMV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_topdown: bad shape");
   BMV_REQUIRE(!coarse_channels_last || C % 4 == 0, "fpn_topdown: a channel-last coarse map needs C %% 4 == 0 (C=%d)", C);
-  dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
+  int csplit = bmv::tuning("BMV_FPN_TOPDOWN_SPLIT", 2);   // measured in the frame: 1: 894 us, 2: 886, 4: 887
+  if (csplit < 1 || C % (4 * csplit) != 0) csplit = 1;
+  dim3 grid(cdiv(W, 64), cdiv(H, 4), B * csplit);
   hipStream_t st = as_stream(stream);
   const int quad = coarse_channels_last == 3;   // 0 planar, 1 channel-last, 3 quad-planar
   if (Cf == 8 && !coarse_channels_last)
-    hipLaunchKernelGGL((fpn_topdown_kernel<8, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad, csplit);
   else if (Cf == 16 && !coarse_channels_last)
-    hipLaunchKernelGGL((fpn_topdown_kernel<16, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, false>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad, csplit);
   else if (Cf == 8)
-    hipLaunchKernelGGL((fpn_topdown_kernel<8, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
+    hipLaunchKernelGGL((fpn_topdown_kernel<8, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad, csplit);
   else if (Cf == 16)
-    hipLaunchKernelGGL((fpn_topdown_kernel<16, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad);
+    hipLaunchKernelGGL((fpn_topdown_kernel<16, true>), grid, dim3(256), 0, st, fine, coarse, w, bias, out, C, H, W, quad, csplit);
   else
     BMV_REQUIRE(false, "fpn_topdown: %d lateral input channels unsupported (FeatureNet has 8 and 16)", Cf);
   BMV_LAUNCH_END("fpn_topdown_fwd");

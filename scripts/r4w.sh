@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r4w
-timeout 900 python -m pytest tests/test_gpu_framegraph.py tests/test_gpu_boost.py -x -q > gpurun_out/r4w/ta.txt 2>&1; tail -5 gpurun_out/r4w/ta.txt | cut -c1-180
-timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r4w/bench_c2.json 2> gpurun_out/r4w/bench_c2.err
-timeout 600 python bench.py --no-cpu-baseline --workload enerf_ours_480x736_6src_k4 > gpurun_out/r4w/bench_c3.json 2> gpurun_out/r4w/bench_c3.err
+for sp in 1 2 4; do
+BMV_FPN_TOPDOWN_SPLIT=$sp timeout 600 python -m pytest tests/test_gpu_conv.py -x -q -k "fpn" 2>&1 | tail -1 | cut -c1-100
+BMV_FPN_TOPDOWN_SPLIT=$sp timeout 600 python scripts/probe_autograph_cost.py 2>&1 | grep -a "resident_inputs=True  alias_outputs=True\|resident_inputs=False alias_outputs=False" | cut -c1-80
+done > gpurun_out/r4w/split.txt 2>&1
