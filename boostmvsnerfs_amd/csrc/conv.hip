@@ -777,8 +777,13 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
   using T = ConvTile<1, 3, 1, 1, R, 0, true>;
   constexpr int IH = T::TYH + 2, IW = T::RS + 2, IN = IH * IW;   // image tile under the intermediate tile
   constexpr int NIN = (3 * IN + 255) / 256;
+  // row pitch of the image tile in LDS: a wave's lanes walk the RS-wide slot rows, so with pitch = RS (mod 32) the
+  // rows a 32-lane half touches land on disjoint banks (pitch RS + 2 = 20 put lanes 30 / 31 on the banks of lanes
+  // 0 / 1: 32 % of the kernel's LDS cycles were conflict cycles, round-2 PMC)
+  constexpr int IWP = T::RS + 32, INP = IH * IWP;
+  static_assert(IWP >= IW, "pitch");
   __shared__ float lds[4 * T::PS];
-  __shared__ float img[3 * IN];
+  __shared__ float img[3 * INP];
   const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
   const int ntx = (a.W + 15) / 16, nty = (a.H + T::TY - 1) / T::TY;
   int bid = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
       const int c = e / IN, r = e - c * IN, sy = r / IW, sx = r - sy * IW;
       const int gx = ix0 - 1 + sx, gy = iy0 - 1 + sy;
       const bool ok = (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-      img[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+      img[c * INP + sy * IWP + sx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                              rsrc, ok ? 4u * (unsigned)(c * hw + gy * a.W + gx) : 0x80000000u, 0, 0));
     }
   }
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
     const int sx = slot % T::RS, sy = slot / T::RS;
     const int gx = ix0 + sx, gy = iy0 + sy;
     ok[j] = (slot < T::SLOTS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    ibase[j] = (slot < T::SLOTS) ? sy * IW + sx : 0;   // top-left input of the slot's 3x3 window
+    ibase[j] = (slot < T::SLOTS) ? sy * IWP + sx : 0;   // top-left input of the slot's 3x3 window
   }
   const float* wp = a.wpack + lane;
   f32x4 acc[T::NACC];
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const float x = img[ci * IN + ibase[j] + ky * IW + kx];
+            const float x = img[ci * INP + ibase[j] + ky * IWP + kx];
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = fmaf(a.w0[((chunk * 4 + c) * 3 + ci) * 9 + ky * 3 + kx], x, v[c]);
           }
