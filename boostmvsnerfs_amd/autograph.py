@@ -147,8 +147,8 @@ class AutoGraph:
     # ------------------------------------------------------------------ call
     def _hot_call(self, batch):
         """The steady state of a loop that hands over other tensors every frame (run.py): the batch has the structure of
-        the last replayed private-copy entry -> the input copy / the pointer table go to the GPU FIRST (harmless
-        whatever the key checks say: the static inputs and the table are private), the host-side checks run under it."""
+        the last replayed private-copy entry and passes the key checks -> its tensors are fed to the captured frame and
+        the graph is replayed (nothing else is launched)."""
         e = self._hot
         st = e["static"]
         n = 0
@@ -162,10 +162,10 @@ class AutoGraph:
             s = st[k]
             if v is None or v.shape != s.shape or v.dtype != s.dtype or v.device != s.device:
                 return None
-        fresh = self._feed(e, batch)
         if (e["version"] != self._param_version() or e["shard"] != self._shard()
                 or e["extra"] != self.net._autograph_key(batch) or self.entries.get(e["key"]) is not e):
             return None
+        fresh = self._feed(e, batch)        # (after the checks: a ring message posted here is read by THIS replay)
         self.stats["replays"] += 1
         out = e["fg"].replay()
         if e.get("ring") is not None:

@@ -625,6 +625,7 @@ class FeedRing:
         self.msgs = self.host.numpy().view(dt)
         self.state = torch.zeros(2, dtype=torch.int32, device=device)     # [executions of the node, sequence faults]
         self.posted = 0
+        self.pending = False      # a message has been posted and its replay not yet reported
         self.fast = None
         self.events = {}          # block number -> event recorded behind the last replay of that block of R / 2 messages
 
@@ -632,6 +633,9 @@ class FeedRing:
     # graph launch only queues): slot n % R must not be rewritten before replay n - R has read it.  Every R / 2
     # replays an event is recorded; the first post of a block waits for the event of the block before the last.
     def _reserve(self):
+        if self.pending:          # the last message was never replayed (an exception, a caller that changed its mind):
+            self.posted -= 1      # it is superseded, not skipped -- execution n of the node reads message n
+        self.pending = True
         n, half = self.posted, self.R // 2
         if n % half == 0 and n >= self.R:
             ev = self.events.pop(n // half - 2, None)
@@ -642,6 +646,7 @@ class FeedRing:
 
     def replayed(self):
         """Call after the replay that followed a post."""
+        self.pending = False
         n, half = self.posted - 1, self.R // 2
         if n % half == half - 1:
             ev = torch.cuda.Event()

@@ -1,4 +1,2 @@
 mkdir -p gpurun_out/r4w
-timeout 600 python -m pytest tests/test_gpu_conv.py tests/test_gpu_fullsize.py -x -q -k "conv0 or feature_net or whole_frame or fused" 2>&1 | tail -2 | cut -c1-120 > gpurun_out/r4w/t.txt
-timeout 600 python scripts/probe_autograph_cost.py 2>&1 | grep -a "resident_inputs=True  alias_outputs=True\|resident_inputs=False alias_outputs=False" | cut -c1-80 >> gpurun_out/r4w/t.txt
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && rocprofv3 --kernel-trace --stats -d /tmp/tl --output-format csv -- python3 /root/repo/bench.py --steps 40 --warmup 3 --no-cpu-baseline > /tmp/tl.out 2>&1; python3 /root/repo/scripts/rocprof_steady.py $(ls /tmp/tl/*/*kernel_trace.csv | head -1) --marker render_pc_kernel --markers-per-step 1 --steps 39 2>/dev/null | head -14 >> /root/repo/gpurun_out/r4w/t.txt
+timeout 900 python -m pytest tests/test_gpu_framegraph.py tests/test_gpu_boost.py tests/test_gpu_configs34.py -x -q > gpurun_out/r4w/ta.txt 2>&1; tail -5 gpurun_out/r4w/ta.txt | cut -c1-180

@@ -238,6 +238,14 @@ def test_forward_captures_itself():
     assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
     for k in want:
         assert torch.equal(f[k], want[k]), k
+    # a message that is posted and never replayed (an exception between the two) is superseded by the next post
+    ring.post()
+    with torch.no_grad():
+        f = net(other)
+    torch.cuda.synchronize()
+    assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
+    for k in want_other:
+        assert torch.equal(f[k], want_other[k]), k
     # a parameter update invalidates the captured frame
     with torch.no_grad():
         next(net.nerf_1.parameters()).mul_(1.01)
@@ -280,6 +288,37 @@ def test_forward_captures_itself():
     net.train()
     assert not ag.usable(batch)
     net.eval()
+
+
+def test_two_captured_frames_alternate():
+    """Two keys alive at once (an execution switch flipped between calls; for the K-volume networks: two targets with
+    different triplets): the steady-state path of one entry must hand over to the other without leaving a ring message
+    un-replayed (every execution of a frame's first node reads the message with its own number)."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    ag = net._autograph
+    a = clone_batch(make_batch(128, 160, n_views=3, seed=0), DEV)
+    b = clone_batch(make_batch(128, 160, n_views=3, seed=1), DEV)
+    want_a, want_b = eager(a), eager(b)
+    with torch.no_grad():
+        for _ in range(3):
+            net(a)
+        net.frame_setup = False          # another key, the same picture
+        for _ in range(3):
+            net(b)
+        assert ag.stats["captures"] == 2
+        frames = []
+        for i in range(8):
+            net.frame_setup = i % 2 == 0
+            frames.append((net(a if i % 3 else b), want_a if i % 3 else want_b))
+    torch.cuda.synchronize()
+    assert ag.stats["captures"] == 2
+    for got, want in frames:
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    for e in ag.entries.values():
+        ring = e["ring"]
+        assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
 
 
 def test_deferral_is_rejected_when_a_kernel_reads_the_captured_copy():
