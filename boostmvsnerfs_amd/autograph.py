@@ -150,17 +150,13 @@ class AutoGraph:
         the last replayed private-copy entry and passes the key checks -> its tensors are fed to the captured frame and
         the graph is replayed (nothing else is launched)."""
         e = self._hot
-        st = e["static"]
-        n = 0
-        for v in batch.values():
-            if torch.is_tensor(v) and not _built(v):
-                n += 1
-        if n != e["n_tensors"]:
+        # the batch has the keys of the captured one (plus, possibly, the keys an earlier forward added: built rays) ...
+        if len(batch) not in e["n_items"] or not e["keys"].issuperset(batch):
             return None
-        for k in e["all_names"]:
+        # ... and the tensors the frame reads have the captured shapes / types
+        for k, shape, dtype, device in e["sig"]:
             v = batch.get(k)
-            s = st[k]
-            if v is None or v.shape != s.shape or v.dtype != s.dtype or v.device != s.device:
+            if v is None or v.shape != shape or v.dtype is not dtype or v.device != device:
                 return None
         if (e["version"] != self._param_version() or e["shard"] != self._shard()
                 or e["extra"] != self.net._autograph_key(batch) or self.entries.get(e["key"]) is not e):
@@ -452,7 +448,11 @@ class AutoGraph:
         all_names = [k for k, v in static.items() if torch.is_tensor(v) and (resident or reads is None or k in reads)]
         e = {"fg": fg, "static": static, "hits": 0, "version": version, "added": added, "resident": resident,
              "all_names": all_names, "names": all_names, "dsts": [static[k] for k in all_names],
-             "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v)), "defer": None}
+             "n_tensors": sum(1 for v in static.values() if torch.is_tensor(v)), "defer": None,
+             # (the steady-state path's structural check: precomputed)
+             "sig": [(k, static[k].shape, static[k].dtype, static[k].device) for k in all_names],
+             "keys": frozenset(batch) | frozenset(added), "n_items": (len(frozenset(batch) - frozenset(added)),
+                                                                       len(frozenset(batch) | frozenset(added)))}
         if tb is not None:
             e["tb"] = tb        # the graph reads the table's memory on every replay, deferral adopted or not: keep it alive
             e["ring"] = tb.ring # ... and its first node reads one ring message per replay: every replay posts one
