@@ -559,9 +559,16 @@ const QuVariant kQu[] = {
 };
 constexpr int kNumQu = sizeof(kQu) / sizeof(kQu[0]);
 
-int pick_variant(int variant, int Ws, int w) {
-  if (variant < 0) variant = (float)Ws / (float)w <= 1.5f ? 0 : 12;
-  return variant < kNumQu ? variant : -1;
+int pick_variant(int variant, int Ws, int w, int h, int D, int C) {
+  if (variant >= 0) return variant < kNumQu ? variant : -1;
+  const bool level0 = (float)Ws / (float)w > 1.5f;   // source maps at twice the volume's resolution
+  variant = level0 ? 12 : 0;
+  // small volumes (BASELINE config 1: 128 / 320 workgroups on 256 CUs): the channel quads of a tile shared by two
+  // workgroups -- 12.6 -> 9.9 us and 9.2 -> 8.3 us at 256 x 320 (profiles/r4/sweep_quad_variants_256x320.txt)
+  const QuVariant& q = kQu[variant];
+  const long wgs = (long)((w + q.txw - 1) / q.txw) * ((h + q.tyh - 1) / q.tyh) * ((D + q.dp * q.pg - 1) / (q.dp * q.pg));
+  if (wgs < 512 && ((C >> 2) & 1) == 0) variant = level0 ? 15 : 16;
+  return variant;
 }
 
 void fill_geom(QuadGeom& g, const QuVariant& v, int S, int Hs, int Ws, int D, int h, int w, int dv_plane_uniform) {
@@ -632,7 +639,7 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   BMV_REQUIRE(feats_quad && proj && depth_values && variance, "bmv_sweep_variance_quad_fwd: null pointer");
   BMV_REQUIRE(B > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "bmv_sweep_variance_quad_fwd: bad shape");
   BMV_REQUIRE(!view_ids || n_all >= S, "bmv_sweep_variance_quad_fwd: n_all=%d < S=%d", n_all, S);
-  variant = pick_variant(variant, Ws, w);
+  variant = pick_variant(variant, Ws, w, h, D, C);
   if (variant < 0 || !shape_ok(S, C, Hs, Ws, D, h, w, view_ids ? n_all : S)) {
     set_error("bmv_sweep_variance_quad_fwd: shape / variant not covered (C=%d, S=%d, variant=%d)", C, S, variant);
     return BMV_ERR_UNSUPPORTED;
