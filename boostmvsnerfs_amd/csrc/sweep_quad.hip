@@ -562,7 +562,8 @@ constexpr int kNumQu = sizeof(kQu) / sizeof(kQu[0]);
 int pick_variant(int variant, int Ws, int w, int h, int D, int C) {
   if (variant >= 0) return variant < kNumQu ? variant : -1;
   const bool level0 = (float)Ws / (float)w > 1.5f;   // source maps at twice the volume's resolution
-  variant = level0 ? 12 : 0;
+  variant = level0 ? bmv::tuning("BMV_SWEEP_QUAD_L0", 12) : bmv::tuning("BMV_SWEEP_QUAD_L1", 0);
+  if (variant < 0 || variant >= kNumQu) return -1;
   // small volumes (BASELINE config 1: 128 / 320 workgroups on 256 CUs): the channel quads of a tile shared by two
   // workgroups -- 12.6 -> 9.9 us and 9.2 -> 8.3 us at 256 x 320 (profiles/r4/sweep_quad_variants_256x320.txt)
   const QuVariant& q = kQu[variant];

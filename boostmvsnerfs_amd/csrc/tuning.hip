@@ -32,6 +32,8 @@ Knob g_knobs[] = {
     {"BMV_CONV0_R", "fused first FeatureNet block: rows per wave (default 4)"},
     {"BMV_FPN_SMOOTH_R", "fused FPN + smooth0: rows per tile (default 8)"},
     {"BMV_FPN_SMOOTH_PERSIST", "fused FPN + smooth0: persistent workgroups per CU (0 = one workgroup per tile)"},
+    {"BMV_SWEEP_QUAD_L0", "quad-planar sweep: default tuning variant where the source maps have twice the volume's resolution"},
+    {"BMV_SWEEP_QUAD_L1", "quad-planar sweep: default tuning variant where the source maps have the volume's resolution"},
     {"BMV_FPN_TOPDOWN_SPLIT", "FPN top-down step: workgroups sharing the output channels of a pixel (1, 2, 4)"},
 };
 constexpr int kNumKnobs = sizeof(g_knobs) / sizeof(g_knobs[0]);
