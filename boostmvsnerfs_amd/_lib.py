@@ -109,6 +109,14 @@ SIGNATURES = {
     "bmv_depth_values_cascade_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_bwd_cl": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_fixed_workspace": [c_l],
+    "bmv_vox_feat_bwd_fixed": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_img_feat_bwd_fixed": [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_build_rays_bwd_fixed": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_depth_values_cascade_bwd_fixed": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_sweep_variance_bwd_fixed": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
+    "bmv_mvs_sweep_bwd_fixed": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "bmv_mvs_vol_feat_bwd_fixed": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_nerf_bwd_blob_size": [c_i],
     "bmv_nerf_bwd_rows": [c_i, C.POINTER(C.c_int)],
     "bmv_nerf_pack_bwd_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],
@@ -172,6 +180,7 @@ def load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.bmv_nerf_bwd_workspace.restype = C.c_long
+    lib.bmv_fixed_workspace.restype = C.c_long
     lib.bmv_mvs_mlp_train_act_floats.restype = C.c_long
     lib.bmv_mvs_mlp_train_scratch_floats.restype = C.c_long
     lib.bmv_conv_wgrad_workspace.restype = C.c_long

@@ -1,8 +1,10 @@
 // Backward kernels of the ENeRF hot path (fine-tuning, BASELINE config 5; SURVEY.md section 8
 // "Backward contract").  Each kernel is the hand-derived adjoint of the forward kernel of the same
 // name; tests compare them with torch.autograd on the CPU oracle.  Scatter-adds are float atomics
-// (global_atomic_add_f32); gradient buffers are zero-initialised by the caller.
+// (global_atomic_add_f32); gradient buffers are zero-initialised by the caller.  The *_fixed entry points run the same
+// kernels with order-independent fixed-point accumulation (scatter.hpp): bit-reproducible gradients.
 #include "render_geom.hpp"
+#include "scatter.hpp"
 
 namespace bmv {
 
@@ -153,8 +155,9 @@ __device__ __forceinline__ bool win_begin(WinBox* box, const TapSet& t, bool act
 
 // one pass of `nc` (<= kWinCh) channels: g[c] = gradient of this thread's sample for channel c of the pass;
 // dst = gradient image plane of the pass's first channel, planes `plane` apart, rows `W` apart
-__device__ __forceinline__ void win_scatter(float* win, const WinBox* box, const TapSet& t, bool active, const float* g,
-                                            int nc, float* __restrict__ dst, size_t plane, int W) {
+template <class Acc>
+__device__ __forceinline__ void win_scatter(Acc& acc, float* win, const WinBox* box, const TapSet& t, bool active,
+                                            const float* g, int nc, float* __restrict__ dst, size_t plane, int W) {
   const int minx = box->minx, miny = box->miny, wx = box->maxx - minx + 1, wy = box->maxy - miny + 1;
   const int n = wx * wy;
   for (int i = threadIdx.x; i < nc * n; i += blockDim.x) win[i] = 0.f;
@@ -182,7 +185,7 @@ __device__ __forceinline__ void win_scatter(float* win, const WinBox* box, const
     for (int xx = lx; xx < wx; xx += 32) {
       const float v = win[c * n + yy * wx + xx];
 #ifndef BMV_BWD_NOFLUSH
-      if (v != 0.f) atomicAdd(dst + c * plane + (size_t)(miny + yy) * W + (minx + xx), v);
+      if (v != 0.f) acc.add(dst + c * plane + (size_t)(miny + yy) * W + (minx + xx), v);
 #else
       if (v == 123.456f) dst[0] = v;
 #endif
@@ -191,14 +194,15 @@ __device__ __forceinline__ void win_scatter(float* win, const WinBox* box, const
   __syncthreads();
 }
 
-__device__ __forceinline__ void direct_scatter(const TapSet& t, const float* g, int nc, float* __restrict__ dst,
+template <class Acc>
+__device__ __forceinline__ void direct_scatter(Acc& acc, const TapSet& t, const float* g, int nc, float* __restrict__ dst,
                                                size_t plane, int W) {
   for (int c = 0; c < nc; ++c) {
     float* d = dst + c * plane;
-    if (t.w00 != 0.f) atomicAdd(d + (size_t)t.y0 * W + t.x0, t.w00 * g[c]);
-    if (t.w01 != 0.f) atomicAdd(d + (size_t)t.y0 * W + t.x1, t.w01 * g[c]);
-    if (t.w10 != 0.f) atomicAdd(d + (size_t)t.y1 * W + t.x0, t.w10 * g[c]);
-    if (t.w11 != 0.f) atomicAdd(d + (size_t)t.y1 * W + t.x1, t.w11 * g[c]);
+    if (t.w00 != 0.f) acc.add(d + (size_t)t.y0 * W + t.x0, t.w00 * g[c]);
+    if (t.w01 != 0.f) acc.add(d + (size_t)t.y0 * W + t.x1, t.w01 * g[c]);
+    if (t.w10 != 0.f) acc.add(d + (size_t)t.y1 * W + t.x0, t.w10 * g[c]);
+    if (t.w11 != 0.f) acc.add(d + (size_t)t.y1 * W + t.x1, t.w11 * g[c]);
   }
 }
 
@@ -210,11 +214,14 @@ __device__ __forceinline__ void direct_scatter(const TapSet& t, const float* g, 
 // samples land in a small box of the volume: found with an LDS min/max, accumulated with ds_add_f32 (C <= 8 channels x
 // kWinCap voxels), added to d_volume once per touched voxel, x-contiguous; a box that does not fit falls back to one
 // global atomic per tap.
+template <int MODE>
 __global__ void __launch_bounds__(256) vox_feat_bwd_kernel(const float* __restrict__ uvd01, const float* __restrict__ vol,
                                                            const float* __restrict__ d_out, int P, int C, int D, int h,
                                                            int w, int ray_w, int Ns, int tw, int th, int tiles_x,
-                                                           float* __restrict__ d_vol, float* __restrict__ d_d01) {
+                                                           float* __restrict__ d_vol, float* __restrict__ d_d01,
+                                                           FixedWs fixed) {
   __shared__ float win[kWinCh * kWinCap];
+  ScatterAcc<MODE> sacc = make_acc<MODE>(d_vol, fixed, 0);
   __shared__ int box[6];   // min x, y, z, max x, y, z
   const int b = blockIdx.y;
   int i;
@@ -251,7 +258,8 @@ __global__ void __launch_bounds__(256) vox_feat_bwd_kernel(const float* __restri
   __syncthreads();
   const int bx = box[0], by = box[1], bz = box[2];
   const int wx = box[3] - bx + 1, wy = box[4] - by + 1, wz = box[5] - bz + 1;
-  const bool use_win = box[3] >= 0 && wx * wy * wz <= kWinCap && C <= kWinCh;
+  // (the LDS pre-reduction adds floats in scheduling order: the fixed-point passes go straight to their accumulators)
+  const bool use_win = MODE == 0 && box[3] >= 0 && wx * wy * wz <= kWinCap && C <= kWinCh;
   const int n = wx * wy * wz;
   if (use_win) {
     for (int k = threadIdx.x; k < C * n; k += blockDim.x) win[k] = 0.f;
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(256) vox_feat_bwd_kernel(const float* __restri
         if (use_win)
           atomicAdd(win + c * n + lo, wgt * g);
         else
-          atomicAdd(dv + c * cs + o, wgt * g);
+          sacc.add(dv + c * cs + o, wgt * g);
         acc += g * v[c * cs + o];
       }
       gz += (dz ? 1.f : -1.f) * wxy * acc;
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(256) vox_feat_bwd_kernel(const float* __restri
       const int c = r0 / (wz * wy), rem = r0 - c * (wz * wy), zz = rem / wy, yy = rem - zz * wy;
       for (int xx = lx; xx < wx; xx += 32) {
         const float val = win[c * n + (zz * wy + yy) * wx + xx];
-        if (val != 0.f) atomicAdd(dv + c * cs + ((size_t)(bz + zz) * h + (by + yy)) * w + (bx + xx), val);
+        if (val != 0.f) sacc.add(dv + c * cs + ((size_t)(bz + zz) * h + (by + yy)) * w + (bx + xx), val);
       }
     }
   }
@@ -313,12 +321,14 @@ __device__ __forceinline__ void unit_eps_bwd(const float* x, float eps, const fl
 // Thread -> sample.  With the layout hint (rays row-major over an image `ray_w` wide, Ns samples per ray, Ns a power
 // of two <= 64) a workgroup takes a compact tw x th tile of rays and all their samples, so that the taps of a view
 // land in a small box (see win_begin); without it, 256 consecutive samples.
+template <int MODE>
 __global__ void __launch_bounds__(256) img_feat_bwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ img, const float* __restrict__ src_exts,
     const float* __restrict__ src_ixts, const float* __restrict__ tar_ext, float render_scale,
     const float* __restrict__ d_out, int P, int S, int C, int c_grad, int H, int W, int ray_w, int Ns, int tw, int th,
-    int tiles_x, float* __restrict__ d_img, float* __restrict__ d_xyz) {
+    int tiles_x, float* __restrict__ d_img, float* __restrict__ d_xyz, FixedWs fixed) {
   __shared__ float win[kWinCh * kWinCap];
+  ScatterAcc<MODE> acc = make_acc<MODE>(d_img, fixed, 0);
   __shared__ WinBox box;
   __shared__ Cam cams[16];
   __shared__ float tar_c[4];
@@ -371,7 +381,7 @@ __global__ void __launch_bounds__(256) img_feat_bwd_kernel(
     size_t o00 = (size_t)y0 * W + x0, o01 = o00 + (vx1 ? 1 : 0), o10 = o00 + (vy1 ? W : 0), o11 = o10 + (vx1 ? 1 : 0);
     TapSet ts{x0, y0, vx1 ? x1 : x0, vy1 ? y1 : y0, ex * ey, vx1 ? ax * ey : 0.f, vy1 ? ex * ay : 0.f,
               (vx1 && vy1) ? ax * ay : 0.f};
-    const bool use_win = win_begin(&box, ts, valid);
+    const bool use_win = MODE == 0 && win_begin(&box, ts, valid);
     for (int cg = 0; cg < C; cg += kWinCh) {
       const int nc = min(kWinCh, C - cg), ng = max(0, min(nc, c_grad - cg));   // channels of the pass / that need d_img
       float g[kWinCh];
@@ -384,9 +394,9 @@ __global__ void __launch_bounds__(256) img_feat_bwd_kernel(
       }
       if (ng > 0) {
         if (use_win)
-          win_scatter(win, &box, ts, valid, g, ng, df + (size_t)cg * plane, plane, W);
+          win_scatter(acc, win, &box, ts, valid, g, ng, df + (size_t)cg * plane, plane, W);
         else if (valid)
-          direct_scatter(ts, g, ng, df + (size_t)cg * plane, plane, W);
+          direct_scatter(acc, ts, g, ng, df + (size_t)cg * plane, plane, W);
       }
     }
     gix *= mx, giy *= my;
@@ -468,20 +478,25 @@ __global__ void sample_along_depth_bwd_kernel(const float* __restrict__ rays, co
 }
 
 // scatter of a bilinear (align_corners) upsample at one destination pixel
-__device__ __forceinline__ void upsample_scatter(float* __restrict__ g, int W, const Lerp1& ly, const Lerp1& lx, float v) {
-  atomicAdd(g + ly.i0 * W + lx.i0, ly.l0 * lx.l0 * v);
-  atomicAdd(g + ly.i0 * W + lx.i1, ly.l0 * lx.l1 * v);
-  atomicAdd(g + ly.i1 * W + lx.i0, ly.l1 * lx.l0 * v);
-  atomicAdd(g + ly.i1 * W + lx.i1, ly.l1 * lx.l1 * v);
+template <class Acc>
+__device__ __forceinline__ void upsample_scatter(Acc& acc, float* __restrict__ g, int W, const Lerp1& ly, const Lerp1& lx,
+                                                 float v) {
+  acc.add(g + ly.i0 * W + lx.i0, ly.l0 * lx.l0 * v);
+  acc.add(g + ly.i0 * W + lx.i1, ly.l0 * lx.l1 * v);
+  acc.add(g + ly.i1 * W + lx.i0, ly.l1 * lx.l0 * v);
+  acc.add(g + ly.i1 * W + lx.i1, ly.l1 * lx.l1 * v);
 }
 
 // ---------------------------------------------------------------------------
 // a6 build_rays backward: d_near_far (B,N,2) (ray near / far) -> d_depth, d_std (B,hv,wv) (atomics).
 // ---------------------------------------------------------------------------
+template <int MODE>
 __global__ void build_rays_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ depth,
                                       const float* __restrict__ std_, const float* __restrict__ near_far,
                                       const float* __restrict__ d_nf, int N, int hv, int wv, int Hr, int Wr,
-                                      int depth_inv, float* __restrict__ d_depth, float* __restrict__ d_std) {
+                                      int depth_inv, float* __restrict__ d_depth, float* __restrict__ d_std, size_t n_out,
+                                      FixedWs fixed) {
+  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out);
   int b = blockIdx.y;
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -504,8 +519,8 @@ __global__ void build_rays_bwd_kernel(const float* __restrict__ rays, const floa
     if (!(dep - sd < vn)) g_dep += g_rn, g_sd -= g_rn;
     if (!(dep + sd > vf)) g_dep += g_rf, g_sd += g_rf;
   }
-  upsample_scatter(d_depth + b * hw, wv, ly, lx, g_dep);
-  upsample_scatter(d_std + b * hw, wv, ly, lx, g_sd);
+  upsample_scatter(acc_d, d_depth + b * hw, wv, ly, lx, g_dep);
+  upsample_scatter(acc_s, d_std + b * hw, wv, ly, lx, g_sd);
 }
 
 // ---------------------------------------------------------------------------
@@ -608,10 +623,12 @@ __global__ void __launch_bounds__(64) depth_regress_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------
 // a2 get_depth_values (cascade) backward: d_depth_values (B,D,h,w) -> d_depth, d_std (B,h0,w0) (atomics)
 // ---------------------------------------------------------------------------
+template <int MODE>
 __global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
                                                 const float* __restrict__ near_far, const float* __restrict__ g_dv,
                                                 int h0, int w0, int h, int w, int D, float* __restrict__ d_depth,
-                                                float* __restrict__ d_std) {
+                                                float* __restrict__ d_std, size_t n_out, FixedWs fixed) {
+  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out);
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int hw = h * w;
@@ -636,8 +653,8 @@ __global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth,
   float g_hi = -g_near / (hi * hi), g_lo = -g_far / (lo * lo);
   float g_dep = (hi_free ? g_hi : 0.f) + (lo_free ? g_lo : 0.f);
   float g_sd = (hi_free ? g_hi : 0.f) - (lo_free ? g_lo : 0.f);
-  upsample_scatter(d_depth + o, w0, ly, lx, g_dep);
-  upsample_scatter(d_std + o, w0, ly, lx, g_sd);
+  upsample_scatter(acc_d, d_depth + o, w0, ly, lx, g_dep);
+  upsample_scatter(acc_s, d_std + o, w0, ly, lx, g_sd);
 }
 
 // ---------------------------------------------------------------------------
@@ -645,15 +662,17 @@ __global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth,
 // One thread per voxel, one workgroup per 16 x 16 tile of one plane and 8 channels: the S warped values per channel
 // are recomputed (never stored by the forward), then the feature gradient of each view goes through the LDS window.
 // ---------------------------------------------------------------------------
-template <int CB, int S>
+template <int CB, int S, int MODE>
 __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict__ feats,
                                                          const float* __restrict__ proj,
                                                          const float* __restrict__ dv,
                                                          const float* __restrict__ g_var, int C, int Hs, int Ws, int D,
                                                          int h, int w, int tiles_x, int tiles_y,
-                                                         float* __restrict__ d_feats, float* __restrict__ d_dv) {
+                                                         float* __restrict__ d_feats, float* __restrict__ d_dv,
+                                                         size_t n_feats, FixedWs fixed) {
   static_assert(CB <= kWinCh, "one window pass per channel block");
   __shared__ float win[kWinCh * kWinCap];
+  ScatterAcc<MODE> acc_f = make_acc<MODE>(d_feats, fixed, 0), acc_v = make_acc<MODE>(d_dv, fixed, n_feats);
   __shared__ WinBox box;
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CB;
@@ -709,10 +728,10 @@ __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict_
   }
   for (int s = 0; s < S; ++s) {
     float* df = d_feats + (((size_t)b * S + s) * C + c0) * plane;
-    if (win_begin(&box, ts[s], valid))
-      win_scatter(win, &box, ts[s], valid, gw[s], CB, df, plane, Ws);
+    if (MODE == 0 && win_begin(&box, ts[s], valid))
+      win_scatter(acc_f, win, &box, ts[s], valid, gw[s], CB, df, plane, Ws);
     else if (valid)
-      direct_scatter(ts[s], gw[s], CB, df, plane, Ws);
+      direct_scatter(acc_f, ts[s], gw[s], CB, df, plane, Ws);
   }
   if (d_dv && valid) {
     float gdepth = 0.f;
@@ -724,7 +743,7 @@ __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict_
       float gpz = pzs[s] > 1e-6f ? -(gix[s] * pxs[s] + giy[s] * pys[s]) / (z * z) : 0.f;
       gdepth += -(gpx * P[3] + gpy * P[7] + gpz * P[11]) / (depth * depth);
     }
-    atomicAdd(d_dv + (size_t)b * nvox + i, gdepth);  // channel blocks of one voxel add up
+    acc_v.add(d_dv + (size_t)b * nvox + i, gdepth);  // channel blocks of one voxel add up
   }
 }
 
@@ -771,32 +790,65 @@ static bool ray_tiles(int P, int& ray_w, int Ns, int& tw, int& th, int& tiles_x,
   return false;
 }
 
-int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
-                     int w, int ray_w, int Ns, float* d_volume, float* d_d01, bmv_stream_t stream) {
-  BMV_REQUIRE(uvd01 && volume && d_out && d_volume && d_d01, "bmv_vox_feat_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && P >= 0 && C > 0 && D > 0 && h > 0 && w > 0, "bmv_vox_feat_bwd: bad shape");
+static int vox_feat_bwd_impl(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D,
+                             int h, int w, int ray_w, int Ns, float* d_volume, float* d_d01, FixedWs fixed,
+                             bmv_stream_t stream, const char* name) {
+  BMV_REQUIRE(uvd01 && volume && d_out && d_volume && d_d01, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && P >= 0 && C > 0 && D > 0 && h > 0 && w > 0, "%s: bad shape", name);
   if (P == 0) return BMV_OK;
   int tw, th, tiles_x, nblocks;
   ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
-  hipLaunchKernelGGL(vox_feat_bwd_kernel, dim3(nblocks, B), dim3(256), 0, as_stream(stream), uvd01, volume, d_out, P, C, D,
-                     h, w, ray_w, Ns, tw, th, tiles_x, d_volume, d_d01);
-  BMV_LAUNCH_END("bmv_vox_feat_bwd");
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL(vox_feat_bwd_kernel<decltype(mode)::value>, dim3(nblocks, B), dim3(256), 0, as_stream(stream), uvd01,
+                       volume, d_out, P, C, D, h, w, ray_w, Ns, tw, th, tiles_x, d_volume, d_d01, fixed);
+  });
+  if (fixed.ws) fixed_finish(fixed, 0, (size_t)B * C * D * h * w, d_volume, as_stream(stream));
+  BMV_LAUNCH_END(name);
+}
+int bmv_vox_feat_bwd(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
+                     int w, int ray_w, int Ns, float* d_volume, float* d_d01, bmv_stream_t stream) {
+  return vox_feat_bwd_impl(uvd01, volume, d_out, B, P, C, D, h, w, ray_w, Ns, d_volume, d_d01, FixedWs{}, stream,
+                           "bmv_vox_feat_bwd");
+}
+int bmv_vox_feat_bwd_fixed(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
+                           int w, int ray_w, int Ns, float* d_volume, float* d_d01, long long* workspace,
+                           bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_vox_feat_bwd_fixed: null workspace");
+  return vox_feat_bwd_impl(uvd01, volume, d_out, B, P, C, D, h, w, ray_w, Ns, d_volume, d_d01, FixedWs{workspace}, stream,
+                           "bmv_vox_feat_bwd_fixed");
 }
 
+static int img_feat_bwd_impl(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                             const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
+                             int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, FixedWs fixed,
+                             bmv_stream_t stream, const char* name) {
+  BMV_REQUIRE(xyz && img_feat_rgb && src_exts && src_ixts && tar_ext && d_out && d_img && d_xyz, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "%s: bad shape", name);
+  BMV_REQUIRE(c_grad >= 0 && c_grad <= C, "%s: c_grad=%d outside [0, %d]", name, c_grad, C);
+  if (P == 0) return BMV_OK;
+  int tw, th, tiles_x, nblocks;
+  ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL(img_feat_bwd_kernel<decltype(mode)::value>, dim3(nblocks, B), dim3(256), 0, as_stream(stream), xyz,
+                       img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, P, S, C, c_grad, H, W, ray_w, Ns,
+                       tw, th, tiles_x, d_img, d_xyz, fixed);
+  });
+  if (fixed.ws) fixed_finish(fixed, 0, (size_t)B * S * C * H * W, d_img, as_stream(stream));
+  BMV_LAUNCH_END(name);
+}
 int bmv_img_feat_bwd(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
                      const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
                      int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, bmv_stream_t stream) {
-  BMV_REQUIRE(xyz && img_feat_rgb && src_exts && src_ixts && tar_ext && d_out && d_img && d_xyz,
-              "bmv_img_feat_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "bmv_img_feat_bwd: bad shape");
-  BMV_REQUIRE(c_grad >= 0 && c_grad <= C, "bmv_img_feat_bwd: c_grad=%d outside [0, %d]", c_grad, C);
-  if (P == 0) return BMV_OK;
-  int tw, th, tiles_x, nblocks;
-  ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
-  hipLaunchKernelGGL(img_feat_bwd_kernel, dim3(nblocks, B), dim3(256), 0, as_stream(stream), xyz, img_feat_rgb, src_exts,
-                     src_ixts, tar_ext, render_scale, d_out, P, S, C, c_grad, H, W, ray_w, Ns, tw, th, tiles_x, d_img,
-                     d_xyz);
-  BMV_LAUNCH_END("bmv_img_feat_bwd");
+  return img_feat_bwd_impl(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, B, P, S, C, c_grad, H, W,
+                           ray_w, Ns, d_img, d_xyz, FixedWs{}, stream, "bmv_img_feat_bwd");
+}
+int bmv_img_feat_bwd_fixed(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                           const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
+                           int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, long long* workspace,
+                           bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_img_feat_bwd_fixed: null workspace");
+  return img_feat_bwd_impl(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d_out, B, P, S, C, c_grad, H, W,
+                           ray_w, Ns, d_img, d_xyz, FixedWs{workspace}, stream, "bmv_img_feat_bwd_fixed");
 }
 
 int bmv_sample_along_depth_bwd(const float* rays, const float* d_xyz, const float* d_dn, int B, int N, int Ns,
@@ -810,15 +862,35 @@ int bmv_sample_along_depth_bwd(const float* rays, const float* d_xyz, const floa
   BMV_LAUNCH_END("bmv_sample_along_depth_bwd");
 }
 
+static int build_rays_bwd_impl(const float* rays, const float* depth, const float* std_, const float* near_far,
+                               const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
+                               float* d_depth, float* d_std, FixedWs fixed, bmv_stream_t stream, const char* name) {
+  BMV_REQUIRE(rays && depth && std_ && near_far && d_near_far && d_depth && d_std, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && N >= 0 && hv > 0 && wv > 0 && Hr > 0 && Wr > 0, "%s: bad shape", name);
+  if (N == 0) return BMV_OK;
+  const size_t n_out = (size_t)B * hv * wv;
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL(build_rays_bwd_kernel<decltype(mode)::value>, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream),
+                       rays, depth, std_, near_far, d_near_far, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std, n_out, fixed);
+  });
+  if (fixed.ws) {
+    fixed_finish(fixed, 0, n_out, d_depth, as_stream(stream));
+    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream));
+  }
+  BMV_LAUNCH_END(name);
+}
 int bmv_build_rays_bwd(const float* rays, const float* depth, const float* std_, const float* near_far,
                        const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
                        float* d_depth, float* d_std, bmv_stream_t stream) {
-  BMV_REQUIRE(rays && depth && std_ && near_far && d_near_far && d_depth && d_std, "bmv_build_rays_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && N >= 0 && hv > 0 && wv > 0 && Hr > 0 && Wr > 0, "bmv_build_rays_bwd: bad shape");
-  if (N == 0) return BMV_OK;
-  hipLaunchKernelGGL(build_rays_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), rays, depth, std_,
-                     near_far, d_near_far, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std);
-  BMV_LAUNCH_END("bmv_build_rays_bwd");
+  return build_rays_bwd_impl(rays, depth, std_, near_far, d_near_far, B, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std,
+                             FixedWs{}, stream, "bmv_build_rays_bwd");
+}
+int bmv_build_rays_bwd_fixed(const float* rays, const float* depth, const float* std_, const float* near_far,
+                             const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
+                             float* d_depth, float* d_std, long long* workspace, bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_build_rays_bwd_fixed: null workspace");
+  return build_rays_bwd_impl(rays, depth, std_, near_far, d_near_far, B, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std,
+                             FixedWs{workspace}, stream, "bmv_build_rays_bwd_fixed");
 }
 
 int bmv_depth_regress_bwd(const float* depth_prob, const float* depth_values, const float* d_depth,
@@ -840,38 +912,91 @@ int bmv_depth_regress_bwd(const float* depth_prob, const float* depth_values, co
   BMV_LAUNCH_END("bmv_depth_regress_bwd");
 }
 
+static int depth_values_cascade_bwd_impl(const float* depth, const float* std_, const float* near_far,
+                                         const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
+                                         float* d_depth, float* d_std, FixedWs fixed, bmv_stream_t stream,
+                                         const char* name) {
+  BMV_REQUIRE(depth && std_ && near_far && d_depth_values && d_depth && d_std, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0 && h0 > 0 && w0 > 0, "%s: bad shape", name);
+  const size_t n_out = (size_t)B * h0 * w0;
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL(depth_values_cascade_bwd_kernel<decltype(mode)::value>, dim3(cdiv(h * w, 256), B), dim3(256), 0,
+                       as_stream(stream), depth, std_, near_far, d_depth_values, h0, w0, h, w, D, d_depth, d_std, n_out,
+                       fixed);
+  });
+  if (fixed.ws) {
+    fixed_finish(fixed, 0, n_out, d_depth, as_stream(stream));
+    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream));
+  }
+  BMV_LAUNCH_END(name);
+}
 int bmv_depth_values_cascade_bwd(const float* depth, const float* std_, const float* near_far,
                                  const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
                                  float* d_depth, float* d_std, bmv_stream_t stream) {
-  BMV_REQUIRE(depth && std_ && near_far && d_depth_values && d_depth && d_std, "bmv_depth_values_cascade_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0 && h0 > 0 && w0 > 0, "bmv_depth_values_cascade_bwd: bad shape");
-  hipLaunchKernelGGL(depth_values_cascade_bwd_kernel, dim3(cdiv(h * w, 256), B), dim3(256), 0, as_stream(stream), depth,
-                     std_, near_far, d_depth_values, h0, w0, h, w, D, d_depth, d_std);
-  BMV_LAUNCH_END("bmv_depth_values_cascade_bwd");
+  return depth_values_cascade_bwd_impl(depth, std_, near_far, d_depth_values, B, h0, w0, h, w, D, d_depth, d_std,
+                                       FixedWs{}, stream, "bmv_depth_values_cascade_bwd");
+}
+int bmv_depth_values_cascade_bwd_fixed(const float* depth, const float* std_, const float* near_far,
+                                       const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
+                                       float* d_depth, float* d_std, long long* workspace, bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_depth_values_cascade_bwd_fixed: null workspace");
+  return depth_values_cascade_bwd_impl(depth, std_, near_far, d_depth_values, B, h0, w0, h, w, D, d_depth, d_std,
+                                       FixedWs{workspace}, stream, "bmv_depth_values_cascade_bwd_fixed");
 }
 
-int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_variance,
-                           int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
-                           float* d_depth_values, bmv_stream_t stream) {
-  BMV_REQUIRE(feats && proj && depth_values && d_variance && d_feats, "bmv_sweep_variance_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "bmv_sweep_variance_bwd: bad shape");
+static int sweep_variance_bwd_impl(const float* feats, const float* proj, const float* depth_values,
+                                   const float* d_variance, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                                   float* d_feats, float* d_depth_values, FixedWs fixed, bmv_stream_t stream,
+                                   const char* name) {
+  BMV_REQUIRE(feats && proj && depth_values && d_variance && d_feats, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && C > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "%s: bad shape", name);
   if (S < 2 || S > 4 || C % 8 != 0) {
-    set_error("bmv_sweep_variance_bwd: built for 2..4 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
+    set_error("%s: built for 2..4 views and C %% 8 == 0 (got S=%d C=%d)", name, S, C);
     return BMV_ERR_UNSUPPORTED;
   }
   const int tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
   const dim3 grid(tiles_x * tiles_y * D, C / 8, B);
-#define SB(SV)                                                                                                       \
-  hipLaunchKernelGGL((sweep_bwd_kernel<8, SV>), grid, dim3(256), 0, as_stream(stream), feats, proj, depth_values, d_variance, \
-                     C, Hs, Ws, D, h, w, tiles_x, tiles_y, d_feats, d_depth_values)
-  if (S == 3)
-    SB(3);
-  else if (S == 2)
-    SB(2);      // ENeRF pre-training draws 2 / 3 / 4 source views (dtu_pretrain.yaml:22-23)
-  else
-    SB(4);
+  const size_t n_feats = (size_t)B * S * C * Hs * Ws, n_dv = d_depth_values ? (size_t)B * D * h * w : 0;
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    constexpr int M = decltype(mode)::value;
+#define SB(SV)                                                                                                          \
+  hipLaunchKernelGGL((sweep_bwd_kernel<8, SV, M>), grid, dim3(256), 0, as_stream(stream), feats, proj, depth_values,      \
+                     d_variance, C, Hs, Ws, D, h, w, tiles_x, tiles_y, d_feats, d_depth_values, n_feats, fixed)
+    if (S == 3)
+      SB(3);
+    else if (S == 2)
+      SB(2);      // ENeRF pre-training draws 2 / 3 / 4 source views (dtu_pretrain.yaml:22-23)
+    else
+      SB(4);
 #undef SB
-  BMV_LAUNCH_END("bmv_sweep_variance_bwd");
+  });
+  if (fixed.ws) {
+    fixed_finish(fixed, 0, n_feats, d_feats, as_stream(stream));
+    fixed_finish(fixed, n_feats, n_dv, d_depth_values, as_stream(stream));
+  }
+  BMV_LAUNCH_END(name);
+}
+int bmv_sweep_variance_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_variance,
+                           int B, int S, int C, int Hs, int Ws, int D, int h, int w, float* d_feats,
+                           float* d_depth_values, bmv_stream_t stream) {
+  return sweep_variance_bwd_impl(feats, proj, depth_values, d_variance, B, S, C, Hs, Ws, D, h, w, d_feats, d_depth_values,
+                                 FixedWs{}, stream, "bmv_sweep_variance_bwd");
+}
+int bmv_sweep_variance_bwd_fixed(const float* feats, const float* proj, const float* depth_values,
+                                 const float* d_variance, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                                 float* d_feats, float* d_depth_values, long long* workspace, bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_sweep_variance_bwd_fixed: null workspace");
+  return sweep_variance_bwd_impl(feats, proj, depth_values, d_variance, B, S, C, Hs, Ws, D, h, w, d_feats, d_depth_values,
+                                 FixedWs{workspace}, stream, "bmv_sweep_variance_bwd_fixed");
+}
+
+// int64 words of the workspace of a *_fixed call whose scatter outputs hold n_out floats in total; zeroed by the caller
+long bmv_fixed_workspace(long n_out) {
+  if (n_out < 0) {
+    set_error("bmv_fixed_workspace: n_out=%ld", n_out);
+    return BMV_ERR_INVALID;
+  }
+  return (long)kFixedHeader + n_out;
 }
 
 }  // extern "C"

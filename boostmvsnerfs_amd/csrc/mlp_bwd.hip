@@ -20,7 +20,9 @@
 //  3. nerf_wgrad_finish_kernel sums the partials in a fixed order (deterministic, no
 //     atomics) straight into tensors of the reference's parameter shapes.
 // Only the two 1-wide heads whose inputs are not stored (agg_w_fc, color.2 weights) are
-// reduced in kernel 1 (per-lane running sums, one wave reduction, 96 atomics per wave).
+// reduced in kernel 1 (per-lane running sums, one wave reduction, one 96-float partial per
+// wave; kernel 3 sums the waves' partials in a fixed order: no atomics anywhere, the whole
+// backward is bit-reproducible).
 #include "mlp.hpp"
 
 namespace bmv {
@@ -174,7 +176,7 @@ struct BwdOut {
   float* rows;   // (ntiles, R_TOTAL, 32)
   float* d_vox;  // (8, P)
   float* d_img;  // (3, IN_ROWS, P)
-  float* vecs;   // 64 color.2 weight grad | 32 agg_w_fc weight grad  (atomics)
+  float* vecs;   // per wave of the grid [128]: 64 color.2 weight grad | 32 agg_w_fc weight grad | 32 unused
 };
 
 template <int FEAT_CH>
@@ -547,7 +549,8 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       BMV_FENCE();
     }
   }
-  // ---- flush the 1-wide weight gradients: reduce over the 32 samples of each half, then one atomic per neuron
+  // ---- flush the 1-wide weight gradients: reduce over the 32 samples of each half into this wave's partial
+  float* __restrict__ vpart = o.vecs + ((long)blockIdx.x * 4 + wave) * 128;
   auto reduce32 = [&](float v) {
 #pragma unroll
     for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
@@ -558,12 +561,12 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float a = reduce32(acc_wc2[tl][r]);
-      if (s == 0) atomicAdd(o.vecs + 32 * tl + n16(r, h), a);
+      if (s == 0) vpart[32 * tl + n16(r, h)] = a;
     }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float a = reduce32(acc_wa[r]);
-    if (s == 0) atomicAdd(o.vecs + 64 + n16(r, h), a);
+    if (s == 0) vpart[64 + n16(r, h)] = a;
   }
 }
 
@@ -737,7 +740,7 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
 // 3-step butterfly), so the result does not depend on scheduling.
 template <int FEAT_CH>
 __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ vecs,
-                                         bmv_nerf_grads g) {
+                                         int nvecs, bmv_nerf_grads g) {
   using LB = MlpBwdLayout<FEAT_CH>;
   constexpr int FC = LB::FC, FCP = LB::FCP, CW = 88 + FC + 4;
   constexpr int N_VW = FC * 4, N_VB = FC, N_GW = 32 * 3 * FC, N_GB = 32, N_AW = 32, N_AB = 1, N_FW = 16 * 32, N_FB = 16,
@@ -803,7 +806,10 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   }
   float acc = 0.f;
   if (vec >= 0) {
-    acc = vecs[vec];
+    for (int w = sub; w < nvecs; w += 8) acc += vecs[(long)w * 128 + vec];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
   } else {
 #pragma unroll 4
     for (int w = sub; w < nparts; w += 8) {
@@ -823,18 +829,15 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
 
 using namespace bmv;
 
-__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
-  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
-}
-
 namespace {
 constexpr int kWgradGrid = 256;   // one workgroup per CU (the kernel takes > 256 registers)
+constexpr int kBwdGrid = 256;     // workgroups of the data-path kernel (4 waves each write a 128-float head partial)
 
 template <int FC>
 long workspace_floats(long npts) {
   using LB = MlpBwdLayout<FC>;
   long ntiles = (npts + 31) / 32;
-  return ntiles * (long)LB::R_TOTAL * 32 + (long)kWgradGrid * LB::PART + 128;
+  return ntiles * (long)LB::R_TOTAL * 32 + (long)kWgradGrid * LB::PART + (long)kBwdGrid * 4 * 128;
 }
 
 template <int FC>
@@ -845,10 +848,9 @@ int run_bwd(const float* vox_feat, const float* img, const float* d_out, const f
   float* rows = ws;
   float* partials = rows + ntiles * (long)LB::R_TOTAL * 32;
   float* vecs = partials + (long)kWgradGrid * LB::PART;
-  // (a kernel, not hipMemsetAsync: inside a captured training step the memset NODE did not reliably clear the buffer
-  // on later replays -- tests/test_gpu_training.py::test_graphed_train_step_equals_eager_steps)
-  hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(128), 0, st, vecs, 128);
-  const unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
+  // (round 3 cleared a 128-float atomics buffer here with hipMemsetAsync: inside a captured training step the memset NODE
+  // did not reliably clear it on later replays; since round 5 every wave writes its own partial, nothing to clear)
+  const unsigned grid = (unsigned)((ntiles + 3) / 4 < kBwdGrid ? (ntiles + 3) / 4 : kBwdGrid);
   const size_t lds = (size_t)(MlpLayout<FC>::TOTAL + LB::TOTAL) * 4;
   BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
@@ -861,7 +863,8 @@ int run_bwd(const float* vox_feat, const float* img, const float* d_out, const f
   hipLaunchKernelGGL(nerf_wgrad_kernel<FC>, dim3(nparts), dim3(256), 0, st, rows, ntiles, partials);
   constexpr int F = FC + 3;
   constexpr int total = F * 4 + F + 32 * 3 * F + 32 + 32 + 1 + 16 * 32 + 16 + 64 * 24 + 64 + 64 + 1 + 64 * (88 + F + 4) + 64 + 64 + 1;
-  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv((long)total * 8, 256)), dim3(256), 0, st, partials, nparts, vecs, *grads);
+  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv((long)total * 8, 256)), dim3(256), 0, st, partials, nparts, vecs,
+                     (int)grid * 4, *grads);
   BMV_LAUNCH_END("bmv_nerf_mlp_bwd");
 }
 }  // namespace

@@ -5,6 +5,7 @@
 //            580-630; renderer.py:111-137.
 #include "mlp.hpp"          // f32x16, n16(), BMV_MFMA, fences, xhalf_sum
 #include "render_geom.hpp"
+#include "scatter.hpp"
 
 namespace bmv {
 
@@ -784,11 +785,12 @@ static constexpr size_t kMvsLds = (kMvsSmall + 2 * MvsMlp::CHUNK_MAX) * sizeof(f
 // channels.  var = sum(v^2) inv - (sum(v) inv)^2 with inv = 1 / count (a constant of the mask): d var / d v_s =
 // 2 inv (v_s - m) for every view that contributes (the reference view inside the un-padded window, a source view
 // through its 4 zero-padded taps).
-template <int CB, int S>
+template <int CB, int S, int MODE>
 __global__ void __launch_bounds__(256) mvs_sweep_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ proj,
                                                              const float* __restrict__ depth_values,
                                                              const float* __restrict__ d_out, int C, int h, int w, int D,
-                                                             int pad, float* __restrict__ d_feats) {
+                                                             int pad, float* __restrict__ d_feats, FixedWs fixed) {
+  ScatterAcc<MODE> sacc = make_acc<MODE>(d_feats, fixed, 0);
   const int b = blockIdx.z, c0 = blockIdx.y * CB;
   const int hp = h + 2 * pad, wp = w + 2 * pad;
   const size_t nvox = (size_t)D * hp * wp;
@@ -826,15 +828,15 @@ __global__ void __launch_bounds__(256) mvs_sweep_bwd_kernel(const float* __restr
     }
     const float m = sum * inv, g = g_var[(size_t)c * nvox];
     if (g == 0.f) continue;
-    if (inside) atomicAdd(d_feats + (((size_t)b * S) * C + c0 + c) * plane + ref_off, 2.f * inv * g * (v[0] - m));
+    if (inside) sacc.add(d_feats + (((size_t)b * S) * C + c0 + c) * plane + ref_off, 2.f * inv * g * (v[0] - m));
 #pragma unroll
     for (int s = 1; s < S; ++s) {
       const float gw = 2.f * inv * g * (v[s] - m);
       float* df = d_feats + (((size_t)b * S + s) * C + c0 + c) * plane;
-      if (tp[s].w00 != 0.f) atomicAdd(df + tp[s].o00, tp[s].w00 * gw);
-      if (tp[s].w01 != 0.f) atomicAdd(df + tp[s].o01, tp[s].w01 * gw);
-      if (tp[s].w10 != 0.f) atomicAdd(df + tp[s].o10, tp[s].w10 * gw);
-      if (tp[s].w11 != 0.f) atomicAdd(df + tp[s].o11, tp[s].w11 * gw);
+      if (tp[s].w00 != 0.f) sacc.add(df + tp[s].o00, tp[s].w00 * gw);
+      if (tp[s].w01 != 0.f) sacc.add(df + tp[s].o01, tp[s].w01 * gw);
+      if (tp[s].w10 != 0.f) sacc.add(df + tp[s].o10, tp[s].w10 * gw);
+      if (tp[s].w11 != 0.f) sacc.add(df + tp[s].o11, tp[s].w11 * gw);
     }
   }
 }
@@ -842,12 +844,14 @@ __global__ void __launch_bounds__(256) mvs_sweep_bwd_kernel(const float* __restr
 // a22 + a23 backward: d_feat (N, Ns, 8) = gradient of the 8 volume channels of the MLP input -> d_volume (8,D,hp,wp)
 // (atomics, trilinear, zeros padding); the NDC point of every sample is recomputed from its ray exactly as the forward
 // does (mvs_point_inputs).
+template <int MODE>
 __global__ void __launch_bounds__(256) mvs_vol_feat_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ ext0,
                                                                 const float* __restrict__ ixt0,
                                                                 const float* __restrict__ near_far,
                                                                 const float* __restrict__ d_feat, long npts, int Ns, int H,
                                                                 int W, int D, int hp, int wp, int pad,
-                                                                float* __restrict__ d_volume) {
+                                                                float* __restrict__ d_volume, FixedWs fixed) {
+  ScatterAcc<MODE> sacc = make_acc<MODE>(d_volume, fixed, 0);
   __shared__ Cam cam;
   __shared__ float nf[2];
   if (threadIdx.x == 0) load_cam(ext0, ixt0, 1.f, cam);
@@ -887,7 +891,7 @@ __global__ void __launch_bounds__(256) mvs_vol_feat_bwd_kernel(const float* __re
     if (gc == 0.f) continue;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (t3.w[q] != 0.f) atomicAdd(d_volume + (size_t)ch * cs + t3.o[q], t3.w[q] * gc);
+      if (t3.w[q] != 0.f) sacc.add(d_volume + (size_t)ch * cs + t3.o[q], t3.w[q] * gc);
   }
 }
 
@@ -1008,30 +1012,63 @@ int bmv_mvs_render_fwd(const bmv_mvs_render_args* a, bmv_stream_t stream) {
   BMV_LAUNCH_END("bmv_mvs_render_fwd");
 }
 
-int bmv_mvs_sweep_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
-                      int S, int C, int h, int w, int D, int pad, float* d_feats, bmv_stream_t stream) {
-  BMV_REQUIRE(feats && proj && depth_values && d_volume && d_feats, "bmv_mvs_sweep_bwd: null pointer");
-  BMV_REQUIRE(B > 0 && h > 1 && w > 1 && D > 0 && pad >= 0, "bmv_mvs_sweep_bwd: bad shape");
+static int mvs_sweep_bwd_impl(const float* feats, const float* proj, const float* depth_values, const float* d_volume,
+                              int B, int S, int C, int h, int w, int D, int pad, float* d_feats, FixedWs fixed,
+                              bmv_stream_t stream, const char* name) {
+  BMV_REQUIRE(feats && proj && depth_values && d_volume && d_feats, "%s: null pointer", name);
+  BMV_REQUIRE(B > 0 && h > 1 && w > 1 && D > 0 && pad >= 0, "%s: bad shape", name);
   if (S != 3 || C % 8 != 0) {
-    set_error("bmv_mvs_sweep_bwd: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", S, C);
+    set_error("%s: built for S=3 views and C %% 8 == 0 (got S=%d C=%d)", name, S, C);
     return BMV_ERR_UNSUPPORTED;
   }
   const size_t nvox = (size_t)D * (h + 2 * pad) * (w + 2 * pad);
-  hipLaunchKernelGGL((mvs_sweep_bwd_kernel<8, 3>), dim3(cdiv(nvox, 256), C / 8, B), dim3(256), 0, as_stream(stream), feats,
-                     proj, depth_values, d_volume, C, h, w, D, pad, d_feats);
-  BMV_LAUNCH_END("bmv_mvs_sweep_bwd");
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL((mvs_sweep_bwd_kernel<8, 3, decltype(mode)::value>), dim3(cdiv(nvox, 256), C / 8, B), dim3(256), 0,
+                       as_stream(stream), feats, proj, depth_values, d_volume, C, h, w, D, pad, d_feats, fixed);
+  });
+  if (fixed.ws) fixed_finish(fixed, 0, (size_t)B * S * C * h * w, d_feats, as_stream(stream));
+  BMV_LAUNCH_END(name);
+}
+int bmv_mvs_sweep_bwd(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
+                      int S, int C, int h, int w, int D, int pad, float* d_feats, bmv_stream_t stream) {
+  return mvs_sweep_bwd_impl(feats, proj, depth_values, d_volume, B, S, C, h, w, D, pad, d_feats, FixedWs{}, stream,
+                            "bmv_mvs_sweep_bwd");
+}
+int bmv_mvs_sweep_bwd_fixed(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
+                            int S, int C, int h, int w, int D, int pad, float* d_feats, long long* workspace,
+                            bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_mvs_sweep_bwd_fixed: null workspace");
+  return mvs_sweep_bwd_impl(feats, proj, depth_values, d_volume, B, S, C, h, w, D, pad, d_feats, FixedWs{workspace}, stream,
+                            "bmv_mvs_sweep_bwd_fixed");
 }
 
+static int mvs_vol_feat_bwd_impl(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
+                                 const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
+                                 float* d_volume, FixedWs fixed, bmv_stream_t stream, const char* name) {
+  BMV_REQUIRE(rays && src_ext0 && src_ixt0 && near_far && d_feat && d_volume, "%s: null pointer", name);
+  BMV_REQUIRE(N >= 0 && Ns > 0 && H > 1 && W > 1 && D > 0 && hp > 0 && wp > 0, "%s: bad shape", name);
+  if (N == 0) return BMV_OK;
+  const long npts = N * Ns;
+  launch_modes(fixed, as_stream(stream), [&](auto mode) {
+    hipLaunchKernelGGL(mvs_vol_feat_bwd_kernel<decltype(mode)::value>, dim3(cdiv(npts, 256)), dim3(256), 0,
+                       as_stream(stream), rays, src_ext0, src_ixt0, near_far, d_feat, npts, Ns, H, W, D, hp, wp, pad,
+                       d_volume, fixed);
+  });
+  if (fixed.ws) fixed_finish(fixed, 0, (size_t)8 * D * hp * wp, d_volume, as_stream(stream));
+  BMV_LAUNCH_END(name);
+}
 int bmv_mvs_vol_feat_bwd(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
                          const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
                          float* d_volume, bmv_stream_t stream) {
-  BMV_REQUIRE(rays && src_ext0 && src_ixt0 && near_far && d_feat && d_volume, "bmv_mvs_vol_feat_bwd: null pointer");
-  BMV_REQUIRE(N >= 0 && Ns > 0 && H > 1 && W > 1 && D > 0 && hp > 0 && wp > 0, "bmv_mvs_vol_feat_bwd: bad shape");
-  if (N == 0) return BMV_OK;
-  const long npts = N * Ns;
-  hipLaunchKernelGGL(mvs_vol_feat_bwd_kernel, dim3(cdiv(npts, 256)), dim3(256), 0, as_stream(stream), rays, src_ext0,
-                     src_ixt0, near_far, d_feat, npts, Ns, H, W, D, hp, wp, pad, d_volume);
-  BMV_LAUNCH_END("bmv_mvs_vol_feat_bwd");
+  return mvs_vol_feat_bwd_impl(rays, src_ext0, src_ixt0, near_far, d_feat, N, Ns, H, W, D, hp, wp, pad, d_volume, FixedWs{},
+                               stream, "bmv_mvs_vol_feat_bwd");
+}
+int bmv_mvs_vol_feat_bwd_fixed(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
+                               const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
+                               float* d_volume, long long* workspace, bmv_stream_t stream) {
+  BMV_REQUIRE(workspace, "bmv_mvs_vol_feat_bwd_fixed: null workspace");
+  return mvs_vol_feat_bwd_impl(rays, src_ext0, src_ixt0, near_far, d_feat, N, Ns, H, W, D, hp, wp, pad, d_volume,
+                               FixedWs{workspace}, stream, "bmv_mvs_vol_feat_bwd_fixed");
 }
 
 }  // extern "C"

@@ -969,13 +969,35 @@ def blend_bwd(raws, masks, d_rgb):
     return d_raws
 
 
+def deterministic():
+    """bmv_tuning "BMV_DETERMINISTIC" (include/bmv.h; `_lib.set_tuning("BMV_DETERMINISTIC", 1)` or the environment variable
+    of that name): the scatter gradients take the *_fixed entry points -- order-independent fixed-point accumulation
+    (csrc/scatter.hpp) instead of float atomics -- and the whole backward is bit-reproducible from run to run."""
+    return bool(_lib.get_tuning("BMV_DETERMINISTIC"))
+
+
+def _fixed_ws(n_out, device):
+    """Zeroed workspace of a *_fixed call whose scatter outputs hold n_out floats together."""
+    words = _lib.load().bmv_fixed_workspace(int(n_out))
+    if words < 0:
+        _lib.check(int(words), "fixed_workspace")
+    return torch.zeros(words, device=device, dtype=torch.int64)
+
+
 def vox_feat_bwd(uvd01, volume, d_out, ray_w=0, Ns=0):
     """ray_w / Ns: layout hint -- the P samples are Ns per ray, rays row-major over an image ray_w wide (0 = unknown)."""
     B, P = uvd01.shape[:2]
     _, C_, D, h, w = volume.shape
-    d_vol = torch.zeros_like(volume, memory_format=torch.contiguous_format)
     d_d = torch.empty(B, P, device=volume.device, dtype=torch.float32)
     lib = _lib.load()
+    if deterministic():
+        d_vol = torch.empty_like(volume, memory_format=torch.contiguous_format)
+        ws = _fixed_ws(d_vol.numel(), volume.device)
+        _lib.check(lib.bmv_vox_feat_bwd_fixed(dptr(_c(uvd01), "uvd"), dptr(_c(volume), "volume"), dptr(_c(d_out), "d_out"),
+                                              B, P, C_, D, h, w, int(ray_w) if Ns else 0, int(Ns), dptr(d_vol), dptr(d_d),
+                                              dptr(ws, "workspace", torch.int64), stream()), "vox_feat_bwd_fixed")
+        return d_vol, d_d
+    d_vol = torch.zeros_like(volume, memory_format=torch.contiguous_format)
     _lib.check(lib.bmv_vox_feat_bwd(dptr(_c(uvd01), "uvd"), dptr(_c(volume), "volume"), dptr(_c(d_out), "d_out"), B, P,
                                     C_, D, h, w, int(ray_w) if Ns else 0, int(Ns), dptr(d_vol), dptr(d_d), stream()),
                "vox_feat_bwd")
@@ -989,9 +1011,19 @@ def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d
     Ns = xyz.shape[-2] if (ray_w and xyz.dim() == 4) else 0
     pts = _c(xyz).reshape(B, -1, 3)
     P = pts.shape[1]
-    d_img = torch.zeros_like(img_feat_rgb, memory_format=torch.contiguous_format)
     d_xyz = torch.empty(B, P, 3, device=xyz.device, dtype=torch.float32)
     lib = _lib.load()
+    if deterministic():
+        d_img = torch.empty_like(img_feat_rgb, memory_format=torch.contiguous_format)
+        ws = _fixed_ws(d_img.numel(), xyz.device)
+        _lib.check(lib.bmv_img_feat_bwd_fixed(dptr(pts, "xyz"), dptr(_c(img_feat_rgb), "img"), dptr(_c(src_exts), "src_exts"),
+                                              dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"),
+                                              float(render_scale), dptr(_c(d_out), "d_out"), B, P, S, C_,
+                                              C_ if n_grad is None else int(n_grad), H, W, int(ray_w) if Ns else 0, int(Ns),
+                                              dptr(d_img), dptr(d_xyz), dptr(ws, "workspace", torch.int64), stream()),
+                   "img_feat_bwd_fixed")
+        return d_img, d_xyz.reshape(xyz.shape)
+    d_img = torch.zeros_like(img_feat_rgb, memory_format=torch.contiguous_format)
     _lib.check(lib.bmv_img_feat_bwd(dptr(pts, "xyz"), dptr(_c(img_feat_rgb), "img"), dptr(_c(src_exts), "src_exts"),
                                     dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"), float(render_scale),
                                     dptr(_c(d_out), "d_out"), B, P, S, C_, C_ if n_grad is None else int(n_grad), H, W,
@@ -1013,9 +1045,18 @@ def sample_along_depth_bwd(rays12, d_xyz, d_dn, Ns, depth_inv):
 def build_rays_bwd(rays, depth, std, near_far, d_nf, Hr, Wr, depth_inv):
     B, N = rays.shape[:2]
     hv, wv = depth.shape[-2:]
+    lib = _lib.load()
+    if deterministic():
+        d_depth = torch.empty_like(depth, memory_format=torch.contiguous_format)
+        d_std = torch.empty_like(std, memory_format=torch.contiguous_format)
+        ws = _fixed_ws(2 * d_depth.numel(), depth.device)
+        _lib.check(lib.bmv_build_rays_bwd_fixed(dptr(_c(rays), "rays"), dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                                dptr(_c(near_far), "near_far"), dptr(_c(d_nf), "d_nf"), B, N, hv, wv,
+                                                int(Hr), int(Wr), int(bool(depth_inv)), dptr(d_depth), dptr(d_std),
+                                                dptr(ws, "workspace", torch.int64), stream()), "build_rays_bwd_fixed")
+        return d_depth, d_std
     d_depth = torch.zeros_like(depth, memory_format=torch.contiguous_format)
     d_std = torch.zeros_like(std, memory_format=torch.contiguous_format)
-    lib = _lib.load()
     _lib.check(lib.bmv_build_rays_bwd(dptr(_c(rays), "rays"), dptr(_c(depth), "depth"), dptr(_c(std), "std"),
                                       dptr(_c(near_far), "near_far"), dptr(_c(d_nf), "d_nf"), B, N, hv, wv, int(Hr),
                                       int(Wr), int(bool(depth_inv)), dptr(d_depth), dptr(d_std), stream()),
@@ -1038,9 +1079,19 @@ def depth_regress_bwd(depth_prob, depth_values, d_depth, d_std, depth_inv):
 def depth_values_cascade_bwd(depth, std, near_far, d_dv):
     B, h0, w0 = depth.shape
     _, D, h, w = d_dv.shape
+    lib = _lib.load()
+    if deterministic():
+        d_depth = torch.empty_like(depth, memory_format=torch.contiguous_format)
+        d_std = torch.empty_like(std, memory_format=torch.contiguous_format)
+        ws = _fixed_ws(2 * d_depth.numel(), depth.device)
+        _lib.check(lib.bmv_depth_values_cascade_bwd_fixed(dptr(_c(depth), "depth"), dptr(_c(std), "std"),
+                                                          dptr(_c(near_far), "near_far"), dptr(_c(d_dv), "d_dv"), B, h0, w0,
+                                                          h, w, D, dptr(d_depth), dptr(d_std),
+                                                          dptr(ws, "workspace", torch.int64), stream()),
+                   "depth_values_cascade_bwd_fixed")
+        return d_depth, d_std
     d_depth = torch.zeros_like(depth, memory_format=torch.contiguous_format)
     d_std = torch.zeros_like(std, memory_format=torch.contiguous_format)
-    lib = _lib.load()
     _lib.check(lib.bmv_depth_values_cascade_bwd(dptr(_c(depth), "depth"), dptr(_c(std), "std"),
                                                 dptr(_c(near_far), "near_far"), dptr(_c(d_dv), "d_dv"), B, h0, w0, h, w,
                                                 D, dptr(d_depth), dptr(d_std), stream()), "depth_values_cascade_bwd")
@@ -1055,6 +1106,15 @@ def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad, algo=N
     B, S, C_, Hs, Ws = feats.shape
     _, D, h, w = depth_values.shape
     lib = _lib.load()
+    if deterministic():          # bit-reproducible: the planar kernel with fixed-point accumulation (csrc/scatter.hpp)
+        d_feats = torch.empty_like(feats, memory_format=torch.contiguous_format)
+        d_dv = torch.empty_like(depth_values, memory_format=torch.contiguous_format) if want_depth_grad else None
+        ws = _fixed_ws(d_feats.numel() + (d_dv.numel() if want_depth_grad else 0), feats.device)
+        _lib.check(lib.bmv_sweep_variance_bwd_fixed(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
+                                                    dptr(_c(depth_values), "depth_values"), dptr(_c(d_var), "d_var"), B, S,
+                                                    C_, Hs, Ws, D, h, w, dptr(d_feats), dptr(d_dv),
+                                                    dptr(ws, "workspace", torch.int64), stream()), "sweep_variance_bwd_fixed")
+        return d_feats, d_dv
     if algo is None:
         algo = os.environ.get("BMV_SWEEP_BWD", "cl")
     if algo == "cl" and S == 3 and C_ in (16, 32):
@@ -1197,8 +1257,16 @@ def mvs_sweep_bwd(feats, proj, depth_values, d_volume, pad):
     """d_volume (B, 3S+C, D, hp, wp) -> d_feats (B,S,C,h,w)."""
     B, S, C_, h, w = feats.shape
     D = depth_values.shape[1]
-    d_feats = torch.zeros_like(feats, memory_format=torch.contiguous_format)
     lib = _lib.load()
+    if deterministic():
+        d_feats = torch.empty_like(feats, memory_format=torch.contiguous_format)
+        ws = _fixed_ws(d_feats.numel(), feats.device)
+        _lib.check(lib.bmv_mvs_sweep_bwd_fixed(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"),
+                                               dptr(_c(depth_values), "depth_values"), dptr(_c(d_volume), "d_volume"), B, S,
+                                               C_, h, w, D, int(pad), dptr(d_feats), dptr(ws, "workspace", torch.int64),
+                                               stream()), "mvs_sweep_bwd_fixed")
+        return d_feats
+    d_feats = torch.zeros_like(feats, memory_format=torch.contiguous_format)
     _lib.check(lib.bmv_mvs_sweep_bwd(dptr(_c(feats), "feats"), dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
                                      dptr(_c(d_volume), "d_volume"), B, S, C_, h, w, D, int(pad), dptr(d_feats), stream()),
                "mvs_sweep_bwd")
@@ -1209,8 +1277,17 @@ def mvs_vol_feat_bwd(rays, src_ext0, src_ixt0, near_far, d_feat, H, W, vol_shape
     """d_feat (N,Ns,8) -> d_volume (8,D,hp,wp)."""
     N, Ns = d_feat.shape[:2]
     _, D, hp, wp = vol_shape
-    d_vol = torch.zeros(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
     lib = _lib.load()
+    if deterministic():
+        d_vol = torch.empty(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
+        ws = _fixed_ws(d_vol.numel(), d_feat.device)
+        _lib.check(lib.bmv_mvs_vol_feat_bwd_fixed(dptr(_c(rays), "rays"), dptr(_c(src_ext0), "src_ext0"),
+                                                  dptr(_c(src_ixt0), "src_ixt0"), dptr(_c(near_far), "near_far"),
+                                                  dptr(_c(d_feat), "d_feat"), N, int(Ns), int(H), int(W), D, hp, wp, int(pad),
+                                                  dptr(d_vol), dptr(ws, "workspace", torch.int64), stream()),
+                   "mvs_vol_feat_bwd_fixed")
+        return d_vol
+    d_vol = torch.zeros(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
     _lib.check(lib.bmv_mvs_vol_feat_bwd(dptr(_c(rays), "rays"), dptr(_c(src_ext0), "src_ext0"), dptr(_c(src_ixt0), "src_ixt0"),
                                         dptr(_c(near_far), "near_far"), dptr(_c(d_feat), "d_feat"), N, int(Ns), int(H), int(W), D,
                                         hp, wp, int(pad), dptr(d_vol), stream()), "mvs_vol_feat_bwd")

@@ -250,6 +250,37 @@ int bmv_sweep_variance_bwd_cl(const float* feats_cl, const float* proj, const fl
                               const float* d_variance, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
                               float* d_feats_cl, float* d_depth_values, bmv_stream_t stream);
 
+/* ---- Bit-reproducible scatter gradients (round 5; bmv_tuning "BMV_DETERMINISTIC" makes the Python host take these).
+ * The entry points above add their contributions with float atomics: a texel's sum depends on the order the hardware
+ * serves the adds, so gradients differ in their last bits from run to run (and training-mode batch norm amplifies
+ * that).  The *_fixed twins below compute the SAME gradients with order-independent accumulation
+ * (csrc/scatter.hpp): one pass finds the largest |contribution| of the launch (an atomic max: order-independent), a
+ * power-of-two scale puts it just under 2^38, a second pass of the same kernel adds llrint(v * scale) with 64-bit
+ * INTEGER atomics (associative), and a finish kernel writes float(q / scale) to the float gradient buffers -- which
+ * then need no zero-initialisation.  Every contribution is rounded once, 38 bits below the largest one of the launch:
+ * at least as accurate as the float form.  Two runs on the same inputs give bit-identical outputs.
+ * `workspace`: bmv_fixed_workspace(n) 64-bit words, ZEROED by the caller, n = number of floats in the launch's
+ * scatter outputs together (d_volume; d_img; d_depth + d_std; d_feats + d_depth_values (if not NULL); ...).
+ * Reference semantics as the float twins (lib/networks/enerf/utils.py:57-95, 324-351, 392-460, 753-786 under
+ * loss.backward(), lib/train/trainers/trainer.py:44-63). */
+long bmv_fixed_workspace(long n_out);
+int bmv_vox_feat_bwd_fixed(const float* uvd01, const float* volume, const float* d_out, int B, int P, int C, int D, int h,
+                           int w, int ray_w, int Ns, float* d_volume, float* d_d01, long long* workspace,
+                           bmv_stream_t stream);
+int bmv_img_feat_bwd_fixed(const float* xyz, const float* img_feat_rgb, const float* src_exts, const float* src_ixts,
+                           const float* tar_ext, float render_scale, const float* d_out, int B, int P, int S, int C,
+                           int c_grad, int H, int W, int ray_w, int Ns, float* d_img, float* d_xyz, long long* workspace,
+                           bmv_stream_t stream);
+int bmv_build_rays_bwd_fixed(const float* rays, const float* depth, const float* std, const float* near_far,
+                             const float* d_near_far, int B, int N, int hv, int wv, int Hr, int Wr, int depth_inv,
+                             float* d_depth, float* d_std, long long* workspace, bmv_stream_t stream);
+int bmv_depth_values_cascade_bwd_fixed(const float* depth, const float* std, const float* near_far,
+                                       const float* d_depth_values, int B, int h0, int w0, int h, int w, int D,
+                                       float* d_depth, float* d_std, long long* workspace, bmv_stream_t stream);
+int bmv_sweep_variance_bwd_fixed(const float* feats, const float* proj, const float* depth_values,
+                                 const float* d_variance, int B, int S, int C, int Hs, int Ws, int D, int h, int w,
+                                 float* d_feats, float* d_depth_values, long long* workspace, bmv_stream_t stream);
+
 /* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89), three launches on `stream`:
  *   1. the data path: the forward of every 32-sample tile is recomputed and back-propagated on the matrix cores;
  *      d_vox (8, P) and d_img (3, IR, P) come out in [row][sample] layout (IR rows per view: the F channels padded
@@ -258,6 +289,8 @@ int bmv_sweep_variance_bwd_cl(const float* feats_cl, const float* proj, const fl
  *   2. every weight / bias gradient, dW = D_pre ACT^T, with the sample index as the MFMA k dimension;
  *   3. a deterministic reduction of the per-workgroup partials into `grads` (tensors of the reference's parameter
  *      shapes, overwritten).
+ * No atomics anywhere (round 5: the two 1-wide heads whose inputs are not parked leave one partial per wave, summed
+ * in a fixed order by launch 3): the call is bit-reproducible.
  * workspace: bmv_nerf_bwd_workspace(feat_ch, npts) floats (about 80 KB per 32 samples for feat_ch 8).
  * npts = 0 is rejected (nothing to write the gradients from).  IR: bmv_nerf_bwd_rows(). */
 typedef struct {
@@ -395,6 +428,14 @@ int bmv_mvs_sweep_bwd(const float* feats, const float* proj, const float* depth_
 int bmv_mvs_vol_feat_bwd(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
                          const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
                          float* d_volume, bmv_stream_t stream);
+/* ... and their bit-reproducible twins (see "Bit-reproducible scatter gradients" above; lib/networks/mvsnerf/network.py:
+ * 887-942, utils.py:357-383 under loss.backward()) */
+int bmv_mvs_sweep_bwd_fixed(const float* feats, const float* proj, const float* depth_values, const float* d_volume, int B,
+                            int S, int C, int h, int w, int D, int pad, float* d_feats, long long* workspace,
+                            bmv_stream_t stream);
+int bmv_mvs_vol_feat_bwd_fixed(const float* rays, const float* src_ext0, const float* src_ixt0, const float* near_far,
+                               const float* d_feat, long N, int Ns, int H, int W, int D, int hp, int wp, int pad,
+                               float* d_volume, long long* workspace, bmv_stream_t stream);
 
 /* ---- boost_mvsnerf calc_mask               lib/networks/boost_mvsnerf/network.py:23-45
  * rays (N,8) marched with Ns samples between columns 6 and 7; src_exts (V,4,4), src_ixts (V,3,3)

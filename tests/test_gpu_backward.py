@@ -44,7 +44,7 @@ def rays_are_full_frame(rays, Hr, Wr):
     return rays.shape[1] == Hr * Wr
 
 
-def test_lookup_and_sampler_bwd(enerf_fx):
+def test_lookup_and_sampler_bwd(enerf_fx, scatter_mode):
     from boostmvsnerfs_amd import autograd as A
     from oracle import enerf as O
     b = enerf_fx.batch()
@@ -95,7 +95,7 @@ def test_lookup_and_sampler_bwd(enerf_fx):
         assert float(got[3][:, :, -3:].abs().max()) == 0.0          # the colour channels were declared data
 
 
-def test_depth_bwd(enerf_fx):
+def test_depth_bwd(enerf_fx, scatter_mode):
     from boostmvsnerfs_amd import autograd as A
     from oracle import enerf as O
     torch.manual_seed(2)
@@ -121,7 +121,7 @@ def test_depth_bwd(enerf_fx):
     assert_close(sg.grad, s.grad, name="cascade d_std", **GTOL)
 
 
-def test_sweep_bwd(enerf_fx):
+def test_sweep_bwd(enerf_fx, scatter_mode):
     from boostmvsnerfs_amd import autograd as A
     from oracle import enerf as O
     torch.manual_seed(3)
@@ -145,7 +145,8 @@ def test_sweep_bwd(enerf_fx):
                 assert (ddv is None) == (not want)
                 if want:
                     assert_close(ddv, d.grad, name=f"d_depth_values{lvl} [{algo}]", rtol=5e-3, atol_scale=5e-3)
-        assert not ops.sweep_variance_bwd(feats[lvl].to(DEV), P.to(DEV), dv.to(DEV), g.to(DEV), False)[0].is_contiguous()   # cl ran
+        if scatter_mode == "atomics":
+            assert not ops.sweep_variance_bwd(feats[lvl].to(DEV), P.to(DEV), dv.to(DEV), g.to(DEV), False)[0].is_contiguous()   # cl ran
     # ragged: a voxel count that is not a multiple of the 64-voxel wave tile, rays leaving the source maps
     P, dv = enerf_fx.t("cap/get_proj_mats#1"), enerf_fx.t("cap/get_depth_values#1.0")
     dv2 = (dv[:, :3, :5, :7] * 1.7).contiguous()
@@ -156,3 +157,37 @@ def test_sweep_bwd(enerf_fx):
     df, ddv = ops.sweep_variance_bwd(feats[1].to(DEV), P.to(DEV), dv2.to(DEV), g2.to(DEV), True, algo="cl")
     assert_close(df, f.grad, name="ragged d_feats", **GTOL)
     assert_close(ddv, d.grad, name="ragged d_depth_values", rtol=5e-3, atol_scale=5e-3)
+
+
+def test_fixed_point_scatter_is_bit_reproducible_and_as_accurate(enerf_fx):
+    """bmv_tuning BMV_DETERMINISTIC (csrc/scatter.hpp): every scatter gradient twice on the same inputs -> torch.equal;
+    against the float-atomic form -> equal to fp32 rounding of the sums (1e-5 of the tensor's scale); NaN in -> NaN out."""
+    from boostmvsnerfs_amd import _lib, ops
+    torch.manual_seed(11)
+    feats = enerf_fx.t("cap/feature_net#0.1")[None].to(DEV)
+    P, dv = enerf_fx.t("cap/get_proj_mats#1").to(DEV), enerf_fx.t("cap/get_depth_values#1.0").to(DEV)
+    g = torch.randn(1, feats.shape[2], *dv.shape[1:], device=DEV) * 1e-4        # gradients of a mean loss are small
+    vol = enerf_fx.t("cap/cost_reg_1#0.0").to(DEV)
+    uvd = torch.rand(1, 5000, 3, device=DEV) * 1.2 - 0.1
+    go = torch.randn(1, 5000, 8, device=DEV) * 3e-6
+
+    def run():
+        a = ops.sweep_variance_bwd(feats, P, dv, g, True)
+        b = ops.vox_feat_bwd(uvd, vol, go)
+        return [a[0].contiguous(), a[1], b[0], b[1]]
+    before = _lib.get_tuning("BMV_DETERMINISTIC")
+    try:
+        _lib.set_tuning("BMV_DETERMINISTIC", 0)
+        ref = run()
+        _lib.set_tuning("BMV_DETERMINISTIC", 1)
+        one, two = run(), run()
+        for x, y, r in zip(one, two, ref):
+            assert torch.equal(x, y)
+            scale = float(r.abs().max())
+            assert float((x - r).abs().max()) <= 1e-5 * scale, (float((x - r).abs().max()), scale)
+        go2 = go.clone()
+        go2[0, 17, 3] = float("nan")
+        assert bool(ops.vox_feat_bwd(uvd, vol, go2)[0].isnan().all())          # loud, like the float form's NaN
+        assert float(ops.vox_feat_bwd(uvd, vol, torch.zeros_like(go))[0].abs().max()) == 0.0
+    finally:
+        _lib.set_tuning("BMV_DETERMINISTIC", before)

@@ -567,3 +567,33 @@ def test_render_pc_lost_wakeup_surfaces_as_an_error(enerf_fx):
     assert lib.bmv_render_pc_check(1) == 0
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("S", [2, 4])
+def test_enerf_with_2_and_4_source_views(enerf_fx, S):
+    """ENeRF with 2 and 4 source views (the reference trains with train_input_views [2, 3, 4],
+    configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23, 75-76): Network.forward (eval) against the reference's own output
+    dict, and every parameter gradient of the fine-tune loss against the reference's (tests/golden/enerf_tiny_views{S}.npz).
+    The sweeps run their S = 2 / 4 instantiations; the MLP takes nerf.NeRF.forward_views (S-agnostic)."""
+    from conftest import check_param_grads, load_fixture
+    from boostmvsnerfs_amd.config import set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.train import NetworkWrapper
+    vfx = load_fixture(f"enerf_tiny_views{S}")
+    cfg = tiny_cfg(enerf_fx, "enerf_pretrain")
+    cfg.enerf.cas_config.render_if = [True, True]
+    set_cfg(cfg)
+    net = Network()
+    net.load_state_dict(enerf_fx.group("sd"), strict=True)
+    net = net.to(DEV).eval()
+    bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vfx.batch().items()}
+    assert bg["src_inps"].shape[1] == S
+    with torch.no_grad():
+        out = net({k: (v.clone() if torch.is_tensor(v) else v) for k, v in bg.items()})
+    for k, v in vfx.group("out").items():
+        assert_close(out[k], v, name=f"S={S} {k}")
+    ref = {k[5:]: torch.from_numpy(v) for k, v in vfx.raw.items() if k.startswith("grad/")}
+    net.zero_grad()
+    _, loss, _, _ = NetworkWrapper(net)(bg)
+    loss.backward()
+    check_param_grads(net, ref, float(loss), float(vfx.raw["extra/loss"]))

@@ -6,7 +6,7 @@ import json
 import pytest
 import torch
 
-from conftest import assert_close, tiny_cfg
+from conftest import assert_close, check_param_grads as _check_grads, tiny_cfg
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -29,27 +29,7 @@ def _oracle_grads(forward, sd, batch, cfg):
     return float(loss), {k: v.grad for k, v in leaves.items() if v.requires_grad}
 
 
-def _check_grads(net, want, loss_g, loss_c, outliers=0.0):
-    """Every parameter gradient within 2e-3 relative (+ 2e-3 of the tensor's rms, + 2e-6 of the largest gradient of
-    the network for tensors that are rounding noise, e.g. a bias in front of a softmax over views).  Measured on the
-    reference's own gradients (scripts/grad_err_vs_reference.py): max |d| <= 1e-4 rms on every tensor, no outliers."""
-    assert abs(loss_g - loss_c) <= 1e-4 * abs(loss_c), (loss_g, loss_c)
-    named = dict(net.named_parameters())
-    assert set(named) == set(want)                       # every parameter tensor of the reference gets a gradient
-    gmax = max(float(g.abs().max()) for g in want.values())
-    worst = {}
-    for k, p in named.items():
-        assert p.grad is not None, f"{k} received no gradient"
-        err = (p.grad.cpu() - want[k]).abs()
-        tol = 2e-3 * want[k].abs() + 2e-3 * float(want[k].pow(2).mean().sqrt()) + 2e-6 * gmax
-        bad = float((err > tol).float().mean())
-        worst[k] = bad
-        assert bad <= outliers, f"{k}: {bad:.2%} of the gradient outside tolerance (max err {float(err.max()):.3e})"
-        assert bool((err <= 3 * tol).all()), f"{k}: an entry more than 3x outside tolerance (max err {float(err.max()):.3e})"
-    return worst
-
-
-def test_enerf_finetune_gradients(enerf_fx):
+def test_enerf_finetune_gradients(enerf_fx, scatter_mode):
     from boostmvsnerfs_amd.config import set_cfg
     from boostmvsnerfs_amd.networks.enerf.network import Network
     from boostmvsnerfs_amd.train import NetworkWrapper
@@ -111,7 +91,7 @@ def test_one_optimiser_step_moves_parameters_like_the_reference(enerf_fx):
         assert float((err > 2e-2 * lr).float().mean()) <= 0.02, k
 
 
-def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path):
+def test_boost_enerf_finetune_gradients(enerf_fx, boost_fx, tmp_path, scatter_mode):
     from boostmvsnerfs_amd.config import set_cfg
     from boostmvsnerfs_amd.networks.boost_enerf.network import Network
     from boostmvsnerfs_amd.train import NetworkWrapper, make_optimizer, train_step
@@ -196,13 +176,13 @@ def test_finetune_step_under_ddp_and_syncbn(enerf_fx):
             dist.destroy_process_group()
 
 
-def test_graphed_train_step_equals_eager_steps(enerf_fx):
+def _lockstep(enerf_fx, exact):
     """train.GraphedTrainStep (forward + loss + backward replayed as one HIP graph, clip + Adam eager) against eager
     train_step calls in lockstep: before every step the eager twin takes over the graphed network's parameters,
-    batch-norm statistics and Adam state (two free-running Adam trajectories diverge by themselves: entries whose
-    gradient is rounding noise step +-lr either way), then both step on the same batch -- training-mode batch norm,
-    new target tensors every step (copied into the captured buffers), 6 steps = 3 eager + 1 capture + 2 more replays.
-    Loss, every gradient and the running statistics after the step must agree."""
+    batch-norm statistics and Adam state, then both step on the same batch -- training-mode batch norm, new target
+    tensors every step (copied into the captured buffers), 6 steps = 3 eager + 1 capture (+ first replay) + 2 more
+    replays.  Yields (step, graphed gradients, eager network) after every step, having checked the loss, the running
+    statistics and the step counters."""
     import copy
     from boostmvsnerfs_amd.config import set_cfg
     from boostmvsnerfs_amd.networks.enerf.network import Network
@@ -227,21 +207,13 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
         loss_a, stats = graphed(dict(b))
         assert "psnr_1" in stats
         loss_b, _ = train_step(wb, ob, dict(b))
-        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, float(loss_a), float(loss_b))
-        ga = {k: p.grad for k, p in net_a.named_parameters()}
-        gmax = max(float(p.grad.abs().max()) for p in net_b.parameters())
-        for k, p in net_b.named_parameters():
-            # scatter kernels accumulate with atomics, so two runs of the SAME eager step differ by summation order;
-            # training-mode batch norm over the few voxels of the tiny fixture's deep levels amplifies that to ~4e-3 of
-            # a tensor's rms in single entries (measured in round 3: 4.1e-3 in train mode, 1.4e-5 in eval
-            # mode).  A replay that read stale inputs or parameters is wrong by O(1): the bar is the tensor's relative
-            # L2 error
-            num = float((ga[k] - p.grad).pow(2).sum().sqrt())
-            den = float(p.grad.pow(2).sum().sqrt()) + 1e-6 * gmax
-            assert num <= 2e-2 * den, f"step {s} {k}: relative L2 error {num / den:.3e}"
+        assert float(loss_a) == float(loss_b), (s, float(loss_a), float(loss_b))     # the forward has no atomics
+        yield s, {k: p.grad for k, p in net_a.named_parameters()}, net_b
         sa, sb = net_a.state_dict(), net_b.state_dict()
         for k in sa:
-            if "running_" in k:
+            if exact:                     # ... and so the parameters after clip + Adam, the statistics, the counters
+                assert torch.equal(sa[k], sb[k]), (s, k)
+            elif "running_" in k:
                 assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * float(sb[k].abs().max()) + 1e-7, (s, k)
             elif "num_batches_tracked" in k:
                 assert torch.equal(sa[k], sb[k]), (s, k)
@@ -250,7 +222,39 @@ def test_graphed_train_step_equals_eager_steps(enerf_fx):
     assert sum(float((v - start[k]).abs().max()) > 0 for k, v in net_a.state_dict().items()) > 100   # ... and it did train
 
 
-def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path):
+def test_graphed_train_step_equals_eager_steps(enerf_fx, deterministic):
+    """Replay == eager, BIT FOR BIT, with the scatter gradients in their order-independent form (bmv_tuning
+    BMV_DETERMINISTIC: csrc/scatter.hpp; the MLP backward, the weight gradients and the batch norm are fixed-order
+    reductions anyway): every one of the 115 gradients of every step -- eager, capture, replays -- `torch.equal`, and the
+    state dict after the optimiser step too.  A replay that read a stale or un-zeroed buffer cannot hide in a
+    tolerance here (round 4's statistical form of this test flaked at 2.6e-2 on the driver's box;
+    tests/tools/graphed_step_flake.py -> profiles/r5/graphed_step_flake.txt: 50 x 6 steps, the graphed-vs-eager and
+    eager-vs-eager distributions of the float-atomic form coincide at every step kind -- it was summation-order noise,
+    amplified by training-mode batch norm over the few voxels of the tiny fixture's deep levels, max 1.2e-2 --;
+    profiles/r5/graphed_step_flake_deterministic.txt: 690 / 690 tensors bit-equal in both pairs)."""
+    for s, ga, net_b in _lockstep(enerf_fx, exact=True):
+        for k, p in net_b.named_parameters():
+            assert torch.equal(ga[k], p.grad), f"step {s} {k}: replayed and eager gradients differ"
+
+
+def test_graphed_train_step_with_float_atomics(enerf_fx):
+    """The default (float-atomic) scatter form: two runs of the SAME step differ by summation order, heavy-tailed
+    (profiles/r5/graphed_step_flake.txt, eager vs eager over 300 steps: median tensor 3e-4 relative L2, p99 4e-3, worst
+    1.2e-2; 2.6e-2 was seen once on another box).  What this asserts is robust against those tails and still far below
+    what a stale buffer does (O(1) on every tensor downstream of it): the MEDIAN over the 115 tensors <= 3e-3 (10 x the
+    measured median) and no tensor beyond 0.25."""
+    for s, ga, net_b in _lockstep(enerf_fx, exact=False):
+        gmax = max(float(p.grad.abs().max()) for p in net_b.parameters())
+        rel = []
+        for k, p in net_b.named_parameters():
+            num = float((ga[k] - p.grad).pow(2).sum().sqrt())
+            rel.append(num / (float(p.grad.pow(2).sum().sqrt()) + 1e-6 * gmax))
+        rel.sort()
+        assert rel[len(rel) // 2] <= 3e-3, f"step {s}: median relative L2 {rel[len(rel) // 2]:.3e}"
+        assert rel[-1] <= 0.25, f"step {s}: worst relative L2 {rel[-1]:.3e}"
+
+
+def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path, deterministic):
     """GraphedTrainStep on boost_enerf (config 5's path: K cost volumes, triplets from view_selection.json baked into the
     captured launches, targets named in batch['meta'] part of the key): losses of the replayed steps against an eager twin
     in lockstep, and a batch whose meta names another target is NOT served by the captured graph."""
@@ -278,7 +282,9 @@ def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path
         ob.load_state_dict(copy.deepcopy(oa.state_dict()))
         loss_a, _ = graphed(dict(base))
         loss_b, _ = train_step(wb, ob, dict(base))
-        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, float(loss_a), float(loss_b))
+        assert float(loss_a) == float(loss_b), (s, float(loss_a), float(loss_b))
+        for (k, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), f"step {s} {k}"      # (deterministic scatter form: bit for bit)
     assert graphed.stats == {"eager": 3, "captures": 1, "replays": 3, "copies": 0}
     other = dict(base)
     other["meta"] = dict(base["meta"], tar_view=[1])            # another target: other triplets -> its own key
@@ -287,7 +293,7 @@ def test_graphed_train_step_on_the_k_volume_network(enerf_fx, boost_fx, tmp_path
     assert graphed.stats["eager"] == 4 and graphed.stats["replays"] == 3
 
 
-def test_graphed_train_step_interleaved_keys(enerf_fx):
+def test_graphed_train_step_interleaved_keys(enerf_fx, deterministic):
     """with more than one key in play a replay of an OLDER graph wrote gradients that no p.grad referenced
     any more (the newer capture / an eager step had rebound them), and clip + Adam stepped on stale ones.  Sequence:
     A x4 (3 eager + capture), B x4 (another ray count: its own eager steps and capture), then A (replay), B (replay),
@@ -323,44 +329,11 @@ def test_graphed_train_step_interleaved_keys(enerf_fx):
         ob.load_state_dict(copy.deepcopy(oa.state_dict()))
         loss_a, _ = graphed(dict(b))
         loss_b, _ = train_step(wb, ob, dict(b))
-        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b)), (s, kind, float(loss_a), float(loss_b))
+        assert float(loss_a) == float(loss_b), (s, kind, float(loss_a), float(loss_b))
         ga = {k: p.grad for k, p in net_a.named_parameters()}
-        gmax = max(float(p.grad.abs().max()) for p in net_b.parameters() if p.grad is not None)
         for k, p in net_b.named_parameters():
             assert (ga[k] is None) == (p.grad is None), (s, kind, k)
             if p.grad is None:
                 continue
-            num = float((ga[k] - p.grad).pow(2).sum().sqrt())
-            den = float(p.grad.pow(2).sum().sqrt()) + 1e-6 * gmax
-            assert num <= 2e-2 * den, f"step {s} ({kind}) {k}: relative L2 error {num / den:.3e}"
+            assert torch.equal(ga[k], p.grad), f"step {s} ({kind}) {k}"       # deterministic scatter form: bit for bit
     assert graphed.stats["captures"] == 2 and graphed.stats["replays"] == 3 + 2, graphed.stats
-
-
-@pytest.mark.parametrize("S", [2, 4])
-def test_enerf_with_2_and_4_source_views(enerf_fx, S):
-    """ENeRF with 2 and 4 source views (the reference trains with train_input_views [2, 3, 4],
-    configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23, 75-76): Network.forward (eval) against the reference's own output
-    dict, and every parameter gradient of the fine-tune loss against the reference's (tests/golden/enerf_tiny_views{S}.npz).
-    The sweeps run their S = 2 / 4 instantiations; the MLP takes nerf.NeRF.forward_views (S-agnostic)."""
-    from conftest import load_fixture
-    from boostmvsnerfs_amd.config import set_cfg
-    from boostmvsnerfs_amd.networks.enerf.network import Network
-    from boostmvsnerfs_amd.train import NetworkWrapper
-    vfx = load_fixture(f"enerf_tiny_views{S}")
-    cfg = tiny_cfg(enerf_fx, "enerf_pretrain")
-    cfg.enerf.cas_config.render_if = [True, True]
-    set_cfg(cfg)
-    net = Network()
-    net.load_state_dict(enerf_fx.group("sd"), strict=True)
-    net = net.to(DEV).eval()
-    bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vfx.batch().items()}
-    assert bg["src_inps"].shape[1] == S
-    with torch.no_grad():
-        out = net({k: (v.clone() if torch.is_tensor(v) else v) for k, v in bg.items()})
-    for k, v in vfx.group("out").items():
-        assert_close(out[k], v, name=f"S={S} {k}")
-    ref = {k[5:]: torch.from_numpy(v) for k, v in vfx.raw.items() if k.startswith("grad/")}
-    net.zero_grad()
-    _, loss, _, _ = NetworkWrapper(net)(bg)
-    loss.backward()
-    _check_grads(net, ref, float(loss), float(vfx.raw["extra/loss"]))
