@@ -71,7 +71,7 @@ SIGNATURES = {
     "bmv_img_feat": [c_f, c_f, c_f, c_f, c_f, c_fl, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     "bmv_nerf_blob_size": [c_i],
     "bmv_nerf_pack_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],
-    "bmv_nerf_mlp_fwd": [c_f, c_f, c_f, c_i, c_l, c_f, c_f],
+    "bmv_nerf_mlp_fwd": [c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_f],
     "bmv_composite_fwd": [c_f, c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_f],
     "bmv_mask_viewport": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_i, c_f, c_f],
     "bmv_ndc_coords": [c_f, c_f, c_f, c_fl, c_fl, c_i, c_i, c_f, c_f],
@@ -118,10 +118,10 @@ SIGNATURES = {
     "bmv_mvs_sweep_bwd_fixed": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_mvs_vol_feat_bwd_fixed": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_nerf_bwd_blob_size": [c_i],
-    "bmv_nerf_bwd_rows": [c_i, C.POINTER(C.c_int)],
+    "bmv_nerf_bwd_rows": [c_i, c_i, C.POINTER(C.c_int)],
     "bmv_nerf_pack_bwd_weights": [C.POINTER(NerfParams), c_i, c_f, c_f],
-    "bmv_nerf_bwd_workspace": [c_i, c_l],
-    "bmv_nerf_mlp_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, C.POINTER(NerfParams), c_f],
+    "bmv_nerf_bwd_workspace": [c_i, c_i, c_l],
+    "bmv_nerf_mlp_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_f, c_f, C.POINTER(NerfParams), c_f],
     "bmv_conv_wgrad_workspace": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i],
     "bmv_conv_wgrad": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_mvs_sweep_bwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],

@@ -177,10 +177,9 @@ class NerfMLP(torch.autograd.Function):
     """a11.  forward: MFMA kernel.  backward: three launches inside bmv_nerf_mlp_bwd (csrc/mlp_bwd.hip): the data
     path (input gradients; pre-activation gradients and layer inputs parked as per-tile matrices), every weight and
     bias gradient as MFMA products over the sample dimension, and a fixed-order reduction of the per-workgroup partials
-    into tensors of the parameters' shapes.  NOT bit-reproducible from run to run as a whole: the two 1-wide heads
-    whose inputs are not parked (agg_w_fc, color.2: 96 values) are accumulated with float atomics in the data-path
-    kernel (mlp_bwd.hip), and so are the scatter gradients of VoxFeat / ImgFeat / SweepVariance (backward.hip);
-    everything else is."""
+    into tensors of the parameters' shapes.  Any number of source views S in {2, 3, 4} (img_feat_rgb_dir (..., S, F + 4)).
+    Bit-reproducible (round 5: no atomics left in mlp_bwd.hip; the scatter gradients of VoxFeat / ImgFeat /
+    SweepVariance are too under bmv_tuning BMV_DETERMINISTIC, csrc/scatter.hpp)."""
 
     @staticmethod
     def forward(ctx, vox_feat, img_feat_rgb_dir, feat_ch, *params):
@@ -198,7 +197,8 @@ class NerfMLP(torch.autograd.Function):
         FCP = 2 * ((FC + 1) // 2)
         blob_bwd = ops.nerf_pack_bwd_weights(list(params), feat_ch)
         lead = vox.shape[:-1]
-        voxf, imgf = vox.reshape(-1, 8), img.reshape(-1, 3, FC + 4)
+        S = img.shape[-2]
+        voxf, imgf = vox.reshape(-1, 8), img.reshape(-1, S, FC + 4)
         d_vox, d_img, grads = ops.nerf_mlp_bwd(voxf, imgf, d_out.reshape(-1, 4).contiguous(), blob, blob_bwd, feat_ch)
         d_vox_feat = d_vox.t().reshape(*lead, 8)
         d_img_feat = torch.cat([d_img[:, :FC], d_img[:, FCP:FCP + 4]], 1).permute(2, 0, 1).reshape(img.shape)

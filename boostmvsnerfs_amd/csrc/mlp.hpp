@@ -13,11 +13,16 @@
 // between layers; only the 1-wide heads (agg weight, sigma, colour logit) need a
 // single cross-half add.
 //
-// Algebra.  global_fc and color.0 are split into a part shared by the S=3 views
+// Algebra.  global_fc and color.0 are split into a part shared by the NV source views
 // (computed once, then used as the C-in of each view's chain) and a per-view part:
 //   global_fc([f_i, var, mean]) = Wg[:, :F] f_i + (Wg[:, F:2F] var + Wg[:, 2F:] mean + b)
 //   color.0([x, v, in_i])       = Wc[:, 88:] in_i + (Wc[:, :88] [x, v] + b)
-// 205 MFMAs per 32 samples for feat_ch = 8 (26.2 kFLOP/sample instead of 50.9).
+// 205 MFMAs per 32 samples for feat_ch = 8 and 3 views (26.2 kFLOP/sample instead of 50.9).
+//
+// Views.  The reference's Agg / NeRF are written for ANY number of source views (nerf.py:29-43, 74-89: var / mean /
+// softmax over dim -2; ENeRF pre-trains with train_input_views [2, 3, 4], configs/exps/pretrain/enerf/
+// dtu_pretrain.yaml:22-23): NV is a template parameter of everything below (2, 3, 4 instantiated); the weight blob does
+// not depend on it.
 #pragma once
 #include "bmv_common.hpp"
 
@@ -217,6 +222,30 @@ __device__ __forceinline__ float relu1(float x) {
   return r;
 }
 
+// softmax over the views of a sample (nerf.py:41, 88), in place; max first, sums left to right
+template <int NV>
+__device__ __forceinline__ void softmax_views(float (&a)[NV]) {
+  float m = a[NV - 1];
+#pragma unroll
+  for (int i = NV - 2; i >= 0; --i) m = fmaxf(a[i], m);
+  float e[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) e[i] = __expf(a[i] - m);
+  float den = e[0];
+#pragma unroll
+  for (int i = 1; i < NV; ++i) den += e[i];
+  const float inv = BMV_DIV(1.f, den);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) a[i] = e[i] * inv;
+}
+template <int NV>
+__device__ __forceinline__ float weighted_views(const float (&w)[NV], const f32x16 (&g)[NV], int t) {
+  float v = w[0] * g[0][t];
+#pragma unroll
+  for (int i = 1; i < NV; ++i) v += w[i] * g[i][t];
+  return v;
+}
+
 // --------------------------------------------------------------------------
 // Per-lane inputs (lane = (sample s, half h)):
 //   fin[i][j]  j <  KFC : channel 2j+h of view i's [feature, rgb] vector (0 beyond FC)
@@ -225,10 +254,11 @@ __device__ __forceinline__ float relu1(float x) {
 //   vox[j]     feature-volume channel 2j+h
 // W: the packed blob in LDS.  out = [r, g, b, sigma], identical in both halves.
 // --------------------------------------------------------------------------
-template <int FEAT_CH>
+template <int FEAT_CH, int NV = 3>
 __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lane,
-                                            const float (&fin)[3][MlpLayout<FEAT_CH>::KF], const float (&dir)[3][4],
+                                            const float (&fin)[NV][MlpLayout<FEAT_CH>::KF], const float (&dir)[NV][4],
                                             const float (&vox)[4], float (&out)[4]) {
+  static_assert(NV >= 2 && NV <= 4, "source views per cost volume");
   using L = MlpLayout<FEAT_CH>;
   constexpr int KFC = L::KFC, KF = L::KF;
   const int h = lane >> 5;
@@ -243,19 +273,28 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
                 Wv[L::V_VF + (j * 5 + 3) * 2] * dir[i][3];
     return fin[i][j] + relu1(pre);
   };
-  // unbiased variance and mean over the 3 views (nerf.py:83-84); the f are kept for the per-view chain (feat_ch 8:
+  // unbiased variance and mean over the NV views (nerf.py:83-84); the f are kept for the per-view chain (feat_ch 8:
   // 18 registers against 144 vector instructions to recompute them)
   constexpr bool KEEP_F = KFC <= 6;
-  float fkeep[KEEP_F ? 3 : 1][KEEP_F ? KFC : 1];
+  float fkeep[KEEP_F ? NV : 1][KEEP_F ? KFC : 1];
   float var[KFC], mean[KFC];
 #pragma unroll
   for (int j = 0; j < KFC; ++j) {
-    float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
-    if constexpr (KEEP_F) fkeep[0][j] = f0, fkeep[1][j] = f1, fkeep[2][j] = f2;
-    float m = (f0 + f1 + f2) / 3.f;
-    float d0 = f0 - m, d1 = f1 - m, d2 = f2 - m;
+    float f[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f[i] = fval(i, j);
+      if constexpr (KEEP_F) fkeep[i][j] = f[i];
+    }
+    float m = f[0];
+#pragma unroll
+    for (int i = 1; i < NV; ++i) m += f[i];
+    m = m / (float)NV;
+    float ss = (f[0] - m) * (f[0] - m);
+#pragma unroll
+    for (int i = 1; i < NV; ++i) ss += (f[i] - m) * (f[i] - m);
     mean[j] = m;
-    var[j] = (d0 * d0 + d1 * d1 + d2 * d2) * 0.5f;
+    var[j] = ss * (1.f / (float)(NV - 1));
     BMV_FENCE_EVERY(j, 6);
   }
   BMV_FENCE();
@@ -264,9 +303,9 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
   for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
   BMV_CHAIN1(L::A_GSH, 2 * KFC, BMV_MLP_G1, (t < KFC ? var[t < KFC ? t : 0] : mean[t >= KFC ? t - KFC : 0]), gsh)
-  f32x16 g[3];
+  f32x16 g[NV];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NV; ++i) {
     g[i] = gsh;
     BMV_CHAIN1(L::A_GV, KFC, BMV_MLP_G1, (KEEP_F ? fkeep[KEEP_F ? i : 0][KEEP_F ? t : 0] : fval(i, t)), g[i])
 #pragma unroll
@@ -274,26 +313,21 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
     BMV_FENCE();
   }
   // agg_w_fc + softmax over views + weighted sum (nerf.py:88-89)
-  float aw[3];
+  float aw[NV];
   const float ba = W[L::V_SC + 0], bs = W[L::V_SC + 1], bc2 = W[L::V_SC + 2];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NV; ++i) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += Wv[L::V_WA + r * 2] * g[i][r];
     aw[i] = fmaxf(xhalf_sum(s) + ba, 0.f);
   }
-  {
-    float m = fmaxf(aw[0], fmaxf(aw[1], aw[2]));
-    float e0 = __expf(aw[0] - m), e1 = __expf(aw[1] - m), e2 = __expf(aw[2] - m);
-    float inv = BMV_DIV(1.f, e0 + e1 + e2);
-    aw[0] = e0 * inv, aw[1] = e1 * inv, aw[2] = e2 * inv;
-  }
+  softmax_views<NV>(aw);
   // agg.fc (nerf.py:90): 32 -> 16
   f32x16 q;
 #pragma unroll
   for (int r = 0; r < 16; ++r) q[r] = Wv[L::V_BFC + r * 2];
-  BMV_CHAIN1(L::A_FC, 16, BMV_MLP_G1, (aw[0] * g[0][t] + aw[1] * g[1][t] + aw[2] * g[2][t]), q)
+  BMV_CHAIN1(L::A_FC, 16, BMV_MLP_G1, (weighted_views<NV>(aw, g, t)), q)
   float im16[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) im16[r] = relu1(q[r]);
@@ -328,9 +362,9 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
              (t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : im16[t >= 36 ? t - 36 : 0]),
              csh[0], csh[1])
   // per-view part + color.2 + softmax over views (nerf.py:39-42)
-  float cl[3];
+  float cl[NV];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NV; ++i) {
     f32x16 hc[2] = {csh[0], csh[1]};
     BMV_CHAIN2(L::A_CV, KF, BMV_MLP_G2, fin[i][t], hc[0], hc[1])
     float s = 0.f;
@@ -341,18 +375,14 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
     cl[i] = fmaxf(xhalf_sum(s) + bc2, 0.f);
     BMV_FENCE();
   }
-  {
-    float m = fmaxf(cl[0], fmaxf(cl[1], cl[2]));
-    float e0 = __expf(cl[0] - m), e1 = __expf(cl[1] - m), e2 = __expf(cl[2] - m);
-    float inv = BMV_DIV(1.f, e0 + e1 + e2);
-    cl[0] = e0 * inv, cl[1] = e1 * inv, cl[2] = e2 * inv;
-  }
+  softmax_views<NV>(cl);
   // blend the sampled source colours: channels FEAT_CH + {0,1,2} sit at
   // (half 0, slot J), (half 1, slot J), (half 0, slot J+1) with J = FEAT_CH / 2
   constexpr int J = FEAT_CH / 2;
   static_assert(FEAT_CH % 2 == 0, "feat_ch must be even");
-  float pa = cl[0] * fin[0][J] + cl[1] * fin[1][J] + cl[2] * fin[2][J];
-  float pb = cl[0] * fin[0][J + 1] + cl[1] * fin[1][J + 1] + cl[2] * fin[2][J + 1];
+  float pa = cl[0] * fin[0][J], pb = cl[0] * fin[0][J + 1];
+#pragma unroll
+  for (int i = 1; i < NV; ++i) pa += cl[i] * fin[i][J], pb += cl[i] * fin[i][J + 1];
   float oa = __shfl_xor(pa, 32, 64), ob = __shfl_xor(pb, 32, 64);
   out[0] = h == 0 ? pa : oa;
   out[1] = h == 0 ? oa : pa;

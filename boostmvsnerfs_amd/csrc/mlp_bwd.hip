@@ -30,8 +30,9 @@ namespace bmv {
 __host__ __device__ constexpr int inv_reg(int rho) { return (rho & 3) + 4 * (rho >> 3); }
 __host__ __device__ constexpr int inv_half(int rho) { return (rho >> 2) & 1; }
 
-template <int FEAT_CH>
+template <int FEAT_CH, int NV = 3>
 struct MlpBwdLayout {
+  static_assert(NV >= 2 && NV <= 4, "source views per cost volume");
   using F = MlpLayout<FEAT_CH>;
   static constexpr int FC = F::FC, KFC = F::KFC, KF = F::KF;
   static constexpr int GSH_TILES = (2 * KFC + 15) / 16;  // 16 input slots (32 inputs) per tile
@@ -49,18 +50,20 @@ struct MlpBwdLayout {
   // rows of the per-tile matrices rows[tile][row][32] read by the weight-gradient kernel
   static constexpr int FCP = 2 * KFC;                          // padded channel rows per view
   static constexpr int INR = FCP + 4;                          // per-view input rows: channels (padded) + 4 dir
-  static constexpr int R_DH = 0;                               // d_pre color.0        3 x 64
-  static constexpr int R_DX = R_DH + 192;                      // d_pre lr0            64
+  static constexpr int R_DH = 0;                               // d_pre color.0        NV x 64
+  static constexpr int R_DX = R_DH + NV * 64;                  // d_pre lr0            64
   static constexpr int R_DFC = R_DX + 64;                      // d_pre agg.fc         16
-  static constexpr int R_DG = R_DFC + 16;                      // d_pre global_fc      3 x 32
-  static constexpr int R_DV = R_DG + 96;                       // d_pre view_fc        3 x FCP
-  static constexpr int R_DS = R_DV + 3 * FCP;                  // d_pre agg_w x3, sigma, color.2 x3  (7 of 8)
-  static constexpr int R_AX = R_DS + 8;                        // x = relu(lr0)        64
+  static constexpr int R_DG = R_DFC + 16;                      // d_pre global_fc      NV x 32
+  static constexpr int R_DV = R_DG + NV * 32;                  // d_pre view_fc        NV x FCP
+  static constexpr int R_DS = R_DV + NV * FCP;                 // d_pre agg_w x NV, sigma, color.2 x NV, one zero row
+  static constexpr int DS_ROWS = 2 * NV + 2;
+  static constexpr int DS_SIGMA = NV, DS_C2 = NV + 1;          // rows of R_DS: agg_w 0.., sigma, color.2 NV + 1..
+  static constexpr int R_AX = R_DS + DS_ROWS;                  // x = relu(lr0)        64
   static constexpr int R_AV24 = R_AX + 64;                     // vox 8 | relu(agg.fc) 16
   static constexpr int R_AIM = R_AV24 + 24;                    // sum_i w_i g_i        32
-  static constexpr int R_IN = R_AIM + 32;                      // per-view inputs      3 x INR
-  static constexpr int R_F = R_IN + 3 * INR;                   // f_i (Agg residual)   3 x FCP
-  static constexpr int R_VAR = R_F + 3 * FCP;                  // var | mean           2 x FCP
+  static constexpr int R_IN = R_AIM + 32;                      // per-view inputs      NV x INR
+  static constexpr int R_F = R_IN + NV * INR;                  // f_i (Agg residual)   NV x FCP
+  static constexpr int R_VAR = R_F + NV * FCP;                 // var | mean           2 x FCP
   static constexpr int R_TOTAL = R_VAR + 2 * FCP;
   static constexpr int IN_ROWS = INR;                          // d_img rows per view
   // 32x32 blocks of the weight-gradient partials (one workgroup writes NBLK blocks + NBB bias vectors of 64)
@@ -68,7 +71,7 @@ struct MlpBwdLayout {
   static constexpr int BLK_WC_SH = 0;                          // [tl 2][tb 3]  sum_i D_h x [x, vox|im16]
   static constexpr int BLK_WC_V = BLK_WC_SH + 6;               // [tl 2][NB_IN] sum_i D_h_i x in_i
   static constexpr int BLK_W0 = BLK_WC_V + 2 * NB_IN;          // [tl 2]        D_x x [vox|im16]
-  static constexpr int BLK_WS = BLK_W0 + 2;                    // [tb 2]        D_s x x      (row 3 = sigma weight)
+  static constexpr int BLK_WS = BLK_W0 + 2;                    // [tb 2]        D_s x x      (row DS_SIGMA = sigma weight)
   static constexpr int BLK_WFC = BLK_WS + 2;                   //               D_fc x im
   static constexpr int BLK_WV = BLK_WFC + 1;                   // [NB_F]        sum_i D_v_i x dir_i
   static constexpr int BLK_WG_V = BLK_WV + NB_F;               // [NB_F]        sum_i D_g_i x f_i
@@ -80,7 +83,7 @@ struct MlpBwdLayout {
 
 template <int FEAT_CH>
 __global__ void nerf_pack_bwd_kernel(bmv_nerf_params p, float* __restrict__ blob) {
-  using L = MlpBwdLayout<FEAT_CH>;
+  using L = MlpBwdLayout<FEAT_CH>;      // (the transposed tables do not depend on the number of views)
   constexpr int FC = L::FC, KFC = L::KFC, KF = L::KF, CW = 88 + FC + 4;
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L::TOTAL) return;
@@ -175,11 +178,11 @@ template <int FEAT_CH>
 struct BwdOut {
   float* rows;   // (ntiles, R_TOTAL, 32)
   float* d_vox;  // (8, P)
-  float* d_img;  // (3, IN_ROWS, P)
+  float* d_img;  // (NV, IN_ROWS, P)
   float* vecs;   // per wave of the grid [128]: 64 color.2 weight grad | 32 agg_w_fc weight grad | 32 unused
 };
 
-template <int FEAT_CH>
+template <int FEAT_CH, int NV>
 __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __restrict__ vox_feat,
                                                                const float* __restrict__ img,
                                                                const float* __restrict__ d_out,
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
                                                                const float* __restrict__ blob_bwd, long npts,
                                                                BwdOut<FEAT_CH> o) {
   using L = MlpLayout<FEAT_CH>;
-  using LB = MlpBwdLayout<FEAT_CH>;
+  using LB = MlpBwdLayout<FEAT_CH, NV>;
   constexpr int KFC = L::KFC, KF = L::KF;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                 // forward blob
@@ -219,15 +222,15 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     // rows past npts hold finite activations of the clamped sample and exactly-zero gradients (go = 0)
     auto put = [&](int row, float v) { rows[row * 32] = v; };
     // ------------------------------------------------------------------ inputs
-    float fin[3][KF], dir[3][4], vox[4];
+    float fin[NV][KF], dir[NV][4], vox[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       vox[j] = vox_feat[pc * 8 + 2 * j + h];
       put(LB::R_AV24 + 2 * j + h, vox[j]);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float* q = img + (pc * 3 + i) * L::IN;
+    for (int i = 0; i < NV; ++i) {
+      const float* q = img + (pc * NV + i) * L::IN;
 #pragma unroll
       for (int j = 0; j < KFC; ++j) fin[i][j] = (2 * j + h < L::FC) ? q[2 * j + h] : 0.f;
 #pragma unroll
@@ -252,19 +255,27 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     // ------------------------------------------------------------------ aggregation forward (mlp.hpp); run twice:
     // first for im16 (and the stored activations), again right before its own backward
     float mean[KFC];
-    f32x16 g[3];
-    float aw[3], apre[3];
+    f32x16 g[NV];
+    float aw[NV], apre[NV];
     auto agg_forward = [&](bool store) {
       float var[KFC];
 #pragma unroll
       for (int j = 0; j < KFC; ++j) {
-        float f0 = fval(0, j), f1 = fval(1, j), f2 = fval(2, j);
-        float m = (f0 + f1 + f2) / 3.f;
+        float f[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) f[i] = fval(i, j);
+        float m = f[0];
+#pragma unroll
+        for (int i = 1; i < NV; ++i) m += f[i];
+        m = m / (float)NV;
+        float ss = (f[0] - m) * (f[0] - m);
+#pragma unroll
+        for (int i = 1; i < NV; ++i) ss += (f[i] - m) * (f[i] - m);
         mean[j] = m;
-        var[j] = ((f0 - m) * (f0 - m) + (f1 - m) * (f1 - m) + (f2 - m) * (f2 - m)) * 0.5f;
+        var[j] = ss * (1.f / (float)(NV - 1));
         if (store) {
-          put(LB::R_F + 0 * LB::FCP + 2 * j + h, f0), put(LB::R_F + 1 * LB::FCP + 2 * j + h, f1);
-          put(LB::R_F + 2 * LB::FCP + 2 * j + h, f2);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) put(LB::R_F + i * LB::FCP + 2 * j + h, f[i]);
           put(LB::R_VAR + 2 * j + h, var[j]), put(LB::R_VAR + LB::FCP + 2 * j + h, m);
         }
         BMV_FENCE_EVERY(j, 6);
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int r = 0; r < 16; ++r) gsh[r] = Wv[L::V_BG + r * 2];
       mfma_chain<2 * KFC, 1, BMV_MLP_G1>(Wa + L::A_GSH, [&](int t) { return t < KFC ? var[t < KFC ? t : 0] : mean[t >= KFC ? t - KFC : 0]; }, &gsh);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         g[i] = gsh;
         mfma_chain<KFC, 1, BMV_MLP_G1>(Wa + L::A_GV, [&](int t) { return fval(i, t); }, &g[i]);
         float sdot = 0.f;
@@ -288,10 +299,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
         aw[i] = fmaxf(apre[i], 0.f);
         BMV_FENCE();
       }
-      float m = fmaxf(aw[0], fmaxf(aw[1], aw[2]));
-      float e0 = __expf(aw[0] - m), e1 = __expf(aw[1] - m), e2 = __expf(aw[2] - m);
-      float inv = 1.f / (e0 + e1 + e2);
-      aw[0] = e0 * inv, aw[1] = e1 * inv, aw[2] = e2 * inv;
+      softmax_views<NV>(aw);
     };
     float im16[8];
     {
@@ -299,7 +307,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       f32x16 im, q16;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        im[r] = aw[0] * g[0][r] + aw[1] * g[1][r] + aw[2] * g[2][r];
+        im[r] = weighted_views<NV>(aw, g, r);
         q16[r] = Wv[L::V_BFC + r * 2];
         put(LB::R_AIM + n16(r, h), im[r]);
       }
@@ -348,9 +356,9 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     }, csh);
     BMV_FENCE();
     // colour logits need all three views before the softmax backward: first pass keeps only c_i
-    float cl[3], cpre[3];
+    float cl[NV], cpre[NV];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NV; ++i) {
       f32x16 hc[2] = {csh[0], csh[1]};
       mfma_chain<KF, 2, BMV_MLP_G2>(Wa + L::A_CV, [&](int t) { return fin[i][t]; }, hc);
       float sdot = 0.f;
@@ -362,40 +370,35 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       cl[i] = fmaxf(cpre[i], 0.f);
       BMV_FENCE();
     }
-    {
-      float m = fmaxf(cl[0], fmaxf(cl[1], cl[2]));
-      float e0 = __expf(cl[0] - m), e1 = __expf(cl[1] - m), e2 = __expf(cl[2] - m);
-      float inv = 1.f / (e0 + e1 + e2);
-      cl[0] = e0 * inv, cl[1] = e1 * inv, cl[2] = e2 * inv;
-    }
+    softmax_views<NV>(cl);
 
     // ------------------------------------------------------------------ colour backward
     // rgb = sum_i cw_i rgb_i : the colour channels FEAT_CH+{0,1,2} sit at (half0, slot J), (half1, J), (half0, J+1)
     constexpr int J = FEAT_CH / 2;
     const float g_mine0 = h == 0 ? go[0] : go[1];  // gradient of the channel in slot J of this half
     const float g_mine1 = h == 0 ? go[2] : 0.f;    // slot J+1: blue (half 0) or padding (half 1)
-    float d_cpre[3];
+    float d_cpre[NV];
     {
-      float d_cw[3], dotc = 0.f;
+      float d_cw[NV], dotc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         d_cw[i] = xhalf_sum(g_mine0 * fin[i][J] + g_mine1 * fin[i][J + 1]);
         dotc += cl[i] * d_cw[i];
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         d_cpre[i] = cpre[i] > 0.f ? cl[i] * (d_cw[i] - dotc) : 0.f;
-        if (h == 0) put(LB::R_DS + 4 + i, d_cpre[i]);
+        if (h == 0) put(LB::R_DS + LB::DS_C2 + i, d_cpre[i]);
       }
-      if (h == 1) put(LB::R_DS + 7, 0.f);
+      if (h == 1) put(LB::R_DS + LB::DS_ROWS - 1, 0.f);
     }
     // per view: recompute hc_i, d_pre_h_i, its rows, the input gradient, and the running sum over views
     f32x16 dhs[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dhs[0][r] = dhs[1][r] = 0.f;
-    float d_in[3][KF];
+    float d_in[NV][KF];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NV; ++i) {
       f32x16 hc[2] = {csh[0], csh[1]};
       mfma_chain<KF, 2, BMV_MLP_G2>(Wa + L::A_CV, [&](int t) { return fin[i][t]; }, hc);
       f32x16 dh[2];
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     BMV_FENCE();
     // ------------------------------------------------------------------ sigma head and lr0 backward (x recomputed)
     const float d_sp = spre > 20.f ? go[3] : go[3] * (1.f / (1.f + __expf(-spre)));  // softplus' = sigmoid
-    if (h == 0) put(LB::R_DS + 3, d_sp);
+    if (h == 0) put(LB::R_DS + LB::DS_SIGMA, d_sp);
     f32x16 dv24;  // slots 0..3 vox, 4..11 im16
     {
       lr0_forward();
@@ -478,11 +481,11 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     agg_forward(false);
     // softmax over views of the aggregation weights, agg_w_fc, global_fc
     f32x16 dgs;
-    f32x16 dg[3];
+    f32x16 dg[NV];
     {
-      float d_w[3], dotw = 0.f;
+      float d_w[NV], dotw = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         float sdot = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sdot += dim[r] * g[i][r];
@@ -492,7 +495,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) dgs[r] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         float d_apre = apre[i] > 0.f ? aw[i] * (d_w[i] - dotw) : 0.f;
         if (h == 0) put(LB::R_DS + i, d_apre);
 #pragma unroll
@@ -516,7 +519,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
     mfma_chain<16, LB::GSH_TILES, BMV_MLP_G2>(Ta + LB::T_GSH, [&](int u) { return dgs[u]; }, dvm);
     BMV_FENCE();
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NV; ++i) {
       f32x16 dfv[LB::GV_TILES];
 #pragma unroll
       for (int tt = 0; tt < LB::GV_TILES; ++tt)
@@ -529,9 +532,9 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
       for (int j = 0; j < KFC; ++j) {
         float pv = pre_v(i, j);
         float fj = fin[i][j] + fmaxf(pv, 0.f);
-        // var = sum (f - m)^2 / 2, mean = sum f / 3
-        float d_f = dfv[j >> 4][j & 15] + dvm[j >> 4][j & 15] * (fj - mean[j]) +
-                    dvm[(KFC + j) >> 4][(KFC + j) & 15] * (1.f / 3.f);
+        // var = sum (f - m)^2 / (NV - 1), mean = sum f / NV
+        float d_f = dfv[j >> 4][j & 15] + dvm[j >> 4][j & 15] * ((fj - mean[j]) * (2.f / (float)(NV - 1))) +
+                    dvm[(KFC + j) >> 4][(KFC + j) & 15] * (1.f / (float)NV);
         if (valid) dimg[(long)(2 * j + h) * P] = d_in[i][j] + d_f;
         float d_pv = pv > 0.f ? d_f : 0.f;
         put(LB::R_DV + i * LB::FCP + 2 * j + h, d_pv);
@@ -573,10 +576,10 @@ __global__ void __launch_bounds__(256, 1) nerf_mlp_bwd_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: dW block (32 x 32) += A (32 rows x 64 samples) B^T (32 rows x 64 samples), samples = MFMA k.
 // ---------------------------------------------------------------------------------------------------------------
-template <int FEAT_CH>
+template <int FEAT_CH, int NV>
 __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restrict__ rows, long ntiles,
                                                              float* __restrict__ partials) {
-  using LB = MlpBwdLayout<FEAT_CH>;
+  using LB = MlpBwdLayout<FEAT_CH, NV>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, kk = lane >> 5;
   const long npairs = (ntiles + 1) / 2;
@@ -630,7 +633,7 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
       const long tile = 2 * pair + kk;
       float asum[32], a[32], b[32];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         load(tile, LB::R_DH + i * 64 + tl * 32, 32, a);
 #pragma unroll
         for (int bb = 0; bb < LB::NB_IN; ++bb) {
@@ -669,7 +672,7 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
         mm(a, b, acc_w0[tl]);
         bias_dx[tl] += rowsum(a);
       }
-      load(tile, LB::R_DS, 8, a);
+      load(tile, LB::R_DS, LB::DS_ROWS, a);
       bias_ds += rowsum(a);
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
@@ -681,7 +684,7 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
       mm(a, b, acc_fc);
       bias_fc += rowsum(a);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         load(tile, LB::R_IN + i * LB::INR + LB::FCP, 4, b);
 #pragma unroll
         for (int ab = 0; ab < LB::NB_F; ++ab) {
@@ -710,7 +713,7 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
       const long tile = 2 * pair + kk;
       float asum[32], a[32], b[32];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NV; ++i) {
         load(tile, LB::R_DG + i * 32, 32, a);
 #pragma unroll
         for (int bb = 0; bb < LB::NB_F; ++bb) {
@@ -738,10 +741,10 @@ __global__ void __launch_bounds__(256, 1) nerf_wgrad_kernel(const float* __restr
 // Eight consecutive lanes per parameter-gradient element: where it sits in a partial (up to 3 places for the summed
 // 1-wide biases), the workgroups' partials summed in a fixed order (lane q takes partials q, q + 8, ...; then a
 // 3-step butterfly), so the result does not depend on scheduling.
-template <int FEAT_CH>
+template <int FEAT_CH, int NV>
 __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ vecs,
                                          int nvecs, bmv_nerf_grads g) {
-  using LB = MlpBwdLayout<FEAT_CH>;
+  using LB = MlpBwdLayout<FEAT_CH, NV>;
   constexpr int FC = LB::FC, FCP = LB::FCP, CW = 88 + FC + 4;
   constexpr int N_VW = FC * 4, N_VB = FC, N_GW = 32 * 3 * FC, N_GB = 32, N_AW = 32, N_AB = 1, N_FW = 16 * 32, N_FB = 16,
                 N_0W = 64 * 24, N_0B = 64, N_SW = 64, N_SB = 1, N_CW = 64 * CW, N_CB = 64, N_2W = 64, N_2B = 1;
@@ -749,7 +752,7 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   auto blk = [](int b, int mm, int nn) { return b * 1024 + mm * 32 + nn; };
   auto bias = [](int bb, int mm) { return LB::NBLK * 1024 + bb * 64 + mm; };   // + 32 for the other sample half
   float* dst = nullptr;
-  int src[3] = {-1, -1, -1};
+  int src[4] = {-1, -1, -1, -1};
   bool is_bias = false;
   int vec = -1;
   int e = idx;
@@ -772,7 +775,9 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   } else if ((e -= N_GB) < N_AW) {
     dst = g.agg_w_w + e, vec = 64 + e;
   } else if ((e -= N_AW) < N_AB) {
-    dst = g.agg_w_b, src[0] = bias(LB::BB_DS, 0), src[1] = bias(LB::BB_DS, 1), src[2] = bias(LB::BB_DS, 2), is_bias = true;
+    dst = g.agg_w_b, is_bias = true;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) src[i] = bias(LB::BB_DS, i);
   } else if ((e -= N_AB) < N_FW) {
     dst = g.fc_w + e, src[0] = blk(LB::BLK_WFC, e / 32, e % 32);
   } else if ((e -= N_FW) < N_FB) {
@@ -783,9 +788,9 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   } else if ((e -= N_0W) < N_0B) {
     dst = g.lr0_b + e, src[0] = bias(LB::BB_DX + e / 32, e % 32), is_bias = true;
   } else if ((e -= N_0B) < N_SW) {
-    dst = g.sigma_w + e, src[0] = blk(LB::BLK_WS + e / 32, 3, e % 32);
+    dst = g.sigma_w + e, src[0] = blk(LB::BLK_WS + e / 32, LB::DS_SIGMA, e % 32);
   } else if ((e -= N_SW) < N_SB) {
-    dst = g.sigma_b, src[0] = bias(LB::BB_DS, 3), is_bias = true;
+    dst = g.sigma_b, src[0] = bias(LB::BB_DS, LB::DS_SIGMA), is_bias = true;
   } else if ((e -= N_SB) < N_CW) {
     int n = e / CW, k = e % CW, tl = n / 32;
     dst = g.color0_w + e;
@@ -800,7 +805,9 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
   } else if ((e -= N_CB) < N_2W) {
     dst = g.color2_w + e, vec = e;
   } else if ((e -= N_2W) < N_2B) {
-    dst = g.color2_b, src[0] = bias(LB::BB_DS, 4), src[1] = bias(LB::BB_DS, 5), src[2] = bias(LB::BB_DS, 6), is_bias = true;
+    dst = g.color2_b, is_bias = true;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) src[i] = bias(LB::BB_DS, LB::DS_C2 + i);
   } else {
     return;
   }
@@ -815,7 +822,7 @@ __global__ void nerf_wgrad_finish_kernel(const float* __restrict__ partials, int
     for (int w = sub; w < nparts; w += 8) {
       const float* p = partials + (long)w * LB::PART;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 4; ++q)
         if (src[q] >= 0) acc += p[src[q]] + (is_bias ? p[src[q] + 32] : 0.f);
     }
     acc += __shfl_xor(acc, 1, 64);
@@ -833,17 +840,17 @@ namespace {
 constexpr int kWgradGrid = 256;   // one workgroup per CU (the kernel takes > 256 registers)
 constexpr int kBwdGrid = 256;     // workgroups of the data-path kernel (4 waves each write a 128-float head partial)
 
-template <int FC>
+template <int FC, int NV>
 long workspace_floats(long npts) {
-  using LB = MlpBwdLayout<FC>;
+  using LB = MlpBwdLayout<FC, NV>;
   long ntiles = (npts + 31) / 32;
   return ntiles * (long)LB::R_TOTAL * 32 + (long)kWgradGrid * LB::PART + (long)kBwdGrid * 4 * 128;
 }
 
-template <int FC>
+template <int FC, int NV>
 int run_bwd(const float* vox_feat, const float* img, const float* d_out, const float* blob_fwd, const float* blob_bwd,
             long npts, float* ws, float* d_vox, float* d_img, const bmv_nerf_grads* grads, hipStream_t st) {
-  using LB = MlpBwdLayout<FC>;
+  using LB = MlpBwdLayout<FC, NV>;
   const long ntiles = (npts + 31) / 32;
   float* rows = ws;
   float* partials = rows + ntiles * (long)LB::R_TOTAL * 32;
@@ -852,21 +859,30 @@ int run_bwd(const float* vox_feat, const float* img, const float* d_out, const f
   // did not reliably clear it on later replays; since round 5 every wave writes its own partial, nothing to clear)
   const unsigned grid = (unsigned)((ntiles + 3) / 4 < kBwdGrid ? (ntiles + 3) / 4 : kBwdGrid);
   const size_t lds = (size_t)(MlpLayout<FC>::TOTAL + LB::TOTAL) * 4;
-  BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC>),
+  BMV_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel<FC, NV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
               "bmv_nerf_mlp_bwd: cannot reserve %zu B of LDS", lds);
   BwdOut<FC> o{rows, d_vox, d_img, vecs};
-  hipLaunchKernelGGL(nerf_mlp_bwd_kernel<FC>, dim3(grid), dim3(256), lds, st, vox_feat, img, d_out, blob_fwd, blob_bwd,
+  hipLaunchKernelGGL((nerf_mlp_bwd_kernel<FC, NV>), dim3(grid), dim3(256), lds, st, vox_feat, img, d_out, blob_fwd, blob_bwd,
                      npts, o);
   const long npairs = (ntiles + 1) / 2;
   const int nparts = (int)(npairs < kWgradGrid ? npairs : kWgradGrid);
-  hipLaunchKernelGGL(nerf_wgrad_kernel<FC>, dim3(nparts), dim3(256), 0, st, rows, ntiles, partials);
+  hipLaunchKernelGGL((nerf_wgrad_kernel<FC, NV>), dim3(nparts), dim3(256), 0, st, rows, ntiles, partials);
   constexpr int F = FC + 3;
   constexpr int total = F * 4 + F + 32 * 3 * F + 32 + 32 + 1 + 16 * 32 + 16 + 64 * 24 + 64 + 64 + 1 + 64 * (88 + F + 4) + 64 + 64 + 1;
-  hipLaunchKernelGGL(nerf_wgrad_finish_kernel<FC>, dim3(cdiv((long)total * 8, 256)), dim3(256), 0, st, partials, nparts, vecs,
-                     (int)grid * 4, *grads);
+  hipLaunchKernelGGL((nerf_wgrad_finish_kernel<FC, NV>), dim3(cdiv((long)total * 8, 256)), dim3(256), 0, st, partials, nparts,
+                     vecs, (int)grid * 4, *grads);
   BMV_LAUNCH_END("bmv_nerf_mlp_bwd");
 }
+
+// (feat_ch, S) -> the instantiation: feat_ch in {8, 32} x S in {2, 3, 4} source views
+#define BMV_MLP_BWD_DISPATCH(EXPR)                  \
+  if (feat_ch == 8 && S == 3) return EXPR(8, 3);    \
+  if (feat_ch == 32 && S == 3) return EXPR(32, 3);  \
+  if (feat_ch == 8 && S == 2) return EXPR(8, 2);    \
+  if (feat_ch == 32 && S == 2) return EXPR(32, 2);  \
+  if (feat_ch == 8 && S == 4) return EXPR(8, 4);    \
+  if (feat_ch == 32 && S == 4) return EXPR(32, 4);
 }  // namespace
 
 extern "C" {
@@ -878,27 +894,23 @@ int bmv_nerf_bwd_blob_size(int feat_ch) {
   return BMV_ERR_UNSUPPORTED;
 }
 
-int bmv_nerf_bwd_rows(int feat_ch, int* d_img_rows) {
-  if (feat_ch == 8) {
-    if (d_img_rows) *d_img_rows = MlpBwdLayout<8>::IN_ROWS;
-    return MlpBwdLayout<8>::R_TOTAL;
-  }
-  if (feat_ch == 32) {
-    if (d_img_rows) *d_img_rows = MlpBwdLayout<32>::IN_ROWS;
-    return MlpBwdLayout<32>::R_TOTAL;
-  }
-  set_error("bmv_nerf_bwd_rows: feat_ch=%d unsupported (8 or 32)", feat_ch);
+int bmv_nerf_bwd_rows(int feat_ch, int S, int* d_img_rows) {
+#define ROWS(FC, NVV) ((d_img_rows ? (void)(*d_img_rows = MlpBwdLayout<FC, NVV>::IN_ROWS) : (void)0), MlpBwdLayout<FC, NVV>::R_TOTAL)
+  BMV_MLP_BWD_DISPATCH(ROWS)
+#undef ROWS
+  set_error("bmv_nerf_bwd_rows: feat_ch=%d (8 or 32) with S=%d source views (2, 3 or 4) unsupported", feat_ch, S);
   return BMV_ERR_UNSUPPORTED;
 }
 
-long bmv_nerf_bwd_workspace(int feat_ch, long npts) {
+long bmv_nerf_bwd_workspace(int feat_ch, int S, long npts) {
   if (npts < 0) {
     set_error("bmv_nerf_bwd_workspace: npts=%ld", npts);
     return BMV_ERR_INVALID;
   }
-  if (feat_ch == 8) return workspace_floats<8>(npts);
-  if (feat_ch == 32) return workspace_floats<32>(npts);
-  set_error("bmv_nerf_bwd_workspace: feat_ch=%d unsupported (8 or 32)", feat_ch);
+#define WSF(FC, NVV) workspace_floats<FC, NVV>(npts)
+  BMV_MLP_BWD_DISPATCH(WSF)
+#undef WSF
+  set_error("bmv_nerf_bwd_workspace: feat_ch=%d (8 or 32) with S=%d source views (2, 3 or 4) unsupported", feat_ch, S);
   return BMV_ERR_UNSUPPORTED;
 }
 
@@ -918,7 +930,7 @@ int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* p, int feat_ch, float* blob
 }
 
 int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img, const float* d_out, const float* blob_fwd,
-                     const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
+                     const float* blob_bwd, int feat_ch, int S, long npts, float* workspace, float* d_vox, float* d_img,
                      const bmv_nerf_grads* grads, bmv_stream_t stream) {
   BMV_REQUIRE(vox_feat && img && d_out && blob_fwd && blob_bwd && workspace && d_vox && d_img && grads,
               "bmv_nerf_mlp_bwd: null pointer");
@@ -927,11 +939,11 @@ int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img, const float* d_out
                   grads->sigma_b && grads->color0_w && grads->color0_b && grads->color2_w && grads->color2_b,
               "bmv_nerf_mlp_bwd: null gradient pointer");
   BMV_REQUIRE(npts > 0, "bmv_nerf_mlp_bwd: npts=%ld", npts);
-  if (feat_ch == 8)
-    return run_bwd<8>(vox_feat, img, d_out, blob_fwd, blob_bwd, npts, workspace, d_vox, d_img, grads, as_stream(stream));
-  if (feat_ch == 32)
-    return run_bwd<32>(vox_feat, img, d_out, blob_fwd, blob_bwd, npts, workspace, d_vox, d_img, grads, as_stream(stream));
-  set_error("bmv_nerf_mlp_bwd: feat_ch=%d unsupported (8 or 32)", feat_ch);
+#define RUN(FC, NVV) \
+  run_bwd<FC, NVV>(vox_feat, img, d_out, blob_fwd, blob_bwd, npts, workspace, d_vox, d_img, grads, as_stream(stream))
+  BMV_MLP_BWD_DISPATCH(RUN)
+#undef RUN
+  set_error("bmv_nerf_mlp_bwd: feat_ch=%d (8 or 32) with S=%d source views (2, 3 or 4) unsupported", feat_ch, S);
   return BMV_ERR_UNSUPPORTED;
 }
 

@@ -16,12 +16,13 @@
 
 namespace bmv {
 
+constexpr int kMaxViews = 4;   // source views per cost volume: 2, 3, 4 (dtu_pretrain.yaml:22-23)
 struct RenderCams {
-  Cam cam[3];
+  Cam cam[kMaxViews];
   float tar_c[4];
 };
 
-template <int FEAT_CH>
+template <int FEAT_CH, int NV>
 __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
                                                            const float* __restrict__ img,
                                                            const float* __restrict__ blob, long npts,
@@ -38,12 +39,12 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
     long pt = tile * 32 + s;
     bool valid = pt < npts;
     long p = valid ? pt : npts - 1;
-    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    float fin[NV][L::KF], dir[NV][4], vox[4], res[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vox[j] = vox_feat[p * 8 + 2 * j + h];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float* q = img + (p * 3 + i) * L::IN;
+    for (int i = 0; i < NV; ++i) {
+      const float* q = img + (p * NV + i) * L::IN;
 #pragma unroll
       for (int j = 0; j < L::KFC; ++j) fin[i][j] = (2 * j + h < L::FC) ? q[2 * j + h] : 0.f;
 #pragma unroll
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) dir[i][k] = q[L::FC + k];
     }
-    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    mlp_forward<FEAT_CH, NV>(lds, lane, fin, dir, vox, res);
     if (valid && h == 0) {
       float4 o = {res[0], res[1], res[2], res[3]};
       reinterpret_cast<float4*>(out)[pt] = o;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void resolve_deferred(RenderArgsDev& a) {
   }
 }
 
-template <int FEAT_CH, int NS, bool INV, int PK = 0>
+template <int FEAT_CH, int NS, bool INV, int PK = 0, int NV = 3>
 #ifndef BMV_RENDER_WPS
 #define BMV_RENDER_WPS 2   // workgroups (= waves per SIMD) resident per CU
 #endif
@@ -94,10 +95,10 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
     reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
-  if (threadIdx.x < 3)
-    load_cam(a.src_exts + ((size_t)b * 3 + threadIdx.x) * 16, a.src_ixts + ((size_t)b * 3 + threadIdx.x) * 9,
+  if (threadIdx.x < NV)
+    load_cam(a.src_exts + ((size_t)b * NV + threadIdx.x) * 16, a.src_ixts + ((size_t)b * NV + threadIdx.x) * 9,
              a.render_scale, rc->cam[threadIdx.x]);
-  if (threadIdx.x == 3) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
+  if (threadIdx.x == NV) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -113,11 +114,11 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
 
   // buffer descriptors of the gathered tensors (wave-uniform, built once): loads are descriptor + 32-bit offsets
   const __amdgpu_buffer_rsrc_t rs_vol = make_rsrc(vol, (size_t)8 * a.Dv * hwv * 4);
-  __amdgpu_buffer_rsrc_t rs_f[3], rs_c[3];
+  __amdgpu_buffer_rsrc_t rs_f[NV], rs_c[NV];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    // source view i of this cost volume: slot i, or view_ids[b*3 + i] of tensors that hold all n_all views
-    const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
+  for (int i = 0; i < NV; ++i) {
+    // source view i of this cost volume: slot i, or view_ids[b*NV + i] of tensors that hold all n_all views
+    const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * NV + i] : (size_t)b * NV + i;
     if constexpr (PK != 0) {
       rs_f[i] = make_rsrc(a.im_packed + vslot * 12 * plane, (size_t)12 * plane * 4);   // 48-byte records
       rs_c[i] = rs_f[i];
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
     float z, xyz[3], dn;
     sample_point(o, d, rn, rf, vn, vf, k, NS, INV, z, xyz, dn);
 
-    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    float fin[NV][L::KF], dir[NV][4], vox[4], res[4];
     RSTAMP(1)
     {  // a9: trilinear lookup, this half's 4 channels
       Taps3 t3 = taps3_zeros(BMV_DIV(px, inv_w), BMV_DIV(py, inv_h), dn, a.wv, a.hv, a.Dv);
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
     RSTAMP(2)
     float vis = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
+    for (int i = 0; i < NV; ++i) {  // a10 (+ a14)
       const Cam& cam = rc->cam[i];
       Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
       if constexpr (PK != 0) {
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
     }
 
     RSTAMP(3)
-    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    mlp_forward<FEAT_CH, NV>(lds, lane, fin, dir, vox, res);
     RSTAMP(4)
 #ifdef BMV_RENDER_STAMPS
     if (tile_no == 2 && lane == 0 && blockIdx.x < 512) {
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
         float4 o4 = {res[0], res[1], res[2], res[3]};
         reinterpret_cast<float4*>(a.out0)[pt] = o4;
         a.out1[pt] = z;
-        a.out2[pt] = vis / 3.f;
+        a.out2[pt] = vis / (float)NV;
       }
       continue;
     }
@@ -331,7 +332,9 @@ __global__ void __launch_bounds__(256, BMV_RENDER_WPS) render_rays_kernel(Render
 #ifndef BMV_RENDER_PC_GATHER
 #define BMV_RENDER_PC_GATHER 4   // gather waves per workgroup: 4 (one per SIMD, 168 registers) or 8 (two, 128 registers)
 #endif
-constexpr int kPcMlp = 8, kPcGather = BMV_RENDER_PC_GATHER, kPcBox = 36;   // waves per role, dwords per MLP lane of a mailbox
+constexpr int kPcMlp = 8, kPcGather = BMV_RENDER_PC_GATHER;   // waves per role
+// dwords per MLP lane of a mailbox: fin[NV][6], dir[NV][4], vox[4], z, visibility
+constexpr int pc_box(int nv) { return 10 * nv + 6; }
 
 #ifdef BMV_RENDER_PC_COUNT
 __device__ unsigned long long g_pc_spins[4];   // tuning: polls that found the flag not ready / waits, per role
@@ -362,7 +365,7 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
   return false;
 }
 
-template <int NS, bool INV>
+template <int NS, bool INV, int NV>
 __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(RenderArgsDev a) {
   resolve_deferred(a);
   constexpr int FEAT_CH = 8;
@@ -370,6 +373,8 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
   static_assert(32 % NS == 0, "samples per ray must divide 32");
   static_assert(L::KFC == 6 && L::KF == 8, "mailbox layout: 6 feature / colour slots + 2 direction slots per view");
   static_assert(kPcGather == 4 || kPcGather == 8, "pair p goes to MLP waves 2 (p % 4), 2 (p % 4) + 1");
+  // mailbox rows: [0, 6 NV) fin, [6 NV, 10 NV) dir, then vox[4], z, visibility
+  constexpr int kPcBox = pc_box(NV), B_DIR = 6 * NV, B_VOX = 10 * NV, B_Z = 10 * NV + 4, B_VIS = 10 * NV + 5;
   constexpr int RAYS_PER_TILE = 32 / NS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   RenderCams* rc = reinterpret_cast<RenderCams*>(lds + L::TOTAL);
@@ -380,10 +385,10 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
     reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
-  if (threadIdx.x < 3)
-    load_cam(a.src_exts + ((size_t)b * 3 + threadIdx.x) * 16, a.src_ixts + ((size_t)b * 3 + threadIdx.x) * 9,
+  if (threadIdx.x < NV)
+    load_cam(a.src_exts + ((size_t)b * NV + threadIdx.x) * 16, a.src_ixts + ((size_t)b * NV + threadIdx.x) * 9,
              a.render_scale, rc->cam[threadIdx.x]);
-  if (threadIdx.x == 3) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
+  if (threadIdx.x == NV) camera_centre(a.tar_ext + (size_t)b * 16, rc->tar_c);
   if (threadIdx.x >= 64 && threadIdx.x < 64 + 16) flags[threadIdx.x - 64] = 0;
   __syncthreads();
 
@@ -411,10 +416,10 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
     const float* nf = a.near_far + b * 2 * hwv;
     const float* vol = a.volume + (size_t)b * 8 * a.Dv * hwv;
     const __amdgpu_buffer_rsrc_t rs_vol = make_rsrc(vol, (size_t)8 * a.Dv * hwv * 4);
-    __amdgpu_buffer_rsrc_t rs_f[3];
+    __amdgpu_buffer_rsrc_t rs_f[NV];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * 3 + i] : (size_t)b * 3 + i;
+    for (int i = 0; i < NV; ++i) {
+      const size_t vslot = a.view_ids ? (size_t)b * a.n_all + a.view_ids[b * NV + i] : (size_t)b * NV + i;
       rs_f[i] = make_rsrc(a.im_packed + vslot * 12 * plane, (size_t)12 * plane * 4);   // 48-byte records
     }
     for (int p = g; 2 * p < njobs; p += kPcGather) {
@@ -466,14 +471,15 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
           if (kk == 3) BMV_FENCE();
         }
         if (job) {
-          box[30 * 64] = e.x, box[31 * 64] = e.y, box[32 * 64] = e.z, box[33 * 64] = e.w;
-          box[30 * 64 + 32] = od.x, box[31 * 64 + 32] = od.y, box[32 * 64 + 32] = od.z, box[33 * 64 + 32] = od.w;
+          float* bv = box + B_VOX * 64;
+          bv[0 * 64] = e.x, bv[1 * 64] = e.y, bv[2 * 64] = e.z, bv[3 * 64] = e.w;
+          bv[0 * 64 + 32] = od.x, bv[1 * 64 + 32] = od.y, bv[2 * 64 + 32] = od.z, bv[3 * 64 + 32] = od.w;
         }
       }
       BMV_FENCE();
       float vis = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {  // a10 (+ a14)
+      for (int i = 0; i < NV; ++i) {  // a10 (+ a14)
         const Cam& cam = rc->cam[i];
         Taps2 t2 = project_taps(cam, xyz, a.Wr, a.Hr);
         const unsigned ob[4] = {(unsigned)t2.o00 * 48u, (unsigned)t2.o01 * 48u, (unsigned)t2.o10 * 48u, (unsigned)t2.o11 * 48u};
@@ -503,15 +509,15 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
           bx[0 * 64] = ve.x, bx[1 * 64] = ve.y, bx[2 * 64] = ve.z, bx[3 * 64] = ve.w, bx[4 * 64] = cr, bx[5 * 64] = cb;
           bx[0 * 64 + 32] = vo.x, bx[1 * 64 + 32] = vo.y, bx[2 * 64 + 32] = vo.z, bx[3 * 64 + 32] = vo.w;
           bx[4 * 64 + 32] = cg, bx[5 * 64 + 32] = 0.f;
-          float* bd = box + (18 + i * 4) * 64;
+          float* bd = box + (B_DIR + i * 4) * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q) bd[q * 64] = dirv[q], bd[q * 64 + 32] = dirv[q];
         }
         BMV_FENCE();
       }
       if (job) {
-        box[34 * 64] = z, box[34 * 64 + 32] = z;
-        box[35 * 64] = vis, box[35 * 64 + 32] = vis;
+        box[B_Z * 64] = z, box[B_Z * 64 + 32] = z;
+        box[B_VIS * 64] = vis, box[B_VIS * 64 + 32] = vis;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (job && s == 0 && !(g_pc_inject && blockIdx.x == 0 && blockIdx.y == 0 && p == 0)) *flag = seq + 1;
@@ -530,24 +536,24 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
     const int tile = (int)blockIdx.x + (int)gridDim.x * j;
     int ray = a.ray_begin + tile * RAYS_PER_TILE + s / NS;
     bool valid = ray < a.ray_end;
-    float fin[3][L::KF], dir[3][4], vox[4], res[4];
+    float fin[NV][L::KF], dir[NV][4], vox[4], res[4];
     bool ok = pc_wait(flag, seq + 1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NV; ++i) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) fin[i][q] = box[(i * 6 + q) * 64];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dir[i][q] = box[(18 + i * 4 + q) * 64];
+      for (int q = 0; q < 4; ++q) dir[i][q] = box[(B_DIR + i * 4 + q) * 64];
       fin[i][L::KFC] = h ? dir[i][1] : dir[i][0];
       fin[i][L::KFC + 1] = h ? dir[i][3] : dir[i][2];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vox[q] = box[(30 + q) * 64];
-    const float z = box[34 * 64];
-    const float vis = box[35 * 64];
+    for (int q = 0; q < 4; ++q) vox[q] = box[(B_VOX + q) * 64];
+    const float z = box[B_Z * 64];
+    const float vis = box[B_VIS * 64];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *flag = seq + 2;     // the next producer may refill while this tile runs through the MLP
-    mlp_forward<FEAT_CH>(lds, lane, fin, dir, vox, res);
+    mlp_forward<FEAT_CH, NV>(lds, lane, fin, dir, vox, res);
     if (!ok) res[0] = res[1] = res[2] = res[3] = __builtin_nanf("");   // protocol error: loud, not silent
 
     if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
@@ -556,7 +562,7 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
         float4 o4 = {res[0], res[1], res[2], res[3]};
         reinterpret_cast<float4*>(a.out0)[pt] = o4;
         a.out1[pt] = z;
-        a.out2[pt] = vis / 3.f;
+        a.out2[pt] = vis / (float)NV;
       }
       continue;
     }
@@ -672,28 +678,30 @@ int bmv_nerf_pack_weights(const bmv_nerf_params* p, int feat_ch, float* blob, bm
   BMV_LAUNCH_END("bmv_nerf_pack_weights");
 }
 
-int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob, int feat_ch, long npts, float* out,
-                     bmv_stream_t stream) {
+int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob, int feat_ch, int S, long npts,
+                     float* out, bmv_stream_t stream) {
   BMV_REQUIRE(vox_feat && img && blob && out, "bmv_nerf_mlp_fwd: null pointer");
   BMV_REQUIRE(npts >= 0, "bmv_nerf_mlp_fwd: npts=%ld", npts);
   if (npts == 0) return BMV_OK;
   long ntiles = (npts + 31) / 32;
   unsigned grid = (unsigned)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
-  if (feat_ch == 8) {
-    size_t lds = MlpLayout<8>::TOTAL * 4;
-    BMV_REQUIRE(set_lds(nerf_mlp_kernel<8>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(nerf_mlp_kernel<8>, dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts,
-                       out);
-  } else if (feat_ch == 32) {
-    size_t lds = MlpLayout<32>::TOTAL * 4;
-    BMV_REQUIRE(set_lds(nerf_mlp_kernel<32>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(nerf_mlp_kernel<32>, dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts,
-                       out);
-  } else {
-    set_error("bmv_nerf_mlp_fwd: feat_ch=%d unsupported (8 or 32)", feat_ch);
-    return BMV_ERR_UNSUPPORTED;
+#define MLP_CASE(FC, NVV)                                                                                            \
+  if (feat_ch == FC && S == NVV) {                                                                                   \
+    size_t lds = MlpLayout<FC>::TOTAL * 4;                                                                           \
+    BMV_REQUIRE(set_lds(nerf_mlp_kernel<FC, NVV>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);  \
+    hipLaunchKernelGGL((nerf_mlp_kernel<FC, NVV>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, \
+                       npts, out);                                                                                   \
+    BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
   }
-  BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
+  MLP_CASE(8, 3)
+  MLP_CASE(32, 3)
+  MLP_CASE(8, 2)
+  MLP_CASE(32, 2)
+  MLP_CASE(8, 4)
+  MLP_CASE(32, 4)
+#undef MLP_CASE
+  set_error("bmv_nerf_mlp_fwd: feat_ch=%d (8 or 32) with S=%d source views (2, 3 or 4) unsupported", feat_ch, S);
+  return BMV_ERR_UNSUPPORTED;
 }
 
 // workgroups of the fused renderer: 2 are resident per CU (launch bounds), tiles are walked grid-stride
@@ -708,7 +716,7 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   BMV_REQUIRE(a->rays && a->depth && a->std && a->near_far && a->volume && (a->im_packed || (a->im_feat && a->rgb_src)) &&
                   a->src_exts && a->src_ixts && a->tar_ext && a->blob && a->out0 && a->out1 && a->out2,
               "bmv_render_rays_fwd: null pointer");
-  BMV_REQUIRE(a->S == 3, "bmv_render_rays_fwd: S=%d, the MLP is built for 3 source views", a->S);
+  BMV_REQUIRE(a->S >= 2 && a->S <= kMaxViews, "bmv_render_rays_fwd: S=%d source views (2, 3 or 4)", a->S);
   BMV_REQUIRE(a->B > 0 && a->N > 0 && a->hv > 0 && a->wv > 0 && a->Dv > 0 && a->Hr > 1 && a->Wr > 1,
               "bmv_render_rays_fwd: bad shape");
   BMV_REQUIRE(a->ray_begin >= 0 && a->ray_end <= a->N && a->ray_begin <= a->ray_end,
@@ -729,61 +737,72 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   }
   // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
   const bool use_pc = bmv::tuning("BMV_RENDER_PC", 1) != 0;
-#define RENDER_CASE_PC(NSV)                                                                                          \
-  if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0) {            \
-    size_t lds = MlpLayout<8>::TOTAL * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * kPcBox * 64 * 4;           \
-    BMV_REQUIRE(set_lds(render_pc_kernel<NSV, false>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");        \
+#define RENDER_CASE_PC(NSV, NVV)                                                                                     \
+  if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0 && a->S == NVV) { \
+    size_t lds = MlpLayout<8>::TOTAL * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(NVV) * 64 * 4;          \
+    BMV_REQUIRE(set_lds(render_pc_kernel<NSV, false, NVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");    \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u)); \
     unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;                                        \
-    hipLaunchKernelGGL((render_pc_kernel<NSV, false>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,      \
+    hipLaunchKernelGGL((render_pc_kernel<NSV, false, NVV>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds, \
                        as_stream(stream), dev);                                                                      \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
-  RENDER_CASE_PC(2)
-  RENDER_CASE_PC(1)
-  RENDER_CASE_PC(4)
-  RENDER_CASE_PC(8)
+  RENDER_CASE_PC(2, 3)
+  RENDER_CASE_PC(1, 3)
+  RENDER_CASE_PC(4, 3)
+  RENDER_CASE_PC(8, 3)
+  RENDER_CASE_PC(2, 2)      // 2 / 4 source views (ENeRF pre-training, dtu_pretrain.yaml:22-23): the shipped sample counts
+  RENDER_CASE_PC(2, 4)
 #undef RENDER_CASE_PC
-#define RENDER_CASE_PK(FC, NSV, INVV, PKV)                                                                          \
-  if (a->im_packed && (a->vol_packed ? 3 : 1) == PKV && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) { \
+#define RENDER_CASE_PK(FC, NSV, INVV, PKV, NVV)                                                                     \
+  if (a->im_packed && (a->vol_packed ? 3 : 1) == PKV && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV && \
+      a->S == NVV) {                                                                                                \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
-    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, PKV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
+    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, PKV, NVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
-    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, PKV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, PKV, NVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
-  RENDER_CASE_PK(8, 2, false, 1)
-  RENDER_CASE_PK(8, 2, false, 3)
-  RENDER_CASE_PK(8, 1, false, 1)
-  RENDER_CASE_PK(8, 1, false, 3)
-  RENDER_CASE_PK(8, 4, false, 1)
-  RENDER_CASE_PK(8, 4, false, 3)
-  RENDER_CASE_PK(8, 8, false, 1)
-  RENDER_CASE_PK(8, 8, false, 3)
+  RENDER_CASE_PK(8, 2, false, 1, 3)
+  RENDER_CASE_PK(8, 2, false, 3, 3)
+  RENDER_CASE_PK(8, 1, false, 1, 3)
+  RENDER_CASE_PK(8, 1, false, 3, 3)
+  RENDER_CASE_PK(8, 4, false, 1, 3)
+  RENDER_CASE_PK(8, 4, false, 3, 3)
+  RENDER_CASE_PK(8, 8, false, 1, 3)
+  RENDER_CASE_PK(8, 8, false, 3, 3)
+  RENDER_CASE_PK(8, 2, false, 1, 2)
+  RENDER_CASE_PK(8, 2, false, 3, 2)
+  RENDER_CASE_PK(8, 2, false, 1, 4)
+  RENDER_CASE_PK(8, 2, false, 3, 4)
 #undef RENDER_CASE_PK
   BMV_REQUIRE(!a->im_packed && !a->vol_packed,
-              "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d (volume records: %d)",
-              a->feat_ch, a->Ns, a->depth_inv, a->vol_packed);
-#define RENDER_CASE(FC, NSV, INVV)                                                                                  \
-  if (a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV) {                                            \
+              "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d S=%d (volume records: %d)",
+              a->feat_ch, a->Ns, a->depth_inv, a->S, a->vol_packed);
+#define RENDER_CASE(FC, NSV, INVV, NVV)                                                                             \
+  if (a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV && a->S == NVV) {                             \
     size_t lds = MlpLayout<FC>::TOTAL * 4 + sizeof(RenderCams);                                                     \
-    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");   \
+    BMV_REQUIRE(set_lds(render_rays_kernel<FC, NSV, INVV, 0, NVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS"); \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     unsigned grid = (unsigned)((ntiles + 3) / 4 < kRenderGrid ? (ntiles + 3) / 4 : kRenderGrid);                    \
-    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
+    hipLaunchKernelGGL((render_rays_kernel<FC, NSV, INVV, 0, NVV>), dim3(grid, a->B), dim3(256), lds, as_stream(stream), dev); \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
   }
-  RENDER_CASE(8, 2, false)
-  RENDER_CASE(32, 8, true)
-  RENDER_CASE(8, 1, false)
-  RENDER_CASE(8, 4, false)
-  RENDER_CASE(8, 8, false)
-  RENDER_CASE(32, 2, true)
-  RENDER_CASE(32, 4, true)
+  RENDER_CASE(8, 2, false, 3)
+  RENDER_CASE(32, 8, true, 3)
+  RENDER_CASE(8, 1, false, 3)
+  RENDER_CASE(8, 4, false, 3)
+  RENDER_CASE(8, 8, false, 3)
+  RENDER_CASE(32, 2, true, 3)
+  RENDER_CASE(32, 4, true, 3)
+  RENDER_CASE(8, 2, false, 2)
+  RENDER_CASE(32, 8, true, 2)
+  RENDER_CASE(8, 2, false, 4)
+  RENDER_CASE(32, 8, true, 4)
 #undef RENDER_CASE
-  set_error("bmv_render_rays_fwd: no kernel for feat_ch=%d Ns=%d depth_inv=%d", a->feat_ch, a->Ns, a->depth_inv);
+  set_error("bmv_render_rays_fwd: no kernel for feat_ch=%d Ns=%d depth_inv=%d S=%d", a->feat_ch, a->Ns, a->depth_inv, a->S);
   return BMV_ERR_UNSUPPORTED;
 }
 

@@ -1,6 +1,8 @@
 """ENeRF's per-sample MLP (lib/networks/enerf/nerf.py:5-89) as a parameter holder
-whose forward runs the MFMA kernel (csrc/mlp.hpp) for S = 3 source views (every BASELINE
-config: no torch math on that path); other view counts run `forward_views` (torch ops).
+whose forward runs the MFMA kernels (csrc/mlp.hpp, mlp_bwd.hip) for S in {2, 3, 4} source
+views per cost volume (the reference's Agg / NeRF are S-agnostic; ENeRF pre-trains with
+train_input_views [2, 3, 4], configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23): no torch
+math on this path.
 
 State-dict keys equal the reference's: agg.{view_fc,global_fc,agg_w_fc,fc}.0,
 lr0.0, sigma.0, color.{0,2} (weight, bias each).
@@ -63,34 +65,8 @@ class NeRF(nn.Module):
             self._blob_key = key
         return self._blob
 
-    def forward_views(self, vox_feat, img_feat_rgb_dir):
-        """The same function for ANY number of source views S (the reference's Agg / NeRF are S-agnostic,
-        lib/networks/enerf/nerf.py:29-43, 74-89; ENeRF pre-training draws S from {2, 3, 4},
-        configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23): torch ops on the GPU over this module's own Linear layers
-        (rocBLAS / hipBLASLt GEMMs, torch autograd).  The fused MFMA kernels (csrc/mlp.hpp, mlp_bwd.hip) are laid out for
-        S = 3 -- every BASELINE config -- and take that case."""
-        F = torch.nn.functional
-        agg = self.agg
-        x = img_feat_rgb_dir                                   # (B,P,S,feat_ch+4): [features, rgb | direction(4)]
-        S = x.shape[-2]
-        f = x[..., :-4] + agg.view_fc(x[..., -4:])             # nerf.py:77-79
-        var = f.var(dim=-2, keepdim=True).expand(-1, -1, S, -1)       # unbiased, over the views
-        mean = f.mean(dim=-2, keepdim=True).expand(-1, -1, S, -1)
-        g = agg.global_fc(torch.cat([f, var, mean], -1))       # (B,P,S,32)
-        w = torch.softmax(agg.agg_w_fc(g), dim=-2)
-        im = agg.fc((g * w).sum(-2))                           # (B,P,16)
-        v = torch.cat([vox_feat, im], -1)                      # (B,P,24)
-        h = self.lr0(v)
-        sigma = self.sigma(h)
-        hv = torch.cat([h, v], -1)[..., None, :].expand(-1, -1, S, -1)
-        c = self.color(torch.cat([hv, x], -1))                 # (B,P,S,1)
-        rgb = (torch.softmax(c, dim=-2) * x[..., -7:-4]).sum(-2)
-        return torch.cat([rgb, sigma], -1)
-
     def forward(self, vox_feat, img_feat_rgb_dir):
-        """vox_feat (B,P,8), img_feat_rgb_dir (B,P,S,feat_ch+4) -> (B,P,4) = [rgb, sigma]."""
-        if img_feat_rgb_dir.shape[-2] != 3:
-            return self.forward_views(vox_feat, img_feat_rgb_dir)
+        """vox_feat (B,P,8), img_feat_rgb_dir (B,P,S,feat_ch+4) -> (B,P,4) = [rgb, sigma]; S in {2, 3, 4}."""
         if torch.is_grad_enabled():
             from ...autograd import NerfMLP
             params = [t for lin in self._linears() for t in (lin.weight, lin.bias)]

@@ -203,11 +203,8 @@ class Network(nn.Module):
         # the colour channels are data; a full frame of rays (train_img) lets the backward tile them in 2-D
         feat = A.ImgFeat.apply(xyz, img, src_exts, src_ixts, tar_ext, rs,
                                None if src_inps.requires_grad else im_feat.shape[2], Wr if full else 0)
-        if feat.shape[-2] == 3:
-            params = [t for lin in nerf._linears() for t in (lin.weight, lin.bias)]
-            raw = A.NerfMLP.apply(vox, feat, nerf.feat_ch - 3, *params).reshape(B, -1, Ns, 4)
-        else:                 # S in {2, 4, ...}: the S-agnostic formulation (nerf.NeRF.forward_views)
-            raw = nerf.forward_views(vox, feat).reshape(B, -1, Ns, 4)
+        params = [t for lin in nerf._linears() for t in (lin.weight, lin.bias)]
+        raw = A.NerfMLP.apply(vox, feat, nerf.feat_ch - 3, *params).reshape(B, -1, Ns, 4)      # S in {2, 3, 4}
         if mode == 1:
             with torch.no_grad():
                 mask = ops.mask_viewport(xyz, src_exts, src_ixts, Wr - 1, Hr - 1).view(B, -1, Ns)
@@ -235,11 +232,6 @@ class Network(nn.Module):
             im_feat = im_feat.to_nchw()            # level 1 image features): the renderer takes the planar tensor
         cc = cfg.enerf.cas_config
         src_inps, src_exts, src_ixts = views
-        if src_exts.shape[1] != 3 and view_ids is None and outs is None and self.ray_range is None \
-                and not isinstance(im_feat, convnet.LookupRecords):
-            # the fused renderer's MLP is laid out for 3 source views (every BASELINE config); other view counts
-            # (test_input_views 2 / 4) take the op-by-op chain with the S-agnostic MLP (nerf.NeRF.forward_views)
-            return self.render_level_train(i, st, im_feat, views, batch, mode=mode)
         H, W = src_inps.shape[-2:]
         rs = cc.render_scale[i]
         Hr, Wr = ops.scaled_size(H, W, rs)
@@ -391,7 +383,7 @@ class Network(nn.Module):
         if self._side_stream is None and batch["src_inps"].is_cuda:
             self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))   # created outside any capture
         self.feature_net.pack_lookup = (self.wants_lookup_records() and engine_ok(self.feature_net, batch["src_inps"])
-                                        and batch["src_inps"].shape[1] == 3)      # (the fused renderer: 3 views)
+                                        and 2 <= batch["src_inps"].shape[1] <= 4)     # (the fused renderer's view counts)
         self.set_volume_records(self.feature_net.pack_lookup)
         try:
             if (self.overlap_front and batch["src_inps"].is_cuda

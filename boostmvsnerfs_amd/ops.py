@@ -431,14 +431,14 @@ def nerf_pack_weights(tensors, feat_ch, out=None):
 
 
 def nerf_mlp(vox_feat_t, img_feat_rgb_dir, blob, feat_ch):
+    """vox_feat (..., 8), img_feat_rgb_dir (..., S, feat_ch + 7) with S in {2, 3, 4} source views -> (..., 4)."""
     lead = vox_feat_t.shape[:-1]
     npts = vox_feat_t.numel() // 8
-    if img_feat_rgb_dir.shape[-2] != 3:
-        raise ValueError("the MLP kernel is built for 3 source views per cost volume")
+    S = int(img_feat_rgb_dir.shape[-2])
     out = torch.empty(*lead, 4, device=vox_feat_t.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.bmv_nerf_mlp_fwd(dptr(_c(vox_feat_t), "vox_feat"), dptr(_c(img_feat_rgb_dir), "img_feat_rgb_dir"),
-                                    dptr(blob, "blob"), int(feat_ch), npts, dptr(out), stream()), "nerf_mlp")
+                                    dptr(blob, "blob"), int(feat_ch), S, npts, dptr(out), stream()), "nerf_mlp")
     return out
 
 
@@ -1146,10 +1146,10 @@ def nerf_pack_bwd_weights(tensors, feat_ch):
     return out
 
 
-def nerf_bwd_rows(feat_ch):
+def nerf_bwd_rows(feat_ch, S=3):
     lib = _lib.load()
     ir = C.c_int(0)
-    r = lib.bmv_nerf_bwd_rows(int(feat_ch), C.byref(ir))
+    r = lib.bmv_nerf_bwd_rows(int(feat_ch), int(S), C.byref(ir))
     if r < 0:
         _lib.check(r, "nerf_bwd_rows")
     return r, ir.value
@@ -1163,25 +1163,27 @@ def nerf_param_shapes(feat_ch):
 
 
 def nerf_mlp_bwd(vox_feat_t, img_feat_rgb_dir, d_out, blob_fwd, blob_bwd, feat_ch):
-    """-> d_vox (8,P), d_img (3,IR,P), grads: the 16 parameter gradients in NERF_PARAM_ORDER (weight, bias).
+    """-> d_vox (8,P), d_img (S,IR,P), grads: the 16 parameter gradients in NERF_PARAM_ORDER (weight, bias); S = the
+    source views of img_feat_rgb_dir (P, S, feat_ch + 7), 2..4.
     Data path, weight gradients (MFMA over the sample dimension) and their reduction are three launches inside
     bmv_nerf_mlp_bwd; the per-tile matrices between them live in a workspace sized by bmv_nerf_bwd_workspace."""
     npts = vox_feat_t.numel() // 8
-    _, IR = nerf_bwd_rows(feat_ch)
+    S = int(img_feat_rgb_dir.shape[-2])
+    _, IR = nerf_bwd_rows(feat_ch, S)
     dev = vox_feat_t.device
     lib = _lib.load()
-    n_ws = lib.bmv_nerf_bwd_workspace(int(feat_ch), npts)
+    n_ws = lib.bmv_nerf_bwd_workspace(int(feat_ch), S, npts)
     if n_ws < 0:
         _lib.check(int(n_ws), "nerf_bwd_workspace")
     ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
     d_vox = torch.empty(8, npts, device=dev, dtype=torch.float32)
-    d_img = torch.zeros(3, IR, npts, device=dev, dtype=torch.float32)
+    d_img = torch.zeros(S, IR, npts, device=dev, dtype=torch.float32)
     grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in nerf_param_shapes(feat_ch)]
     gp = _lib.NerfParams(*[dptr(t, f"nerf grad {i}") for i, t in enumerate(grads)])
     with ktimer.region(f"nerf_mlp_bwd[feat={feat_ch}]"):
         rc = lib.bmv_nerf_mlp_bwd(dptr(_c(vox_feat_t), "vox_feat"), dptr(_c(img_feat_rgb_dir), "img"),
                                   dptr(_c(d_out), "d_out"), dptr(blob_fwd, "blob_fwd"), dptr(blob_bwd, "blob_bwd"),
-                                  int(feat_ch), npts, dptr(ws), dptr(d_vox), dptr(d_img), C.byref(gp), stream())
+                                  int(feat_ch), S, npts, dptr(ws), dptr(d_vox), dptr(d_img), C.byref(gp), stream())
     _lib.check(rc, "nerf_mlp_bwd")
     return d_vox, d_img, grads
 

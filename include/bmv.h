@@ -146,9 +146,11 @@ typedef struct {
 /* floats needed for the packed (MFMA-ordered) weight blob of a given feat_ch (8 or 32) */
 int bmv_nerf_blob_size(int feat_ch);
 int bmv_nerf_pack_weights(const bmv_nerf_params* params, int feat_ch, float* blob, bmv_stream_t stream);
-/* vox_feat (B*P,8), img_feat_rgb_dir (B*P,3,F+4) -> out (B*P,4) = [rgb, sigma]; S must be 3 */
-int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* blob, int feat_ch, long npts,
-                     float* out, bmv_stream_t stream);
+/* vox_feat (B*P,8), img_feat_rgb_dir (B*P,S,F+4) -> out (B*P,4) = [rgb, sigma]; S source views in {2, 3, 4} (the
+ * reference's Agg / NeRF take any S: var / mean / softmax over the view axis, nerf.py:29-43, 74-89; ENeRF pre-trains
+ * with 2, 3 and 4 views, configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23).  The blob does not depend on S. */
+int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* blob, int feat_ch, int S,
+                     long npts, float* out, bmv_stream_t stream);
 
 /* ---- a12 raw2outputs                      lib/networks/enerf/utils.py:605-637
  * raw (B*N,Ns,4), z_vals (B*N,Ns) -> rgb (B*N,3), depth (B*N), weights (B*N,Ns) (softmaxed) */
@@ -283,7 +285,7 @@ int bmv_sweep_variance_bwd_fixed(const float* feats, const float* proj, const fl
 
 /* ---- a11 backward (lib/networks/enerf/nerf.py:29-43, 74-89), three launches on `stream`:
  *   1. the data path: the forward of every 32-sample tile is recomputed and back-propagated on the matrix cores;
- *      d_vox (8, P) and d_img (3, IR, P) come out in [row][sample] layout (IR rows per view: the F channels padded
+ *      d_vox (8, P) and d_img (S, IR, P) come out in [row][sample] layout (IR rows per view: the F channels padded
  *      to an even count, then the 4 direction components), and the pre-activation gradients + layer inputs go to
  *      `workspace` as per-tile matrices;
  *   2. every weight / bias gradient, dW = D_pre ACT^T, with the sample index as the MFMA k dimension;
@@ -291,18 +293,19 @@ int bmv_sweep_variance_bwd_fixed(const float* feats, const float* proj, const fl
  *      shapes, overwritten).
  * No atomics anywhere (round 5: the two 1-wide heads whose inputs are not parked leave one partial per wave, summed
  * in a fixed order by launch 3): the call is bit-reproducible.
- * workspace: bmv_nerf_bwd_workspace(feat_ch, npts) floats (about 80 KB per 32 samples for feat_ch 8).
+ * S source views in {2, 3, 4} (img_feat_rgb_dir is (P, S, F + 4); nerf.py's Agg / NeRF take any S).
+ * workspace: bmv_nerf_bwd_workspace(feat_ch, S, npts) floats (about 80 KB per 32 samples for feat_ch 8, S = 3).
  * npts = 0 is rejected (nothing to write the gradients from).  IR: bmv_nerf_bwd_rows(). */
 typedef struct {
   float *view_fc_w, *view_fc_b, *global_fc_w, *global_fc_b, *agg_w_w, *agg_w_b, *fc_w, *fc_b;
   float *lr0_w, *lr0_b, *sigma_w, *sigma_b, *color0_w, *color0_b, *color2_w, *color2_b;
 } bmv_nerf_grads;   /* same order and shapes as bmv_nerf_params */
 int bmv_nerf_bwd_blob_size(int feat_ch);
-int bmv_nerf_bwd_rows(int feat_ch, int* d_img_rows);
-long bmv_nerf_bwd_workspace(int feat_ch, long npts);
+int bmv_nerf_bwd_rows(int feat_ch, int S, int* d_img_rows);
+long bmv_nerf_bwd_workspace(int feat_ch, int S, long npts);
 int bmv_nerf_pack_bwd_weights(const bmv_nerf_params* params, int feat_ch, float* blob, bmv_stream_t stream);
 int bmv_nerf_mlp_bwd(const float* vox_feat, const float* img_feat_rgb_dir, const float* d_out, const float* blob_fwd,
-                     const float* blob_bwd, int feat_ch, long npts, float* workspace, float* d_vox, float* d_img,
+                     const float* blob_bwd, int feat_ch, int S, long npts, float* workspace, float* d_vox, float* d_img,
                      const bmv_nerf_grads* grads, bmv_stream_t stream);
 
 /* ---- f1 / f2 (training leg): weight gradient of the convolutions

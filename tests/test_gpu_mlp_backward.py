@@ -8,8 +8,20 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _views(img, S):
+    """The fixture's (1,P,3,F+4) per-view inputs as S in {2, 3, 4} views (a fourth view = a perturbed copy of the first)."""
+    if S <= 3:
+        return img[:, :, :S].contiguous()
+    g = torch.Generator().manual_seed(5)
+    extra = img[:, :, :1] * 0.9 + 0.05 * torch.randn(img[:, :, :1].shape, generator=g)
+    return torch.cat([img, extra], 2).contiguous()
+
+
+@pytest.mark.parametrize("S", [3, 2, 4])
 @pytest.mark.parametrize("lvl,feat_ch", [(1, 8), (0, 32)])
-def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch):
+def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch, S):
+    """Forward and every gradient of the MLP kernels for S = 2, 3, 4 source views (the reference's Agg / NeRF take any
+    S, lib/networks/enerf/nerf.py:29-43, 74-89; pre-training draws 2..4, dtu_pretrain.yaml:22-23) vs the oracle."""
     from boostmvsnerfs_amd import autograd as A, ops
     from oracle import enerf as O
     sd = enerf_fx.group("sd")
@@ -17,7 +29,7 @@ def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch):
     names = [f"{prefix}{n}.{k}" for n in ops.NERF_PARAM_ORDER for k in ("weight", "bias")]
     P = 1003                                            # ragged: not a multiple of the 32-sample tile
     vox = enerf_fx.t(f"cap/get_vox_feat#{lvl}")[:, :P].contiguous()
-    img = enerf_fx.t(f"cap/get_img_feat#{lvl}")[:, :P].contiguous()
+    img = _views(enerf_fx.t(f"cap/get_img_feat#{lvl}")[:, :P], S)
     torch.manual_seed(4)
     g = torch.randn(1, P, 4)
     # CPU oracle + autograd
@@ -30,6 +42,9 @@ def test_nerf_mlp_backward(enerf_fx, lvl, feat_ch):
     v_g, i_g = vox.to(DEV).requires_grad_(True), img.to(DEV).requires_grad_(True)
     out_g = A.NerfMLP.apply(v_g, i_g, feat_ch, *params)
     assert_close(out_g, out_c, name="forward")
+    with torch.no_grad():       # the inference entry point (bmv_nerf_mlp_fwd) with the cached blob
+        blob = ops.nerf_pack_weights([p.detach() for p in params], feat_ch)
+        assert torch.equal(ops.nerf_mlp(v_g.detach(), i_g.detach(), blob, feat_ch), out_g.detach())
     (out_g * g.to(DEV)).sum().backward()
     assert_close(v_g.grad, v_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_vox_feat")
     assert_close(i_g.grad, i_c.grad, rtol=2e-3, atol_scale=2e-3, name="d_img_feat")

@@ -574,7 +574,8 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
     """ENeRF with 2 and 4 source views (the reference trains with train_input_views [2, 3, 4],
     configs/exps/pretrain/enerf/dtu_pretrain.yaml:22-23, 75-76): Network.forward (eval) against the reference's own output
     dict, and every parameter gradient of the fine-tune loss against the reference's (tests/golden/enerf_tiny_views{S}.npz).
-    The sweeps run their S = 2 / 4 instantiations; the MLP takes nerf.NeRF.forward_views (S-agnostic)."""
+    Everything runs on the HIP kernels' S = 2 / 4 instantiations (sweeps, fused renderer, MLP forward / backward): the
+    profiler must not see a single GEMM launch (round 4 ran the MLP of S != 3 as torch ops on rocBLAS)."""
     from conftest import check_param_grads, load_fixture
     from boostmvsnerfs_amd.config import set_cfg
     from boostmvsnerfs_amd.networks.enerf.network import Network
@@ -588,12 +589,20 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
     net = net.to(DEV).eval()
     bg = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vfx.batch().items()}
     assert bg["src_inps"].shape[1] == S
-    with torch.no_grad():
-        out = net({k: (v.clone() if torch.is_tensor(v) else v) for k, v in bg.items()})
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with torch.no_grad():
+            out = net({k: (v.clone() if torch.is_tensor(v) else v) for k, v in bg.items()})
+        net.zero_grad()
+        _, loss, _, _ = NetworkWrapper(net)(bg)
+        loss.backward()
+        torch.cuda.synchronize()
     for k, v in vfx.group("out").items():
         assert_close(out[k], v, name=f"S={S} {k}")
     ref = {k[5:]: torch.from_numpy(v) for k, v in vfx.raw.items() if k.startswith("grad/")}
-    net.zero_grad()
-    _, loss, _, _ = NetworkWrapper(net)(bg)
-    loss.backward()
     check_param_grads(net, ref, float(loss), float(vfx.raw["extra/loss"]))
+    kernels = {e.key for e in prof.key_averages() if getattr(e, "device_type", None) is not None and
+               str(e.device_type).endswith("CUDA")}
+    assert any("render" in k for k in kernels) and any("nerf_mlp_bwd" in k for k in kernels), sorted(kernels)[:40]
+    gemms = [k for k in kernels if any(t in k.lower() for t in ("gemm", "cijk", "rocblas", "hipblas"))]
+    assert not gemms, f"S={S}: GEMM launches on the path: {gemms}"
