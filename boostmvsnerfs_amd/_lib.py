@@ -193,8 +193,25 @@ def load():
     # are applied HERE, once, in the open -- the C side never reads the environment
     for name in tuning_names():
         if name in os.environ:
-            set_tuning(name, int(os.environ[name], 0))
+            raw = os.environ[name].strip()
+            try:
+                value = int(raw, 0)
+            except ValueError:
+                try:
+                    value = int(raw)          # "08" and the like, as the C side's atoi read them before round 4
+                except ValueError:
+                    raise ValueError(f"environment variable {name}={os.environ[name]!r}: expected an integer "
+                                     "(a tuning switch of libbmv, include/bmv.h bmv_tuning_set)") from None
+            set_tuning(name, value)
+    for name in REMOVED_SWITCHES:
+        if name in os.environ:
+            import warnings
+            warnings.warn(f"{name} is set but no longer read: its kernels were removed in round 4 (csrc/sweep_quad.hip is "
+                          "the inference sweep; see bmv_tuning_name for the current switches)", stacklevel=2)
     return lib
+
+
+REMOVED_SWITCHES = ("BMV_SWEEP_WIN", "BMV_SWEEP_ZP", "BMV_SWEEP_SPLIT", "BMV_RING_DEFS")
 
 
 def tuning_names():
@@ -229,11 +246,22 @@ def get_tuning(name):
 # copy of the same call -- whose copy kernel then overwrites the first argument before the launch reads it (round 4:
 # two non-contiguous arguments in one call are all it takes).  Every tensor handed to dptr() is therefore kept
 # referenced until the launch has been enqueued: check() -- called after every entry point -- lets go.
-_held = []
+# Per THREAD, like the C side's deferral list: a check() on another thread must not let go of the tensors of a launch
+# this thread is still assembling.
+import threading  # noqa: E402
+
+_tls = threading.local()
+
+
+def _held_list():
+    h = getattr(_tls, "held", None)
+    if h is None:
+        h = _tls.held = []
+    return h
 
 
 def check(rc, what=""):
-    _held.clear()
+    _held_list().clear()
     if rc != 0:
         msg = load().bmv_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libbmv {what} failed (code {rc}): {msg}")
@@ -252,7 +280,7 @@ def dptr(t, name="tensor", dtype=torch.float32):
                            "there is no CPU fallback")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
-    _held.append(t)
+    _held_list().append(t)
     return C.c_void_p(t.data_ptr())
 
 

@@ -101,7 +101,18 @@ class AutoGraph:
         self.__init__(state["net"])
 
     # ------------------------------------------------------------------ keys
+    def check_faults(self):
+        """Sequence faults of the captured frames' feed rings (ops.FeedRing.state[1]: a frame that ran on a message that
+        was not its own): raises.  Reads the device -- call where the caller is synchronised anyway (evaluate(), bench's
+        timed loop, invalidate())."""
+        for e in self.entries.values():
+            ring = e.get("ring")
+            if ring is not None:
+                ring.raise_on_faults()
+
     def invalidate(self):
+        if self.entries and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            self.check_faults()           # the entries are about to go: what they counted must not go unseen
         self.epoch += 1
         self._tensors = None
         self._last = None

@@ -42,10 +42,13 @@ __device__ __forceinline__ T* deferred_load(const void* const* table, int slot, 
   return (table && slot >= 0) ? static_cast<T*>(const_cast<void*>(table[slot])) : direct;
 }
 
+// (a failed check also drops the deferrals registered for the launch that is not going to happen: they must not attach
+// themselves to the next, unrelated one)
 #define BMV_REQUIRE(cond, ...)                  \
   do {                                          \
     if (!(cond)) {                              \
       ::bmv::set_error(__VA_ARGS__);            \
+      (void)::bmv::deferred_finish();           \
       return BMV_ERR_INVALID;                   \
     }                                           \
   } while (0)

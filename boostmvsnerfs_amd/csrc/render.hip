@@ -723,7 +723,10 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
               "bmv_render_rays_fwd: ray range [%d,%d) outside [0,%d)", a->ray_begin, a->ray_end, a->N);
   BMV_REQUIRE(a->mode == 0 || a->mode == 1, "bmv_render_rays_fwd: mode=%d", a->mode);
   BMV_REQUIRE(a->view_ids == nullptr || a->n_all >= a->S, "bmv_render_rays_fwd: view_ids with n_all=%d < S", a->n_all);
-  if (a->ray_begin == a->ray_end) return deferred_finish() ? BMV_ERR_UNSUPPORTED : BMV_OK;
+  if (a->ray_begin == a->ray_end) {   // an empty ray shard / chunk: nothing is launched, so nothing is baked into a capture --
+    (void)deferred_finish();          // the deferrals registered for this launch are simply dropped
+    return BMV_OK;
+  }
   int nrays = a->ray_end - a->ray_begin;
   RenderArgsDev dev;
   static_cast<bmv_render_args&>(dev) = *a;

@@ -621,12 +621,13 @@ int qu_launch_s(const QuadArgs& a, int B, int S, bool pu, hipStream_t stream) {
   return BMV_ERR_UNSUPPORTED;
 }
 
-bool shape_ok(int S, int C, int Hs, int Ws, int D, int h, int w, int n_views) {
+bool shape_ok(int S, int C, int Hs, int Ws, int D, int h, int w, int n_views, bool plane_uniform) {
   if ((C & 3) || C < 4 || C > 64 || S < 2 || S > 4) return false;
   if ((size_t)n_views * Hs * Ws * C * 4 >= ((size_t)1 << 31)) return false;   // 32-bit source offsets
   if (Hs >= (1 << 14) - 2 || Ws >= (1 << 14) - 2) return false;
   if ((size_t)C * D * h * w * 4 >= ((size_t)1 << 31)) return false;           // 32-bit volume offsets
-  if ((size_t)D * h * w >= ((size_t)1 << 23)) return false;                   // 24-bit multiplies of the hypothesis offsets
+  // 24-bit multiplies of the per-voxel hypothesis offsets (plane-uniform hypotheses are scalar loads: no such limit)
+  if (!plane_uniform && (size_t)D * h * w >= ((size_t)1 << 23)) return false;
   return true;
 }
 
@@ -641,7 +642,7 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   BMV_REQUIRE(B > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "bmv_sweep_variance_quad_fwd: bad shape");
   BMV_REQUIRE(!view_ids || n_all >= S, "bmv_sweep_variance_quad_fwd: n_all=%d < S=%d", n_all, S);
   variant = pick_variant(variant, Ws, w, h, D, C);
-  if (variant < 0 || !shape_ok(S, C, Hs, Ws, D, h, w, view_ids ? n_all : S)) {
+  if (variant < 0 || !shape_ok(S, C, Hs, Ws, D, h, w, view_ids ? n_all : S, dv_plane_uniform != 0)) {
     set_error("bmv_sweep_variance_quad_fwd: shape / variant not covered (C=%d, S=%d, variant=%d)", C, S, variant);
     return BMV_ERR_UNSUPPORTED;
   }

@@ -83,4 +83,17 @@ def evaluate(network, batches, on_output=None, graph=None):
     ag = getattr(network, "_autograph", None)
     if ag is not None:
         res["stats"] = dict(ag.stats)
+    check_device_faults(network)
     return res
+
+
+def check_device_faults(network=None):
+    """The two device-side fault counters of the inference path, read where the caller is synchronised anyway: lost
+    wake-ups of the producer / consumer renderer (bmv_render_pc_check: frames with unwritten pixels) and, for a network
+    that replays captured frames, sequence mismatches of their feed rings (a frame that ran on another call's
+    pointers).  Raises instead of handing back silently wrong frames."""
+    from . import _lib
+    _lib.check(_lib.load().bmv_render_pc_check(1), "render_pc_check")
+    ag = getattr(network, "_autograph", None) if network is not None else None
+    if ag is not None:
+        ag.check_faults()

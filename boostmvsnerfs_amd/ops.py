@@ -13,6 +13,8 @@ import torch
 from . import _lib, ktimer
 from ._lib import dptr, stream
 
+BMV_ERR_UNSUPPORTED = -3      # include/bmv.h
+
 
 def _c(t):
     """`t`, contiguous.  (A copy made here outlives the launch it is made for: `_lib.dptr` keeps every tensor it is
@@ -226,6 +228,16 @@ def _sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plan
                                              V, dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
                                              _plane_uniform(depth_values, plane_uniform), B, S, C_,
                                              Hs, Ws, D, h, w, dptr(out), int(variant), int(flags), stream())
+    if rc == BMV_ERR_UNSUPPORTED and variant < 0 and isinstance(feats, QuadFeats):
+        # a shape outside the planned kernel's 32-bit / 24-bit offset budget (e.g. 1440 x 2560 inputs: level 0 is
+        # 360 x 640 x 64), or more than 64 channels: the reference-layout direct-gather kernel (algo 1), views gathered
+        # by index -- slow and correct instead of a failed forward
+        _lib.load().bmv_last_error()
+        nchw = feats.to_nchw()                                        # (B, V, C, Hs, Ws)
+        if view_ids is not None:
+            nchw = torch.gather(nchw, 1, view_ids.long()[:, :, None, None, None].expand(-1, -1, *nchw.shape[2:]))
+        dv = depth_values if depth_values.dim() == 4 else depth_values[:, :, None, None].expand(B, D, h, w).contiguous()
+        return _sweep_variance(nchw.contiguous(), proj, dv, 1, out, False, False)
     _lib.check(rc, "sweep_variance_quad")
     return out
 
@@ -643,6 +655,7 @@ class FeedRing:
                 ev.synchronize()
             else:                 # (a replay nobody reported: be safe)
                 torch.cuda.current_stream().synchronize()
+            self.raise_on_faults()        # (already waiting on the device here: the read is nearly free)
 
     def replayed(self):
         """Call after the replay that followed a post."""
@@ -677,6 +690,11 @@ class FeedRing:
         """The steady state posts the same slots / destinations / counts every time: written into all R messages
         once, a post then stores the sequence number, the table values and the copy sources only."""
         n, c = len(slots), len(dsts)
+        # Messages posted and not yet consumed are about to be rewritten (a caller that does not synchronise per frame
+        # has replays queued; after a slow post() one of them carries n_copy = 0 and must keep it: ADVICE r4) -- wait for
+        # the device first.  Only at a slow -> fast transition, never in the steady state.
+        if self.posted:
+            torch.cuda.synchronize()
         for m in self.msgs:
             m["n_ptr"], m["n_copy"] = n, c
             if n:
@@ -699,6 +717,14 @@ class FeedRing:
 
     def faults(self):
         return int(self.state[1].item())
+
+    def raise_on_faults(self):
+        """state[1] counts frames whose first node found a message with another sequence number than its own execution
+        count (it ran on a stale pointer table / stale small inputs): a silently wrong frame otherwise."""
+        n = self.faults()
+        if n:
+            raise RuntimeError(f"FeedRing: {n} captured frame(s) ran on a message that was not theirs (sequence mismatch): "
+                               "the frames since the last check are wrong")
 
 
 def copy_to_slot(t, table, slot):

@@ -290,6 +290,44 @@ def test_forward_captures_itself():
     net.eval()
 
 
+def test_pipelined_caller_alternating_contiguous_and_strided_small_inputs():
+    """a caller that does NOT synchronise per frame hands `tar_ext` alternately as a strided view
+    (the slow post(): private copy + a message with n_copy = 0) and as a contiguous tensor (the fast path, whose
+    prepare_fast used to rewrite n_copy / sources in ALL ring messages, also the queued slow one the GPU had not
+    consumed yet -> that frame's first node overwrote the just-copied camera with stale sources).  Every frame must be
+    the eager frame of its own camera."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    ag = net._autograph
+    cams = [clone_batch(make_batch(128, 160, n_views=3, seed=0, tar_offset=(0.02 * i, 0.0, 0.0)), DEV) for i in range(4)]
+    wants = [eager(b) for b in cams]
+    assert not torch.equal(wants[0]["rgb_level1"], wants[1]["rgb_level1"])
+
+    def strided(b):
+        c = dict(b)
+        wide = torch.zeros(1, 4, 8, device=DEV)
+        wide[..., ::2] = b["tar_ext"]
+        c["tar_ext"] = wide[..., ::2]                   # same values, not contiguous
+        assert not c["tar_ext"].is_contiguous()
+        return c
+    with torch.no_grad():
+        for _ in range(3):
+            net(cams[0])                                # eager, capture, first replay
+        torch.cuda.synchronize()
+        frames = []
+        for i in range(40):                             # no synchronize inside: the host runs ahead of the GPU
+            b = cams[i % 4]
+            frames.append((net(strided(b) if i % 2 else b), wants[i % 4]))
+    torch.cuda.synchronize()
+    assert ag.stats["captures"] == 1
+    for got, want in frames:
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    ring = ag._hot["ring"]
+    assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
+    ag.check_faults()
+
+
 def test_two_captured_frames_alternate():
     """Two keys alive at once (an execution switch flipped between calls; for the K-volume networks: two targets with
     different triplets): the steady-state path of one entry must hand over to the other without leaving a ring message
