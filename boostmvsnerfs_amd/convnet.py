@@ -53,6 +53,52 @@ def pack_conv(weight, bias, stride=1, allow_pair=True):
     return wpack, b
 
 
+def pack_conv_c4(weight, bias):
+    """weight (Cout <= 12, Cin, [3,] 3, 3), bias (Cout) or None -> (wpack, bias) of bmv_conv_c4_fwd (csrc/conv_c4.hip):
+    wpack[chunk][tap][g][i][k] = weight[4 g + i][4 chunk + k][tap], zero padded."""
+    Cout, Cin = weight.shape[:2]
+    taps = int(weight[0, 0].numel())
+    ng, nc = (Cout + 3) // 4, (Cin + 3) // 4
+    dev = weight.device
+    w = torch.zeros(ng * 4, nc * 4, taps, device=dev, dtype=torch.float32)
+    w[:Cout, :Cin] = weight.detach().reshape(Cout, Cin, taps).float()
+    wpack = w.view(ng, 4, nc, 4, taps).permute(2, 4, 0, 1, 3).contiguous()       # (chunk, tap, g, i, k)
+    b = torch.zeros(ng * 4, device=dev, dtype=torch.float32)
+    if bias is not None:
+        b[:Cout] = bias.detach().float()
+    return wpack, b
+
+
+def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, variant=0):
+    """x (B,Cin,D,H,W) or (B,Cin,H,W) -> act(conv(x, 3x3[x3], stride 1, padding 1) + bias) with Cout <= 12 output
+    channels on the 4-row matrix blocks (csrc/conv_c4.hip).  records: the renderer's volume records (VolumeRecords of
+    channels 0..7 + the planar channel 8 when Cout == 9) instead of the planar tensor."""
+    is3d = x.dim() == 5
+    if is3d:
+        B, Cin, D, H, W = x.shape
+    else:
+        B, Cin, H, W = x.shape
+        D = 1
+    kd = 3 if is3d else 1
+    lib = _lib.load()
+    assert wpack.numel() == lib.bmv_conv_c4_wpack_floats(Cout, Cin, kd)
+    x = x if x.is_contiguous() else x.contiguous()
+    out2 = None
+    if records:
+        out = torch.empty(B, D, H, W, 8, device=x.device, dtype=torch.float32)
+        out2 = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32) if Cout == 9 else None
+    else:
+        out = torch.empty((B, Cout, D, H, W) if is3d else (B, Cout, H, W), device=x.device, dtype=torch.float32)
+    with ktimer.region(f"conv_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"), dptr(out),
+                                 dptr(out2) if out2 is not None else None, B, Cin, D, H, W, Cout, kd, _slope(relu, slope),
+                                 2 if records else 0, int(variant), stream())
+    _lib.check(rc, "conv_c4_fwd")
+    if records:
+        return VolumeRecords(out), out2
+    return out
+
+
 def pack_conv_split(weight, bias, parts=3):
     """weight (Cout <= 16, Cin % 8 == 0, 3, 3, 3) -> the split-bf16 A operands of bmv_conv3d_split_fwd (csrc/conv_split.hip),
     int32 [octet][step 7][part][lane 64][4]: lane = 16 * (tap % 4) + cout, the 8 bf16 of a lane = the 8 channels of the
@@ -121,6 +167,10 @@ def conv3d_split_heads_records(x, wsplit, bias, parts):
 #   "3" / "2": all four layers with three / two pieces (two = 2^-16 per product: the opt-in experiment, +7 % of the frame).
 _split_env = os.environ.get("BMV_CONV_SPLIT", "0")
 SPLIT_BF16 = _split_env if _split_env == "auto" else int(_split_env)
+
+
+# The regularisers' first layers and heads on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip): BMV_CONV_C4=1 / 0
+CONV_C4 = os.environ.get("BMV_CONV_C4", "1") == "1"
 
 
 def split_parts(policy, kind, cin):

@@ -1,0 +1,263 @@
+// 3x3x3 / 3x3 stride-1 convolutions with FEW output channels (Cout <= 12: the regularisers' first layers 32|16 -> 8,
+// their 8 -> 8 + 1 heads, FeatureNet's smooth layers) on v_mfma_f32_4x4x1_16b_f32.
+//   conv block of the reference          lib/networks/enerf/utils.py:10-33  (ConvBnReLU / ConvBnReLU3D)
+//   MinCostRegNet / CostRegNet           lib/networks/enerf/cost_reg_net.py:4-86  (conv0, feat_conv, depth_conv)
+//
+// Why another kernel (round 5).  csrc/conv.hip computes every layer on 16-row MFMA tiles (v_mfma_f32_16x16x4_f32: rows =
+// output channels).  A layer with 8 output channels fills half of a tile; ROW PAIRING (rows = 8 channels x 2 output rows,
+// K + 1 input rows per filter column) recovers 2K / (K + 1) = 75 % for K = 3 -- and no pairing can do better (two shifted
+// copies of the 27-tap cube cover at least 36 positions).  The 9-channel heads fill 9 / 16 = 56 %.  These four layers are
+// ~290 us of a ~930 us frame and are bound by the fp32 matrix rate (64 FLOP / clk / SIMD whatever the shape).
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4 x 4 x 1 outer products: 4 output channels x 4 positions per block, 64
+// positions per wave-instruction, K = 1 = ONE (input channel, tap) pair -- 512 FLOP in 8 cycles, the same rate, with
+// every row useful for Cout = 4 g (8: 100 %, 9 -> 12: 75 %): 1.33 x fewer matrix cycles for the same fp32 FMA chain.
+//
+// Operands.  lane l = (block l / 4, index l % 4): A[l] = W[cout 4 g + l % 4][cin][tap] (the same in all blocks), B[l] = the
+// input at lane l's OWN position shifted by the tap, D[r] at lane l = out[cout 4 g + r] at lane l's position.  A k-step
+// needs one new A and one new B register per lane, so operands are fetched four input channels at a time: the input tile
+// sits in LDS CHANNEL-LAST per 4-channel chunk (`tile[pos][4]`: one ds_read_b128 = the B operands of 4 k-steps), the
+// weights as `w[chunk][tap][g][cout 4][cin 4]` (one ds_read_b128, 4 distinct addresses per wave: broadcast).  Per tap and
+// wave: 2 A reads + TZ B reads feed 8 TZ MFMAs (64 TZ matrix cycles per SIMD against 4 (2 + TZ) LDS cycles per CU).
+// Lanes are mapped to positions so that every 16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS: {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} and the same + 32) reads 16 CONSECUTIVE x of one row: conflict-free on any row pitch.
+#include <stdlib.h>
+
+#include "bmv_common.hpp"
+
+namespace bmv {
+
+using f32x4c = __attribute__((ext_vector_type(4))) float;
+
+struct C4Args {
+  const float* in;      // (B, Cin, D, H, W)
+  const float* wpack;   // [chunk][tap][g][cout 4][cin 4], batch norm folded in, zero padded
+  const float* bias;    // (4 NG)
+  float* out;           // mode 0: planar (B, Cout, D, H, W); mode 2: the renderer's volume records (B, D, H, W, 8)
+  float* out2;          // mode 2: channel 8 (the depth logits), planar (B, D, H, W)
+  int B, Cin, D, H, W, Cout;
+  float slope;          // activation: v > 0 ? v : slope * v
+  int mode;
+};
+
+constexpr int kC4RS = 18;   // tile row pitch in positions: 16 outputs + halo
+
+// NG: groups of 4 output channels; NW: waves per workgroup (a wave = 16 x by 4 y); TZ: output planes per wave; KD: 3 / 1
+template <int NG, int NW, int TZ, int KD>
+__global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
+  constexpr int NT = 64 * NW, TY = 4 * NW, TYH = TY + 2, TZH = TZ + KD - 1;
+  constexpr int POS = TZH * TYH * kC4RS, NSLOT = (POS + NT - 1) / NT, TAPS = KD * 9;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nchunk = (a.Cin + 3) >> 2;
+  f32x4c* wl = reinterpret_cast<f32x4c*>(lds);                               // [nchunk][TAPS][NG][4] x float4
+  f32x4c* tile = reinterpret_cast<f32x4c*>(lds) + nchunk * TAPS * NG * 4;     // [POS] x float4 (4 input channels)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntx = (a.W + 15) >> 4, nty = (a.H + TY - 1) / TY, ntz = (a.D + TZ - 1) / TZ;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int ty = bid % nty;
+  bid /= nty;
+  const int tz = bid % ntz, b = bid / ntz;
+  const int x0 = tx * 16, y0 = ty * TY, z0 = tz * TZ;
+  const int plane = a.D * a.H * a.W;
+
+  // weights of every chunk, once per workgroup
+  {
+    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
+    for (int i = tid; i < nchunk * TAPS * NG * 4; i += NT) wl[i] = src[i];
+  }
+  // tile slots of this thread: byte offset inside a channel plane, or out of range (zero padding)
+  unsigned goff[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int slot = tid + NT * j;
+    const int sx = slot % kC4RS, t = slot / kC4RS, sy = t % TYH, sz = t / TYH;
+    const int gx = x0 - 1 + sx, gy = y0 - 1 + sy, gz = z0 - KD / 2 + sz;
+    const bool ok = (slot < POS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D);
+    goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
+  }
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
+  f32x4c pre[NSLOT];
+  auto load_tile = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // (channels past Cin: the plane offset leaves the buffer -> 0)
+        const unsigned cb = 4u * (unsigned)((chunk * 4 + c) * plane);
+        pre[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff[j] + cb, 0, 0));
+      }
+  };
+  load_tile(0);
+
+  // lane -> position of the wave's 16 x 4 patch: the 16-lane groups of ds_read_b128 take 16 consecutive x of one row
+  const unsigned lh = (unsigned)lane & 31u, odd = 0xF00F0FF0u;
+  const int rb = (int)((odd >> lh) & 1u);
+  const int xi = __popc((rb ? odd : ~odd) & ((1u << lh) - 1u));
+  const int ry = 2 * (lane >> 5) + rb;
+  const int ai = lane & 3;
+  const f32x4c* bp = tile + (wave * 4 + ry) * kC4RS + xi;          // + ((z + kz) * TYH + ky) * RS + kx
+  const f32x4c* ap = wl + ai;                                       // + ((chunk * TAPS + tap) * NG + g) * 4
+
+  f32x4c acc[TZ][NG];
+#pragma unroll
+  for (int z = 0; z < TZ; ++z)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[z][g] = f32x4c{0.f, 0.f, 0.f, 0.f};
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();   // every wave is done with the previous tile (first pass: the weights are being written)
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if ((j + 1) * NT <= POS || tid + NT * j < POS) tile[tid + NT * j] = pre[j];
+    __syncthreads();
+    if (chunk + 1 < nchunk) load_tile(chunk + 1);   // in flight under the MFMAs below
+    const f32x4c* aw = ap + chunk * (TAPS * NG * 4);
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kd * 3 + ky) * 3 + kx;
+          f32x4c A[NG], Bv[TZ];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) A[g] = aw[(tap * NG + g) * 4];
+#pragma unroll
+          for (int z = 0; z < TZ; ++z) Bv[z] = bp[((z + kd) * TYH + ky) * kC4RS + kx];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+#pragma unroll
+              for (int g = 0; g < NG; ++g)
+                acc[z][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g][k], Bv[z][k], acc[z][g], 0, 0, 0);
+        }
+  }
+
+  // epilogue: register r of group g = output channel 4 g + r at this lane's position
+  const int x = x0 + xi, y = y0 + wave * 4 + ry;
+  if (x >= a.W || y >= a.H) return;
+  const size_t cs = (size_t)plane;
+#pragma unroll
+  for (int z = 0; z < TZ; ++z) {
+    const int zz = z0 + z;
+    if (zz >= a.D) continue;
+    const size_t vox = ((size_t)zz * a.H + y) * a.W + x;
+    if (a.mode == 2) {
+      // the renderer's volume records: 8 feature channels as one 32-byte record per voxel (the caller packed the
+      // weights with the output channels in the record's even | odd order), channel 8 -- the depth logit -- planar
+      float v[4 * NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[z][g][r] + a.bias[4 * g + r];
+          v[4 * g + r] = fmaxf(t, 0.f) + a.slope * fminf(t, 0.f);
+        }
+      f32x4c* rec = reinterpret_cast<f32x4c*>(a.out + ((size_t)b * cs + vox) * 8);
+      rec[0] = f32x4c{v[0], v[1], v[2], v[3]};
+      rec[1] = f32x4c{v[4], v[5], v[6], v[7]};
+      if (NG > 2) a.out2[(size_t)b * cs + vox] = v[8];
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 4 * g + r;
+          if (co >= a.Cout) continue;
+          const float t = acc[z][g][r] + a.bias[co];
+          a.out[((size_t)b * a.Cout + co) * cs + vox] = fmaxf(t, 0.f) + a.slope * fminf(t, 0.f);
+        }
+    }
+  }
+}
+
+template <int NG, int NW, int TZ, int KD>
+static int c4_launch(const C4Args& a, hipStream_t st) {
+  constexpr int TY = 4 * NW, POS = (TZ + KD - 1) * (TY + 2) * kC4RS;
+  const int nchunk = (a.Cin + 3) >> 2;
+  const size_t lds = ((size_t)nchunk * KD * 9 * NG * 4 + POS) * 16;
+  auto kern = conv_c4_kernel<NG, NW, TZ, KD>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return BMV_ERR_UNSUPPORTED;
+  }
+  const unsigned ntx = (a.W + 15) / 16, nty = (a.H + TY - 1) / TY, ntz = (a.D + TZ - 1) / TZ;
+  hipLaunchKernelGGL(kern, dim3(ntx * nty * ntz * a.B), dim3(64 * NW), lds, st, a);
+  return BMV_OK;
+}
+
+}  // namespace bmv
+
+using namespace bmv;
+
+extern "C" {
+
+// floats of the packed weights for bmv_conv_c4_fwd: [chunk][tap][g][cout 4][cin 4]
+int bmv_conv_c4_wpack_floats(int Cout, int Cin, int kd) {
+  if (Cout < 1 || Cout > 12 || Cin < 1 || (kd != 1 && kd != 3)) {
+    set_error("bmv_conv_c4_wpack_floats: Cout=%d (1..12), Cin=%d, kd=%d (1 or 3)", Cout, Cin, kd);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  return ((Cin + 3) / 4) * kd * 9 * ((Cout + 3) / 4) * 16;
+}
+
+int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, float* out, float* out2, int B, int Cin, int D,
+                    int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream) {
+  BMV_REQUIRE(in && wpack && bias && out, "bmv_conv_c4_fwd: null pointer");
+  BMV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "bmv_conv_c4_fwd: bad shape");
+  BMV_REQUIRE(mode == 0 || (mode == 2 && (Cout == 8 || (Cout == 9 && out2))), "bmv_conv_c4_fwd: mode=%d with Cout=%d", mode, Cout);
+  if (Cout < 1 || Cout > 12 || (kd != 1 && kd != 3) || (kd == 1 && D != 1) ||
+      (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 31) || (size_t)((Cin + 3) / 4) * kd * 9 * ((Cout + 3) / 4) * 64 > 100 * 1024) {
+    set_error("bmv_conv_c4_fwd: shape not covered (Cout=%d Cin=%d kd=%d %dx%dx%d)", Cout, Cin, kd, D, H, W);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  C4Args a{in, wpack, bias, out, out2, B, Cin, D, H, W, Cout, slope, mode};
+  const int ng = (Cout + 3) / 4;
+  int rc = BMV_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  // variant: 0 = default tile of the shape; 1.. = tuning (tests / scripts/bench_conv_c4.py)
+#define C4(NGV, NWV, TZV, KDV) \
+  if (ng == NGV && kd == KDV) rc = c4_launch<NGV, NWV, TZV, KDV>(a, st)
+  if (kd == 3) {
+    // (measured on the frame's four layers, profiles/r5/conv_c4_layers_first.txt: one plane per wave -- 58 registers,
+    // 7-8 waves per SIMD -- beats two planes per wave at 106 registers everywhere: 56.8 / 54.2 / 38.3 / 22.1 us against
+    // 60.0 / 54.5 / 41.7 / 25.0)
+    if (variant == 0 || variant == 3) {
+      C4(1, 4, 1, 3);
+      C4(2, 4, 1, 3);
+      C4(3, 4, 1, 3);
+    } else if (variant == 1) {
+      C4(1, 4, 2, 3);
+      C4(2, 4, 2, 3);
+      C4(3, 4, 2, 3);
+    } else if (variant == 2) {
+      C4(1, 2, 2, 3);
+      C4(2, 2, 2, 3);
+      C4(3, 2, 2, 3);
+    } else if (variant == 4) {
+      C4(2, 4, 4, 3);
+      C4(3, 2, 4, 3);
+    }
+  } else {
+    if (variant == 0 || variant == 1) {
+      C4(1, 4, 1, 1);
+      C4(2, 4, 1, 1);
+      C4(3, 4, 1, 1);
+    } else if (variant == 2) {
+      C4(1, 2, 1, 1);
+      C4(2, 2, 1, 1);
+      C4(3, 2, 1, 1);
+    }
+  }
+#undef C4
+  if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_conv_c4_fwd: variant %d not instantiated for Cout=%d kd=%d", variant, Cout, kd);
+  if (rc != BMV_OK) return rc;
+  BMV_LAUNCH_END("bmv_conv_c4_fwd");
+}
+
+}  // extern "C"

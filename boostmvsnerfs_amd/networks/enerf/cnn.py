@@ -234,6 +234,9 @@ class _CostReg(nn.Module):
         # first layer and heads on the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip): 0 = fp32 MFMA
         # engine (default), "auto" = three pieces (fp32-equivalent) where faster stand-alone, 3 / 2 = all with 3 / 2 pieces
         self.split_bf16 = convnet.SPLIT_BF16
+        # first layer (32 | 16 -> 8) and heads (8 -> 8 + 1) on v_mfma_f32_4x4x1 (csrc/conv_c4.hip: every matrix row useful
+        # for 8 output channels; the 16-row kernels of conv.hip reach 75 % / 56 %): same fp32 FMA chains per output
+        self.conv_c4 = convnet.CONV_C4
 
     def _apply(self, fn, *args, **kwargs):
         self._packed.invalidate()
@@ -252,6 +255,10 @@ class _CostReg(nn.Module):
             P["heads"] = convnet.pack_conv(heads, None)
             # the same layer with its output channels in the order of the renderer's volume records
             P["heads_rec"] = convnet.pack_conv(heads[list(convnet.VolumeRecords.ORDER)], None)
+            # first layer and heads on the 4 x 4 x 1 matrix blocks (csrc/conv_c4.hip; used when self.conv_c4)
+            P["conv0_c4"] = convnet.pack_conv_c4(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn))
+            P["heads_c4"] = convnet.pack_conv_c4(heads, None)
+            P["heads_rec_c4"] = convnet.pack_conv_c4(heads[list(convnet.VolumeRecords.ORDER)], None)
             for parts in (2, 3):     # (csrc/conv_split.hip; used when self.split_bf16 == parts; < 100 KB per regulariser)
                 P[f"conv0_split{parts}"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn), parts=parts)
                 P[f"heads_split{parts}"] = convnet.pack_conv_split(heads, None, parts=parts)
@@ -265,6 +272,8 @@ class _CostReg(nn.Module):
         split = convnet.split_parts(self.split_bf16, "conv0", x.shape[1]) if ok4 else 0
         if split:
             s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
+        elif self.conv_c4:
+            s0 = convnet.conv_c4_fwd(x, *P["conv0_c4"], 8, relu=True)
         else:
             s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
         s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)
@@ -279,9 +288,14 @@ class _CostReg(nn.Module):
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:
                 return convnet.conv3d_split_heads_records(y, *P[f"heads_rec_split{split}"])
+            if self.conv_c4:
+                return convnet.conv_c4_fwd(y, *P["heads_rec_c4"], 9, records=True)
             return convnet.conv_heads_records(y, *P["heads_rec"])
         if split:
             heads = convnet.conv3d_split_fwd(y, *P[f"heads_split{split}"], 9)
+            return heads[:, :8], heads[:, 8]
+        if self.conv_c4:
+            heads = convnet.conv_c4_fwd(y, *P["heads_c4"], 9)
             return heads[:, :8], heads[:, 8]
         heads = convnet.conv_fwd(y, *P["heads"], 9, 3, 3)
         return heads[:, :8], heads[:, 8]

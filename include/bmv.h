@@ -500,6 +500,20 @@ int bmv_fpn_topdown_fwd(const float* fine, const float* coarse, const float* w, 
 int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, float* records_out, float* depth_out,
                        int B, int Cin, int D, int H, int W, bmv_stream_t stream);
 
+/* ---- f1 / f2: stride-1 3x3x3 (kd = 3) / 3x3 (kd = 1, D = 1) convolutions with FEW output channels (Cout <= 12: the
+ * regularisers' first layers and heads, lib/networks/enerf/cost_reg_net.py:4-86 conv0 / feat_conv + depth_conv;
+ * FeatureNet's smooth layers, feature_net.py:17-19) on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip): 4 output channels
+ * x 4 positions per block, 16 blocks per wave-instruction -- every matrix row useful for Cout = 8 (the 16-row tiles of
+ * bmv_conv_fwd: 75 % with row pairing, 56 % for the 9-channel heads) at the same fp32 FMA chain per output.
+ * in (B,Cin,D,H,W); wpack: bmv_conv_c4_wpack_floats(Cout, Cin, kd) floats [cin chunk of 4][tap][cout group of 4][cout][cin],
+ * eval-mode batch norm folded in, zero padded; bias (4 ceil(Cout / 4)); act(v) = v > 0 ? v : slope v.
+ * mode 0: out planar (B,Cout,D,H,W).  mode 2: the renderer's volume records -- out (B,D,H,W,8) = output channels 0..7
+ * (the caller packs them in the record's [even | odd] order), out2 (B,D,H,W) = channel 8 (Cout = 9: the depth logits).
+ * variant: 0 = default tiling, 1.. = tuning. */
+int bmv_conv_c4_wpack_floats(int Cout, int Cin, int kd);
+int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, float* out, float* out2, int B, int Cin, int D,
+                    int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream);
+
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =
  * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights

@@ -429,3 +429,41 @@ def test_conv3d_split_bf16(cin, cout, dhw, parts):
         assert err <= max(2.0 * err32, 1e-6 * scale)          # fp32-equivalent
     else:
         assert err <= 2e-5 * scale
+
+
+C4_CASES = [  # nd, B, Cin, Cout, spatial: ragged tiles, Cin not a multiple of 4, every cout-group count, both ranks
+    (3, 1, 32, 8, (8, 8, 12)), (3, 1, 16, 8, (4, 32, 48)), (3, 2, 8, 9, (5, 9, 19)), (3, 1, 8, 8, (3, 17, 33)),
+    (3, 1, 6, 4, (2, 5, 7)), (3, 1, 8, 12, (4, 16, 16)), (3, 1, 8, 1, (7, 20, 18)),
+    (2, 2, 32, 8, (40, 72)), (2, 3, 16, 8, (33, 47)), (2, 1, 3, 8, (37, 53)),
+    # BASELINE configs[1] shapes: the regularisers' first layers and heads, FeatureNet's smooth0
+    (3, 1, 32, 8, (64, 64, 80)), (3, 1, 16, 8, (8, 256, 320)), (3, 1, 8, 9, (8, 256, 320)), (2, 3, 32, 8, (512, 640)),
+]
+
+
+@pytest.mark.parametrize("nd,B,Cin,Cout,sp", C4_CASES)
+def test_conv_c4(nd, B, Cin, Cout, sp):
+    """csrc/conv_c4.hip (few output channels on the 4 x 4 x 1 matrix blocks) against torch's fp32 convolution and against
+    the 16-row engine kernel it replaces; every tuning variant; bias / ReLU / leaky slope; the volume-record epilogue."""
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + nd)
+    x = torch.randn(B, Cin, *sp, generator=g).to(DEV)
+    k3 = (3,) * nd
+    w = (torch.randn(Cout, Cin, *k3, generator=g) / (Cin * 3 ** nd) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    conv = F.conv3d if nd == 3 else F.conv2d
+    want = conv(x, w, b, 1, 1)
+    wp, bp = convnet.pack_conv_c4(w, b)
+    big = x.numel() > 4e6
+    for variant in ((0,) if big else ((0, 1, 2, 4) if nd == 3 else (0, 2))):
+        if variant == 4 and Cout not in (8, 9, 12):
+            continue
+        _close(convnet.conv_c4_fwd(x, wp, bp, Cout, variant=variant), want, tol=2e-5)
+    _close(convnet.conv_c4_fwd(x, wp, bp, Cout, relu=True), F.relu(want), tol=2e-5)
+    _close(convnet.conv_c4_fwd(x, wp, bp, Cout, slope=0.01), F.leaky_relu(want, 0.01), tol=2e-5)
+    wp16, bp16 = convnet.pack_conv(w, b, 1)
+    _close(convnet.conv_c4_fwd(x, wp, bp, Cout), convnet.conv_fwd(x, wp16, bp16, Cout, 3 if nd == 3 else 1, 3, 1), tol=2e-5)
+    if nd == 3 and Cout in (8, 9):
+        rec, logit = convnet.conv_c4_fwd(x, wp, bp, Cout, records=True)
+        _close(rec.t.permute(0, 4, 1, 2, 3), want[:, :8], tol=2e-5)          # (channels in the order they were packed)
+        if Cout == 9:
+            _close(logit, want[:, 8], tol=2e-5)
