@@ -894,9 +894,13 @@ __global__ __launch_bounds__(256) void conv0_fused_kernel(Conv0Args a) {
 // 4 rows of the tile but only every 4th k-step (4 input channels) of a 16-channel LDS stage; the 4 partial sums meet
 // in LDS and wave r finishes row r.  The dependent chain per wave is 4x shorter.
 // ---------------------------------------------------------------------------------------------------
-template <int KD, int K, int S, bool IS3D>
+// TYV: output rows per workgroup (4, 2 or 1).  Every wave runs all TYV rows of its k-steps, so a wave's dependent chain
+// is TYV x taps x (k-steps / 4) matrix instructions: 432 x 32 cycles = 6.5 us for a 64 -> 64 layer with 4 rows -- most of
+// what such a launch takes, on a grid (96 workgroups for 1 x 32 x 40) that fills a third of the chip.  Fewer rows per
+// workgroup = more workgroups with shorter chains (round 5).
+template <int KD, int K, int S, bool IS3D, int TYV = 4>
 struct SplitKTile {
-  static constexpr int TY = 4;
+  static constexpr int TY = TYV;
   static constexpr int TZH = KD, TYH = (TY - 1) * S + K, RS = 15 * S + K;
   static constexpr int SLOTS = TZH * TYH * RS;
   static constexpr int PS = (S == 1) ? ((SLOTS + 15) / 32 * 32 + 16) : (SLOTS | 1);
@@ -904,15 +908,16 @@ struct SplitKTile {
   static constexpr int TAPS = KD * K * K;
 };
 
-template <int KD, int K, int S, bool IS3D>
+template <int KD, int K, int S, bool IS3D, int TYV = 4>
 // stride 1: 4 workgroups per CU fit the LDS (38 KB each); the allocator needs 121 instead of 160 registers for that
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BMV_CONV_WPE_TUNED && S == 1) ? 4 : 1, 8)))
 void conv_splitk_kernel(ConvArgs a) {
-  using T = SplitKTile<KD, K, S, IS3D>;
+  using T = SplitKTile<KD, K, S, IS3D, TYV>;
+  constexpr int TY = TYV;
   __shared__ float lds[16 * T::PS];
-  __shared__ f32x4 red[4][4][64];
+  __shared__ f32x4 red[4][TY][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + 3) / 4;
+  const int ntx = (a.Wo + 15) / 16, nty = (a.Ho + TY - 1) / TY;
   int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % ntx;
   bid /= ntx;
@@ -920,7 +925,7 @@ void conv_splitk_kernel(ConvArgs a) {
   bid /= nty;
   const int z0 = bid % a.Do;
   const int b = bid / a.Do;
-  const int x0 = tx * 16, y0 = ty * 4;
+  const int x0 = tx * 16, y0 = ty * TY;
   const int ix0 = x0 * S - K / 2, iy0 = y0 * S - K / 2, iz0 = z0 * S - KD / 2;
   const int plane = a.D * a.H * a.W;
 
@@ -939,9 +944,9 @@ void conv_splitk_kernel(ConvArgs a) {
   const int cot = blockIdx.y;
   const float* wp = a.wpack + (size_t)cot * nk * (T::TAPS * 64) + lane;
 
-  f32x4 acc[4];
+  f32x4 acc[TY];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < TY; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* ap = lds + (wave * 4 + (lane >> 4)) * T::PS + (lane & 15) * S;
   // 16 channels of the tile -> registers; channels past Cin (last stage) must read as 0: the offsets stay below 2^31
@@ -999,7 +1004,7 @@ void conv_splitk_kernel(ConvArgs a) {
           for (int kw = 0; kw < K; ++kw) {
             const float w = wv[(kd * K + kh) * K + kw];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < TY; ++r)
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, ap[(kd * T::TYH + r * S + kh) * T::RS + kw], acc[r], 0,
                                                             0, 0);
           }
@@ -1011,8 +1016,9 @@ void conv_splitk_kernel(ConvArgs a) {
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  for (int r = 0; r < TY; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
+  if (wave >= TY) return;
   const f32x4 sum = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
 
   // wave r finishes row r: lane = output x, registers = 4 consecutive output channels
@@ -1045,8 +1051,17 @@ void conv_splitk_kernel(ConvArgs a) {
 
 template <int KD, int K, int S, bool IS3D>
 static void launch_splitk(const ConvArgs& a, hipStream_t st) {
-  dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, 4) * a.Do * a.B, cdiv(a.Cout, 16));
-  hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D>), grid, dim3(256), 0, st, a);
+  // rows per workgroup: 4 while that already gives the chip >= 1024 workgroups, else 2, else 1 (BMV_CONV_SPLITK_ROWS forces)
+  const unsigned base = cdiv(a.Wo, 16) * a.Do * a.B * cdiv(a.Cout, 16);
+  int rows = bmv::tuning("BMV_CONV_SPLITK_ROWS", 0);
+  if (rows != 1 && rows != 2 && rows != 4) rows = base * cdiv(a.Ho, 4) >= 1024 ? 4 : base * cdiv(a.Ho, 2) >= 1024 ? 2 : 1;
+  dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, rows) * a.Do * a.B, cdiv(a.Cout, 16));
+  if (rows == 4)
+    hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 4>), grid, dim3(256), 0, st, a);
+  else if (rows == 2)
+    hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 2>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 1>), grid, dim3(256), 0, st, a);
 }
 
 // Split-K form of the transposed convolution for the deep levels: one input row x 16 input x per workgroup, wave w takes

@@ -259,12 +259,18 @@ def test_config4_full_size_matches_oracle_on_a_ray_subset(tmp_path):
 def test_config5_full_size_gradients_match_oracle_on_a_ray_subset(tmp_path):
     """BASELINE configs[4]: the enerf_ours_ft fine-tune step at 480x736, N = 6, K = 4, both levels rendered
     (lib/train/trainers/trainer.py:44-63, lib/train/losses/enerf.py:7-56): loss and ALL 115 parameter gradients of the
-    HIP forward + backward against the oracle's forward + MSE loss + torch.autograd backward.  The front end (FeatureNet
-    on 6 views, 4 x 2 cost volumes and regularisers, with their whole backward) runs in full on both sides, the per-ray
-    part on every 16th ray of each level (the sample bench.py's cpu_baseline leg extrapolates from; ~1 min of host
-    time).  Both scatter forms: float atomics and the bit-reproducible fixed-point accumulation."""
+    HIP forward + backward.  The front end (FeatureNet on 6 views, 4 x 2 cost volumes and regularisers, with their whole
+    backward) runs in full on both sides, the per-ray part on every 16th ray of each level (the sample bench.py's
+    cpu_baseline leg extrapolates from).
+
+    At this size a weight gradient is an fp32 sum over ~1e6 voxels and the fp32 ORACLE itself is up to 10 x the tiny
+    fixtures' 2e-3 bar away from its own float64 run (tests/tools/config5_grad_probe.py --fp64 ->
+    profiles/r5/config5_grad_probe_fp64.txt: worst entry / tol 10.6 for the fp32 oracle, 7.9 for HIP; HIP the closer one
+    on 101 of 115 tensors).  So the truth here is the oracle in FLOAT64, and the yardstick for every tensor is how far
+    the fp32 oracle -- the reference's own arithmetic -- sits from it: the HIP gradient's relative L2 distance from the
+    float64 gradient must not exceed 1.5 x the fp32 oracle's (+ 1e-3), and HIP must be the closer of the two on most
+    tensors.  Both scatter forms: float atomics and the bit-reproducible fixed-point accumulation."""
     import json
-    from conftest import check_param_grads
     from boostmvsnerfs_amd import _lib
     from boostmvsnerfs_amd.config import make_cfg, set_cfg
     from boostmvsnerfs_amd.networks.boost_enerf.network import Network
@@ -287,14 +293,27 @@ def test_config5_full_size_gradients_match_oracle_on_a_ray_subset(tmp_path):
     for i in range(cc.num):
         batch[f"rays_{i}"] = batch[f"rays_{i}"][:, ::16].contiguous()
         batch[f"rgb_{i}"] = torch.rand(1, batch[f"rays_{i}"].shape[1], 3, generator=g)
-    leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
-              for k, v in net.state_dict().items()}
-    out = O.boost_enerf_forward(leaves, clone_batch(batch), cfg, sel)
-    loss_c = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - batch[f"rgb_{i}"]) ** 2).mean()
-                 for i in range(cc.num) if f"rgb_level{i}" in out)
-    loss_c.backward()
-    want = {k: v.grad for k, v in leaves.items() if v.requires_grad}
-    assert len(want) == 115
+
+    def oracle(dtype):
+        torch.set_default_dtype(dtype)
+        try:
+            leaves = {k: (v.detach().to(dtype) if v.is_floating_point() else v.clone()).requires_grad_(
+                v.is_floating_point() and "running" not in k) for k, v in net.state_dict().items()}
+            bb = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in clone_batch(batch).items()}
+            out = O.boost_enerf_forward(leaves, bb, cfg, sel)
+            loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - bb[f"rgb_{i}"]) ** 2).mean()
+                       for i in range(cc.num) if f"rgb_level{i}" in out)
+            loss.backward()
+            return float(loss.detach()), {k: v.grad.double() for k, v in leaves.items() if v.requires_grad}
+        finally:
+            torch.set_default_dtype(torch.float32)
+    loss32, g32 = oracle(torch.float32)
+    loss64, g64 = oracle(torch.float64)
+    assert len(g64) == 115
+    gmax = max(float(v.abs().max()) for v in g64.values())
+
+    def dist(x, k):
+        return float((x - g64[k]).pow(2).sum().sqrt()) / (float(g64[k].pow(2).sum().sqrt()) + 1e-6 * gmax)
     net = net.to(DEV)
     bg = clone_batch(batch, DEV)
     before = _lib.get_tuning("BMV_DETERMINISTIC")
@@ -304,8 +323,17 @@ def test_config5_full_size_gradients_match_oracle_on_a_ray_subset(tmp_path):
             net.zero_grad(set_to_none=True)
             _, loss, _, _ = NetworkWrapper(net)(bg)
             loss.mean().backward()
-            # (the K-volume budget of test_boost_enerf_finetune_gradients: a visibility flip shifts the sums it feeds)
-            worst = check_param_grads(net, want, float(loss), float(loss_c), outliers=2e-3)
-            print(f"config 5 gradients (deterministic={det}): worst outlier share {max(worst.values()):.2e}")
+            assert abs(float(loss) - loss64) <= 1e-5 * abs(loss64), (float(loss), loss64, loss32)
+            closer, worst = 0, (0.0, None)
+            for k, p in net.named_parameters():
+                assert p.grad is not None, f"{k} received no gradient"
+                d_hip, d_o32 = dist(p.grad.double().cpu(), k), dist(g32[k], k)
+                closer += d_hip <= d_o32
+                worst = max(worst, (d_hip / max(d_o32, 1e-12), k))
+                assert d_hip <= 1.5 * d_o32 + 1e-3, (f"{k} (deterministic={det}): HIP is {d_hip:.3e} from the float64 gradient, "
+                                                     f"the fp32 oracle {d_o32:.3e}")
+            print(f"config 5 gradients (deterministic={det}): HIP closer to float64 than the fp32 oracle on {closer} of 115 "
+                  f"tensors; worst ratio {worst[0]:.2f} ({worst[1]})")
+            assert closer >= 70, closer
     finally:
         _lib.set_tuning("BMV_DETERMINISTIC", before)
