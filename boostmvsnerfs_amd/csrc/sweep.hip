@@ -140,7 +140,7 @@ struct FrameSetupArgs {
   float src_scale[4], tar_scale[4];
   int L, B, S, D, hw, depth_inv;
 };
-__global__ void frame_setup_kernel(FrameSetupArgs a) {
+__device__ __forceinline__ void frame_setup_body(const FrameSetupArgs& a) {
   const int zgroups = (a.D + 7) / 8;
   if ((int)blockIdx.z < zgroups) {
     depth_values_uniform_group(blockIdx.z, a.near_far, a.D, a.hw, a.depth_inv, a.dv, a.nf_out);
@@ -152,6 +152,49 @@ __global__ void frame_setup_kernel(FrameSetupArgs a) {
   const int l = idx / per;
   proj_mats_one(idx - l * per, a.src_exts, a.src_ixts, a.tar_ext, a.tar_ixt, a.src_scale[l], a.tar_scale[l], a.S,
                 a.proj + (size_t)l * per * 12);
+}
+__global__ void frame_setup_kernel(FrameSetupArgs a) { frame_setup_body(a); }
+
+// The same launch as the FIRST NODE of a captured frame (round 5): it is also the frame's feed
+// (csrc/timing.hip frame_feed_ring_kernel: this replay's message from the ring in pinned host memory -> the pointer
+// table, the small inputs copied into the captured buffers).  As two nodes the feed cost its own 7.8 us single-wave
+// kernel plus a 13.8 us gap in front of the next node (profiles/r5/r5_config2_frame_timeline_fork.txt).  Here EVERY
+// workgroup reads the message (368 bytes over PCIe, all in parallel) and takes the camera tensors it needs from the
+// message's copy SOURCES (this call's tensors) instead of the captured buffers they are being copied into; workgroup 0
+// does the feed's own work for the later consumers (renderer, cascade hypotheses); the workgroup that finishes LAST
+// advances the execution counter -- every workgroup has read it by then (ticket in state[2]).
+__global__ void __launch_bounds__(256) frame_setup_feed_kernel(FrameSetupArgs a, const void** table, const FrameFeedMsg* ring,
+                                                               unsigned* state, int R) {
+  __shared__ FrameFeedMsg m;
+  const int t = threadIdx.x;
+  const unsigned n = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const volatile unsigned* g = reinterpret_cast<const volatile unsigned*>(ring + (n % (unsigned)R));
+  if (t < (int)(sizeof(FrameFeedMsg) / 4)) reinterpret_cast<unsigned*>(&m)[t] = g[t];
+  __syncthreads();
+  const int nc = m.n_copy < 8 ? m.n_copy : 8;
+  auto fresh = [&](const float* p) {
+    for (int c = 0; c < nc; ++c)
+      if (m.dst[c] == p) return m.src[c];
+    return p;
+  };
+  a.src_exts = fresh(a.src_exts), a.src_ixts = fresh(a.src_ixts), a.tar_ext = fresh(a.tar_ext), a.tar_ixt = fresh(a.tar_ixt);
+  a.near_far = fresh(a.near_far);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (t == 0 && m.seq != n) atomicAdd(&state[1], 1u);
+    if (t < m.n_ptr && t < 16) table[m.slot[t]] = m.value[t];
+    for (int c = 0; c < nc; ++c)
+      for (int j = t; j < m.count[c]; j += 256) m.dst[c][j] = m.src[c][j];
+  }
+  frame_setup_body(a);
+  __syncthreads();
+  if (t == 0) {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    __threadfence();
+    if (atomicAdd(&state[2], 1u) == total - 1u) {
+      state[2] = 0u;
+      __hip_atomic_store(&state[0], n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ void depth_values_cascade_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
@@ -429,6 +472,27 @@ int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* t
   a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
   hipLaunchKernelGGL(frame_setup_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a);
   BMV_LAUNCH_END("bmv_frame_setup");
+}
+
+int bmv_frame_setup_feed(const void** table, const void* ring, unsigned* state, int R, const float* src_exts,
+                         const float* src_ixts, const float* tar_ext, const float* tar_ixt, const float* src_scales,
+                         const float* tar_scales, int L, int B, int S, float* proj, const float* near_far, int D, int h, int w,
+                         int depth_inv, float* depth_values, float* near_far_out, bmv_stream_t stream) {
+  BMV_REQUIRE(table && ring && state && R > 0, "bmv_frame_setup_feed: null table / ring / state");
+  BMV_REQUIRE(src_exts && src_ixts && tar_ext && tar_ixt && src_scales && tar_scales && proj && near_far &&
+                  depth_values && near_far_out,
+              "bmv_frame_setup_feed: null pointer");
+  BMV_REQUIRE(L > 0 && L <= 4 && B > 0 && S > 0 && D > 0 && h > 0 && w > 0, "bmv_frame_setup_feed: bad shape (L=%d)", L);
+  BMV_REQUIRE(L * B * S <= 256 * (int)cdiv(h * w, 256), "bmv_frame_setup_feed: %d projection matrices do not fit one grid slice",
+              L * B * S);
+  FrameSetupArgs a;
+  a.src_exts = src_exts, a.src_ixts = src_ixts, a.tar_ext = tar_ext, a.tar_ixt = tar_ixt, a.near_far = near_far;
+  a.proj = proj, a.dv = depth_values, a.nf_out = near_far_out;
+  for (int l = 0; l < L; ++l) a.src_scale[l] = src_scales[l], a.tar_scale[l] = tar_scales[l];
+  a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
+  hipLaunchKernelGGL(frame_setup_feed_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a,
+                     table, static_cast<const FrameFeedMsg*>(ring), state, R);
+  BMV_LAUNCH_END("bmv_frame_setup_feed");
 }
 
 int bmv_depth_values_cascade(const float* depth, const float* std_, const float* near_far, int B, int h0, int w0,
