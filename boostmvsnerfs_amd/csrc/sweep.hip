@@ -158,19 +158,41 @@ __global__ void frame_setup_kernel(FrameSetupArgs a) { frame_setup_body(a); }
 // The same launch as the FIRST NODE of a captured frame (round 5): it is also the frame's feed
 // (csrc/timing.hip frame_feed_ring_kernel: this replay's message from the ring in pinned host memory -> the pointer
 // table, the small inputs copied into the captured buffers).  As two nodes the feed cost its own 7.8 us single-wave
-// kernel plus a 13.8 us gap in front of the next node (profiles/r5/r5_config2_frame_timeline_fork.txt).  Here EVERY
-// workgroup reads the message (368 bytes over PCIe, all in parallel) and takes the camera tensors it needs from the
-// message's copy SOURCES (this call's tensors) instead of the captured buffers they are being copied into; workgroup 0
-// does the feed's own work for the later consumers (renderer, cascade hypotheses); the workgroup that finishes LAST
-// advances the execution counter -- every workgroup has read it by then (ticket in state[2]).
+// kernel plus a 13.8 us gap in front of the next node (profiles/r5/r5_config2_frame_timeline_fork.txt: the gap follows
+// whatever node is FIRST in the graph -- the rest of the graph is still being submitted -- so a first node that already
+// does the frame's camera work hides it).  Workgroup 0 reads the message over PCIe (ONE reader: 180 workgroups each
+// reading it took 42 us), does the feed's work for the later consumers (renderer, cascade hypotheses) and PUBLISHES the
+// message in device memory (state[8..]) under the tag n + 1 in state[3]; the other workgroups wait for the tag (they are
+// all resident: the grid is a fraction of the chip) and take the camera tensors they need from the message's copy
+// SOURCES (this call's tensors) instead of the captured buffers those are being copied into.  The workgroup that
+// finishes LAST advances the execution counter state[0] -- every workgroup has read it by then (ticket in state[2]).
+constexpr int kFeedPubWords = 8;   // state[kFeedPubWords ..]: the published message (92 words)
 __global__ void __launch_bounds__(256) frame_setup_feed_kernel(FrameSetupArgs a, const void** table, const FrameFeedMsg* ring,
                                                                unsigned* state, int R) {
   __shared__ FrameFeedMsg m;
+  constexpr int NW = (int)(sizeof(FrameFeedMsg) / 4);
   const int t = threadIdx.x;
   const unsigned n = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const volatile unsigned* g = reinterpret_cast<const volatile unsigned*>(ring + (n % (unsigned)R));
-  if (t < (int)(sizeof(FrameFeedMsg) / 4)) reinterpret_cast<unsigned*>(&m)[t] = g[t];
-  __syncthreads();
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  unsigned* pub = state + kFeedPubWords;
+  if (first) {
+    const volatile unsigned* g = reinterpret_cast<const volatile unsigned*>(ring + (n % (unsigned)R));
+    if (t < NW) {
+      const unsigned v = g[t];
+      reinterpret_cast<unsigned*>(&m)[t] = v;
+      pub[t] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&state[3], n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (t == 0) {
+      while (__hip_atomic_load(&state[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != n + 1u) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    if (t < NW) reinterpret_cast<unsigned*>(&m)[t] = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
   const int nc = m.n_copy < 8 ? m.n_copy : 8;
   auto fresh = [&](const float* p) {
     for (int c = 0; c < nc; ++c)
@@ -179,7 +201,7 @@ __global__ void __launch_bounds__(256) frame_setup_feed_kernel(FrameSetupArgs a,
   };
   a.src_exts = fresh(a.src_exts), a.src_ixts = fresh(a.src_ixts), a.tar_ext = fresh(a.tar_ext), a.tar_ixt = fresh(a.tar_ixt);
   a.near_far = fresh(a.near_far);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+  if (first) {
     if (t == 0 && m.seq != n) atomicAdd(&state[1], 1u);
     if (t < m.n_ptr && t < 16) table[m.slot[t]] = m.value[t];
     for (int c = 0; c < nc; ++c)
@@ -316,7 +338,8 @@ template <int DT>
 __global__ void __launch_bounds__(64) depth_regress_kernel(const float* __restrict__ prob,
                                                             const float* __restrict__ dv, int D, int hw,
                                                             int depth_inv, float* __restrict__ depth,
-                                                            float* __restrict__ std_) {
+                                                            float* __restrict__ std_, const void* const* table,
+                                                            int s_depth, int s_std) {
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
@@ -367,8 +390,17 @@ __global__ void __launch_bounds__(64) depth_regress_kernel(const float* __restri
       var += (expf(p[(size_t)d * hw] - mx) / den) * (df * df);
     }
   }
+  const float sd = sqrtf(fmaxf(var, 1e-10f));
   depth[(size_t)b * hw + i] = mean;
-  std_[(size_t)b * hw + i] = sqrtf(fmaxf(var, 1e-10f));
+  std_[(size_t)b * hw + i] = sd;
+  // deferred outputs (bmv_defer_pointer): the maps are ALSO written to the tensors the table points at -- the later
+  // kernels of a captured frame read the captured buffers above, the caller gets these (no copy node at the frame's end)
+  if (table) {
+    float* d2 = deferred_load(table, s_depth, (float*)nullptr);
+    float* s2 = deferred_load(table, s_std, (float*)nullptr);
+    if (d2 && d2 != depth) d2[(size_t)b * hw + i] = mean;
+    if (s2 && s2 != std_) s2[(size_t)b * hw + i] = sd;
+  }
 }
 
 // The coarse level (64 planes on a few thousand pixels) is 80 one-wave workgroups for the kernel above, each issuing
@@ -490,6 +522,9 @@ int bmv_frame_setup_feed(const void** table, const void* ring, unsigned* state, 
   a.proj = proj, a.dv = depth_values, a.nf_out = near_far_out;
   for (int l = 0; l < L; ++l) a.src_scale[l] = src_scales[l], a.tar_scale[l] = tar_scales[l];
   a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
+  // (every workgroup must be resident: the others wait for workgroup 0)
+  BMV_REQUIRE((long)cdiv(h * w, 256) * B * (cdiv(D, 8) + 1) <= 1024, "bmv_frame_setup_feed: grid of %ld workgroups is not co-resident",
+              (long)cdiv(h * w, 256) * B * (cdiv(D, 8) + 1));
   hipLaunchKernelGGL(frame_setup_feed_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a,
                      table, static_cast<const FrameFeedMsg*>(ring), state, R);
   BMV_LAUNCH_END("bmv_frame_setup_feed");
@@ -571,10 +606,13 @@ int bmv_depth_regress_fwd(const float* depth_prob, const float* depth_values, in
                           int depth_inv, float* depth, float* std_, bmv_stream_t stream) {
   BMV_REQUIRE(depth_prob && depth_values && depth && std_, "bmv_depth_regress_fwd: null pointer");
   BMV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bmv_depth_regress_fwd: bad shape");
+  const DeferredPtr dd = deferred_for(depth), ds = deferred_for(std_);
+  BMV_REQUIRE(!dd.table || !ds.table || dd.table == ds.table, "bmv_depth_regress_fwd: the deferred outputs must share one table");
+  const void* const* table = dd.table ? dd.table : ds.table;
 #define DR(DT)                                                                                                 \
   hipLaunchKernelGGL(depth_regress_kernel<DT>, dim3(cdiv(h * w, 64), B), dim3(64), 0, as_stream(stream), depth_prob, \
-                     depth_values, D, h * w, depth_inv, depth, std_)
-  if (D == 64 && h * w <= 65536) {   // coarse level: four lanes per pixel
+                     depth_values, D, h * w, depth_inv, depth, std_, table, dd.table ? dd.slot : -1, ds.table ? ds.slot : -1)
+  if (D == 64 && h * w <= 65536 && !table) {   // coarse level: four lanes per pixel
     hipLaunchKernelGGL(depth_regress_quad_kernel<64>, dim3(cdiv(h * w, 16), B), dim3(64), 0, as_stream(stream),
                        depth_prob, depth_values, h * w, depth_inv, depth, std_);
     BMV_LAUNCH_END("bmv_depth_regress_fwd");

@@ -60,6 +60,7 @@ class Network(nn.Module):
         self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
         self.lookup_records = os.environ.get("BMV_LOOKUP_RECORDS", "1") == "1"
         self.frame_setup = os.environ.get("BMV_FRAME_SETUP", "1") == "1"
+        self.depth_maps_through_table = os.environ.get("BMV_DEPTH_MAPS_TABLE", "1") == "1"
         self._pre = None
         self.volume_records = os.environ.get("BMV_VOLUME_RECORDS", "1") == "1"
         self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
@@ -168,7 +169,9 @@ class Network(nn.Module):
         if train:
             st.depth, st.std = A.DepthRegress.apply(depth_prob, st.depth_values, cc.depth_inv[i])
         else:
-            st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i])
+            # (a rendered level's std / depth_mvs maps are frame outputs: written through the pointer table as well)
+            outs = (("std",) + (() if cc.depth_inv[i] else ("depth",))) if (cc.render_if[i] and self.depth_maps_through_table) else ()
+            st.depth, st.std = ops.depth_regress(depth_prob, st.depth_values, cc.depth_inv[i], frame_outputs=outs)
         return st
 
     def wants_grad(self):

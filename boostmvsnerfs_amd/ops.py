@@ -93,6 +93,9 @@ def frame_setup(src_exts, src_ixts, tar_ext, tar_ixt, src_scales, tar_scales, ne
         if not torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ops.pending_feed outside a stream capture")
         ring = tb.ring
+        if -(-h * w // 256) * B * (-(-D // 8) + 1) > 1024:      # (its workgroups wait for workgroup 0: all must be resident)
+            ring.node(tb)
+            return frame_setup(src_exts, src_ixts, tar_ext, tar_ixt, src_scales, tar_scales, near_far, D, h, w, depth_inv)
         _lib.check(lib.bmv_frame_setup_feed(tb.t.data_ptr(), ring.host.data_ptr(), ring.state.data_ptr(), ring.R,
                                             dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
                                             dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), ss, ts, L, B, S,
@@ -378,11 +381,18 @@ def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=N
     return out
 
 
-def depth_regress(depth_prob, depth_values, depth_inv):
+def depth_regress(depth_prob, depth_values, depth_inv, frame_outputs=()):
+    """frame_outputs: which of ("depth", "std") are outputs of the frame being captured as they are (autograph): the
+    kernel then ALSO writes them to the caller's tensors through the pointer table (no copy node at the frame's end)."""
     B, D, h, w = depth_values.shape
     depth = torch.empty(B, h, w, device=depth_values.device, dtype=torch.float32)
     std = torch.empty_like(depth)
     lib = _lib.load()
+    if frame_outputs and _deferring():
+        if "depth" in frame_outputs:
+            defer_output(depth, fresh=True)
+        if "std" in frame_outputs:
+            defer_output(std, fresh=True)
     _lib.check(lib.bmv_depth_regress_fwd(dptr(_c(depth_prob), "depth_prob"), dptr(_c(depth_values), "depth_values"),
                                          B, D, h, w, int(bool(depth_inv)), dptr(depth), dptr(std), stream()),
                "depth_regress")
@@ -655,8 +665,9 @@ class FeedRing:
         assert dt.itemsize == _lib.load().bmv_frame_feed_msg_bytes()
         self.host = torch.zeros(self.R * dt.itemsize, dtype=torch.uint8).pin_memory()
         self.msgs = self.host.numpy().view(dt)
-        # [executions of the node, sequence faults, workgroup ticket of bmv_frame_setup_feed, -]
-        self.state = torch.zeros(4, dtype=torch.int32, device=device)
+        # [executions of the node, sequence faults, bmv_frame_setup_feed: workgroup ticket, tag of the published message,
+        #  - x 4, the published message (92 words)]
+        self.state = torch.zeros(128, dtype=torch.int32, device=device)
         self.posted = 0
         self.pending = False      # a message has been posted and its replay not yet reported
         self.fast = None

@@ -49,8 +49,9 @@ int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* t
                     float* near_far_out, bmv_stream_t stream);
 /* ... and, as the FIRST node of a captured frame, the frame's feed as well (bmv_frame_feed_ring below: this replay's
  * message from the ring in pinned host memory -> pointer table + small-input copies): every workgroup reads the message
- * and takes the camera tensors from the message's copy sources; state (4 x u32, zeroed): [0] executions, [1] sequence
- * faults, [2] workgroup ticket.  One node and no gap instead of two nodes (7.8 us + a 13.8 us gap). */
+ * and takes the camera tensors from the message's copy sources; state (128 x u32, zeroed): [0] executions, [1] sequence
+ * faults, [2] workgroup ticket, [3] tag of the published message, [8..99] the message as workgroup 0 read it (one
+ * PCIe reader; the grid must be co-resident: <= 1024 workgroups).  One node instead of two nodes and a gap. */
 int bmv_frame_setup_feed(const void** table, const void* ring, unsigned* state, int R, const float* src_exts,
                          const float* src_ixts, const float* tar_ext, const float* tar_ixt, const float* src_scales,
                          const float* tar_scales, int L, int B, int S, float* proj, const float* near_far, int D, int h, int w,
@@ -107,7 +108,10 @@ int bmv_nchw_to_nhwc(const float* src, int n, int C, int H, int W, float* dst, b
 
 /* ---- a5  depth_regression                 lib/networks/enerf/utils.py:722-731
  * depth_prob, depth_values (B,D,h,w) -> depth, std (B,h,w); softmax over D,
- * values inverted (1/clamp_min(v,1e-6)) first when depth_inv. */
+ * values inverted (1/clamp_min(v,1e-6)) first when depth_inv.
+ * Honours bmv_defer_pointer for `depth` / `std` with an "ALSO" meaning: the maps are written to the given buffers (the
+ * later kernels of a captured frame read those) and, in addition, to the tensors table[slot] points at when the kernel
+ * runs (the frame's caller-visible depth_mvs / std outputs: no copy node at the end of the frame). */
 int bmv_depth_regress_fwd(const float* depth_prob, const float* depth_values, int B, int D, int h, int w,
                           int depth_inv, float* depth, float* std, bmv_stream_t stream);
 
