@@ -56,8 +56,6 @@ SIGNATURES = {
     "bmv_depth_values_uniform": [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_frame_setup": [c_f, c_f, c_f, c_f, C.POINTER(C.c_float), C.POINTER(C.c_float), c_i, c_i, c_i, c_f, c_f, c_i, c_i,
                         c_i, c_i, c_f, c_f, c_f],
-    "bmv_frame_setup_feed": [C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_f, c_f, c_f, c_f, C.POINTER(C.c_float),
-                             C.POINTER(C.c_float), c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_depth_values_cascade": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_homo_warp_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "bmv_sweep_variance_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f],

@@ -422,18 +422,8 @@ class AutoGraph:
             bb = dict(b)
             tb0 = ops.defer_table
             if tb0 is not None and tb0.ring is not None and torch.cuda.is_current_stream_capturing():
-                fused = getattr(self.net, "feeds_in_frame_setup", None)
-                if fused is not None and fused(bb):
-                    # the network's first launch (ops.frame_setup: cameras of the frame) is the feed node too
-                    ops.pending_feed = tb0
-                else:
-                    tb0.ring.node(tb0)      # first node of the frame: this replay's table entries and small inputs
-            try:
-                out = self.eager_forward(bb)
-                if ops.pending_feed is not None:
-                    raise RuntimeError("autograph: the network declared feeds_in_frame_setup but launched no frame_setup")
-            finally:
-                ops.pending_feed = None
+                tb0.ring.node(tb0)          # first node of the frame: this replay's table entries and small inputs
+            out = self.eager_forward(bb)
             for k, v in bb.items():
                 if k not in b:
                     added[k] = v

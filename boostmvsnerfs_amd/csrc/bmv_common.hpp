@@ -16,19 +16,6 @@
 namespace bmv {
 
 void set_error(const char* fmt, ...);
-
-// One message of the feed ring (bmv_frame_feed_ring / bmv_frame_setup_feed; boostmvsnerfs_amd/ops.py FeedRing): what ONE
-// replay of a captured frame reads from pinned host memory -- its table entries and the small inputs to copy.
-struct FrameFeedMsg {
-  unsigned seq;
-  int n_ptr, n_copy, pad;
-  int slot[16];
-  const void* value[16];
-  const float* src[8];
-  float* dst[8];
-  int count[8];
-};
-static_assert(sizeof(FrameFeedMsg) == 368, "layout shared with boostmvsnerfs_amd/ops.py FeedRing");
 // explicit tuning switch of the launchers (csrc/tuning.hip; include/bmv.h bmv_tuning_set): its value, or dflt when unset
 int tuning(const char* name, int dflt);
 

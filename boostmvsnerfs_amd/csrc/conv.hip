@@ -908,7 +908,7 @@ struct SplitKTile {
   static constexpr int TAPS = KD * K * K;
 };
 
-template <int KD, int K, int S, bool IS3D, int TYV = 4, bool PF = false>
+template <int KD, int K, int S, bool IS3D, int TYV = 4>
 // stride 1: 4 workgroups per CU fit the LDS (38 KB each); the allocator needs 121 instead of 160 registers for that
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BMV_CONV_WPE_TUNED && S == 1) ? 4 : 1, 8)))
 void conv_splitk_kernel(ConvArgs a) {
@@ -970,9 +970,7 @@ void conv_splitk_kernel(ConvArgs a) {
   for (int kd = 0; kd < KD; ++kd) zin[kd] = !IS3D || (iz0 + kd >= 0 && iz0 + kd < a.D);
   // stride 1: the loads of stage s + 1 are in flight during the MFMAs of stage s (the tile registers are free once
   // they are in LDS); the stride-2 tile is 64 registers in a 256-register kernel and stays single-buffered
-  // (4 rows per workgroup: tried twice -- tile only; tile + weights double-buffered --, slower; with one
-  // row per workgroup the tile is a quarter of the registers: PF)
-  constexpr bool PREFETCH = PF;
+  constexpr bool PREFETCH = false;   // tried twice (tile only; tile + weights double-buffered): slower, see DESIGN 4.7
   float wv[T::TAPS], wnext[T::TAPS];
   auto load_w = [&](int stage, float (&w)[T::TAPS]) {   // this wave's k-step of the stage
     const int ks = stage * 4 + wave;
@@ -1058,13 +1056,10 @@ static void launch_splitk(const ConvArgs& a, hipStream_t st) {
   int rows = bmv::tuning("BMV_CONV_SPLITK_ROWS", 0);
   if (rows != 1 && rows != 2 && rows != 4) rows = base * cdiv(a.Ho, 4) >= 1024 ? 4 : base * cdiv(a.Ho, 2) >= 1024 ? 2 : 1;
   dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, rows) * a.Do * a.B, cdiv(a.Cout, 16));
-  const bool pf = bmv::tuning("BMV_CONV_SPLITK_PF", 0) != 0;
   if (rows == 4)
     hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 4>), grid, dim3(256), 0, st, a);
   else if (rows == 2)
     hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 2>), grid, dim3(256), 0, st, a);
-  else if (pf)
-    hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 1, true>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_splitk_kernel<KD, K, S, IS3D, 1>), grid, dim3(256), 0, st, a);
 }

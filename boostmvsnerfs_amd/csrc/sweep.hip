@@ -140,7 +140,7 @@ struct FrameSetupArgs {
   float src_scale[4], tar_scale[4];
   int L, B, S, D, hw, depth_inv;
 };
-__device__ __forceinline__ void frame_setup_body(const FrameSetupArgs& a) {
+__global__ void frame_setup_kernel(FrameSetupArgs a) {
   const int zgroups = (a.D + 7) / 8;
   if ((int)blockIdx.z < zgroups) {
     depth_values_uniform_group(blockIdx.z, a.near_far, a.D, a.hw, a.depth_inv, a.dv, a.nf_out);
@@ -152,71 +152,6 @@ __device__ __forceinline__ void frame_setup_body(const FrameSetupArgs& a) {
   const int l = idx / per;
   proj_mats_one(idx - l * per, a.src_exts, a.src_ixts, a.tar_ext, a.tar_ixt, a.src_scale[l], a.tar_scale[l], a.S,
                 a.proj + (size_t)l * per * 12);
-}
-__global__ void frame_setup_kernel(FrameSetupArgs a) { frame_setup_body(a); }
-
-// The same launch as the FIRST NODE of a captured frame (round 5): it is also the frame's feed
-// (csrc/timing.hip frame_feed_ring_kernel: this replay's message from the ring in pinned host memory -> the pointer
-// table, the small inputs copied into the captured buffers).  As two nodes the feed cost its own 7.8 us single-wave
-// kernel plus a 13.8 us gap in front of the next node (profiles/r5/r5_config2_frame_timeline_fork.txt: the gap follows
-// whatever node is FIRST in the graph -- the rest of the graph is still being submitted -- so a first node that already
-// does the frame's camera work hides it).  Workgroup 0 reads the message over PCIe (ONE reader: 180 workgroups each
-// reading it took 42 us), does the feed's work for the later consumers (renderer, cascade hypotheses) and PUBLISHES the
-// message in device memory (state[8..]) under the tag n + 1 in state[3]; the other workgroups wait for the tag (they are
-// all resident: the grid is a fraction of the chip) and take the camera tensors they need from the message's copy
-// SOURCES (this call's tensors) instead of the captured buffers those are being copied into.  The workgroup that
-// finishes LAST advances the execution counter state[0] -- every workgroup has read it by then (ticket in state[2]).
-constexpr int kFeedPubWords = 8;   // state[kFeedPubWords ..]: the published message (92 words)
-__global__ void __launch_bounds__(256) frame_setup_feed_kernel(FrameSetupArgs a, const void** table, const FrameFeedMsg* ring,
-                                                               unsigned* state, int R) {
-  __shared__ FrameFeedMsg m;
-  constexpr int NW = (int)(sizeof(FrameFeedMsg) / 4);
-  const int t = threadIdx.x;
-  const unsigned n = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-  unsigned* pub = state + kFeedPubWords;
-  if (first) {
-    const volatile unsigned* g = reinterpret_cast<const volatile unsigned*>(ring + (n % (unsigned)R));
-    if (t < NW) {
-      const unsigned v = g[t];
-      reinterpret_cast<unsigned*>(&m)[t] = v;
-      pub[t] = v;
-    }
-    __threadfence();
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(&state[3], n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    if (t == 0) {
-      while (__hip_atomic_load(&state[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != n + 1u) __builtin_amdgcn_s_sleep(2);
-    }
-    __syncthreads();
-    if (t < NW) reinterpret_cast<unsigned*>(&m)[t] = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-  }
-  const int nc = m.n_copy < 8 ? m.n_copy : 8;
-  auto fresh = [&](const float* p) {
-    for (int c = 0; c < nc; ++c)
-      if (m.dst[c] == p) return m.src[c];
-    return p;
-  };
-  a.src_exts = fresh(a.src_exts), a.src_ixts = fresh(a.src_ixts), a.tar_ext = fresh(a.tar_ext), a.tar_ixt = fresh(a.tar_ixt);
-  a.near_far = fresh(a.near_far);
-  if (first) {
-    if (t == 0 && m.seq != n) atomicAdd(&state[1], 1u);
-    if (t < m.n_ptr && t < 16) table[m.slot[t]] = m.value[t];
-    for (int c = 0; c < nc; ++c)
-      for (int j = t; j < m.count[c]; j += 256) m.dst[c][j] = m.src[c][j];
-  }
-  frame_setup_body(a);
-  __syncthreads();
-  if (t == 0) {
-    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-    __threadfence();
-    if (atomicAdd(&state[2], 1u) == total - 1u) {
-      state[2] = 0u;
-      __hip_atomic_store(&state[0], n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
 
 __global__ void depth_values_cascade_kernel(const float* __restrict__ depth, const float* __restrict__ std_,
@@ -504,30 +439,6 @@ int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* t
   a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
   hipLaunchKernelGGL(frame_setup_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a);
   BMV_LAUNCH_END("bmv_frame_setup");
-}
-
-int bmv_frame_setup_feed(const void** table, const void* ring, unsigned* state, int R, const float* src_exts,
-                         const float* src_ixts, const float* tar_ext, const float* tar_ixt, const float* src_scales,
-                         const float* tar_scales, int L, int B, int S, float* proj, const float* near_far, int D, int h, int w,
-                         int depth_inv, float* depth_values, float* near_far_out, bmv_stream_t stream) {
-  BMV_REQUIRE(table && ring && state && R > 0, "bmv_frame_setup_feed: null table / ring / state");
-  BMV_REQUIRE(src_exts && src_ixts && tar_ext && tar_ixt && src_scales && tar_scales && proj && near_far &&
-                  depth_values && near_far_out,
-              "bmv_frame_setup_feed: null pointer");
-  BMV_REQUIRE(L > 0 && L <= 4 && B > 0 && S > 0 && D > 0 && h > 0 && w > 0, "bmv_frame_setup_feed: bad shape (L=%d)", L);
-  BMV_REQUIRE(L * B * S <= 256 * (int)cdiv(h * w, 256), "bmv_frame_setup_feed: %d projection matrices do not fit one grid slice",
-              L * B * S);
-  FrameSetupArgs a;
-  a.src_exts = src_exts, a.src_ixts = src_ixts, a.tar_ext = tar_ext, a.tar_ixt = tar_ixt, a.near_far = near_far;
-  a.proj = proj, a.dv = depth_values, a.nf_out = near_far_out;
-  for (int l = 0; l < L; ++l) a.src_scale[l] = src_scales[l], a.tar_scale[l] = tar_scales[l];
-  a.L = L, a.B = B, a.S = S, a.D = D, a.hw = h * w, a.depth_inv = depth_inv;
-  // (every workgroup must be resident: the others wait for workgroup 0)
-  BMV_REQUIRE((long)cdiv(h * w, 256) * B * (cdiv(D, 8) + 1) <= 1024, "bmv_frame_setup_feed: grid of %ld workgroups is not co-resident",
-              (long)cdiv(h * w, 256) * B * (cdiv(D, 8) + 1));
-  hipLaunchKernelGGL(frame_setup_feed_kernel, dim3(cdiv(h * w, 256), B, cdiv(D, 8) + 1), dim3(256), 0, as_stream(stream), a,
-                     table, static_cast<const FrameFeedMsg*>(ring), state, R);
-  BMV_LAUNCH_END("bmv_frame_setup_feed");
 }
 
 int bmv_depth_values_cascade(const float* depth, const float* std_, const float* near_far, int B, int h0, int w0,

@@ -72,6 +72,16 @@ __global__ void __launch_bounds__(256) frame_feed_kernel(const void** table, Fra
 // the host writes message number n (plain stores) and replays the graph -- no launch in front of the replay at all.
 // `state[0]` counts the replays on the device (the host counts its posts; up to R frames may be in flight), a message
 // whose sequence number is not the replay's number raises state[1] (bmv_frame_feed_ring_faults).
+struct FrameFeedMsg {
+  unsigned seq;
+  int n_ptr, n_copy, pad;
+  int slot[16];
+  const void* value[16];
+  const float* src[8];
+  float* dst[8];
+  int count[8];
+};
+static_assert(sizeof(FrameFeedMsg) == 368, "layout shared with boostmvsnerfs_amd/ops.py FeedRing");
 __global__ void __launch_bounds__(256) frame_feed_ring_kernel(const void** table, const FrameFeedMsg* ring, unsigned* state,
                                                               int R) {
   __shared__ FrameFeedMsg m;

@@ -29,7 +29,6 @@ Knob g_knobs[] = {
     {"BMV_CONV_SPLIT_RW", "split-bf16 convolution: rows per wave"},
     {"BMV_CONV_SPLITK", "0 = no split-K for the small interior layers of the regularisers"},
     {"BMV_CONV_SPLITK_ROWS", "split-K layers: output rows per workgroup (4, 2, 1; default: the largest that gives >= 1024 workgroups)"},
-    {"BMV_CONV_SPLITK_PF", "split-K layers with one row per workgroup: 1 = next 16-channel stage loaded under the current one's matrix instructions"},
     {"BMV_CONV_PAIR_ROWS", "row-paired 3-D layers: rows per wave (4: half-height tiles, 5: only below 1024 workgroups)"},
     {"BMV_CONV0_R", "fused first FeatureNet block: rows per wave (default 4)"},
     {"BMV_FPN_SMOOTH_R", "fused FPN + smooth0: rows per tile (default 8)"},

@@ -289,10 +289,6 @@ class Network(enerf_network.Network):
         batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
         return ret
 
-    def feeds_in_frame_setup(self, batch):
-        """The K-volume frame computes its cameras on a side stream under FeatureNet: the feed stays its own first node."""
-        return False
-
     def _forward_checked(self, batch):           # (forward itself, with the self-capturing replay, is the base class's)
         try:
             return self._forward_boost(batch)

@@ -286,7 +286,7 @@ class Network(nn.Module):
         return {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
 
     # ------------------------------------------------------------------ overlapped front end (inference)
-    def _front_overlapped(self, batch, views, early=None):
+    def _front_overlapped(self, batch, views):
         """FeatureNet's coarsest map is all the level-0 cost volume needs: the level-0 chain (sweep, 3-D
         regulariser, depth regression: ~20 short launches that fill a fraction of the chip) runs on a second
         HIP stream while the main stream finishes FeatureNet's top-down path (4 large launches).
@@ -294,7 +294,7 @@ class Network(nn.Module):
         x = batch["src_inps"]
         B, V, C, H, W = x.shape
         fn = self.feature_net
-        self._pre = early if early is not None else (self.camera_only(views, batch) if self.frame_setup else None)
+        self._pre = self.camera_only(views, batch) if self.frame_setup else None
         fn.quad_out = self.sweep_algo == 0 or self.sweep_algo >= 500
         c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
         main = torch.cuda.current_stream()
@@ -379,20 +379,10 @@ class Network(nn.Module):
             ag.invalidate()
         return super()._apply(fn, *args, **kwargs)
 
-    def feeds_in_frame_setup(self, batch):
-        """autograph: this frame's FIRST launch is ops.frame_setup (`camera_only`, before anything reads a table entry or
-        a small input), so the feed node of a captured frame can ride in it (bmv_frame_setup_feed).  True for the plain
-        ENeRF inference frame; subclasses with another launch order (K-volume networks) say no."""
-        return (type(self)._forward is Network._forward and self.frame_setup and not self.wants_grad()
-                and batch["src_inps"].is_cuda and os.environ.get("BMV_FEED_IN_SETUP", "1") == "1")
-
     def _forward(self, batch):
         cc = cfg.enerf.cas_config
-        views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
-        early = None
-        if ops.pending_feed is not None:       # (captured frame: the cameras first -- that launch is the feed node)
-            early = self.camera_only(views, batch)
         self.ensure_rays(batch)
+        views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         st0 = None
         if self._side_stream is None and batch["src_inps"].is_cuda:
             self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))   # created outside any capture
@@ -403,11 +393,10 @@ class Network(nn.Module):
             if (self.overlap_front and batch["src_inps"].is_cuda
                     and (self.overlap_eager or torch.cuda.is_current_stream_capturing())
                     and engine_ok(self.feature_net, batch["src_inps"])):
-                feats, st0 = self._front_overlapped(batch, views, early)
+                feats, st0 = self._front_overlapped(batch, views)
             else:
-                self._pre = early if early is not None else (
-                    self.camera_only(views, batch) if (self.frame_setup and not self.wants_grad()
-                                                       and batch["src_inps"].is_cuda) else None)
+                self._pre = self.camera_only(views, batch) if (self.frame_setup and not self.wants_grad()
+                                                               and batch["src_inps"].is_cuda) else None
                 feats = self.forward_feat(batch["src_inps"])
         finally:
             self.feature_net.pack_lookup = False

@@ -84,33 +84,10 @@ def frame_setup(src_exts, src_ixts, tar_ext, tar_ixt, src_scales, tar_scales, ne
     ss = (C.c_float * L)(*[float(v) for v in src_scales])
     ts = (C.c_float * L)(*[float(v) for v in tar_scales])
     lib = _lib.load()
-    global pending_feed
-    tb = pending_feed
-    if tb is not None:
-        # the frame being captured handed its feed node to this launch (autograph: the network's first launch): ONE node
-        # reads this replay's ring message, points the table, copies the small inputs AND computes the cameras
-        pending_feed = None
-        if not torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("ops.pending_feed outside a stream capture")
-        ring = tb.ring
-        if -(-h * w // 256) * B * (-(-D // 8) + 1) > 1024:      # (its workgroups wait for workgroup 0: all must be resident)
-            ring.node(tb)
-            return frame_setup(src_exts, src_ixts, tar_ext, tar_ixt, src_scales, tar_scales, near_far, D, h, w, depth_inv)
-        _lib.check(lib.bmv_frame_setup_feed(tb.t.data_ptr(), ring.host.data_ptr(), ring.state.data_ptr(), ring.R,
-                                            dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"),
-                                            dptr(_c(tar_ext), "tar_ext"), dptr(_c(tar_ixt), "tar_ixt"), ss, ts, L, B, S,
-                                            dptr(proj), dptr(_c(near_far), "near_far"), D, h, w, int(bool(depth_inv)),
-                                            dptr(dv), dptr(nf), stream()), "frame_setup_feed")
-        return [proj[l] for l in range(L)], (dv, nf)
     _lib.check(lib.bmv_frame_setup(dptr(_c(src_exts), "src_exts"), dptr(_c(src_ixts), "src_ixts"), dptr(_c(tar_ext), "tar_ext"),
                                    dptr(_c(tar_ixt), "tar_ixt"), ss, ts, L, B, S, dptr(proj), dptr(_c(near_far), "near_far"),
                                    D, h, w, int(bool(depth_inv)), dptr(dv), dptr(nf), stream()), "frame_setup")
     return [proj[l] for l in range(L)], (dv, nf)
-
-
-# The PtrTable of a frame being captured whose feed node (FeedRing.node) has been handed to the network's first launch:
-# frame_setup() above takes it (autograph sets it when the network says `feeds_in_frame_setup(batch)`).
-pending_feed = None
 
 
 def depth_values_cascade(depth, std, near_far, h, w, D):
@@ -665,9 +642,7 @@ class FeedRing:
         assert dt.itemsize == _lib.load().bmv_frame_feed_msg_bytes()
         self.host = torch.zeros(self.R * dt.itemsize, dtype=torch.uint8).pin_memory()
         self.msgs = self.host.numpy().view(dt)
-        # [executions of the node, sequence faults, bmv_frame_setup_feed: workgroup ticket, tag of the published message,
-        #  - x 4, the published message (92 words)]
-        self.state = torch.zeros(128, dtype=torch.int32, device=device)
+        self.state = torch.zeros(2, dtype=torch.int32, device=device)     # [executions of the node, sequence faults]
         self.posted = 0
         self.pending = False      # a message has been posted and its replay not yet reported
         self.fast = None

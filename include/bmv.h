@@ -47,15 +47,6 @@ int bmv_frame_setup(const float* src_exts, const float* src_ixts, const float* t
                     const float* src_scales, const float* tar_scales, int L, int B, int S, float* proj,
                     const float* near_far, int D, int h, int w, int depth_inv, float* depth_values,
                     float* near_far_out, bmv_stream_t stream);
-/* ... and, as the FIRST node of a captured frame, the frame's feed as well (bmv_frame_feed_ring below: this replay's
- * message from the ring in pinned host memory -> pointer table + small-input copies): every workgroup reads the message
- * and takes the camera tensors from the message's copy sources; state (128 x u32, zeroed): [0] executions, [1] sequence
- * faults, [2] workgroup ticket, [3] tag of the published message, [8..99] the message as workgroup 0 read it (one
- * PCIe reader; the grid must be co-resident: <= 1024 workgroups).  One node instead of two nodes and a gap. */
-int bmv_frame_setup_feed(const void** table, const void* ring, unsigned* state, int R, const float* src_exts,
-                         const float* src_ixts, const float* tar_ext, const float* tar_ixt, const float* src_scales,
-                         const float* tar_scales, int L, int B, int S, float* proj, const float* near_far, int D, int h, int w,
-                         int depth_inv, float* depth_values, float* near_far_out, bmv_stream_t stream);
 
 /* cascade level (:112-153, prev level in disparity, this level in depth): bilinear
  * (align_corners) upsample of depth/std (B,h0,w0) and near_far (B,2,h0,w0) to (h,w);
