@@ -99,6 +99,29 @@ def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, var
     return out
 
 
+def pack_convT_c4(weight, bias):
+    """ConvTranspose3d weight (Cin, Cout <= 8, 3, 3, 3) (batch norm folded: fold_bn(..., out_dim=1)), bias (Cout) ->
+    (wpack, bias) of bmv_conv3d_transpose_c4_fwd: wpack[chunk][tap][g][i][k] = weight[4 chunk + k][4 g + i][tap]."""
+    return pack_conv_c4(weight.detach().transpose(0, 1), bias)
+
+
+def convT_c4_fwd(x, wpack, bias, Cout, skip=None, relu=False, slope=None, variant=0):
+    """x (B,Cin,D,H,W) -> act(conv_transpose3d(x, k=3, stride=2, padding=1, output_padding=1) + bias) + skip, Cout <= 8,
+    on the 4 x 4 x 1 matrix blocks (csrc/conv_c4.hip)."""
+    B, Cin, D, H, W = x.shape
+    out = torch.empty(B, Cout, 2 * D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    if skip is not None:
+        assert skip.shape == out.shape and skip.is_contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    lib = _lib.load()
+    with ktimer.region(f"convT_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv3d_transpose_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
+                                  dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout,
+                                  _slope(relu, slope), int(variant), stream())
+    _lib.check(rc, "convT_c4_fwd")
+    return out
+
+
 def pack_conv_split(weight, bias, parts=3):
     """weight (Cout <= 16, Cin % 8 == 0, 3, 3, 3) -> the split-bf16 A operands of bmv_conv3d_split_fwd (csrc/conv_split.hip),
     int32 [octet][step 7][part][lane 64][4]: lane = 16 * (tap % 4) + cout, the 8 bf16 of a lane = the 8 channels of the

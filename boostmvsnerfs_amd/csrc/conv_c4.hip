@@ -42,8 +42,13 @@ struct C4Args {
 constexpr int kC4RS = 18;   // tile row pitch in positions: 16 outputs + halo
 
 // NG: groups of 4 output channels; NW: waves per workgroup (a wave = 16 x by 4 y); TZ: output planes per wave; KD: 3 / 1
-template <int NG, int NW, int TZ, int KD>
+// VD (NG == 3, Cout == 9: feat_conv + depth_conv): the ninth channel -- the depth logit -- is 4 vector FMAs per (tap,
+// chunk) on the B operands the matrix instructions use anyway, with its weights as a wave-uniform LDS read, instead of a
+// third matrix group that would be 1 / 4 full: 8 instead of 12 matrix instructions per tap, the same fp32 FMA chain.
+template <int NG, int NW, int TZ, int KD, bool VD = false>
 __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
+  constexpr int NGM = VD ? NG - 1 : NG;     // groups on the matrix cores
+  static_assert(!VD || NG == 3, "the vector channel is channel 8 of a 9-channel layer");
   constexpr int NT = 64 * NW, TY = 4 * NW, TYH = TY + 2, TZH = TZ + KD - 1;
   constexpr int POS = TZH * TYH * kC4RS, NSLOT = (POS + NT - 1) / NT, TAPS = KD * 9;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -106,6 +111,7 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   for (int z = 0; z < TZ; ++z)
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[z][g] = f32x4c{0.f, 0.f, 0.f, 0.f};
+  const f32x4c* dp = wl + (NG - 1) * 4;     // VD: row 0 of the last group = the depth channel's 4 input-channel weights
 
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();   // every wave is done with the previous tile (first pass: the weights are being written)
@@ -122,9 +128,9 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int tap = (kd * 3 + ky) * 3 + kx;
-          f32x4c A[NG], Bv[TZ];
+          f32x4c A[NGM], Bv[TZ];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) A[g] = aw[(tap * NG + g) * 4];
+          for (int g = 0; g < NGM; ++g) A[g] = aw[(tap * NG + g) * 4];
 #pragma unroll
           for (int z = 0; z < TZ; ++z) Bv[z] = bp[((z + kd) * TYH + ky) * kC4RS + kx];
 #pragma unroll
@@ -132,8 +138,15 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
 #pragma unroll
             for (int z = 0; z < TZ; ++z)
 #pragma unroll
-              for (int g = 0; g < NG; ++g)
+              for (int g = 0; g < NGM; ++g)
                 acc[z][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g][k], Bv[z][k], acc[z][g], 0, 0, 0);
+          if constexpr (VD) {
+            const f32x4c wd = dp[(chunk * TAPS + tap) * NG * 4];
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[z][NG - 1][0] = fmaf(wd[k], Bv[z][k], acc[z][NG - 1][0]);
+          }
         }
   }
 
@@ -175,12 +188,12 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   }
 }
 
-template <int NG, int NW, int TZ, int KD>
+template <int NG, int NW, int TZ, int KD, bool VD = false>
 static int c4_launch(const C4Args& a, hipStream_t st) {
   constexpr int TY = 4 * NW, POS = (TZ + KD - 1) * (TY + 2) * kC4RS;
   const int nchunk = (a.Cin + 3) >> 2;
   const size_t lds = ((size_t)nchunk * KD * 9 * NG * 4 + POS) * 16;
-  auto kern = conv_c4_kernel<NG, NW, TZ, KD>;
+  auto kern = conv_c4_kernel<NG, NW, TZ, KD, VD>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
@@ -188,6 +201,155 @@ static int c4_launch(const C4Args& a, hipStream_t st) {
   }
   const unsigned ntx = (a.W + 15) / 16, nty = (a.H + TY - 1) / TY, ntz = (a.D + TZ - 1) / TZ;
   hipLaunchKernelGGL(kern, dim3(ntx * nty * ntz * a.B), dim3(64 * NW), lds, st, a);
+  return BMV_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k = 3, stride 2, padding 1, output_padding 1) with Cout <= 8 (cost_reg_net.py:23-41 conv11: 16 -> 8,
+// the regularisers' last up-sampling step, + the U-Net skip) on the same 4 x 4 x 1 blocks.  Output o = 2 m + p per axis:
+// p = 0: in[m] w[1];  p = 1: in[m] w[2] + in[m + 1] w[0] -- the 8 output parities of an input position take 1 + 2 + 2 +
+// 4 + 2 + 4 + 4 + 8 = 27 taps, no product with a stuffed zero.  A wave owns 16 x 4 INPUT positions of one plane and ONE
+// group of 4 output channels with the 8 parity accumulators (32 registers); the 8 shifted B operands of a 4-channel
+// chunk are 8 ds_read_b128.  The two x parities of a lane are adjacent in the output row: one 8-byte store, rows of 16
+// lanes = 128 contiguous bytes.  (The 16-row kernel of conv.hip ran this layer at 23 TF/s: half of every tile empty and
+// a 144-register epilogue; 24.9 us at level 1.)
+// ---------------------------------------------------------------------------------------------------------------
+struct CT4Args {
+  const float* in;      // (B, Cin, D, H, W)
+  const float* wpack;   // [chunk][tap][g][cout 4][cin 4] (taps of the ConvTranspose3d weight, batch norm folded in)
+  const float* bias;    // (4 NG)
+  const float* skip;    // nullable, layout of out
+  float* out;           // (B, Cout, 2 D, 2 H, 2 W)
+  int B, Cin, D, H, W, Cout;
+  float slope;
+};
+
+template <int NG, int NYS>   // NG cout groups x NYS slabs of 4 input rows = waves per workgroup
+__global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
+  constexpr int NT = 64 * NG * NYS, TY = 4 * NYS, TYH = TY + 1, RS = 17;
+  constexpr int POS = 2 * TYH * RS, NSLOT = (POS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nchunk = (a.Cin + 3) >> 2;
+  f32x4c* wl = reinterpret_cast<f32x4c*>(lds);                     // [nchunk][27][NG][4]
+  f32x4c* tile = wl + nchunk * 27 * NG * 4;                         // [2][TYH][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = wave % NG, ys = wave / NG;
+  const int ntx = (a.W + 15) >> 4, nty = (a.H + TY - 1) / TY;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % ntx;
+  bid /= ntx;
+  const int ty = bid % nty;
+  bid /= nty;
+  const int mz = bid % a.D, b = bid / a.D;
+  const int x0 = tx * 16, y0 = ty * TY;
+  const int plane = a.D * a.H * a.W;
+  {
+    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
+    for (int i = tid; i < nchunk * 27 * NG * 4; i += NT) wl[i] = src[i];
+  }
+  unsigned goff[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int slot = tid + NT * j;
+    const int sx = slot % RS, t = slot / RS, sy = t % TYH, sz = t / TYH;
+    const int gx = x0 + sx, gy = y0 + sy, gz = mz + sz;
+    const bool ok = (slot < POS) & (gx < a.W) & (gy < a.H) & (gz < a.D);
+    goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
+  }
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
+  f32x4c pre[NSLOT];
+  auto load_tile = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        pre[j][c] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff[j] + 4u * (unsigned)((chunk * 4 + c) * plane), 0, 0));
+  };
+  load_tile(0);
+  const unsigned lh = (unsigned)lane & 31u, odd = 0xF00F0FF0u;
+  const int rb = (int)((odd >> lh) & 1u);
+  const int xi = __popc((rb ? odd : ~odd) & ((1u << lh) - 1u));
+  const int ry = 2 * (lane >> 5) + rb;
+  const f32x4c* bp = tile + (ys * 4 + ry) * RS + xi;                // + (oz * TYH + oy) * RS + ox
+  const f32x4c* ap = wl + g * 4 + (lane & 3);                       // + (chunk * 27 + tap) * NG * 4
+  f32x4c acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = f32x4c{0.f, 0.f, 0.f, 0.f};
+  const bool z1 = mz + 1 < a.D;    // the second input plane exists (else its taps multiply zeros: skipped, wave-uniform)
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if ((j + 1) * NT <= POS || tid + NT * j < POS) tile[tid + NT * j] = pre[j];
+    __syncthreads();
+    if (chunk + 1 < nchunk) load_tile(chunk + 1);
+    const f32x4c* aw = ap + chunk * (27 * NG * 4);
+    f32x4c Bv[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) Bv[o] = bp[((o >> 2) * TYH + ((o >> 1) & 1)) * RS + (o & 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+#pragma unroll
+      for (int dz = 0; dz <= pz; ++dz) {
+        const int kz = pz ? 2 * dz : 1, oz = pz ? 1 - dz : 0;
+        if (oz == 1 && !z1) continue;
+#pragma unroll
+        for (int dy = 0; dy <= py; ++dy)
+#pragma unroll
+          for (int dx = 0; dx <= px; ++dx) {
+            const int ky = py ? 2 * dy : 1, oy = py ? 1 - dy : 0;
+            const int kx = px ? 2 * dx : 1, ox = px ? 1 - dx : 0;
+            const f32x4c A = aw[((kz * 3 + ky) * 3 + kx) * NG * 4];
+            const f32x4c Bq = Bv[oz * 4 + oy * 2 + ox];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[k], Bq[k], acc[q], 0, 0, 0);
+          }
+      }
+    }
+  }
+  const int mx = x0 + xi, my = y0 + ys * 4 + ry;
+  if (mx >= a.W || my >= a.H) return;
+  const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+  const size_t cs = (size_t)Do * Ho * Wo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = 4 * g + r;
+    if (co >= a.Cout) continue;
+    const float bs = a.bias[co];
+    float2 sk[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const size_t o = (((size_t)b * a.Cout + co) * Do + 2 * mz + (qq >> 1)) * (size_t)Ho * Wo + (size_t)(2 * my + (qq & 1)) * Wo + 2 * mx;
+      sk[qq] = a.skip ? *reinterpret_cast<const float2*>(a.skip + o) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const size_t o = (((size_t)b * a.Cout + co) * Do + 2 * mz + (qq >> 1)) * (size_t)Ho * Wo + (size_t)(2 * my + (qq & 1)) * Wo + 2 * mx;
+      float v0 = acc[2 * qq][r] + bs, v1 = acc[2 * qq + 1][r] + bs;
+      v0 = fmaxf(v0, 0.f) + a.slope * fminf(v0, 0.f), v1 = fmaxf(v1, 0.f) + a.slope * fminf(v1, 0.f);
+      *reinterpret_cast<float2*>(a.out + o) = make_float2(v0 + sk[qq].x, v1 + sk[qq].y);
+    }
+  }
+  (void)cs;
+}
+
+template <int NG, int NYS>
+static int ct4_launch(const CT4Args& a, hipStream_t st) {
+  constexpr int TY = 4 * NYS, POS = 2 * (TY + 1) * 17;
+  const int nchunk = (a.Cin + 3) >> 2;
+  const size_t lds = ((size_t)nchunk * 27 * NG * 4 + POS) * 16;
+  auto kern = convT_c4_kernel<NG, NYS>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return BMV_ERR_UNSUPPORTED;
+  }
+  const unsigned ntx = (a.W + 15) / 16, nty = (a.H + TY - 1) / TY;
+  hipLaunchKernelGGL(kern, dim3(ntx * nty * a.D * a.B), dim3(64 * NG * NYS), lds, st, a);
   return BMV_OK;
 }
 
@@ -227,7 +389,9 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
     // (measured on the frame's four layers, profiles/r5/conv_c4_layers_first.txt: one plane per wave -- 58 registers,
     // 7-8 waves per SIMD -- beats two planes per wave at 106 registers everywhere: 56.8 / 54.2 / 38.3 / 22.1 us against
     // 60.0 / 54.5 / 41.7 / 25.0)
-    if (variant == 0 || variant == 3) {
+    if (variant == 0 && Cout == 9) {
+      rc = c4_launch<3, 4, 1, 3, true>(a, st);       // the 9-channel heads: 8 channels on the matrix cores + 1 on the vector ALU
+    } else if (variant == 0 || variant == 3) {
       C4(1, 4, 1, 3);
       C4(2, 4, 1, 3);
       C4(3, 4, 1, 3);
@@ -258,6 +422,31 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
   if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_conv_c4_fwd: variant %d not instantiated for Cout=%d kd=%d", variant, Cout, kd);
   if (rc != BMV_OK) return rc;
   BMV_LAUNCH_END("bmv_conv_c4_fwd");
+}
+
+// ConvTranspose3d(k = 3, stride 2, padding 1, output_padding 1) for Cout <= 8 on the 4 x 4 x 1 blocks:
+// in (B,Cin,D,H,W) -> out (B,Cout,2D,2H,2W) = act(convT(in) + bias) + skip; wpack as bmv_conv_c4_fwd's (kd = 3) with the
+// taps of the transposed weight (Cin,Cout,3,3,3) -> [chunk][tap][g][cout][cin]
+int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
+                     int D, int H, int W, int Cout, float slope, int variant, bmv_stream_t stream) {
+  BMV_REQUIRE(in && wpack && bias && out, "bmv_conv3d_transpose_c4_fwd: null pointer");
+  BMV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "bmv_conv3d_transpose_c4_fwd: bad shape");
+  if (Cout < 1 || Cout > 8 || (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 31) || (size_t)Cout * D * H * W * 32 >= ((size_t)1 << 33) ||
+      (size_t)((Cin + 3) / 4) * 27 * ((Cout + 3) / 4) * 64 > 100 * 1024) {
+    set_error("bmv_conv3d_transpose_c4_fwd: shape not covered (Cout=%d Cin=%d %dx%dx%d)", Cout, Cin, D, H, W);
+    return BMV_ERR_UNSUPPORTED;
+  }
+  CT4Args a{in, wpack, bias, skip, out, B, Cin, D, H, W, Cout, slope};
+  const int ng = (Cout + 3) / 4;
+  hipStream_t st = as_stream(stream);
+  int rc = BMV_ERR_UNSUPPORTED;
+  if (ng == 2) rc = variant == 1 ? ct4_launch<2, 1>(a, st) : variant == 2 ? ct4_launch<2, 4>(a, st) : ct4_launch<2, 2>(a, st);
+  if (ng == 1) rc = variant == 1 ? ct4_launch<1, 1>(a, st) : variant == 2 ? ct4_launch<1, 4>(a, st) : ct4_launch<1, 2>(a, st);
+  if (rc != BMV_OK) {
+    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_conv3d_transpose_c4_fwd: cannot reserve LDS");
+    return rc;
+  }
+  BMV_LAUNCH_END("bmv_conv3d_transpose_c4_fwd");
 }
 
 }  // extern "C"

@@ -259,6 +259,7 @@ class _CostReg(nn.Module):
             P["conv0_c4"] = convnet.pack_conv_c4(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn))
             P["heads_c4"] = convnet.pack_conv_c4(heads, None)
             P["heads_rec_c4"] = convnet.pack_conv_c4(heads[list(convnet.VolumeRecords.ORDER)], None)
+            P["conv11_c4"] = convnet.pack_convT_c4(*convnet.fold_bn(self.conv11[0].weight, self.conv11[1], out_dim=1))
             for parts in (2, 3):     # (csrc/conv_split.hip; used when self.split_bf16 == parts; < 100 KB per regulariser)
                 P[f"conv0_split{parts}"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn), parts=parts)
                 P[f"heads_split{parts}"] = convnet.pack_conv_split(heads, None, parts=parts)
@@ -283,7 +284,10 @@ class _CostReg(nn.Module):
             t = convnet.conv_fwd(convnet.conv_fwd(s2, *P["conv5"], 64, 3, 3, 2, relu=True), *P["conv6"], 64, 3, 3, relu=True)
             y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2)
         y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
-        y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
+        if self.conv_c4:
+            y = convnet.convT_c4_fwd(y, *P["conv11_c4"], 8, skip=s0)
+        else:
+            y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
         split = convnet.split_parts(self.split_bf16, "heads", 8) if ok4 else 0
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:

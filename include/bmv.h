@@ -516,6 +516,12 @@ int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, f
 int bmv_conv_c4_wpack_floats(int Cout, int Cin, int kd);
 int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, float* out, float* out2, int B, int Cin, int D,
                     int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream);
+/* ... and the regularisers' last up-sampling step on the same blocks (cost_reg_net.py:23-41 conv11 = ConvTranspose3d(16, 8,
+ * k 3, stride 2, padding 1, output_padding 1) + BatchNorm3d, then the U-Net skip add): in (B,Cin,D,H,W) -> out
+ * (B,Cout,2D,2H,2W) = act(convT(in) + bias) + skip (skip nullable, layout of out), Cout <= 8.  wpack as above (kd = 3)
+ * with the taps of the transposed weight (Cin,Cout,3,3,3): [cin chunk][tap][cout group][cout][cin]. */
+int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
+                     int D, int H, int W, int Cout, float slope, int variant, bmv_stream_t stream);
 
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =

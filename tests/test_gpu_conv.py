@@ -467,3 +467,24 @@ def test_conv_c4(nd, B, Cin, Cout, sp):
         _close(rec.t.permute(0, 4, 1, 2, 3), want[:, :8], tol=2e-5)          # (channels in the order they were packed)
         if Cout == 9:
             _close(logit, want[:, 8], tol=2e-5)
+
+
+@pytest.mark.parametrize("Cin,Cout,D,H,W", [(16, 8, 2, 8, 12), (16, 8, 3, 9, 19), (6, 5, 1, 4, 33), (32, 4, 2, 5, 16),
+                                            (16, 8, 4, 128, 160), (16, 8, 32, 32, 40)])
+def test_convT_c4(Cin, Cout, D, H, W):
+    """The transposed convolution of the regularisers' last up-sampling step on the 4 x 4 x 1 blocks (csrc/conv_c4.hip)
+    against torch's conv_transpose3d and the 16-row engine kernel, with the skip add; every tiling."""
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(Cin + Cout + D)
+    x = torch.randn(1, Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (Cin * 27 / 8) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)
+    skip = torch.randn(want.shape, generator=g).to(DEV)
+    wp, bp = convnet.pack_convT_c4(w, b)
+    for variant in (0, 1, 2):
+        _close(convnet.convT_c4_fwd(x, wp, bp, Cout, variant=variant), want, tol=2e-5)
+    _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip), want + skip, tol=2e-5)
+    _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip, relu=True), F.relu(want) + skip, tol=2e-5)
+    wp16, bp16 = convnet.pack_convT(w, b)
+    _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip), convnet.convT3d_fwd(x, wp16, bp16, Cout, skip=skip), tol=2e-5)
