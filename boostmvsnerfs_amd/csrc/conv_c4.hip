@@ -386,7 +386,7 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
 #define C4(NGV, NWV, TZV, KDV) \
   if (ng == NGV && kd == KDV) rc = c4_launch<NGV, NWV, TZV, KDV>(a, st)
   if (kd == 3) {
-    // (measured on the frame's four layers, profiles/r5/conv_c4_layers_first.txt: one plane per wave -- 58 registers,
+    // (measured on the frame's four layers, profiles/r5/conv_c4_layers.txt: one plane per wave -- 58 registers,
     // 7-8 waves per SIMD -- beats two planes per wave at 106 registers everywhere: 56.8 / 54.2 / 38.3 / 22.1 us against
     // 60.0 / 54.5 / 41.7 / 25.0)
     if (variant == 0 && Cout == 9) {
