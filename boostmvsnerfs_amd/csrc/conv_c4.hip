@@ -6,11 +6,15 @@
 // Why another kernel (round 5).  csrc/conv.hip computes every layer on 16-row MFMA tiles (v_mfma_f32_16x16x4_f32: rows =
 // output channels).  A layer with 8 output channels fills half of a tile; ROW PAIRING (rows = 8 channels x 2 output rows,
 // K + 1 input rows per filter column) recovers 2K / (K + 1) = 75 % for K = 3 -- and no pairing can do better (two shifted
-// copies of the 27-tap cube cover at least 36 positions).  The 9-channel heads fill 9 / 16 = 56 %.  These four layers are
-// ~290 us of a ~930 us frame and are bound by the fp32 matrix rate (64 FLOP / clk / SIMD whatever the shape).
+// copies of the 27-tap cube cover at least 36 positions).  The 9-channel heads fill 9 / 16 = 56 %, the 8-channel transposed
+// convolution 50 %.  These layers were ~315 us of a ~930 us frame and run at the fp32 matrix rate.
 // v_mfma_f32_4x4x1_16b_f32 is 16 independent 4 x 4 x 1 outer products: 4 output channels x 4 positions per block, 64
-// positions per wave-instruction, K = 1 = ONE (input channel, tap) pair -- 512 FLOP in 8 cycles, the same rate, with
-// every row useful for Cout = 4 g (8: 100 %, 9 -> 12: 75 %): 1.33 x fewer matrix cycles for the same fp32 FMA chain.
+// positions per wave-instruction, K = 1 = ONE (input channel, tap) pair, every row useful for Cout = 4 g.  Measured issue
+// rates on MI355X (scripts/ubench/mfma_f32_shapes.hip -> profiles/r5/mfma_f32_shapes_ubench.txt, 4 waves per SIMD,
+// independent accumulators): 32x32x2 65 cycles = 154 TFLOP/s, 16x16x4 36 cycles = 139, 4x4x1 10.3 cycles = 122 -- the small
+// shape pays 12 % in issue rate and wins 1 / 0.75 (8 channels) or 0.75 / 0.56 (9 channels) in useful rows: 122 effective
+// TFLOP/s against 104 / 78.  Stand-alone on the frame's layers (profiles/r5/conv_c4_layers.txt): 71 -> 59, 64 -> 56, 51 ->
+// 39, 28 -> 22 us, the transposed layer 26 -> 19 and 17.5 -> 13; in the frame 356 -> 375 Mray/s.
 //
 // Operands.  lane l = (block l / 4, index l % 4): A[l] = W[cout 4 g + l % 4][cin][tap] (the same in all blocks), B[l] = the
 // input at lane l's OWN position shifted by the tap, D[r] at lane l = out[cout 4 g + r] at lane l's position.  A k-step

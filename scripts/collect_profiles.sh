@@ -1,10 +1,10 @@
 #!/bin/bash
-# Per-round evidence (PFX=r4 by default) for profiles/: per workload a bench line (bench.py, cpu_baseline included) and the rocprofv3
+# Per-round evidence (PFX=r5 by default) for profiles/: per workload a bench line (bench.py, cpu_baseline included) and the rocprofv3
 # --kernel-trace summary of the same command reduced to its steady-state steps (scripts/rocprof_steady.py).
 # Run on the MI355X box from the repo root:  bash scripts/collect_profiles.sh <outdir> [workload ...]
 set -u
-OUT=${1:-gpurun_out/r4_profiles}; shift || true
-PFX=${PFX:-r4}
+OUT=${1:-gpurun_out/r5_profiles}; shift || true
+PFX=${PFX:-r5}
 RM=${RENDER_MARKER:-render_pc_kernel}
 R=$(pwd); mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
@@ -26,7 +26,7 @@ for w in $WL; do
     c3) run ${PFX}_config3_enerf_ours480x736_k4 enerf_ours_480x736_6src_k4 "blend_wave_kernel" 1 60 3 ;;
     c4) run ${PFX}_config4_mvsnerf_ours_128planes_k4 mvsnerf_ours_224x352_128planes_k4 "blend_wave_kernel" 1 4 2 ;;
     c5) run ${PFX}_config5_enerf_ours_ft480x736_k4 enerf_ours_ft_480x736_6src_k4 "blend_bwd_kernel" 2 6 4 ;;
-    ft) run ${PFX}_enerf_ft512x640 enerf_ft_512x640_3src "nerf_mlp_bwd_kernel<8>" 1 16 6 ;;
+    ft) run ${PFX}_enerf_ft512x640 enerf_ft_512x640_3src "nerf_mlp_bwd_kernel<8, 3>" 1 16 6 ;;
   esac
 done
 ls -la $R/$OUT

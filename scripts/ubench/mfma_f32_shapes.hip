@@ -9,10 +9,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 
 __global__ void layout_probe(float* out) {
-  // A[lane] = 1000 * lane, B[lane] = lane: D[r] at lane l = A[?] * B[?]
+  // A[lane] = 2 lane + 1 (odd), B[lane] = 2^lane: every product (odd x power of two) names its two lanes uniquely
   const int l = threadIdx.x;
   f4 c = {0.f, 0.f, 0.f, 0.f};
-  c = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(1000 * l), (float)l + 0.5f, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(2 * l + 1), ldexpf(1.f, l), c, 0, 0, 0);
   for (int r = 0; r < 4; ++r) out[l * 4 + r] = c[r];
 }
 
@@ -57,22 +57,20 @@ int main() {
   hipLaunchKernelGGL(layout_probe, dim3(1), dim3(64), 0, 0, out);
   float h[256];
   hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-  printf("v_mfma_f32_4x4x1_16b_f32 with A[lane] = 1000 lane, B[lane] = lane + 0.5: D[reg] at lane l = A[la] * B[lb]\n");
+  printf("v_mfma_f32_4x4x1_16b_f32 with A[lane] = 2 lane + 1, B[lane] = 2^lane: D[reg] at lane l = A[la] * B[lb]\n");
   for (int l = 0; l < 64; l += (l < 8 ? 1 : 13)) {
     printf("  lane %2d:", l);
     for (int r = 0; r < 4; ++r) {
-      // factor: D = 1000 la * (lb + 0.5)
-      int la = -1, lb = -1;
-      for (int x = 0; x < 64 && la < 0; ++x)
-        for (int y = 0; y < 64; ++y)
-          if (h[l * 4 + r] == (float)(1000 * x) * ((float)y + 0.5f) && x != 0) {
-            la = x, lb = y;
-            break;
-          }
-      printf("  reg %d = A[%2d] B[%2d]", r, la, lb);
+      int e = 0;
+      const float m = frexpf(h[l * 4 + r], &e);          // value = m 2^e, m in [0.5, 1): odd part = m 2^k
+      float odd = m;
+      int lb = e;
+      while (odd != floorf(odd)) odd *= 2.f, --lb;
+      printf("  reg %d = A[%2d] B[%2d]", r, ((int)odd - 1) / 2, lb);
     }
     printf("\n");
   }
+  printf("  (expected: reg r at lane l = A[4 (l / 4) + r] * B[l]: block l / 4, row r, column l %% 4)\n");
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int iters = 4000;
