@@ -317,7 +317,7 @@ def parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev):
         net.zero_grad(set_to_none=True)
         _, loss, _, _ = NetworkWrapper(net)(b)
         loss.mean().backward()
-        worst, worst_name, n_tensors = 0.0, None, 0
+        worst, worst_name, n_tensors, rels = 0.0, None, 0, []
         gmax = max(float(v.abs().max()) for v in stp["grads"].values())
         for k, p in net.named_parameters():
             want = stp["grads"].get(k)
@@ -326,16 +326,21 @@ def parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev):
             num = float((p.grad.detach().cpu() - want).pow(2).sum().sqrt())
             rel = num / (float(want.pow(2).sum().sqrt()) + 1e-6 * gmax)
             n_tensors += 1
+            rels.append(rel)
             if rel > worst:
                 worst, worst_name = rel, k
         net.zero_grad(set_to_none=True)
         net.train(was)
         out["parity_max_rel"] = {
             "loss": abs(float(loss) - stp["loss"]) / abs(stp["loss"]), "grad_rel_l2_max": worst, "grad_worst_tensor": worst_name,
-            "grad_tensors": n_tensors, "max": max(worst, abs(float(loss) - stp["loss"]) / abs(stp["loss"])),
+            "grad_tensors": n_tensors, "grad_rel_l2_median": sorted(rels)[len(rels) // 2] if rels else None,
+            "grad_tensors_over_1e-2": sum(r > 1e-2 for r in rels),
+            "max": max(worst, abs(float(loss) - stp["loss"]) / abs(stp["loss"])),
             "against": (f"oracle forward + MSE loss + torch.autograd backward (eval-mode batch norm) on rays ::{stp['stride']} of the "
                         "workload's frame, same weights and targets: relative loss difference and the worst per-tensor relative "
-                        "L2 distance of the parameter gradients"),
+                        "L2 distance of the parameter gradients.  Both sides are fp32: at these sizes the fp32 oracle is itself "
+                        "up to 1e-2 (relative L2) away from its float64 run on the deep levels' batch-norm and convolution "
+                        "parameters (sums over 1e5-1e6 voxels that cancel), tests/test_gpu_fullsize.py arbitrates in float64"),
             "tolerance": "tests: 2e-3 per entry (relative + of the tensor's rms), tests/test_gpu_training.py"}
         return out
     if ref and not wl.get("train"):

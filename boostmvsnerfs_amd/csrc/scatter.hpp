@@ -37,11 +37,11 @@ struct ScatterAcc {
     if constexpr (MODE == 0) {
       atomicAdd(p, v);
     } else if constexpr (MODE == 1) {
+      // (a thread publishes only what beats everything it has seen -- its own contributions, the slot's value when it
+      // started and what the slot held at its last publication: skipping a value <= a former slot value cannot change
+      // the final maximum, so the result stays order-independent while almost no thread ever issues an atomic)
       const unsigned b = __float_as_uint(fabsf(v));
-      if (b > seen) {
-        seen = b;
-        atomicMax(slots + ((blockIdx.x * blockDim.x + threadIdx.x) & (kFixedSlots - 1)), b);
-      }
+      if (b > seen) seen = max(b, atomicMax(slots + ((blockIdx.x * blockDim.x + threadIdx.x) & (kFixedSlots - 1)), b));
     } else {
       atomicAdd(reinterpret_cast<unsigned long long*>(q + (p - base)), (unsigned long long)__float2ll_rn(v * scale));
     }
@@ -59,7 +59,10 @@ template <int MODE>
 __device__ __forceinline__ ScatterAcc<MODE> make_acc(const float* base, FixedWs f, size_t offset) {
   ScatterAcc<MODE> a;
   a.base = base, a.q = nullptr, a.slots = nullptr, a.scale = 0.f, a.seen = 0u;
-  if constexpr (MODE == 1) a.slots = f.slots();
+  if constexpr (MODE == 1) {
+    a.slots = f.slots();
+    a.seen = __atomic_load_n(a.slots + ((blockIdx.x * blockDim.x + threadIdx.x) & (kFixedSlots - 1)), __ATOMIC_RELAXED);
+  }
   if constexpr (MODE == 2) a.q = f.acc(offset), a.scale = f.scale2()[0];
   return a;
 }
