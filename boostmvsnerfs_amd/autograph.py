@@ -36,21 +36,20 @@ Not noticed: a parameter whose storage is swapped through `p.data = ...` (no ver
 """
 from __future__ import annotations
 
-import os
 from operator import attrgetter
 
 import ctypes as C
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, switches
 
 _version_of = attrgetter("_version")
 
-ENABLED = os.environ.get("BMV_AUTOGRAPH", "1") != "0"
-DEFER = os.environ.get("BMV_AUTOGRAPH_DEFER", "1") != "0"    # large inputs / outputs through a pointer table (no copies)
-RING = os.environ.get("BMV_AUTOGRAPH_RING", "1") != "0"      # ... fed by the frame's own first node from a host ring (no launch)
-MAX_GRAPHS = int(os.environ.get("BMV_AUTOGRAPH_MAX", "4"))
+ENABLED = switches.get("BMV_AUTOGRAPH") != 0
+DEFER = switches.get("BMV_AUTOGRAPH_DEFER") != 0    # large inputs / outputs through a pointer table (no copies)
+RING = switches.get("BMV_AUTOGRAPH_RING") != 0      # ... fed by the frame's own first node from a host ring (no launch)
+MAX_GRAPHS = switches.get("BMV_AUTOGRAPH_MAX")
 
 
 def _built(v):

@@ -8,11 +8,9 @@ state-dict names (networks/enerf/cnn.py) and are re-packed only when one of them
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
-from . import _lib, ktimer, ops
+from . import _lib, ktimer, ops, switches
 from ._lib import dptr, stream
 
 
@@ -188,12 +186,12 @@ def conv3d_split_heads_records(x, wsplit, bias, parts):
 #           frame only -7 us of 881: the level-0 first layer runs beside FeatureNet's top-down path and is no faster
 #           there -- all 183 GPU tests pass unchanged with it, but it is not worth a default);
 #   "3" / "2": all four layers with three / two pieces (two = 2^-16 per product: the opt-in experiment, +7 % of the frame).
-_split_env = os.environ.get("BMV_CONV_SPLIT", "0")
+_split_env = str(switches.get("BMV_CONV_SPLIT"))
 SPLIT_BF16 = _split_env if _split_env == "auto" else int(_split_env)
 
 
 # The regularisers' first layers and heads on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip): BMV_CONV_C4=1 / 0
-CONV_C4 = os.environ.get("BMV_CONV_C4", "1") == "1"
+CONV_C4 = switches.on("BMV_CONV_C4")
 
 
 def split_parts(policy, kind, cin):

@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from ... import ops
+from ... import ops, switches
 from ...config import cfg
 from ..enerf import network as enerf_network
 
@@ -59,12 +59,12 @@ class Network(enerf_network.Network):
         self._sel_cache = {}
         self._streams = []
         self._cam_pre = None
-        self.side_setup = os.environ.get("BMV_BOOST_SIDE_SETUP", "1") == "1"
-        self.parallel_volumes = os.environ.get("BMV_BOOST_STREAMS", "1") == "1"
+        self.side_setup = switches.on("BMV_BOOST_SIDE_SETUP")
+        self.parallel_volumes = switches.on("BMV_BOOST_STREAMS")
         # the K cost volumes as one batch through the regularisers instead of K chains on K streams (round 3; opt-in:
         # measured 3.29 ms against 3.15 ms per 480x736 K = 4 frame -- the frame is 4 x 0.7 ms of render launches, and
         # under K streams the regularisers' short launches already hide under the other volumes' renders)
-        self.batched_volumes = os.environ.get("BMV_BOOST_BATCHED", "0") == "1"
+        self.batched_volumes = switches.on("BMV_BOOST_BATCHED")
         # multi-GPU, `--shard volumes` (boostmvsnerfs_amd/sharding.py VolumeShard): build and render only these cost
         # volumes (indices into the K selected ones) and return their stacked (raw, z, mask) instead of the fused picture
         self.volume_ids = None

@@ -10,14 +10,13 @@ Module/parameter names reproduce the reference's state-dict keys exactly
 (lib/networks/enerf/feature_net.py:4-36, cost_reg_net.py:4-86, utils.py:10-33)
 so `load_state_dict(ckpt['net'], strict=True)` accepts reference checkpoints.
 """
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import autograd as A
-from ... import convnet, ops
+from ... import convnet, ops, switches
 from .conv_train import Conv2d, Conv3d, ConvTranspose3d, _Conv3dFn   # engine forward / data gradients, MFMA weight gradients
 
 
@@ -33,12 +32,12 @@ def _engine_ok(module, x):
         raise RuntimeError(f"{type(module).__name__}: the BoostMVSNeRFs hot path runs on the GPU only (input is on "
                            f"{x.device}); there is no CPU fallback")
     return (not module.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
-            and os.environ.get("BMV_CNN", "engine") != "torch")
+            and switches.get("BMV_CNN") != "torch")
 
 
-FUSE_FPN_SMOOTH = os.environ.get("BMV_FPN_FUSE", "1") == "1"
-FUSE_CONV0 = os.environ.get("BMV_CONV0_FUSE", "1") == "1"
-FUSE_TOP = os.environ.get("BMV_TOP_FUSE", "1") == "1"
+FUSE_FPN_SMOOTH = switches.on("BMV_FPN_FUSE")
+FUSE_CONV0 = switches.on("BMV_CONV0_FUSE")
+FUSE_TOP = switches.on("BMV_TOP_FUSE")
 
 class _Packed:
     """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
@@ -75,7 +74,7 @@ def _bn_forward(bn, x, relu):
     eval mode, SyncBatchNorm under DDP, BMV_BN=torch -- stays on torch."""
     if (type(bn) in (nn.BatchNorm2d, nn.BatchNorm3d) and bn.training and bn.track_running_stats and bn.affine
             and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32
-            and os.environ.get("BMV_BN", "hip") != "torch"):
+            and switches.get("BMV_BN") != "torch"):
         bn.num_batches_tracked.add_(1)
         return A.BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
     y = bn(x)

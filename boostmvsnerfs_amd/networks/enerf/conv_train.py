@@ -15,20 +15,19 @@ convolution over the four input parities + a pixel shuffle).
 SURVEY.md section 8(f) ranks 1-2; module and parameter names are unchanged (subclasses of nn.Conv2d / nn.Conv3d /
 nn.ConvTranspose3d).
 """
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import convnet
+from ... import convnet, switches
 
 
 def _engine_forward(x):
     """The training FORWARD of a convolution runs on the package's engine (csrc/conv.hip, weights repacked on the
     device every step: one launch) unless BMV_TRAIN_CONV=torch; the backward never does (MIOpen data gradients, own
     weight-gradient kernel for 3-D)."""
-    return x.is_cuda and x.dtype == torch.float32 and os.environ.get("BMV_TRAIN_CONV", "engine") != "torch"
+    return x.is_cuda and x.dtype == torch.float32 and switches.get("BMV_TRAIN_CONV") != "torch"
 
 
 def _wgrad(big, small, stride, kd=3, k=3):
@@ -132,7 +131,7 @@ class _Conv2dFn(torch.autograd.Function):
         k = w.shape[-1]
         want_x, eng = ctx.needs_input_grad[0], _engine_forward(gy)
         # stride 1: the convolution with the flipped, transposed filter; stride-2 5x5: four parity sub-filters
-        s2 = s == 2 and k == 5 and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and os.environ.get("BMV_TRAIN_DGRAD5", "1") != "0"
+        s2 = s == 2 and k == 5 and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and switches.on("BMV_TRAIN_DGRAD5")
         gx_engine = want_x and (s == 1 or s2) and eng
         gw_engine = ctx.needs_input_grad[1] and eng                # weight gradient: own MFMA kernel over (batch, pixel)
         gx = gw = gb = None

@@ -12,13 +12,12 @@ rays to composited pixels (per-ray bounds, samples, volume + image lookups,
 MFMA MLP, alpha compositing).  No warped volume, sample tensor or per-view
 feature tensor is ever materialised.
 """
-import os
 
 import torch
 import torch.nn as nn
 
 from ... import autograd as A
-from ... import convnet, ops
+from ... import convnet, ops, switches
 from ...config import cfg
 from .cnn import CostRegNet, FeatureNet, MinCostRegNet, engine_ok
 from .nerf import NeRF
@@ -57,13 +56,13 @@ class Network(nn.Module):
         # the level-0 sweep (regulariser + depth regression) -- the sweep stays on the main stream.  By default the fork
         # is used under HIP-graph capture only (replay: +3 % frames/s); issued eagerly a 512x640 frame is bound by the
         # host's ~45 launches and the extra stream traffic costs 3 % (BMV_OVERLAP_EAGER=1 forks there too).
-        self.overlap_front = int(os.environ.get("BMV_OVERLAP", "2"))
-        self.lookup_records = os.environ.get("BMV_LOOKUP_RECORDS", "1") == "1"
-        self.frame_setup = os.environ.get("BMV_FRAME_SETUP", "1") == "1"
-        self.depth_maps_through_table = os.environ.get("BMV_DEPTH_MAPS_TABLE", "1") == "1"
+        self.overlap_front = switches.get("BMV_OVERLAP")
+        self.lookup_records = switches.on("BMV_LOOKUP_RECORDS")
+        self.frame_setup = switches.on("BMV_FRAME_SETUP")
+        self.depth_maps_through_table = switches.on("BMV_DEPTH_MAPS_TABLE")
         self._pre = None
-        self.volume_records = os.environ.get("BMV_VOLUME_RECORDS", "1") == "1"
-        self.overlap_eager = os.environ.get("BMV_OVERLAP_EAGER", "0") == "1"
+        self.volume_records = switches.on("BMV_VOLUME_RECORDS")
+        self.overlap_eager = switches.on("BMV_OVERLAP_EAGER")
         from ...autograph import AutoGraph
         object.__setattr__(self, "_autograph", AutoGraph(self))
         # autograph opt-ins (autograph.py): the caller declares its batch resident / accepts outputs that the next
@@ -299,7 +298,7 @@ class Network(nn.Module):
         c0, c1, p2, p2_cl = fn.engine_bottom_up(x.reshape(B * V, C, H, W))
         main = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))
+            self._side_stream = torch.cuda.Stream(priority=switches.get("BMV_SIDE_PRIO"))
         side = self._side_stream
         level0 = _views(p2_cl, B, V, H // 4, W // 4)
         if self.overlap_front == 2:
@@ -385,7 +384,7 @@ class Network(nn.Module):
         views = (batch["src_inps"], batch["src_exts"], batch["src_ixts"])
         st0 = None
         if self._side_stream is None and batch["src_inps"].is_cuda:
-            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("BMV_SIDE_PRIO", "0")))   # created outside any capture
+            self._side_stream = torch.cuda.Stream(priority=switches.get("BMV_SIDE_PRIO"))   # created outside any capture
         self.feature_net.pack_lookup = (self.wants_lookup_records() and engine_ok(self.feature_net, batch["src_inps"])
                                         and 2 <= batch["src_inps"].shape[1] <= 4)     # (the fused renderer's view counts)
         self.set_volume_records(self.feature_net.pack_lookup)
@@ -411,7 +410,7 @@ class Network(nn.Module):
             rgb, depth, weights = render(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)
             ret_i = {"rgb": rgb, "depth": depth, "weights": weights,
                      "depth_mvs": torch.reciprocal(st.depth) if cc.depth_inv[i] else st.depth, "std": st.std}
-            if os.environ.get("BMV_CHECK_NAN") == "1" and bool(rgb.isnan().any()):
+            if switches.on("BMV_CHECK_NAN") and bool(rgb.isnan().any()):
                 raise FloatingPointError(f"NaN in rgb_level{i}")   # reference: ipdb trap, network.py:110-111
             ret.update({f"{k}_level{i}": v for k, v in ret_i.items()})
         return ret

@@ -15,7 +15,6 @@ kernels build the MLP inputs, the sweep and the volume lookup have HIP backward 
 6 x 128 MLP runs on the layer-wise MFMA kernels with a HIP backward (csrc/mvs_mlp_train.hip, autograd.MvsMLP;
 BMV_MVS_MLP_TRAIN=torch keeps nn.Linear + torch autograd).
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -23,7 +22,7 @@ import torch.nn.functional as F
 
 from ... import autograd as A
 from ... import ops
-from ... import convnet
+from ... import convnet, switches
 from ...config import cfg
 from ..enerf.cnn import _Packed, _engine_ok
 from ..enerf.conv_train import Conv2d, Conv3d, ConvTranspose3d   # under autograd: engine forward, own weight gradients
@@ -45,7 +44,7 @@ class ABN(nn.Module):
         self.eps, self.momentum, self.slope = eps, momentum, slope
 
     def forward(self, x):
-        if self.training and x.is_cuda and x.dtype == torch.float32 and os.environ.get("BMV_BN", "hip") != "torch":
+        if self.training and x.is_cuda and x.dtype == torch.float32 and switches.get("BMV_BN") != "torch":
             # batch statistics + leaky ReLU on csrc/bn.hip (as ConvBnReLU's training path, enerf/cnn.py)
             return A.BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                           self.momentum, float(self.slope))
@@ -223,7 +222,7 @@ class RendererMLP(nn.Module):
         layer-wise MFMA kernels with a HIP backward (autograd.MvsMLP; BMV_MVS_MLP_TRAIN=torch: nn.Linear + torch
         autograd); otherwise the fused inference kernel."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            if not x.is_cuda or os.environ.get("BMV_MVS_MLP_TRAIN", "hip") == "torch":
+            if not x.is_cuda or switches.get("BMV_MVS_MLP_TRAIN") == "torch":
                 return self.forward_torch(x)
             flat = x.reshape(-1, 86)
             params = self._param_list()

@@ -6,11 +6,10 @@ Everything runs on torch's current stream.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
-from . import _lib, ktimer
+from . import _lib, ktimer, switches
 from ._lib import dptr, stream
 
 BMV_ERR_UNSUPPORTED = -3      # include/bmv.h
@@ -1149,7 +1148,7 @@ def sweep_variance_bwd(feats, proj, depth_values, d_var, want_depth_grad, algo=N
                                                     dptr(ws, "workspace", torch.int64), stream()), "sweep_variance_bwd_fixed")
         return d_feats, d_dv
     if algo is None:
-        algo = os.environ.get("BMV_SWEEP_BWD", "cl")
+        algo = switches.get("BMV_SWEEP_BWD")
     if algo == "cl" and S == 3 and C_ in (16, 32):
         cl = feats.permute(0, 1, 3, 4, 2)
         cl = cl if cl.is_contiguous() else nchw_to_nhwc(feats)

@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from boostmvsnerfs_amd import switches
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -192,7 +194,7 @@ def test_feature_net_engine_matches_torch_modules(monkeypatch):
     x = torch.randn(3, 3, 64, 96, device=DEV)
     with torch.no_grad():
         got = net(x)
-        monkeypatch.setenv("BMV_CNN", "torch")
+        monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
         want = net(x)
     from boostmvsnerfs_amd.ops import QuadFeats
     assert isinstance(got[0], QuadFeats) and isinstance(got[1], QuadFeats)                  # the sweep's layout
@@ -200,7 +202,7 @@ def test_feature_net_engine_matches_torch_modules(monkeypatch):
         assert g_.shape == w_.shape
         _close(g_.contiguous(), w_)
     # ... and the channel-last form (training / other sweep kernels): (N,C,H,W) views of (N,H,W,C) buffers
-    monkeypatch.delenv("BMV_CNN")
+    monkeypatch.delitem(switches.VALUES, "BMV_CNN")
     net.quad_out = False
     with torch.no_grad():
         got_cl = net(x)
@@ -208,9 +210,9 @@ def test_feature_net_engine_matches_torch_modules(monkeypatch):
     assert not got_cl[0].is_contiguous() and got_cl[0].permute(0, 2, 3, 1).is_contiguous()
     for g_, w_ in zip(got_cl, want):
         _close(g_, w_)
-    monkeypatch.setenv("BMV_CNN", "torch")
+    monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
     # a parameter update invalidates the packed weights
-    monkeypatch.delenv("BMV_CNN")
+    monkeypatch.delitem(switches.VALUES, "BMV_CNN")
     with torch.no_grad():
         net.smooth0.bias.add_(1.0)
         _close(net(x)[2], want[2] + 1.0)
@@ -226,7 +228,7 @@ def test_cost_reg_engine_matches_torch_modules(monkeypatch, cls, cin, shape):
     x = torch.rand(1, cin, *shape, device=DEV)
     with torch.no_grad():
         feat, prob = net(x)
-        monkeypatch.setenv("BMV_CNN", "torch")
+        monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
         feat_t, prob_t = net(x)
     assert feat.shape == feat_t.shape and prob.shape == prob_t.shape
     _close(feat, feat_t)
@@ -254,7 +256,7 @@ def test_leaky_slope_and_mvsnerf_stacks(monkeypatch):
     vol = torch.rand(1, 41, 8, 40, 48, device=DEV)
     with torch.no_grad():
         got_f, got_r = feat(img), reg(vol)
-        monkeypatch.setenv("BMV_CNN", "torch")
+        monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
         want_f, want_r = feat(img), reg(vol)
     assert got_f.shape == want_f.shape and got_r.shape == want_r.shape
     _close(got_f, want_f)
@@ -375,7 +377,7 @@ def test_cost_reg_training_forward_matches_torch_modules(monkeypatch):
     ref.load_state_dict(net.state_dict())
     x = torch.randn(1, 16, 8, 32, 48, device=DEV)
     f1, d1 = net(x)
-    monkeypatch.setenv("BMV_BN", "torch")
+    monkeypatch.setitem(switches.VALUES, "BMV_BN", "torch")
     f2, d2 = ref(x)
     _close(f1, f2, 2e-4), _close(d1, d2, 2e-4)
     for (k, a), (_, bb) in zip(net.state_dict().items(), ref.state_dict().items()):

@@ -6,6 +6,8 @@ against the torch modules it replaces (same device, same weights)."""
 import pytest
 import torch
 
+from boostmvsnerfs_amd import switches
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 H, W = 512, 640
@@ -209,7 +211,7 @@ def test_conv_engine_matches_torch_modules_full_size(full, monkeypatch):
         got_f = [t.contiguous() for t in net.feature_net(x)]
         got_0 = net.cost_reg_0(var0)
         got_1 = net.cost_reg_1(var1)
-        monkeypatch.setenv("BMV_CNN", "torch")
+        monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
         want_f = net.feature_net(x)
         want_0 = net.cost_reg_0(var0)
         want_1 = net.cost_reg_1(var1)
