@@ -32,6 +32,8 @@ if os.environ.get("BMV_BWD_DEFS"):   # ablation builds of the scatter kernels (s
     EXTRA_FLAGS["backward.hip"] = os.environ["BMV_BWD_DEFS"].split()
 if os.environ.get("BMV_MVS_DEFS"):
     EXTRA_FLAGS["mvs.hip"] = os.environ["BMV_MVS_DEFS"].split()
+if os.environ.get("BMV_C4_DEFS"):   # ablation builds of the 4-row-block convolutions (scripts/ablate_conv_c4.py)
+    EXTRA_FLAGS["conv_c4.hip"] = os.environ["BMV_C4_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

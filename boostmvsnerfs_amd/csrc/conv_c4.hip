@@ -41,9 +41,15 @@ struct C4Args {
   int B, Cin, D, H, W, Cout;
   float slope;          // activation: v > 0 ? v : slope * v
   int mode;
-  int flags;            // ablations (bmv_tuning BMV_CONV_C4_FLAGS): 1 no matrix instructions, 2 no tile loads, 4 no LDS reads in
-                        // the tap loop (operands kept from the first tap), 8 no weight copy, 16 no stores
 };
+
+// ablation builds (scripts/ablate_conv_c4.py: BMV_C4_DEFS=-DBMV_C4_ABLATE=n; timing only, wrong results): 1 no matrix
+// instructions, 2 no tile loads, 4 no LDS reads per tap (tap 0's operands), 8 no weight copy, 16 no stores.  Compile-time:
+// the same switches as run-time flags cost the full kernel 59 -> 76 us (the tap loop's LDS offsets stopped being immediates)
+#ifndef BMV_C4_ABLATE
+#define BMV_C4_ABLATE 0
+#endif
+constexpr int kC4Ablate = BMV_C4_ABLATE;
 
 constexpr int kC4RS = 18;   // tile row pitch in positions: 16 outputs + halo
 
@@ -76,7 +82,7 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   // weights of every chunk, once per workgroup
   {
     const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
-    if (!(a.flags & 8))
+    if (!(kC4Ablate & 8))
       for (int i = tid; i < nchunk * TAPS * NG * 4; i += NT) wl[i] = src[i];
   }
   // tile slots of this thread: byte offset inside a channel plane, or out of range (zero padding)
@@ -86,7 +92,7 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
     const int slot = tid + NT * j;
     const int sx = slot % kC4RS, t = slot / kC4RS, sy = t % TYH, sz = t / TYH;
     const int gx = x0 - 1 + sx, gy = y0 - 1 + sy, gz = z0 - KD / 2 + sz;
-    const bool ok = (slot < POS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D) & !(a.flags & 2);
+    const bool ok = (slot < POS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D) & !(kC4Ablate & 2);
     goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
   }
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -136,13 +142,12 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
         for (int kx = 0; kx < 3; ++kx) {
           const int tap = (kd * 3 + ky) * 3 + kx;
           f32x4c A[NGM], Bv[TZ];
-          const int tap_l = (a.flags & 4) ? 0 : tap;        // (ablation 4: every tap re-reads tap 0's operands -- the
-          const int koff = (a.flags & 4) ? 0 : ((kd * TYH + ky) * kC4RS + kx);   // compiler hoists them out of the loop)
+          constexpr bool kOneTap = (kC4Ablate & 4) != 0;
 #pragma unroll
-          for (int g = 0; g < NGM; ++g) A[g] = aw[(tap_l * NG + g) * 4];
+          for (int g = 0; g < NGM; ++g) A[g] = aw[((kOneTap ? 0 : tap) * NG + g) * 4];
 #pragma unroll
-          for (int z = 0; z < TZ; ++z) Bv[z] = bp[z * TYH * kC4RS + koff];
-          if (a.flags & 1) {
+          for (int z = 0; z < TZ; ++z) Bv[z] = bp[kOneTap ? z * TYH * kC4RS : ((z + kd) * TYH + ky) * kC4RS + kx];
+          if (kC4Ablate & 1) {
 #pragma unroll
             for (int z = 0; z < TZ; ++z)
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   // epilogue: register r of group g = output channel 4 g + r at this lane's position
   const int x = x0 + xi, y = y0 + wave * 4 + ry;
   if (x >= a.W || y >= a.H) return;
-  if ((a.flags & 16) && acc[0][0][0] != 12345.f) return;
+  if ((kC4Ablate & 16) && acc[0][0][0] != 12345.f) return;
   const size_t cs = (size_t)plane;
 #pragma unroll
   for (int z = 0; z < TZ; ++z) {
@@ -395,7 +400,7 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
     set_error("bmv_conv_c4_fwd: shape not covered (Cout=%d Cin=%d kd=%d %dx%dx%d)", Cout, Cin, kd, D, H, W);
     return BMV_ERR_UNSUPPORTED;
   }
-  C4Args a{in, wpack, bias, out, out2, B, Cin, D, H, W, Cout, slope, mode, tuning("BMV_CONV_C4_FLAGS", 0)};
+  C4Args a{in, wpack, bias, out, out2, B, Cin, D, H, W, Cout, slope, mode};
   const int ng = (Cout + 3) / 4;
   int rc = BMV_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);

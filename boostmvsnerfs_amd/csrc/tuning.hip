@@ -36,7 +36,6 @@ Knob g_knobs[] = {
     {"BMV_SWEEP_QUAD_L0", "quad-planar sweep: default tuning variant where the source maps have twice the volume's resolution"},
     {"BMV_SWEEP_QUAD_L1", "quad-planar sweep: default tuning variant where the source maps have the volume's resolution"},
     {"BMV_DETERMINISTIC", "1 = the host takes the *_fixed scatter entry points (order-independent fixed-point accumulation): bit-reproducible gradients"},
-    {"BMV_CONV_C4_FLAGS", "4-row-block convolutions, ablations (timing only, wrong results): 1 no matrix instructions, 2 no tile loads, 4 no LDS reads per tap, 8 no weight copy, 16 no stores"},
     {"BMV_FPN_TOPDOWN_SPLIT", "FPN top-down step: workgroups sharing the output channels of a pixel (1, 2, 4)"},
 };
 constexpr int kNumKnobs = sizeof(g_knobs) / sizeof(g_knobs[0]);
