@@ -70,11 +70,18 @@ def pack_conv_c4(weight, bias):
 def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, variant=0):
     """x (B,Cin,D,H,W) or (B,Cin,H,W) -> act(conv(x, 3x3[x3], stride 1, padding 1) + bias) with Cout <= 12 output
     channels on the 4-row matrix blocks (csrc/conv_c4.hip).  records: the renderer's volume records (VolumeRecords of
-    channels 0..7 + the planar channel 8 when Cout == 9) instead of the planar tensor."""
-    is3d = x.dim() == 5
-    if is3d:
+    channels 0..7 + the planar channel 8 when Cout == 9) instead of the planar tensor.  x may be an ops.QuadVolume (the
+    plane sweep's quad-record output, (B,Cin/4,D,H,W,4)): staged with 16-byte loads (include/bmv.h: mode | 4)."""
+    qin = isinstance(x, ops.QuadVolume)
+    if qin:
+        x = x.data
+        B, Q, D, H, W, _ = x.shape
+        Cin, is3d = 4 * Q, True
+    elif x.dim() == 5:
+        is3d = True
         B, Cin, D, H, W = x.shape
     else:
+        is3d = False
         B, Cin, H, W = x.shape
         D = 1
     kd = 3 if is3d else 1
@@ -90,7 +97,7 @@ def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, var
     with ktimer.region(f"conv_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"), dptr(out),
                                  dptr(out2) if out2 is not None else None, B, Cin, D, H, W, Cout, kd, _slope(relu, slope),
-                                 2 if records else 0, int(variant), stream())
+                                 (2 if records else 0) | (4 if qin else 0), int(variant), stream())
     _lib.check(rc, "conv_c4_fwd")
     if records:
         return VolumeRecords(out), out2

@@ -57,7 +57,9 @@ constexpr int kC4RS = 18;   // tile row pitch in positions: 16 outputs + halo
 // VD (NG == 3, Cout == 9: feat_conv + depth_conv): the ninth channel -- the depth logit -- is 4 vector FMAs per (tap,
 // chunk) on the B operands the matrix instructions use anyway, with its weights as a wave-uniform LDS read, instead of a
 // third matrix group that would be 1 / 4 full: 8 instead of 12 matrix instructions per tap, the same fp32 FMA chain.
-template <int NG, int NW, int TZ, int KD, bool VD = false>
+// QIN: the input is QUAD RECORDS (B, Cin/4, D, H, W, 4) -- what the plane sweep writes with OQ (csrc/sweep_quad.hip): a
+// position's 4-channel chunk is ONE 16-byte load instead of four dword loads from four channel planes
+template <int NG, int NW, int TZ, int KD, bool VD = false, bool QIN = false>
 __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   constexpr int NGM = VD ? NG - 1 : NG;     // groups on the matrix cores
   static_assert(!VD || NG == 3, "the vector channel is channel 8 of a 9-channel layer");
@@ -93,12 +95,19 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
     const int sx = slot % kC4RS, t = slot / kC4RS, sy = t % TYH, sz = t / TYH;
     const int gx = x0 - 1 + sx, gy = y0 - 1 + sy, gz = z0 - KD / 2 + sz;
     const bool ok = (slot < POS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D) & !(kC4Ablate & 2);
-    goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
+    goff[j] = ok ? (QIN ? 16u : 4u) * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
   }
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
   f32x4c pre[NSLOT];
   auto load_tile = [&](int chunk) {
+    if constexpr (QIN) {
+      const unsigned cb = 16u * (unsigned)(chunk * plane);
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        pre[j] = __builtin_bit_cast(f32x4c, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[j] + cb, 0, 0));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j)
 #pragma unroll
@@ -210,12 +219,12 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   }
 }
 
-template <int NG, int NW, int TZ, int KD, bool VD = false>
+template <int NG, int NW, int TZ, int KD, bool VD = false, bool QIN = false>
 static int c4_launch(const C4Args& a, hipStream_t st) {
   constexpr int TY = 4 * NW, POS = (TZ + KD - 1) * (TY + 2) * kC4RS;
   const int nchunk = (a.Cin + 3) >> 2;
   const size_t lds = ((size_t)nchunk * KD * 9 * NG * 4 + POS) * 16;
-  auto kern = conv_c4_kernel<NG, NW, TZ, KD, VD>;
+  auto kern = conv_c4_kernel<NG, NW, TZ, KD, VD, QIN>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
@@ -394,7 +403,10 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
                     int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream) {
   BMV_REQUIRE(in && wpack && bias && out, "bmv_conv_c4_fwd: null pointer");
   BMV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "bmv_conv_c4_fwd: bad shape");
+  const bool qin = (mode & 4) != 0;      // input as quad records
+  mode &= ~4;
   BMV_REQUIRE(mode == 0 || (mode == 2 && (Cout == 8 || (Cout == 9 && out2))), "bmv_conv_c4_fwd: mode=%d with Cout=%d", mode, Cout);
+  BMV_REQUIRE(!qin || (Cin % 4 == 0), "bmv_conv_c4_fwd: quad-record input needs Cin %% 4 == 0 (Cin=%d)", Cin);
   if (Cout < 1 || Cout > 12 || (kd != 1 && kd != 3) || (kd == 1 && D != 1) ||
       (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 31) || (size_t)((Cin + 3) / 4) * kd * 9 * ((Cout + 3) / 4) * 64 > 100 * 1024) {
     set_error("bmv_conv_c4_fwd: shape not covered (Cout=%d Cin=%d kd=%d %dx%dx%d)", Cout, Cin, kd, D, H, W);
@@ -411,7 +423,11 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
     // (measured on the frame's four layers, profiles/r5/conv_c4_layers.txt: one plane per wave -- 58 registers,
     // 7-8 waves per SIMD -- beats two planes per wave at 106 registers everywhere: 56.8 / 54.2 / 38.3 / 22.1 us against
     // 60.0 / 54.5 / 41.7 / 25.0)
-    if (variant == 0 && Cout == 9) {
+    if (qin) {
+      // (the regularisers' first layer behind the plane sweep: the default tile only)
+      if (variant == 0 && ng == 2) rc = c4_launch<2, 4, 1, 3, false, true>(a, st);
+      if (variant == 0 && ng == 1) rc = c4_launch<1, 4, 1, 3, false, true>(a, st);
+    } else if (variant == 0 && Cout == 9) {
       rc = c4_launch<3, 4, 1, 3, true>(a, st);       // the 9-channel heads: 8 channels on the matrix cores + 1 on the vector ALU
     } else if (variant == 0 || variant == 3) {
       C4(1, 4, 1, 3);
@@ -429,7 +445,7 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
       C4(2, 4, 4, 3);
       C4(3, 2, 4, 3);
     }
-  } else {
+  } else if (!qin) {
     if (variant == 0 || variant == 1) {
       C4(1, 4, 1, 1);
       C4(2, 4, 1, 1);

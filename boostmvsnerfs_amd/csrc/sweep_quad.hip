@@ -114,8 +114,10 @@ struct QuadArgs {
   int qsplit;                                 // the C/4 channel quads of a tile are shared by qsplit workgroups
 };
 
-// PU: plane-uniform hypotheses (one depth per plane)
-template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU>
+// PU: plane-uniform hypotheses (one depth per plane).  OQ: the variance leaves as QUAD RECORDS (B, C/4, D, h, w, 4) -- one
+// 16-byte store per voxel and channel quad instead of four dword stores into four channel planes -- the layout the
+// regulariser's first layer (csrc/conv_c4.hip, input mode 4) stages with one 16-byte load per position.
+template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false>
 __global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 sweep_quad_kernel(const QuadArgs a) {
   constexpr int NT = TXW * TYH * DP, NW = NT / 64;
@@ -370,7 +372,7 @@ sweep_quad_kernel(const QuadArgs a) {
   __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out + (size_t)b * a.C * D * hw, 0, (int)((size_t)a.C * D * hw * 4), 0x00020000);
   // lanes outside the volume store out of range (dropped by the buffer's bounds check); planes past D likewise
-  const unsigned voff0 = (inb_xy && !(a.flags & 4)) ? (unsigned)((size_t)d0 * hw + (size_t)yc * w + xc) * 4u : 0x80000000u;
+  const unsigned voff0 = (inb_xy && !(a.flags & 4)) ? (unsigned)((size_t)d0 * hw + (size_t)yc * w + xc) * (OQ ? 16u : 4u) : 0x80000000u;
   bool all_staged = true;
 #pragma unroll
   for (int sv = 0; sv < S; ++sv) all_staged &= (wmode[sv] == 1) | (wmode[sv] == 2);
@@ -382,12 +384,19 @@ sweep_quad_kernel(const QuadArgs a) {
     // (a raw s_barrier: __syncthreads() carries a workgroup-scope fence that would wait for the stores as well)
     if (q == q_begin)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (OQ)
+      asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");   // (quad records: the last plane is ONE store)
     else
       asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // ... and in every wave's
     float4 V[PG];
-    const unsigned soff = (unsigned)(4 * q) * cstride;
+    const unsigned soff = (unsigned)(4 * q) * cstride;    // (quad records: quad q's block of D planes starts at the same byte)
     // lanes outside the volume store too, out of range (dropped by the buffer's bounds check): the vmcnt count is exact
     auto store_plane = [&](int pl) {
+      if constexpr (OQ) {
+        const int vo = (d0 + pl < D) ? (int)(voff0 + (unsigned)pl * (unsigned)hw * 16u) : (int)0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4q, V[pl]), orsrc, vo, (int)soff, kStoreAux);
+        return;
+      }
       const int vo = (d0 + pl < D) ? (int)(voff0 + (unsigned)pl * (unsigned)hw * 4u) : (int)0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, V[pl].x), orsrc, vo, (int)soff, kStoreAux);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, V[pl].y), orsrc, vo, (int)(soff + cstride), kStoreAux);
@@ -585,9 +594,9 @@ void fill_geom(QuadGeom& g, const QuVariant& v, int S, int Hs, int Ws, int D, in
     g.dv_ps = h * w, g.dv_rs = w, g.dv_cs = 1, g.dv_bs = (long long)D * h * w;
 }
 
-template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU>
+template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false>
 int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
-  auto kern = sweep_quad_kernel<TXW, TYH, DP, PG, S, WPE, PU>;
+  auto kern = sweep_quad_kernel<TXW, TYH, DP, PG, S, WPE, PU, OQ>;
   const size_t lds = (size_t)a.budget * 1024;
   static size_t allowed = 0;
   if (lds > allowed) {
@@ -605,6 +614,21 @@ int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
   else
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   return BMV_OK;
+}
+
+// quad-record output: instantiated for the tilings the default variants use (0, 12, 15, 16)
+template <int TXW, int TYH, int DP, int PG, int WPE>
+int qu_launch_s_oq(const QuadArgs& a, int B, int S, bool pu, hipStream_t stream) {
+  if (pu) {
+    if (S == 3) return qu_launch_one<TXW, TYH, DP, PG, 3, WPE, true, true>(a, B, stream);
+    if (S == 2) return qu_launch_one<TXW, TYH, DP, PG, 2, WPE, true, true>(a, B, stream);
+    if (S == 4) return qu_launch_one<TXW, TYH, DP, PG, 4, WPE, true, true>(a, B, stream);
+  } else {
+    if (S == 3) return qu_launch_one<TXW, TYH, DP, PG, 3, WPE, false, true>(a, B, stream);
+    if (S == 2) return qu_launch_one<TXW, TYH, DP, PG, 2, WPE, false, true>(a, B, stream);
+    if (S == 4) return qu_launch_one<TXW, TYH, DP, PG, 4, WPE, false, true>(a, B, stream);
+  }
+  return BMV_ERR_UNSUPPORTED;
 }
 
 template <int TXW, int TYH, int DP, int PG, int WPE>
@@ -663,6 +687,13 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   if (8 * a.pgroups * a.qsplit >= 65536) return BMV_ERR_UNSUPPORTED;
   const bool pu = dv_plane_uniform != 0;
   int rc = BMV_ERR_UNSUPPORTED;
+  if (flags & (1 << 24)) {   // variance as quad records
+    if (v.txw == 32 && v.tyh == 8 && v.dp == 1 && v.pg == 2 && v.wpe == 5) rc = qu_launch_s_oq<32, 8, 1, 2, 5>(a, B, S, pu, as_stream(stream));
+    if (v.txw == 32 && v.tyh == 2 && v.dp == 4 && v.pg == 2 && v.wpe == 5) rc = qu_launch_s_oq<32, 2, 4, 2, 5>(a, B, S, pu, as_stream(stream));
+    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_quad_fwd: variant %d has no quad-record output", variant);
+    if (rc != BMV_OK) return rc;
+    BMV_LAUNCH_END("bmv_sweep_variance_quad_fwd");
+  }
 #define V(TXW, TYH, DP, PG, WPE) \
   if (v.txw == TXW && v.tyh == TYH && v.dp == DP && v.pg == PG && v.wpe == WPE) rc = qu_launch_s<TXW, TYH, DP, PG, WPE>(a, B, S, pu, as_stream(stream));
   V(32, 8, 1, 2, 5)

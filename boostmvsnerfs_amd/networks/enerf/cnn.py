@@ -236,6 +236,13 @@ class _CostReg(nn.Module):
         # first layer (32 | 16 -> 8) and heads (8 -> 8 + 1) on v_mfma_f32_4x4x1 (csrc/conv_c4.hip: every matrix row useful
         # for 8 output channels; the 16-row kernels of conv.hip reach 75 % / 56 %): same fp32 FMA chains per output
         self.conv_c4 = convnet.CONV_C4
+        self.quad_volume = switches.on("BMV_QUAD_VOLUME")
+
+    def takes_quad_volume(self):
+        """True: hand forward() the cost volume as ops.QuadVolume (the sweep's quad-record output) -- the first layer runs
+        on the 4-row-block kernel, which stages such an input with one 16-byte load per position."""
+        return (self.quad_volume and self.conv_c4 and not self.training and not torch.is_grad_enabled()
+                and switches.get("BMV_CNN") != "torch" and not convnet.split_parts(self.split_bf16, "conv0", self.conv0.conv.weight.shape[1]))
 
     def _apply(self, fn, *args, **kwargs):
         self._packed.invalidate()
@@ -270,6 +277,8 @@ class _CostReg(nn.Module):
         P = self.prepack()
         ok4 = x.shape[-1] % 4 == 0
         split = convnet.split_parts(self.split_bf16, "conv0", x.shape[1]) if ok4 else 0
+        if isinstance(x, ops.QuadVolume) and (split or not self.conv_c4):
+            x = x.to_planar()
         if split:
             s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
         elif self.conv_c4:
@@ -306,6 +315,8 @@ class _CostReg(nn.Module):
     def forward(self, x):
         if _engine_ok(self, x):
             return self._forward_engine(x)
+        if isinstance(x, ops.QuadVolume):
+            x = x.to_planar()
         s0 = self.conv0(x)
         s1 = self.conv2(self.conv1(s0))
         s2 = self.conv4(self.conv3(s1))

@@ -152,9 +152,11 @@ class Network(nn.Module):
         if train:
             variance = A.SweepVariance.apply(feats_i, proj, st.depth_values, self.sweep_algo)
         elif view_ids is not None:
-            variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values, plane_uniform=uniform)
+            variance = ops.sweep_variance_views(feats_i, view_ids, proj, st.depth_values, plane_uniform=uniform,
+                                                quad_out=getattr(self, f"cost_reg_{i}").takes_quad_volume())
         else:
-            variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo, plane_uniform=uniform)
+            variance = ops.sweep_variance(feats_i, proj, st.depth_values, algo=self.sweep_algo, plane_uniform=uniform,
+                                          quad_out=getattr(self, f"cost_reg_{i}").takes_quad_volume())
         if fork_after_sweep is not None:
             fork_after_sweep.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(fork_after_sweep):
@@ -370,7 +372,7 @@ class Network(nn.Module):
         (tests and tuning scripts flip them between calls)."""
         return (self.sweep_algo, self.overlap_front, self.lookup_records, self.frame_setup, self.volume_records,
                 self.overlap_eager, self.cost_reg_0.split_bf16, self.cost_reg_1.split_bf16,
-                self.cost_reg_0.conv_c4, self.cost_reg_1.conv_c4)
+                self.cost_reg_0.conv_c4, self.cost_reg_1.conv_c4, self.cost_reg_0.quad_volume, self.cost_reg_1.quad_volume)
 
     def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() replace storage: captured graphs are stale
         ag = self.__dict__.get("_autograph")

@@ -188,20 +188,57 @@ def _plane_uniform(depth_values, plane_uniform):
     return 2 if plane_uniform else 0
 
 
+class QuadVolume:
+    """A cost volume as QUAD RECORDS: `data` is (B, C/4, D, h, w, 4) contiguous -- what the inference sweep writes with
+    `quad_out=True` (one 16-byte store per voxel and channel quad, csrc/sweep_quad.hip) and the regulariser's first layer
+    stages with one 16-byte load per position (convnet.conv_c4_fwd).  `to_planar()` gives (B, C, D, h, w)."""
+
+    def __init__(self, data):
+        if data.dim() != 6 or data.shape[-1] != 4 or not data.is_contiguous():
+            raise ValueError("QuadVolume takes a contiguous (B, C/4, D, h, w, 4) tensor")
+        self.data = data
+
+    @property
+    def shape(self):
+        B, Q, D, h, w, _ = self.data.shape
+        return torch.Size((B, 4 * Q, D, h, w))
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def to_planar(self):
+        B, Q, D, h, w, _ = self.data.shape
+        return self.data.permute(0, 1, 5, 2, 3, 4).reshape(B, 4 * Q, D, h, w)
+
+
+QUAD_VOLUME_FLAG = 1 << 24      # include/bmv.h: bmv_sweep_variance_quad_fwd flags
+
+
 def sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plane_uniform=False, variant=-1, out=None,
-                        flags=0):
+                        flags=0, quad_out=False):
     """Plane sweep on quad-planar features (QuadFeats or its (B,V,C/4,Hs,Ws,4) tensor).  `view_ids` (B,S) int32 picks the
     S views of proj from the V views of feats; None: V == S.  flags: include/bmv.h (bits 16-23: LDS budget in KB)."""
     if sweep_hook is not None:
         r = sweep_hook(_sweep_variance_quad, (feats, proj, depth_values),
-                       dict(view_ids=view_ids, hw=hw, plane_uniform=plane_uniform, variant=variant, out=out, flags=flags))
+                       dict(view_ids=view_ids, hw=hw, plane_uniform=plane_uniform, variant=variant, out=out, flags=flags,
+                            quad_out=quad_out))
         if r is not None:
             return r
-    return _sweep_variance_quad(feats, proj, depth_values, view_ids, hw, plane_uniform, variant, out, flags)
+    return _sweep_variance_quad(feats, proj, depth_values, view_ids, hw, plane_uniform, variant, out, flags, quad_out)
 
 
 def _sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plane_uniform=False, variant=-1, out=None,
-                         flags=0):
+                         flags=0, quad_out=False):
+    """quad_out: the variance as a QuadVolume (quad records) when the kernel variant has that output, else planar."""
     data = feats.data if isinstance(feats, QuadFeats) else feats
     if data.dim() != 6:
         raise ValueError("the quad-planar sweep takes (B, V, C/4, Hs, Ws, 4) features (QuadFeats.reshape_views)")
@@ -219,9 +256,23 @@ def _sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plan
         check_view_ids(view_ids, V)
     elif V != S:
         raise ValueError(f"{V} source views but {S} projection matrices (pass view_ids to pick)")
+    lib = _lib.load()
+    if isinstance(out, QuadVolume) or (quad_out and out is None):
+        given = isinstance(out, QuadVolume)        # (framegraph.py replays a sweep into the buffer of its first run)
+        qv = out.data if given else torch.empty(B, Q, D, h, w, 4, device=data.device, dtype=torch.float32)
+        with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]", bind=True):
+            rc = lib.bmv_sweep_variance_quad_fwd(dptr(data, "feats_quad"), dptr(_c(view_ids), "view_ids", torch.int32) if view_ids is not None else None,
+                                                 V, dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
+                                                 _plane_uniform(depth_values, plane_uniform), B, S, C_,
+                                                 Hs, Ws, D, h, w, dptr(qv), int(variant), int(flags) | QUAD_VOLUME_FLAG, stream())
+        if rc == 0:
+            return out if given else QuadVolume(qv)
+        if rc != BMV_ERR_UNSUPPORTED or given:
+            _lib.check(rc, "sweep_variance_quad")
+        lib.bmv_last_error()            # a variant without the quad-record output (tuning), or an uncovered shape: planar
+        del qv
     if out is None:
         out = torch.empty(B, C_, D, h, w, device=data.device, dtype=torch.float32)
-    lib = _lib.load()
     with ktimer.region(f"sweep_variance[C={C_},D={D},{h}x{w}]", bind=True):
         rc = lib.bmv_sweep_variance_quad_fwd(dptr(data, "feats_quad"), dptr(_c(view_ids), "view_ids", torch.int32) if view_ids is not None else None,
                                              V, dptr(_c(proj), "proj"), dptr(_c(depth_values), "depth_values"),
@@ -244,19 +295,20 @@ def _sweep_variance_quad(feats, proj, depth_values, view_ids=None, hw=None, plan
 sweep_hook = None     # framegraph.FrameGraph: hook(impl, args, kwargs) lets a graph capture step around one sweep launch
 
 
-def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False):
+def sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False, quad_out=False):
     """feats: QuadFeats (the inference layout: csrc/sweep_quad.hip), or (B,S,C,Hs,Ws) in the reference layout, or
     channel-last (B,S,Hs,Ws,C) when channels_last=True.  With channels_last=None (default) a reference-layout input
     with C in {16, 32} is first put into the channel-last layout (one transpose kernel) and the windowed channel-last
     sweep runs; algo=1 forces the reference-layout direct-gather kernel; algo 500 + i / 600 + i: the quad-planar kernel
     (tuning variant i; 600: hypotheses declared plane-uniform) after a layout conversion.  `plane_uniform`: the caller
-    vouches that every plane of depth_values is constant (cascade level 0)."""
+    vouches that every plane of depth_values is constant (cascade level 0).  `quad_out`: the variance as a QuadVolume
+    (quad records, for convnet.conv_c4_fwd) where the quad-planar kernel runs; planar otherwise."""
     if sweep_hook is not None:
         r = sweep_hook(_sweep_variance, (feats, proj, depth_values),
-                       dict(algo=algo, out=out, channels_last=channels_last, plane_uniform=plane_uniform))
+                       dict(algo=algo, out=out, channels_last=channels_last, plane_uniform=plane_uniform, quad_out=quad_out))
         if r is not None:
             return r
-    return _sweep_variance(feats, proj, depth_values, algo, out, channels_last, plane_uniform)
+    return _sweep_variance(feats, proj, depth_values, algo, out, channels_last, plane_uniform, quad_out)
 
 
 def mark_view_ids(view_ids, n_all):
@@ -282,20 +334,21 @@ def check_view_ids(view_ids, n_all):
     return mark_view_ids(view_ids, n_all)
 
 
-def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False):
+def sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False, quad_out=False):
     """Plane sweep over the S views `view_ids` (B,S) int32 picked from feats_all = ALL source views: QuadFeats (what
     FeatureNet's engine path returns in inference), or a (B,n_all,C,Hs,Ws) view of a channel-last (B,n_all,Hs,Ws,C)
     buffer.  No gathered copy of the feature maps is made."""
     if sweep_hook is not None:
-        r = sweep_hook(_sweep_variance_views, (feats_all, view_ids, proj, depth_values), dict(out=out, plane_uniform=plane_uniform))
+        r = sweep_hook(_sweep_variance_views, (feats_all, view_ids, proj, depth_values),
+                       dict(out=out, plane_uniform=plane_uniform, quad_out=quad_out))
         if r is not None:
             return r
-    return _sweep_variance_views(feats_all, view_ids, proj, depth_values, out, plane_uniform)
+    return _sweep_variance_views(feats_all, view_ids, proj, depth_values, out, plane_uniform, quad_out)
 
 
-def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False):
+def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, plane_uniform=False, quad_out=False):
     if isinstance(feats_all, QuadFeats):
-        return _sweep_variance_quad(feats_all, proj, depth_values, view_ids, None, plane_uniform, -1, out)
+        return _sweep_variance_quad(feats_all, proj, depth_values, view_ids, None, plane_uniform, -1, out, 0, quad_out)
     cl = feats_all.permute(0, 1, 3, 4, 2) if feats_all.dim() == 5 else None
     if cl is None or not cl.is_contiguous():
         raise ValueError("sweep_variance_views needs a (B,n_all,C,Hs,Ws) view of channel-last feature maps")
@@ -316,7 +369,7 @@ def _sweep_variance_views(feats_all, view_ids, proj, depth_values, out=None, pla
     return out
 
 
-def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False):
+def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=None, plane_uniform=False, quad_out=False):
     if isinstance(feats, QuadFeats) and not (algo == 0 or algo >= 500):
         feats, channels_last = feats.to_nchw(), None     # another kernel was asked for by id: back to the planar layout
     if isinstance(feats, QuadFeats) or algo >= 500:      # quad-planar kernel (500 + i: tuning variant i; 600 + i: the same
@@ -332,7 +385,7 @@ def _sweep_variance(feats, proj, depth_values, algo=0, out=None, channels_last=N
                 if cl.is_contiguous():
                     feats, channels_last = cl, True
             feats = QuadFeats(to_quad_planar(feats, channels_last=bool(channels_last)))
-        return _sweep_variance_quad(feats, proj, depth_values, None, None, pu, variant, out)
+        return _sweep_variance_quad(feats, proj, depth_values, None, None, pu, variant, out, 0, quad_out)
     if channels_last is None and feats.dim() == 5 and not feats.is_contiguous() and algo != 1:
         cl = feats.permute(0, 1, 3, 4, 2)
         if cl.is_contiguous():        # (B,S,C,Hs,Ws) view of a channel-last buffer (the conv engine writes it so)

@@ -87,7 +87,9 @@ int bmv_sweep_variance_views_fwd(const float* feats_all, const int* view_ids, in
  * whose planes are constant ([b,d,0,0] is read).  view_ids (B,S) int32 or NULL: views picked from the n_all views of
  * feats_quad (n_all ignored when NULL: feats_quad holds exactly S views per item).  variant: -1 = by the source / volume
  * scale; 0.. = tuning table of sweep_quad.hip.  flags: 0; tuning ablations: 1 no fill, 2 no blend, 4 no store; bits 16-23:
- * LDS budget in 1-KB pieces for the S windows together (tests: small budgets force the global-gather fallback).
+ * LDS budget in 1-KB pieces for the S windows together (tests: small budgets force the global-gather fallback); bit 24
+ * (round 5): `variance` is written as QUAD RECORDS (B, C/4, D, h, w, 4) -- one 16-byte store per voxel and channel quad
+ * -- for bmv_conv_c4_fwd's input mode 4 (default variants only; BMV_ERR_UNSUPPORTED otherwise).
  * S in 2..4, C % 4 == 0, C <= 64. */
 int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, int n_all, const float* proj,
                                 const float* depth_values, int dv_plane_uniform, int B, int S, int C, int Hs, int Ws,
@@ -512,7 +514,9 @@ int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, f
  * eval-mode batch norm folded in, zero padded; bias (4 ceil(Cout / 4)); act(v) = v > 0 ? v : slope v.
  * mode 0: out planar (B,Cout,D,H,W).  mode 2: the renderer's volume records -- out (B,D,H,W,8) = output channels 0..7
  * (the caller packs them in the record's [even | odd] order), out2 (B,D,H,W) = channel 8 (Cout = 9: the depth logits).
- * variant: 0 = default tiling, 1.. = tuning. */
+ * mode | 4 (round 5): `in` is QUAD RECORDS (B, Cin/4, D, H, W, 4), Cin % 4 == 0 -- what bmv_sweep_variance_quad_fwd
+ * writes with flags bit 24: the regulariser's first layer stages its tile with one 16-byte load per position and chunk
+ * (kd = 3, Cout <= 8, variant 0).  variant: 0 = default tiling, 1.. = tuning. */
 int bmv_conv_c4_wpack_floats(int Cout, int Cin, int kd);
 int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, float* out, float* out2, int B, int Cin, int D,
                     int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream);

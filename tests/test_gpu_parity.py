@@ -371,6 +371,15 @@ def test_sweep_kernels_agree_at_scale(ops, level):
     if level == 0:     # hypotheses handed over as (B, D): one per plane (dv_plane_uniform 1)
         got = ops.sweep_variance_quad(q, Pd, dvd[:, :, 0, 0].contiguous(), hw=(h, w))
         assert_close(got, want, name="level 0 quad, (B, D) hypotheses")
+    # the variance as quad records (what the regulariser's first layer stages with 16-byte loads): the same values, bit
+    # for bit, in another layout -- default variants, small LDS budgets (gather fallback) included; a tuning variant
+    # without that output falls back to the planar tensor
+    for variant, budget in ((-1, 0), (0, 0), (12, 0), (12, 6), (0, 1)):
+        planar = ops.sweep_variance_quad(q, Pd, dvd, variant=variant, flags=budget << 16)
+        qv = ops.sweep_variance_quad(q, Pd, dvd, variant=variant, flags=budget << 16, quad_out=True)
+        assert isinstance(qv, ops.QuadVolume) and qv.shape == planar.shape
+        assert torch.equal(qv.to_planar(), planar), f"level {level} variant {variant}: quad records differ from the planar volume"
+    assert torch.is_tensor(ops.sweep_variance_quad(q, Pd, dvd, variant=3, quad_out=True))
     # views picked by index from a larger set (the K-volume networks)
     extra = torch.randn(1, 2, cfgl["C"], Hs, Ws, device=DEV)
     allv = torch.cat([extra[:, :1], fd[:, 2:3], fd[:, 0:1], extra[:, 1:], fd[:, 1:2]], 1)      # views 2, 4, 1 are ours
