@@ -110,21 +110,26 @@ def pack_convT_c4(weight, bias):
     return pack_conv_c4(weight.detach().transpose(0, 1), bias)
 
 
-def convT_c4_fwd(x, wpack, bias, Cout, skip=None, relu=False, slope=None, variant=0):
+def convT_c4_fwd(x, wpack, bias, Cout, skip=None, relu=False, slope=None, variant=0, quad_out=False):
     """x (B,Cin,D,H,W) -> act(conv_transpose3d(x, k=3, stride=2, padding=1, output_padding=1) + bias) + skip, Cout <= 8,
-    on the 4 x 4 x 1 matrix blocks (csrc/conv_c4.hip)."""
+    on the 4 x 4 x 1 matrix blocks (csrc/conv_c4.hip).  quad_out (Cout = 8): the result as an ops.QuadVolume (quad
+    records, for conv_c4_fwd's 16-byte staging); `skip` is planar either way."""
     B, Cin, D, H, W = x.shape
-    out = torch.empty(B, Cout, 2 * D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    quad_out = bool(quad_out) and Cout == 8 and variant == 0
+    if quad_out:
+        out = torch.empty(B, 2, 2 * D, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Cout, 2 * D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
     if skip is not None:
-        assert skip.shape == out.shape and skip.is_contiguous()
+        assert tuple(skip.shape) == (B, Cout, 2 * D, 2 * H, 2 * W) and skip.is_contiguous()
     x = x if x.is_contiguous() else x.contiguous()
     lib = _lib.load()
     with ktimer.region(f"convT_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv3d_transpose_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                                   dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout,
-                                  _slope(relu, slope), int(variant), stream())
+                                  _slope(relu, slope), int(variant) | (16 if quad_out else 0), stream())
     _lib.check(rc, "convT_c4_fwd")
-    return out
+    return ops.QuadVolume(out) if quad_out else out
 
 
 def pack_conv_split(weight, bias, parts=3):

@@ -256,7 +256,10 @@ struct CT4Args {
   float slope;
 };
 
-template <int NG, int NYS>   // NG cout groups x NYS slabs of 4 input rows = waves per workgroup
+// OQ: the output as QUAD RECORDS (B, Cout/4, 2D, 2H, 2W, 4) -- a wave's 4 output channels of a voxel are one 16-byte
+// store, the two x parities 32 contiguous bytes -- the layout the heads' kernel (conv_c4_kernel, QIN) stages with one
+// 16-byte load per position; the skip stays planar (it is the first layer's output, which the stride-2 layer reads too)
+template <int NG, int NYS, bool OQ = false>   // NG cout groups x NYS slabs of 4 input rows = waves per workgroup
 __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
   constexpr int NT = 64 * NG * NYS, TY = 4 * NYS, TYH = TY + 1, RS = 17;
   constexpr int POS = 2 * TYH * RS, NSLOT = (POS + NT - 1) / NT;
@@ -346,6 +349,29 @@ __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
   if (mx >= a.W || my >= a.H) return;
   const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
   const size_t cs = (size_t)Do * Ho * Wo;
+  if constexpr (OQ) {
+    float bs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[r] = a.bias[4 * g + r];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const size_t sp = (size_t)(2 * mz + (qq >> 1)) * Ho * Wo + (size_t)(2 * my + (qq & 1)) * Wo + 2 * mx;
+      float2 sk[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sk[r] = a.skip ? *reinterpret_cast<const float2*>(a.skip + ((size_t)b * a.Cout + 4 * g + r) * cs + sp) : make_float2(0.f, 0.f);
+      f32x4c v0, v1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t0 = acc[2 * qq][r] + bs[r], t1 = acc[2 * qq + 1][r] + bs[r];
+        v0[r] = fmaxf(t0, 0.f) + a.slope * fminf(t0, 0.f) + sk[r].x;
+        v1[r] = fmaxf(t1, 0.f) + a.slope * fminf(t1, 0.f) + sk[r].y;
+      }
+      f32x4c* rec = reinterpret_cast<f32x4c*>(a.out) + ((size_t)b * NG + g) * cs + sp;
+      rec[0] = v0, rec[1] = v1;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = 4 * g + r;
@@ -368,12 +394,12 @@ __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
   (void)cs;
 }
 
-template <int NG, int NYS>
+template <int NG, int NYS, bool OQ = false>
 static int ct4_launch(const CT4Args& a, hipStream_t st) {
   constexpr int TY = 4 * NYS, POS = 2 * (TY + 1) * 17;
   const int nchunk = (a.Cin + 3) >> 2;
   const size_t lds = ((size_t)nchunk * 27 * NG * 4 + POS) * 16;
-  auto kern = convT_c4_kernel<NG, NYS>;
+  auto kern = convT_c4_kernel<NG, NYS, OQ>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
@@ -424,7 +450,9 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
     // 7-8 waves per SIMD -- beats two planes per wave at 106 registers everywhere: 56.8 / 54.2 / 38.3 / 22.1 us against
     // 60.0 / 54.5 / 41.7 / 25.0)
     if (qin) {
-      // (the regularisers' first layer behind the plane sweep: the default tile only)
+      // (the regularisers' first layer behind the plane sweep, the heads behind conv11: the default tiles only)
+      if (variant == 0 && Cout == 9) rc = c4_launch<3, 4, 1, 3, true, true>(a, st);
+      else if (variant == 0 && ng == 3) rc = c4_launch<3, 4, 1, 3, false, true>(a, st);
       if (variant == 0 && ng == 2) rc = c4_launch<2, 4, 1, 3, false, true>(a, st);
       if (variant == 0 && ng == 1) rc = c4_launch<1, 4, 1, 3, false, true>(a, st);
     } else if (variant == 0 && Cout == 9) {
@@ -478,6 +506,13 @@ int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float
   const int ng = (Cout + 3) / 4;
   hipStream_t st = as_stream(stream);
   int rc = BMV_ERR_UNSUPPORTED;
+  if (variant & 16) {      // out as quad records (default tiling)
+    BMV_REQUIRE(Cout == 8 && (variant & 15) == 0, "bmv_conv3d_transpose_c4_fwd: quad-record output is built for Cout = 8, variant 0");
+    rc = ct4_launch<2, 2, true>(a, st);
+    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_conv3d_transpose_c4_fwd: cannot reserve LDS");
+    if (rc != BMV_OK) return rc;
+    BMV_LAUNCH_END("bmv_conv3d_transpose_c4_fwd");
+  }
   if (ng == 2) rc = variant == 1 ? ct4_launch<2, 1>(a, st) : variant == 2 ? ct4_launch<2, 4>(a, st) : ct4_launch<2, 2>(a, st);
   if (ng == 1) rc = variant == 1 ? ct4_launch<1, 1>(a, st) : variant == 2 ? ct4_launch<1, 4>(a, st) : ct4_launch<1, 2>(a, st);
   if (rc != BMV_OK) {

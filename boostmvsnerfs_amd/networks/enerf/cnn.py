@@ -292,11 +292,12 @@ class _CostReg(nn.Module):
             t = convnet.conv_fwd(convnet.conv_fwd(s2, *P["conv5"], 64, 3, 3, 2, relu=True), *P["conv6"], 64, 3, 3, relu=True)
             y = convnet.convT3d_fwd(t, *P["conv7"], 32, skip=s2)
         y = convnet.convT3d_fwd(y, *P["conv9"], 16, skip=s1)
+        split = convnet.split_parts(self.split_bf16, "heads", 8) if ok4 else 0
         if self.conv_c4:
-            y = convnet.convT_c4_fwd(y, *P["conv11_c4"], 8, skip=s0)
+            # (the heads run on the same 4-row-block kernel: they take conv11's result as quad records)
+            y = convnet.convT_c4_fwd(y, *P["conv11_c4"], 8, skip=s0, quad_out=self.quad_volume and not split)
         else:
             y = convnet.convT3d_fwd(y, *P["conv11"], 8, skip=s0)
-        split = convnet.split_parts(self.split_bf16, "heads", 8) if ok4 else 0
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:
                 return convnet.conv3d_split_heads_records(y, *P[f"heads_rec_split{split}"])

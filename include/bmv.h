@@ -523,7 +523,9 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
 /* ... and the regularisers' last up-sampling step on the same blocks (cost_reg_net.py:23-41 conv11 = ConvTranspose3d(16, 8,
  * k 3, stride 2, padding 1, output_padding 1) + BatchNorm3d, then the U-Net skip add): in (B,Cin,D,H,W) -> out
  * (B,Cout,2D,2H,2W) = act(convT(in) + bias) + skip (skip nullable, layout of out), Cout <= 8.  wpack as above (kd = 3)
- * with the taps of the transposed weight (Cin,Cout,3,3,3): [cin chunk][tap][cout group][cout][cin]. */
+ * with the taps of the transposed weight (Cin,Cout,3,3,3): [cin chunk][tap][cout group][cout][cin].
+ * variant | 16 (round 5): `out` is written as QUAD RECORDS (B, Cout/4, 2D, 2H, 2W, 4) (Cout = 8; `skip` stays planar) for
+ * bmv_conv_c4_fwd's input mode 4. */
 int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                      int D, int H, int W, int Cout, float slope, int variant, bmv_stream_t stream);
 

@@ -464,13 +464,16 @@ def test_conv_c4(nd, B, Cin, Cout, sp):
     _close(convnet.conv_c4_fwd(x, wp, bp, Cout, slope=0.01), F.leaky_relu(want, 0.01), tol=2e-5)
     wp16, bp16 = convnet.pack_conv(w, b, 1)
     _close(convnet.conv_c4_fwd(x, wp, bp, Cout), convnet.conv_fwd(x, wp16, bp16, Cout, 3 if nd == 3 else 1, 3, 1), tol=2e-5)
-    if nd == 3 and Cin % 4 == 0 and Cout <= 8:
+    if nd == 3 and Cin % 4 == 0:
         # the input as quad records (the plane sweep's output layout): bit-identical to the planar input
         from boostmvsnerfs_amd import ops
         D_, H_, W_ = sp
         qv = ops.QuadVolume(x.view(B, Cin // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
         assert torch.equal(qv.to_planar(), x)
         assert torch.equal(convnet.conv_c4_fwd(qv, wp, bp, Cout, relu=True), convnet.conv_c4_fwd(x, wp, bp, Cout, relu=True))
+        if Cout in (8, 9):
+            (r0, l0), (r1, l1) = convnet.conv_c4_fwd(qv, wp, bp, Cout, records=True), convnet.conv_c4_fwd(x, wp, bp, Cout, records=True)
+            assert torch.equal(r0.t, r1.t) and (l0 is None or torch.equal(l0, l1))
     if nd == 3 and Cout in (8, 9):
         rec, logit = convnet.conv_c4_fwd(x, wp, bp, Cout, records=True)
         _close(rec.t.permute(0, 4, 1, 2, 3), want[:, :8], tol=2e-5)          # (channels in the order they were packed)
@@ -497,3 +500,9 @@ def test_convT_c4(Cin, Cout, D, H, W):
     _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip, relu=True), F.relu(want) + skip, tol=2e-5)
     wp16, bp16 = convnet.pack_convT(w, b)
     _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip), convnet.convT3d_fwd(x, wp16, bp16, Cout, skip=skip), tol=2e-5)
+    if Cout == 8:     # the result as quad records (what the heads' kernel stages with 16-byte loads): the same bits
+        from boostmvsnerfs_amd import ops
+        for sk in (None, skip):
+            qv = convnet.convT_c4_fwd(x, wp, bp, Cout, skip=sk, relu=True, quad_out=True)
+            assert isinstance(qv, ops.QuadVolume)
+            assert torch.equal(qv.to_planar(), convnet.convT_c4_fwd(x, wp, bp, Cout, skip=sk, relu=True))
