@@ -67,11 +67,12 @@ def pack_conv_c4(weight, bias):
     return wpack, b
 
 
-def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, variant=0):
+def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, variant=0, quad_out=False):
     """x (B,Cin,D,H,W) or (B,Cin,H,W) -> act(conv(x, 3x3[x3], stride 1, padding 1) + bias) with Cout <= 12 output
     channels on the 4-row matrix blocks (csrc/conv_c4.hip).  records: the renderer's volume records (VolumeRecords of
     channels 0..7 + the planar channel 8 when Cout == 9) instead of the planar tensor.  x may be an ops.QuadVolume (the
-    plane sweep's quad-record output, (B,Cin/4,D,H,W,4)): staged with 16-byte loads (include/bmv.h: mode | 4)."""
+    plane sweep's quad-record output, (B,Cin/4,D,H,W,4)): staged with 16-byte loads (include/bmv.h: mode | 4).
+    quad_out (3-D, Cout % 4 == 0): the result as an ops.QuadVolume (mode 8) for a consumer that stages 16-byte records."""
     qin = isinstance(x, ops.QuadVolume)
     if qin:
         x = x.data
@@ -89,19 +90,22 @@ def conv_c4_fwd(x, wpack, bias, Cout, relu=False, slope=None, records=False, var
     assert wpack.numel() == lib.bmv_conv_c4_wpack_floats(Cout, Cin, kd)
     x = x if x.is_contiguous() else x.contiguous()
     out2 = None
+    quad_out = bool(quad_out) and is3d and Cout % 4 == 0 and not records
     if records:
         out = torch.empty(B, D, H, W, 8, device=x.device, dtype=torch.float32)
         out2 = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32) if Cout == 9 else None
+    elif quad_out:
+        out = torch.empty(B, Cout // 4, D, H, W, 4, device=x.device, dtype=torch.float32)
     else:
         out = torch.empty((B, Cout, D, H, W) if is3d else (B, Cout, H, W), device=x.device, dtype=torch.float32)
     with ktimer.region(f"conv_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"), dptr(out),
                                  dptr(out2) if out2 is not None else None, B, Cin, D, H, W, Cout, kd, _slope(relu, slope),
-                                 (2 if records else 0) | (4 if qin else 0), int(variant), stream())
+                                 (2 if records else 8 if quad_out else 0) | (4 if qin else 0), int(variant), stream())
     _lib.check(rc, "conv_c4_fwd")
     if records:
         return VolumeRecords(out), out2
-    return out
+    return ops.QuadVolume(out) if quad_out else out
 
 
 def pack_convT_c4(weight, bias):
@@ -120,14 +124,19 @@ def convT_c4_fwd(x, wpack, bias, Cout, skip=None, relu=False, slope=None, varian
         out = torch.empty(B, 2, 2 * D, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
     else:
         out = torch.empty(B, Cout, 2 * D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    skip_quad = isinstance(skip, ops.QuadVolume)
+    if skip_quad and not quad_out:
+        skip, skip_quad = skip.to_planar().contiguous(), False
     if skip is not None:
-        assert tuple(skip.shape) == (B, Cout, 2 * D, 2 * H, 2 * W) and skip.is_contiguous()
+        assert tuple(skip.shape) == (B, Cout, 2 * D, 2 * H, 2 * W)
+        skip = skip.data if skip_quad else skip
+        assert skip.is_contiguous()
     x = x if x.is_contiguous() else x.contiguous()
     lib = _lib.load()
     with ktimer.region(f"convT_c4[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv3d_transpose_c4_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                                   dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout,
-                                  _slope(relu, slope), int(variant) | (16 if quad_out else 0), stream())
+                                  _slope(relu, slope), int(variant) | (16 if quad_out else 0) | (32 if skip_quad else 0), stream())
     _lib.check(rc, "convT_c4_fwd")
     return ops.QuadVolume(out) if quad_out else out
 
@@ -420,10 +429,15 @@ def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, 
 def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):
     """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
     ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout)), or -- channels_last="quad" -- quad-planar (B,Cout/4,[Do,]Ho,Wo,4)."""
-    is3d = x.dim() == 5
+    qin = isinstance(x, ops.QuadVolume)
+    if qin and not (kd == 3 and k == 3 and stride == 2 and x.shape[1] < 16 and Cout <= 16):
+        x, qin = x.to_planar().contiguous(), False       # (only the regularisers' stride-2 layer stages quad records)
+    is3d = qin or x.dim() == 5
     B, Cin = x.shape[:2]
     D = x.shape[2] if is3d else 1
     H, W = x.shape[-2:]
+    if qin:
+        x = x.data
     p, pd = k // 2, kd // 2
     Do, Ho, Wo = (D + 2 * pd - kd) // stride + 1, (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
     quad = channels_last == "quad"          # (B, Cout/4, [Do,] Ho, Wo, 4): the plane sweep's source layout
@@ -443,6 +457,6 @@ def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, chann
     with ktimer.region(f"conv[{Cin}->{Cout},k{kd}x{k}x{k},s{stride},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_fwd(dptr(x, "conv input"), dptr(wpack, "wpack"), dptr(bias, "bias"),
                               dptr(skip) if skip is not None else None, dptr(out), B, Cin, D, H, W, Cout, kd, k, stride,
-                              _slope(relu, slope), 3 if quad else int(bool(channels_last)), stream())
+                              _slope(relu, slope), (3 if quad else int(bool(channels_last))) | (16 if qin else 0), stream())
     _lib.check(rc, "conv_fwd")
     return out

@@ -49,6 +49,8 @@ struct ConvArgs {
   const float* w2;     // second stage (TOP): packed 1x1 weights [2 tiles][8 chunks][4][16] and bias (32)
   const float* b2;
 };
+// QIN (conv_mfma_kernel): `in` is QUAD RECORDS (B, Cin/4, D, H, W, 4) -- the regularisers' first layer writes them
+// (csrc/conv_c4.hip, mode 8): a slot's 4-channel chunk is one 16-byte load instead of four dword loads
 
 // MAP: 0 = 2-D (row groups along y), 1 = 3-D with the block's 4/NCT row groups along z, 2 = 3-D along y
 template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
@@ -89,7 +91,7 @@ constexpr int conv_wpe(int KD, int K, int S, int NCT, int R, int MAP, bool PAIR)
 // second stage of the same workgroup -- the activated tile goes to LDS, each wave finishes two rows x both output
 // tiles with 32 MFMAs and writes the channel-last map the level-0 sweep reads; the 32-channel intermediate is never
 // written and one launch disappears from the head of the frame.  Needs both output tiles in the workgroup (NCT = 2).
-template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, bool TOP = false>
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, bool TOP = false, bool QIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_wpe(KD, K, S, NCT, R, MAP, PAIR), 8)))
 void conv_mfma_kernel(ConvArgs a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
@@ -130,7 +132,7 @@ void conv_mfma_kernel(ConvArgs a) {
     const int sx = slot % T::RS, t = slot / T::RS, sy = t % T::TYH, sz = t / T::TYH;
     const int gx = ix0 + sx, gy = iy0 + sy, gz = iz0 + sz;
     const bool ok = (slot < T::SLOTS) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H) & (gz >= 0) & (gz < a.D);
-    goff[j] = ok ? 4u * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
+    goff[j] = ok ? (QIN ? 16u : 4u) * (unsigned)((gz * a.H + gy) * a.W + gx) : 0x80000000u;
   }
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in + (size_t)b * a.Cin * plane), 0, (int)(4u * (unsigned)(a.Cin * plane)), 0x00020000);
@@ -145,6 +147,15 @@ void conv_mfma_kernel(ConvArgs a) {
 
   float pre[4][T::NSLOT];
   auto load_tile = [&](int chunk) {
+    if constexpr (QIN) {
+      const unsigned cb = 16u * (unsigned)(chunk * plane);
+#pragma unroll
+      for (int j = 0; j < T::NSLOT; ++j) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[j] + cb, 0, 0));
+        pre[0][j] = v[0], pre[1][j] = v[1], pre[2][j] = v[2], pre[3][j] = v[3];
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const unsigned cb = 4u * (unsigned)((chunk * 4 + c) * plane);
@@ -1175,12 +1186,21 @@ static unsigned conv_blocks(const ConvArgs& a) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   return cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B * cdiv(cdiv(a.Cout, 16), NCT);
 }
-template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR>
+template <int KD, int K, int S, int NCT, int R, int MAP, bool PAIR, bool QIN = false>
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
   using T = ConvTile<KD, K, S, NCT, R, MAP, PAIR>;
   dim3 grid(cdiv(a.Wo, 16) * cdiv(a.Ho, T::TY) * cdiv(a.Do, T::TZ) * a.B, cdiv(cdiv(a.Cout, 16), NCT));
   if (a.band_map) grid.x = 8u * cdiv(a.Wo, 16) * cdiv(cdiv(a.Ho, T::TY), 8) * cdiv(a.Do, T::TZ) * a.B;
-  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<KD, K, S, NCT, R, MAP, PAIR, false, QIN>), grid, dim3(256), 0, st, a);
+}
+
+// the regularisers' stride-2 layer behind a first layer that wrote quad records (conv1: 8 -> 16): the tilings
+// dispatch_conv<3, 3, 2, 4, 2, true> picks for one 16-channel output tile, with 16-byte staging
+static bool dispatch_conv_s2_quad(const ConvArgs& a, hipStream_t st) {
+  if (cdiv(a.Cout, 16) != 1) return false;
+  if (conv_blocks<3, 3, 2, 1, 4, 1, false>(a) >= 512) return launch_conv<3, 3, 2, 1, 4, 1, false, true>(a, st), true;
+  if (conv_blocks<3, 3, 2, 1, 2, 1, false>(a) >= 512) return launch_conv<3, 3, 2, 1, 2, 1, false, true>(a, st), true;
+  return launch_conv<3, 3, 2, 1, 1, 2, false, true>(a, st), true;
 }
 
 constexpr unsigned kEnoughBlocks = 512;  // 2 per CU
@@ -1310,6 +1330,10 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
   a.B = B, a.Cin = Cin, a.D = D, a.H = H, a.W = W, a.Cout = Cout;
   const int p = k / 2, pd = kd / 2;
   a.Do = (D + 2 * pd - kd) / stride + 1, a.Ho = (H + 2 * p - k) / stride + 1, a.Wo = (W + 2 * p - k) / stride + 1;
+  const bool in_quad = (out_channels_last & 16) != 0;      // `in` as quad records (B, Cin/4, D, H, W, 4)
+  out_channels_last &= ~16;
+  BMV_REQUIRE(!in_quad || (kd == 3 && k == 3 && stride == 2 && Cin % 4 == 0 && Cin < 16 && Cout <= 16),
+              "conv: quad-record input is built for the regularisers' stride-2 layer (3x3x3, Cin 4 / 8 / 12, Cout <= 16)");
   BMV_REQUIRE(out_channels_last == 0 || out_channels_last == 1 || out_channels_last == 3, "conv: out layout %d", out_channels_last);
   BMV_REQUIRE(out_channels_last != 3 || ((Cout & 3) == 0 && !skip), "conv: quad-planar output needs Cout %% 4 == 0 and no skip");
   a.slope = act_slope, a.channels_last = out_channels_last, a.out2 = nullptr;
@@ -1323,6 +1347,8 @@ int bmv_conv_fwd(const float* in, const float* wpack, const float* bias, const f
     dispatch_conv<1, 1, 1, 8, 2, false>(a, st);
   else if (kd == 3 && k == 3 && stride == 1)
     dispatch_conv<3, 3, 1, 8, 2, true>(a, st);
+  else if (kd == 3 && k == 3 && stride == 2 && in_quad)
+    dispatch_conv_s2_quad(a, st);
   else if (kd == 3 && k == 3 && stride == 2)
     dispatch_conv<3, 3, 2, 4, 2, true>(a, st);
   else

@@ -81,12 +81,6 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
   const int x0 = tx * 16, y0 = ty * TY, z0 = tz * TZ;
   const int plane = a.D * a.H * a.W;
 
-  // weights of every chunk, once per workgroup
-  {
-    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
-    if (!(kC4Ablate & 8))
-      for (int i = tid; i < nchunk * TAPS * NG * 4; i += NT) wl[i] = src[i];
-  }
   // tile slots of this thread: byte offset inside a channel plane, or out of range (zero padding)
   unsigned goff[NSLOT];
 #pragma unroll
@@ -118,6 +112,13 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
       }
   };
   load_tile(0);
+  // weights of every chunk, once per workgroup -- BEHIND the first tile's loads: one exposed L2 round trip per workgroup
+  // instead of two (the copy waits for its own loads before it can write LDS)
+  {
+    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
+    if (!(kC4Ablate & 8))
+      for (int i = tid; i < nchunk * TAPS * NG * 4; i += NT) wl[i] = src[i];
+  }
 
   // lane -> position of the wave's 16 x 4 patch: the 16-lane groups of ds_read_b128 take 16 consecutive x of one row
   const unsigned lh = (unsigned)lane & 31u, odd = 0xF00F0FF0u;
@@ -205,6 +206,18 @@ __global__ void __launch_bounds__(64 * NW) conv_c4_kernel(C4Args a) {
       rec[0] = f32x4c{v[0], v[1], v[2], v[3]};
       rec[1] = f32x4c{v[4], v[5], v[6], v[7]};
       if (NG > 2) a.out2[(size_t)b * cs + vox] = v[8];
+    } else if (a.mode == 8) {
+      // quad records (B, Cout/4, D, H, W, 4), Cout % 4 == 0: a group's 4 channels of a voxel are one 16-byte store
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        f32x4c v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[z][g][r] + a.bias[4 * g + r];
+          v[r] = fmaxf(t, 0.f) + a.slope * fminf(t, 0.f);
+        }
+        reinterpret_cast<f32x4c*>(a.out)[((size_t)b * NG + g) * cs + vox] = v;
+      }
     } else {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
@@ -254,6 +267,7 @@ struct CT4Args {
   float* out;           // (B, Cout, 2 D, 2 H, 2 W)
   int B, Cin, D, H, W, Cout;
   float slope;
+  int skip_quad;        // (quad-record output only) the skip is quad records too: (B, Cout/4, 2D, 2H, 2W, 4)
 };
 
 // OQ: the output as QUAD RECORDS (B, Cout/4, 2D, 2H, 2W, 4) -- a wave's 4 output channels of a voxel are one 16-byte
@@ -278,10 +292,6 @@ __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
   const int mz = bid % a.D, b = bid / a.D;
   const int x0 = tx * 16, y0 = ty * TY;
   const int plane = a.D * a.H * a.W;
-  {
-    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
-    for (int i = tid; i < nchunk * 27 * NG * 4; i += NT) wl[i] = src[i];
-  }
   unsigned goff[NSLOT];
 #pragma unroll
   for (int j = 0; j < NSLOT; ++j) {
@@ -303,6 +313,10 @@ __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
             float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff[j] + 4u * (unsigned)((chunk * 4 + c) * plane), 0, 0));
   };
   load_tile(0);
+  {   // (the weights behind the first tile's loads, as in conv_c4_kernel)
+    const f32x4c* src = reinterpret_cast<const f32x4c*>(a.wpack);
+    for (int i = tid; i < nchunk * 27 * NG * 4; i += NT) wl[i] = src[i];
+  }
   const unsigned lh = (unsigned)lane & 31u, odd = 0xF00F0FF0u;
   const int rb = (int)((odd >> lh) & 1u);
   const int xi = __popc((rb ? odd : ~odd) & ((1u << lh) - 1u));
@@ -357,9 +371,16 @@ __global__ void __launch_bounds__(64 * NG * NYS) convT_c4_kernel(CT4Args a) {
     for (int qq = 0; qq < 4; ++qq) {
       const size_t sp = (size_t)(2 * mz + (qq >> 1)) * Ho * Wo + (size_t)(2 * my + (qq & 1)) * Wo + 2 * mx;
       float2 sk[4];
+      if (a.skip && a.skip_quad) {
+        const f32x4c* sq = reinterpret_cast<const f32x4c*>(a.skip) + ((size_t)b * NG + g) * cs + sp;
+        const f32x4c s0 = sq[0], s1 = sq[1];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sk[r] = a.skip ? *reinterpret_cast<const float2*>(a.skip + ((size_t)b * a.Cout + 4 * g + r) * cs + sp) : make_float2(0.f, 0.f);
+        for (int r = 0; r < 4; ++r) sk[r] = make_float2(s0[r], s1[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sk[r] = a.skip ? *reinterpret_cast<const float2*>(a.skip + ((size_t)b * a.Cout + 4 * g + r) * cs + sp) : make_float2(0.f, 0.f);
+      }
       f32x4c v0, v1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -431,7 +452,8 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
   BMV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "bmv_conv_c4_fwd: bad shape");
   const bool qin = (mode & 4) != 0;      // input as quad records
   mode &= ~4;
-  BMV_REQUIRE(mode == 0 || (mode == 2 && (Cout == 8 || (Cout == 9 && out2))), "bmv_conv_c4_fwd: mode=%d with Cout=%d", mode, Cout);
+  BMV_REQUIRE(mode == 0 || (mode == 2 && (Cout == 8 || (Cout == 9 && out2))) || (mode == 8 && Cout % 4 == 0),
+              "bmv_conv_c4_fwd: mode=%d with Cout=%d", mode, Cout);
   BMV_REQUIRE(!qin || (Cin % 4 == 0), "bmv_conv_c4_fwd: quad-record input needs Cin %% 4 == 0 (Cin=%d)", Cin);
   if (Cout < 1 || Cout > 12 || (kd != 1 && kd != 3) || (kd == 1 && D != 1) ||
       (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 31) || (size_t)((Cin + 3) / 4) * kd * 9 * ((Cout + 3) / 4) * 64 > 100 * 1024) {
@@ -502,7 +524,9 @@ int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float
     set_error("bmv_conv3d_transpose_c4_fwd: shape not covered (Cout=%d Cin=%d %dx%dx%d)", Cout, Cin, D, H, W);
     return BMV_ERR_UNSUPPORTED;
   }
-  CT4Args a{in, wpack, bias, skip, out, B, Cin, D, H, W, Cout, slope};
+  CT4Args a{in, wpack, bias, skip, out, B, Cin, D, H, W, Cout, slope, (variant & 32) ? 1 : 0};
+  BMV_REQUIRE(!(variant & 32) || (variant & 16), "bmv_conv3d_transpose_c4_fwd: a quad-record skip goes with the quad-record output");
+  variant &= ~32;
   const int ng = (Cout + 3) / 4;
   hipStream_t st = as_stream(stream);
   int rc = BMV_ERR_UNSUPPORTED;

@@ -237,6 +237,7 @@ class _CostReg(nn.Module):
         # for 8 output channels; the 16-row kernels of conv.hip reach 75 % / 56 %): same fp32 FMA chains per output
         self.conv_c4 = convnet.CONV_C4
         self.quad_volume = switches.on("BMV_QUAD_VOLUME")
+        self.quad_s0 = switches.on("BMV_QUAD_S0")
 
     def takes_quad_volume(self):
         """True: hand forward() the cost volume as ops.QuadVolume (the sweep's quad-record output) -- the first layer runs
@@ -282,7 +283,8 @@ class _CostReg(nn.Module):
         if split:
             s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
         elif self.conv_c4:
-            s0 = convnet.conv_c4_fwd(x, *P["conv0_c4"], 8, relu=True)
+            # (quad records out as well: the stride-2 layer and conv11's skip add stage them with 16-byte loads)
+            s0 = convnet.conv_c4_fwd(x, *P["conv0_c4"], 8, relu=True, quad_out=self.quad_volume and self.quad_s0)
         else:
             s0 = convnet.conv_fwd(x, *P["conv0"], 8, 3, 3, relu=True)
         s1 = convnet.conv_fwd(convnet.conv_fwd(s0, *P["conv1"], 16, 3, 3, 2, relu=True), *P["conv2"], 16, 3, 3, relu=True)

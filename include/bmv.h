@@ -462,6 +462,8 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
  * InPlaceABN's leaky ReLU of the MVSNeRF stacks, mvsnerf/network.py:699-779).
  * out = act(conv(in) + bias) + skip, planar (B,Cout,Do,Ho,Wo)
  * or channel-last (B,Do,Ho,Wo,Cout) (the sweep's feature layout); skip (nullable) has out's layout.
+ * out_channels_last | 16 (round 5; 3x3x3 stride 2, Cin in {4, 8, 12}, Cout <= 16: the regularisers' conv1): `in` is quad
+ * records (B, Cin/4, D, H, W, 4) as bmv_conv_c4_fwd's mode 8 writes them.
  * wpack: bmv_conv_wpack_floats() floats laid out [ceil(Cout/16)][ceil(Cin/4)][tap][4][16], zero padded:
  *   wpack[t][c][tap][k][o] = weight[16 t + o][4 c + k][tap]  (tap = (kz*k + ky)*k + kx).
  * Row pairing (bmv_conv_pairs_rows() == 1: Cout <= 8, 3x3 / 3x3x3, stride 1): the 16 rows are the 8 output
@@ -516,7 +518,9 @@ int bmv_conv_heads_fwd(const float* in, const float* wpack, const float* bias, f
  * (the caller packs them in the record's [even | odd] order), out2 (B,D,H,W) = channel 8 (Cout = 9: the depth logits).
  * mode | 4 (round 5): `in` is QUAD RECORDS (B, Cin/4, D, H, W, 4), Cin % 4 == 0 -- what bmv_sweep_variance_quad_fwd
  * writes with flags bit 24: the regulariser's first layer stages its tile with one 16-byte load per position and chunk
- * (kd = 3, Cout <= 8, variant 0).  variant: 0 = default tiling, 1.. = tuning. */
+ * (kd = 3, variant 0).  mode 8 (| 4): out as quad records (B, Cout/4, D, H, W, 4), Cout % 4 == 0 -- for consumers that
+ * stage 16-byte records (bmv_conv_fwd's out_channels_last | 16, bmv_conv3d_transpose_c4_fwd's variant | 32).
+ * variant: 0 = default tiling, 1.. = tuning. */
 int bmv_conv_c4_wpack_floats(int Cout, int Cin, int kd);
 int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, float* out, float* out2, int B, int Cin, int D,
                     int H, int W, int Cout, int kd, float slope, int mode, int variant, bmv_stream_t stream);
@@ -525,7 +529,7 @@ int bmv_conv_c4_fwd(const float* in, const float* wpack, const float* bias, floa
  * (B,Cout,2D,2H,2W) = act(convT(in) + bias) + skip (skip nullable, layout of out), Cout <= 8.  wpack as above (kd = 3)
  * with the taps of the transposed weight (Cin,Cout,3,3,3): [cin chunk][tap][cout group][cout][cin].
  * variant | 16 (round 5): `out` is written as QUAD RECORDS (B, Cout/4, 2D, 2H, 2W, 4) (Cout = 8; `skip` stays planar) for
- * bmv_conv_c4_fwd's input mode 4. */
+ * bmv_conv_c4_fwd's input mode 4; variant | 32 (with | 16): `skip` is quad records too. */
 int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float* bias, const float* skip, float* out, int B, int Cin,
                      int D, int H, int W, int Cout, float slope, int variant, bmv_stream_t stream);
 

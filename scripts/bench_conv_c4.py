@@ -55,6 +55,12 @@ def main():
                 line += f"  c4 v{v} {t4:6.1f} us ({flops / t4 / 1e6:5.1f})"
             except RuntimeError as e:
                 line += f"  c4 v{v} n/a"
+        if nd == 3 and Cin % 4 == 0:      # the input as quad records (what the sweep / conv11 hand over in the frame)
+            from boostmvsnerfs_amd import ops
+            D_, H_, W_ = sp
+            qv = ops.QuadVolume(x.view(B, Cin // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
+            t4 = timed(lambda: convnet.conv_c4_fwd(qv, wp4, bp4, Cout, relu=True))
+            line += f"  c4 v0, quad-record input {t4:6.1f} us ({flops / t4 / 1e6:5.1f})"
         print(line, flush=True)
 
 

@@ -474,6 +474,9 @@ def test_conv_c4(nd, B, Cin, Cout, sp):
         if Cout in (8, 9):
             (r0, l0), (r1, l1) = convnet.conv_c4_fwd(qv, wp, bp, Cout, records=True), convnet.conv_c4_fwd(x, wp, bp, Cout, records=True)
             assert torch.equal(r0.t, r1.t) and (l0 is None or torch.equal(l0, l1))
+        if Cout % 4 == 0:     # ... and the result as quad records (for the stride-2 layer and conv11's skip add)
+            qo = convnet.conv_c4_fwd(qv, wp, bp, Cout, relu=True, quad_out=True)
+            assert isinstance(qo, ops.QuadVolume) and torch.equal(qo.to_planar(), convnet.conv_c4_fwd(x, wp, bp, Cout, relu=True))
     if nd == 3 and Cout in (8, 9):
         rec, logit = convnet.conv_c4_fwd(x, wp, bp, Cout, records=True)
         _close(rec.t.permute(0, 4, 1, 2, 3), want[:, :8], tol=2e-5)          # (channels in the order they were packed)
@@ -506,3 +509,23 @@ def test_convT_c4(Cin, Cout, D, H, W):
             qv = convnet.convT_c4_fwd(x, wp, bp, Cout, skip=sk, relu=True, quad_out=True)
             assert isinstance(qv, ops.QuadVolume)
             assert torch.equal(qv.to_planar(), convnet.convT_c4_fwd(x, wp, bp, Cout, skip=sk, relu=True))
+        skq = ops.QuadVolume(skip.view(1, 2, 4, *skip.shape[2:]).permute(0, 1, 3, 4, 5, 2).contiguous())
+        assert torch.equal(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skq, relu=True, quad_out=True).to_planar(),
+                           convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skip, relu=True))
+        _close(convnet.convT_c4_fwd(x, wp, bp, Cout, skip=skq), want + skip, tol=2e-5)       # (planar out: the skip is converted)
+
+
+@pytest.mark.parametrize("Cin,Cout,D,H,W", [(8, 16, 8, 64, 80), (8, 16, 8, 256, 320), (8, 16, 64, 64, 80), (4, 16, 5, 9, 19), (12, 9, 3, 17, 33)])
+def test_stride2_layer_stages_quad_records(Cin, Cout, D, H, W):
+    """The regularisers' stride-2 layer (conv1: 3x3x3, 8 -> 16) behind a first layer that wrote quad records
+    (bmv_conv_fwd, out_channels_last | 16): bit-identical to the planar input, every tiling the dispatch picks."""
+    from boostmvsnerfs_amd import convnet, ops
+    g = torch.Generator().manual_seed(Cin + Cout + D)
+    x = torch.randn(1, Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    wp, bp = convnet.pack_conv(w, b, 2)
+    qv = ops.QuadVolume(x.view(1, Cin // 4, 4, D, H, W).permute(0, 1, 3, 4, 5, 2).contiguous())
+    want = convnet.conv_fwd(x, wp, bp, Cout, 3, 3, 2, relu=True)
+    _close(want, F.relu(F.conv3d(x, w, b, 2, 1)), tol=2e-5)
+    assert torch.equal(convnet.conv_fwd(qv, wp, bp, Cout, 3, 3, 2, relu=True), want)
