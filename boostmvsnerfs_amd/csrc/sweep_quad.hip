@@ -117,7 +117,10 @@ struct QuadArgs {
 // PU: plane-uniform hypotheses (one depth per plane).  OQ: the variance leaves as QUAD RECORDS (B, C/4, D, h, w, 4) -- one
 // 16-byte store per voxel and channel quad instead of four dword stores into four channel planes -- the layout the
 // regulariser's first layer (csrc/conv_c4.hip, input mode 4) stages with one 16-byte load per position.
-template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false>
+// NPG > 1 (tuning variants 17-19; VERDICT r4's "persistent tile column"): the workgroup walks NPG consecutive plane groups of
+// its tile -- what does not depend on the plane group (tile / lane coordinates, the views' projection rows, buffer
+// resources) is set up once -- at the price of NPG times fewer workgroups.  Measured: profiles/r5/sweep_quad_plane_walk.txt.
+template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false, int NPG = 1>
 __global__ void __launch_bounds__(TXW* TYH* DP) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 sweep_quad_kernel(const QuadArgs a) {
   constexpr int NT = TXW * TYH * DP, NW = NT / 64;
@@ -131,7 +134,7 @@ sweep_quad_kernel(const QuadArgs a) {
   // whose L2 holds that band's source rows
   const int b = blockIdx.z;
   const int band = blockIdx.x & 7;
-  const int pgrp = (int)(blockIdx.x >> 3) / a.qsplit, qpart = (int)(blockIdx.x >> 3) - pgrp * a.qsplit;
+  const int pgrp_w = (int)(blockIdx.x >> 3) / a.qsplit, qpart = (int)(blockIdx.x >> 3) - pgrp_w * a.qsplit;
   const int j = a.tiles_x_magic ? (int)__umulhi((unsigned)blockIdx.y, (unsigned)a.tiles_x_magic) : (int)blockIdx.y;
   const int tx = blockIdx.y - j * a.tiles_x;
   const int ty = band * a.tyb + j;
@@ -154,10 +157,14 @@ sweep_quad_kernel(const QuadArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lx = tid % TXW, ly = (tid / TXW) % TYH, ld = __builtin_amdgcn_readfirstlane(tid / (TXW * TYH));
   const int x = tx * TXW + lx, y = ty * TYH + ly;
-  const int d0 = (pgrp * DP + ld) * PG;           // this lane's first plane
   const bool inb_xy = (x < w) & (y < h);
   const int xc = min(x, w - 1), yc = min(y, h - 1);
   const float fx = (float)xc, fy = (float)yc;
+#pragma unroll 1
+  for (int gi = 0; gi < NPG; ++gi) {
+  const int pgrp = pgrp_w * NPG + gi;
+  if (NPG > 1 && pgrp >= a.pgroups) break;
+  const int d0 = (pgrp * DP + ld) * PG;           // this lane's first plane
 
   // ---- 1. hypotheses of this lane's PG planes; corner lanes (lane < 8 S: corner (lane & 7) of the tile box in
   // (x, y, 1/depth), view lane >> 3) fetch their projection rows under the latency of that load
@@ -506,6 +513,8 @@ sweep_quad_kernel(const QuadArgs a) {
     run_quads(std::true_type{});
   else
     run_quads(std::false_type{});
+  if (NPG > 1) barrier_lds();   // every wave is done with this group's windows before the next group plans its own
+  }
 }
 
 // (n, C, H, W) -> (n, H, W, C), C % 4 == 0: one thread per pixel, C coalesced plane reads, then C contiguous floats out
@@ -545,6 +554,7 @@ namespace {
 struct QuVariant {
   int txw, tyh, dp, pg, wpe, cap;   // tile, planes across waves x per lane, waves per SIMD budgeted, records per view window
   int qsplit = 1;                   // workgroups sharing the channel quads of a tile (more, shorter workgroups)
+  int npg = 1;                      // plane groups a workgroup walks (fewer, longer workgroups)
 };
 // tuning table (algo 500 + i); cap = LDS records (16 bytes) per view ON AVERAGE, multiples of 64: the S windows share cap x S
 const QuVariant kQu[] = {
@@ -565,6 +575,10 @@ const QuVariant kQu[] = {
     {16, 4, 4, 2, 5, 640, 2}, // 14: level 0, 16 x 4 tiles, the 8 quads over two workgroups: 1280 = one round
     {32, 2, 4, 2, 5, 640, 2}, // 15
     {32, 8, 1, 2, 5, 640, 2}, // 16: level 1 with the quads split (2560 workgroups)
+    {32, 2, 4, 2, 5, 640, 1, 2}, // 17: variant 12 walking 2 plane groups per workgroup (level 0: 384 workgroups)
+    {32, 2, 4, 2, 5, 640, 1, 8}, // 18: ... all 8 (the persistent tile column: 96 workgroups)
+    {32, 8, 1, 2, 5, 640, 1, 2}, // 19: variant 0 walking 2 plane groups (level 1: 640 workgroups)
+    {32, 8, 1, 2, 5, 640, 1, 4}, // 20: ... all 4 (320 workgroups)
 };
 constexpr int kNumQu = sizeof(kQu) / sizeof(kQu[0]);
 
@@ -594,9 +608,9 @@ void fill_geom(QuadGeom& g, const QuVariant& v, int S, int Hs, int Ws, int D, in
     g.dv_ps = h * w, g.dv_rs = w, g.dv_cs = 1, g.dv_bs = (long long)D * h * w;
 }
 
-template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false>
+template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false, int NPG = 1>
 int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
-  auto kern = sweep_quad_kernel<TXW, TYH, DP, PG, S, WPE, PU, OQ>;
+  auto kern = sweep_quad_kernel<TXW, TYH, DP, PG, S, WPE, PU, OQ, NPG>;
   const size_t lds = (size_t)a.budget * 1024;
   static size_t allowed = 0;
   if (lds > allowed) {
@@ -607,7 +621,7 @@ int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
     }
     allowed = lds;
   }
-  dim3 grid(8u * (unsigned)(a.pgroups * a.qsplit), (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
+  dim3 grid(8u * (unsigned)(((a.pgroups + NPG - 1) / NPG) * a.qsplit), (unsigned)(a.tiles_x * a.tyb), B), block(TXW * TYH * DP);
   const LaunchEvents ev = take_launch_events();
   if (ev.start)   // bench.py's roofline bracket: events bound to this dispatch (bmv_bind_next_launch)
     hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev.start, ev.stop, 0, a);
@@ -687,6 +701,18 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   if (8 * a.pgroups * a.qsplit >= 65536) return BMV_ERR_UNSUPPORTED;
   const bool pu = dv_plane_uniform != 0;
   int rc = BMV_ERR_UNSUPPORTED;
+  if (v.npg > 1) {           // plane-walking tuning variants (S = 3, planar output)
+    if (S == 3 && !(flags & (1 << 24))) {
+      const hipStream_t st = as_stream(stream);
+      if (v.txw == 32 && v.tyh == 2 && v.npg == 2) rc = pu ? qu_launch_one<32, 2, 4, 2, 3, 5, true, false, 2>(a, B, st) : qu_launch_one<32, 2, 4, 2, 3, 5, false, false, 2>(a, B, st);
+      if (v.txw == 32 && v.tyh == 2 && v.npg == 8) rc = pu ? qu_launch_one<32, 2, 4, 2, 3, 5, true, false, 8>(a, B, st) : qu_launch_one<32, 2, 4, 2, 3, 5, false, false, 8>(a, B, st);
+      if (v.txw == 32 && v.tyh == 8 && v.npg == 2) rc = pu ? qu_launch_one<32, 8, 1, 2, 3, 5, true, false, 2>(a, B, st) : qu_launch_one<32, 8, 1, 2, 3, 5, false, false, 2>(a, B, st);
+      if (v.txw == 32 && v.tyh == 8 && v.npg == 4) rc = pu ? qu_launch_one<32, 8, 1, 2, 3, 5, true, false, 4>(a, B, st) : qu_launch_one<32, 8, 1, 2, 3, 5, false, false, 4>(a, B, st);
+    }
+    if (rc == BMV_ERR_UNSUPPORTED) set_error("bmv_sweep_variance_quad_fwd: variant %d (plane walk) is built for 3 views, planar output", variant);
+    if (rc != BMV_OK) return rc;
+    BMV_LAUNCH_END("bmv_sweep_variance_quad_fwd");
+  }
   if (flags & (1 << 24)) {   // variance as quad records
     if (v.txw == 32 && v.tyh == 8 && v.dp == 1 && v.pg == 2 && v.wpe == 5) rc = qu_launch_s_oq<32, 8, 1, 2, 5>(a, B, S, pu, as_stream(stream));
     if (v.txw == 32 && v.tyh == 2 && v.dp == 4 && v.pg == 2 && v.wpe == 5) rc = qu_launch_s_oq<32, 2, 4, 2, 5>(a, B, S, pu, as_stream(stream));

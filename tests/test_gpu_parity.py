@@ -364,7 +364,7 @@ def test_sweep_kernels_agree_at_scale(ops, level):
     # quad-planar kernel with LDS budgets below the union windows: 1 KB = no view fits (every view gathered from global
     # memory), 6 / 12 KB = some views staged, the rest gathered, in one workgroup
     q = _quad(ops, fd)
-    for variant in (0, 12, 3, 14):
+    for variant in (0, 12, 3, 14, 17, 18, 19, 20):     # (17-20: a workgroup walks 2 / all plane groups of its tile)
         for budget in (1, 6, 12):
             got = ops.sweep_variance_quad(q, Pd, dvd, variant=variant, flags=budget << 16)
             assert_close(got, want, name=f"level {level} quad variant {variant} budget {budget} KB")
