@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r["Kernel_Name"]
     if "sweep" not in k: continue
-    key = (k[:60], r.get("Grid_Size"), r.get("VGPR_Count"), r.get("LDS_Block_Size"))
+    key = (k[:90], r.get("Grid_Size"), r.get("VGPR_Count"), r.get("LDS_Block_Size"))
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, cs in sorted(agg.items()):
     print(key)

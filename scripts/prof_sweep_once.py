@@ -4,7 +4,8 @@ hypotheses captured from one forward of the workload), for rocprofv3 --pmc / --k
 
     python scripts/prof_sweep_once.py [algos, default "0,4"] [reps, default 3] [HxW, default 512x640]
 
-algo 0 = the shipped kernels (quad-planar source maps, level defaults), 4 = the windowed channel-last kernel,
+algo 0 = the shipped kernels (quad-planar source maps, level defaults, quad-record output), 1 = the same with the planar
+output, 4 = the windowed channel-last kernel,
 500 + i / 600 + i = tuning variants of the quad kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,7 +38,9 @@ for feats, proj, dv in calls:
     pu = bool((dv[:, :, :1, :1] == dv).all())
     for algo in algos:
         for _ in range(reps):
-            if algo == 0:
+            if algo == 0:      # the frame's form: the variance leaves as quad records (round 5)
+                ops._sweep_variance_quad(quad, proj, dv, plane_uniform=pu, variant=-1, quad_out=True)
+            elif algo == 1:    # ... and with the planar output
                 ops._sweep_variance_quad(quad, proj, dv, plane_uniform=pu, variant=-1)
             elif algo >= 500:
                 ops._sweep_variance_quad(quad, proj, dv, plane_uniform=algo >= 600 and pu, variant=algo % 100)
