@@ -425,6 +425,9 @@ def test_sweep_quad_channel_counts(ops, C, S):
     for variant in (-1, 0, 1, 3, 12, 14):
         got = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=variant)
         assert_close(got, want, name=f"C {C} S {S} variant {variant}")
+        if variant in (-1, 0, 12):     # ... and as quad records (ragged tiles, every view count): the same bits
+            qv = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=variant, quad_out=True)
+            assert isinstance(qv, ops.QuadVolume) and torch.equal(qv.to_planar(), got)
     with pytest.raises(RuntimeError, match="not covered"):
         ops.sweep_variance_quad(torch.zeros(1, 5, 1, 8, 8, 4, device=DEV), torch.zeros(1, 5, 3, 4, device=DEV), dv.to(DEV))
 

@@ -33,3 +33,16 @@ def test_no_other_module_reads_the_environment_for_behaviour():
     offenders = [str(p.relative_to(root)) for p in root.rglob("*.py")
                  if p.name not in allowed and re.search(r"os\.environ|os\.getenv", p.read_text())]
     assert not offenders, offenders
+
+
+def test_quad_volume_is_a_view_of_the_reference_layout():
+    """ops.QuadVolume (B, C/4, D, h, w, 4): the layout the inference kernels hand cost volumes on in; to_planar() is the
+    reference tensor, the wrapper answers the shape / dtype / device questions the modules ask of a tensor."""
+    import torch
+    from boostmvsnerfs_amd import ops
+    x = torch.arange(2 * 8 * 3 * 4 * 5, dtype=torch.float32).view(2, 8, 3, 4, 5)
+    q = ops.QuadVolume(x.view(2, 2, 4, 3, 4, 5).permute(0, 1, 3, 4, 5, 2).contiguous())
+    assert q.shape == x.shape and q.dtype == x.dtype and q.device == x.device and not q.is_cuda
+    assert torch.equal(q.to_planar(), x)
+    with pytest.raises(ValueError):
+        ops.QuadVolume(x)
