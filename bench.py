@@ -561,6 +561,7 @@ def main():
     # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
     split_frame = None
+    render_split_frame = {}
     if not wl.get("train"):
         graphed_train = None
     eager_step = step
@@ -716,6 +717,34 @@ def main():
             finally:
                 for i in range(cc.num):
                     getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
+        if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
+                and cc.num_samples[-1] == 2 and batch["src_inps"].shape[1] == 3):
+            # EXPERIMENT, not the metric: the fused renderer's largest matrix chain (color.0's shared part, 88 of the MLP's
+            # 206 fp32 MFMAs per tile) on the bf16 matrix pipe with BOTH operands split into three bf16 pieces -- the fp32
+            # values exactly, products below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT)
+            from boostmvsnerfs_amd import _lib as _bl
+            _bl.set_tuning("BMV_RENDER_SPLIT", 1)
+            net._autograph.invalidate()                  # (the captured frame has the fp32 renderer baked in)
+            try:
+                for _ in range(4):                      # eager, capture, first replays of the new configuration
+                    step_plain()
+                torch.cuda.synchronize()
+                t_r = bracketed(step_plain, max(n_x, 50))
+                with torch.no_grad():
+                    rs_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
+                render_split_frame.update(rs_frame)
+                extra["render_split_bf16x3"] = {
+                    "value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
+                    "parity_max_rel": None,        # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
+                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=1: the renderer's color.0 shared part as six bf16 "
+                            "MFMAs per product group on three-piece operands (fp32-equivalent; NOT the default, NOT `value`); "
+                            "parity_max_rel = its frame against the oracle's"}
+            finally:
+                _bl.set_tuning("BMV_RENDER_SPLIT", None)
+                net._autograph.invalidate()
+                for _ in range(3):
+                    step_plain()
+                torch.cuda.synchronize()
         if args.graph and hasattr(net, "_autograph") and not args.all_kernel_events:
             # the opt-in a serving loop with a resident batch can make (autograph.py): captured on the caller's own
             # tensors, no input copies, the graph's static outputs handed out.  NOT `value`: run.py hands over other
@@ -933,6 +962,11 @@ def main():
             if cb is not None:
                 line["cpu_baseline"] = cb
             line.update(parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev))
+            ref_frame = getattr(cpu_baseline, "last_frame", None)
+            if render_split_frame and ref_frame and "render_split_bf16x3" in extra:
+                rs_par = {k: _rel_err(render_split_frame[k], want)[0] for k, want in ref_frame.items()
+                          if k in render_split_frame and torch.is_tensor(want)}
+                extra["render_split_bf16x3"]["parity_max_rel"] = max(rs_par.values()) if rs_par else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -56,6 +56,13 @@ struct MlpLayout {
   static constexpr int V_WC2 = V_BC + 64;                  // color.2 weight [2*16]
   static constexpr int V_SC = V_WC2 + 64;                  // scalars: agg_w bias, sigma bias, color.2 bias
   static constexpr int TOTAL = (V_SC + 4 + 3) / 4 * 4;
+  // Experiment (round 5, bmv_tuning BMV_RENDER_SPLIT): color.0's shared part on the bf16 matrix pipe with both operands
+  // split into THREE bf16 pieces (8 + 8 + 8 mantissa bits: the fp32 value exactly) -- the A tables of that chain a
+  // second time, behind the fp32 blob: [piece 3][k-step 6 (of 16)][tile 2][lane 64] x 8 bf16 (16 bytes)
+  static constexpr int SK = 6;                             // 44 fp32 k-steps of 2 = 88 inputs, padded to 96 = 6 x 16
+  static constexpr int S_CSH = TOTAL;
+  static constexpr int S_WORDS = 3 * SK * 2 * 64 * 4;
+  static constexpr int TOTAL_S = TOTAL + S_WORDS;
 };
 
 // --------------------------------------------------------------------------
@@ -68,7 +75,37 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
   constexpr int FC = L::FC, KFC = L::KFC;
   constexpr int CW = 88 + FC + 4;  // color.0 input width
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= L::TOTAL) return;
+  if (idx >= L::TOTAL_S) return;
+  if (idx >= L::TOTAL) {
+    // split tables of color.0's shared part: dword q of (piece, k-step T, tile, lane (i, h)) = pieces of the fp32 table's
+    // entries of fp32 k-steps t = 8 T + 2 q, 8 T + 2 q + 1 for this tile and lane (low | high half)
+    int e = idx - L::TOTAL;
+    const int q = e & 3;
+    e >>= 2;
+    const int lane = e & 63;
+    e >>= 6;
+    const int tl = e & 1;
+    e >>= 1;
+    const int T = e % L::SK, pc = e / L::SK;
+    const int i = lane & 31, h = lane >> 5, n = 32 * tl + i;
+    unsigned packed = 0;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = 8 * T + 2 * q + jj;
+      float w = 0.f;
+      if (t < 44) {
+        const int k = t < 32 ? 32 * (t >> 4) + n16(t & 15, h) : t < 36 ? 64 + 2 * (t - 32) + h : 72 + n16(t - 36, h);
+        w = p.color0_w[n * CW + k];
+      }
+      const float hi = __uint_as_float(__float_as_uint(w) & 0xffff0000u);
+      const float r1 = w - hi;
+      const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      const float r2 = r1 - mid;
+      const float piece = pc == 0 ? hi : pc == 1 ? mid : r2;        // (the last piece: truncated below)
+      packed |= (__float_as_uint(piece) >> 16) << (16 * jj);
+    }
+    blob[idx] = __uint_as_float(packed);
+    return;
+  }
   float v = 0.f;
   if (idx < L::V_VF) {
     int lane = idx & 63, e = idx >> 6;  // all A tables are 64-aligned
@@ -269,7 +306,7 @@ __device__ __forceinline__ float weighted_views(const float (&w)[NV], const f32x
 //   vox[j]     feature-volume channel 2j+h
 // W: the packed blob in LDS.  out = [r, g, b, sigma], identical in both halves.
 // --------------------------------------------------------------------------
-template <int FEAT_CH, int NV = 3>
+template <int FEAT_CH, int NV = 3, bool CSPLIT = false>
 __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lane,
                                             const float (&fin)[NV][MlpLayout<FEAT_CH>::KF], const float (&dir)[NV][4],
                                             const float (&vox)[4], float (&out)[4]) {
@@ -373,9 +410,55 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) csh[tl][r] = Wv[L::V_BC + (tl * 16 + r) * 2];
+  if constexpr (CSPLIT) {
+    // the same sum on v_mfma_f32_32x32x16_bf16: 8 fp32 k-steps = one bf16 k-step (a lane's 8 B values are its own
+    // registers of those steps, as the fp32 chain takes them one by one); operands = hi + mid + lo bf16 pieces, products
+    // hi hi + hi mid + mid hi + hi lo + lo hi + mid mid (what is dropped is below 2^-24 of the product), small terms first
+    using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4* Ws = reinterpret_cast<const u32x4*>(W + L::S_CSH) + lane;
+#pragma unroll
+    for (int T = 0; T < L::SK; ++T) {
+      u32x4 bh, bm, bl;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        unsigned ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int t = 8 * T + 2 * q4 + jj;
+          const float bv = t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : t < 44 ? im16[t >= 36 && t < 44 ? t - 36 : 0] : 0.f;
+          const unsigned uh = __float_as_uint(bv) & 0xffff0000u;
+          const float r1 = bv - __uint_as_float(uh);
+          const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(um);
+          ph[jj] = uh, pm[jj] = um, pl[jj] = __float_as_uint(r2);
+        }
+        bh[q4] = (ph[0] >> 16) | ph[1];
+        bm[q4] = (pm[0] >> 16) | pm[1];
+        bl[q4] = (pl[0] >> 16) | (pl[1] & 0xffff0000u);
+      }
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, Ws[((0 * L::SK + T) * 2 + tl) * 64]);
+        const bf16x8 Am = __builtin_bit_cast(bf16x8, Ws[((1 * L::SK + T) * 2 + tl) * 64]);
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, Ws[((2 * L::SK + T) * 2 + tl) * 64]);
+        f32x16 c = csh[tl];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, c, 0, 0, 0);
+        csh[tl] = c;
+      }
+      BMV_FENCE();
+    }
+  } else {
   BMV_CHAIN2(L::A_CSH, 44, BMV_MLP_G2,
              (t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : im16[t >= 36 ? t - 36 : 0]),
              csh[0], csh[1])
+  }
   // per-view part + color.2 + softmax over views (nerf.py:39-42)
   float cl[NV];
 #pragma unroll

@@ -22,14 +22,14 @@ struct RenderCams {
   float tar_c[4];
 };
 
-template <int FEAT_CH, int NV>
-__global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
+template <int FEAT_CH, int NV, bool CS = false>
+__global__ void __launch_bounds__(256, CS ? 1 : 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
                                                            const float* __restrict__ img,
                                                            const float* __restrict__ blob, long npts,
                                                            float* __restrict__ out) {
   using L = MlpLayout<FEAT_CH>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+  for (int i = threadIdx.x; i < (CS ? L::TOTAL_S : L::TOTAL) / 4; i += blockDim.x)
     reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(blob)[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) dir[i][k] = q[L::FC + k];
     }
-    mlp_forward<FEAT_CH, NV>(lds, lane, fin, dir, vox, res);
+    mlp_forward<FEAT_CH, NV, CS>(lds, lane, fin, dir, vox, res);
     if (valid && h == 0) {
       float4 o = {res[0], res[1], res[2], res[3]};
       reinterpret_cast<float4*>(out)[pt] = o;
@@ -365,7 +365,8 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
   return false;
 }
 
-template <int NS, bool INV, int NV>
+// CS: color.0's shared part on the bf16 matrix pipe with three-piece operands (mlp.hpp, CSPLIT; experiment, BMV_RENDER_SPLIT)
+template <int NS, bool INV, int NV, bool CS = false>
 __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(RenderArgsDev a) {
   resolve_deferred(a);
   constexpr int FEAT_CH = 8;
@@ -376,14 +377,15 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
   // mailbox rows: [0, 6 NV) fin, [6 NV, 10 NV) dir, then vox[4], z, visibility
   constexpr int kPcBox = pc_box(NV), B_DIR = 6 * NV, B_VOX = 10 * NV, B_Z = 10 * NV + 4, B_VIS = 10 * NV + 5;
   constexpr int RAYS_PER_TILE = 32 / NS;
+  constexpr int BLOB = CS ? L::TOTAL_S : L::TOTAL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  RenderCams* rc = reinterpret_cast<RenderCams*>(lds + L::TOTAL);
+  RenderCams* rc = reinterpret_cast<RenderCams*>(lds + BLOB);
   // [kPcMlp] sequence words: 2 n = empty, waiting for this MLP wave's n-th job; 2 n + 1 = holds it (with more gather
   // waves than pairs of MLP waves a mailbox has two producers taking turns: the count keeps them in order)
   int* flags = reinterpret_cast<int*>(rc + 1);
   float* boxes = reinterpret_cast<float*>(flags + 16);              // [kPcMlp][kPcBox][64 MLP lanes]
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+  for (int i = threadIdx.x; i < BLOB / 4; i += blockDim.x)
     reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
   if (threadIdx.x < NV)
     load_cam(a.src_exts + ((size_t)b * NV + threadIdx.x) * 16, a.src_ixts + ((size_t)b * NV + threadIdx.x) * 9,
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
     const float vis = box[B_VIS * 64];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *flag = seq + 2;     // the next producer may refill while this tile runs through the MLP
-    mlp_forward<FEAT_CH, NV>(lds, lane, fin, dir, vox, res);
+    mlp_forward<FEAT_CH, NV, CS>(lds, lane, fin, dir, vox, res);
     if (!ok) res[0] = res[1] = res[2] = res[3] = __builtin_nanf("");   // protocol error: loud, not silent
 
     if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
@@ -655,8 +657,8 @@ int bmv_debug_fetch_stamps(float* dst) {
 #endif
 
 int bmv_nerf_blob_size(int feat_ch) {
-  if (feat_ch == 8) return MlpLayout<8>::TOTAL;
-  if (feat_ch == 32) return MlpLayout<32>::TOTAL;
+  if (feat_ch == 8) return MlpLayout<8>::TOTAL_S;       // (the fp32 tables + the split tables of the BMV_RENDER_SPLIT experiment)
+  if (feat_ch == 32) return MlpLayout<32>::TOTAL_S;
   set_error("bmv_nerf_blob_size: feat_ch=%d unsupported (8 or 32)", feat_ch);
   return BMV_ERR_UNSUPPORTED;
 }
@@ -666,10 +668,10 @@ int bmv_nerf_pack_weights(const bmv_nerf_params* p, int feat_ch, float* blob, bm
   const float* const* pp = reinterpret_cast<const float* const*>(p);
   for (int i = 0; i < 16; ++i) BMV_REQUIRE(pp[i], "bmv_nerf_pack_weights: parameter %d is null", i);
   if (feat_ch == 8)
-    hipLaunchKernelGGL(nerf_pack_kernel<8>, dim3(cdiv(MlpLayout<8>::TOTAL, 256)), dim3(256), 0, as_stream(stream), *p,
+    hipLaunchKernelGGL(nerf_pack_kernel<8>, dim3(cdiv(MlpLayout<8>::TOTAL_S, 256)), dim3(256), 0, as_stream(stream), *p,
                        blob);
   else if (feat_ch == 32)
-    hipLaunchKernelGGL(nerf_pack_kernel<32>, dim3(cdiv(MlpLayout<32>::TOTAL, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(nerf_pack_kernel<32>, dim3(cdiv(MlpLayout<32>::TOTAL_S, 256)), dim3(256), 0, as_stream(stream),
                        *p, blob);
   else {
     set_error("bmv_nerf_pack_weights: feat_ch=%d unsupported (8 or 32)", feat_ch);
@@ -692,6 +694,12 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
     hipLaunchKernelGGL((nerf_mlp_kernel<FC, NVV>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, \
                        npts, out);                                                                                   \
     BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
+  }
+  if (feat_ch == 8 && S == 3 && bmv::tuning("BMV_RENDER_SPLIT", 0)) {   // the experiment's MLP by itself (accuracy probes)
+    size_t lds = MlpLayout<8>::TOTAL_S * 4;
+    BMV_REQUIRE(set_lds(nerf_mlp_kernel<8, 3, true>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((nerf_mlp_kernel<8, 3, true>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts, out);
+    BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
   }
   MLP_CASE(8, 3)
   MLP_CASE(32, 3)
@@ -750,6 +758,18 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
     hipLaunchKernelGGL((render_pc_kernel<NSV, false, NVV>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds, \
                        as_stream(stream), dev);                                                                      \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
+  }
+  if (use_pc && bmv::tuning("BMV_RENDER_SPLIT", 0) && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == 2 &&
+      a->depth_inv == 0 && a->S == 3) {
+    // experiment: color.0's shared part on the bf16 pipe with three-piece operands (the headline shape only)
+    size_t lds = MlpLayout<8>::TOTAL_S * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(3) * 64 * 4;
+    BMV_REQUIRE(set_lds(render_pc_kernel<2, false, 3, true>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");
+    int ntiles = (nrays + 15) / 16;
+    const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u));
+    unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;
+    hipLaunchKernelGGL((render_pc_kernel<2, false, 3, true>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,
+                       as_stream(stream), dev);
+    BMV_LAUNCH_END("bmv_render_rays_fwd");
   }
   RENDER_CASE_PC(2, 3)
   RENDER_CASE_PC(1, 3)

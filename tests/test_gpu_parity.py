@@ -618,3 +618,32 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
     assert any("render" in k for k in kernels) and any("nerf_mlp_bwd" in k for k in kernels), sorted(kernels)[:40]
     gemms = [k for k in kernels if any(t in k.lower() for t in ("gemm", "cijk", "rocblas", "hipblas"))]
     assert not gemms, f"S={S}: GEMM launches on the path: {gemms}"
+
+
+def test_renderer_split_bf16_experiment_is_fp32_equivalent():
+    """bmv_tuning BMV_RENDER_SPLIT (experiment, off by default): color.0's shared part -- 43 % of the MLP's matrix
+    instructions -- on the bf16 matrix pipe with BOTH operands split into three bf16 pieces (the fp32 values exactly; the
+    product terms dropped are below 2^-24 of a product).  The frame it renders must agree with the fp32-MFMA frame to fp32
+    rounding (not bit for bit: the summation order differs), far inside the 1e-3 bar of the parity tests."""
+    from boostmvsnerfs_amd import _lib
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    cfg = make_cfg("enerf_eval")
+    cfg.enerf.cas_config.volume_planes = [32, 8]
+    set_cfg(cfg)
+    torch.manual_seed(3)
+    net = Network().eval().to(DEV)
+    batch = clone_batch(make_batch(128, 160, n_views=3, seed=3), DEV)
+    with torch.no_grad():
+        ref = net._forward_checked(dict(batch))
+        _lib.set_tuning("BMV_RENDER_SPLIT", 1)
+        try:
+            got = net._forward_checked(dict(batch))
+        finally:
+            _lib.set_tuning("BMV_RENDER_SPLIT", None)
+    assert not torch.equal(got["rgb_level1"], ref["rgb_level1"]), "the split path did not run"
+    for k in ("rgb_level1", "depth_level1", "weights_level1"):
+        d = float((got[k] - ref[k]).abs().max())
+        scale = float(ref[k].abs().max())
+        assert d <= 2e-6 * scale, f"{k}: {d:.3e} against scale {scale:.3e}"
