@@ -739,6 +739,9 @@ def main():
                     "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=1: the renderer's color.0 shared part as six bf16 "
                             "MFMAs per product group on three-piece operands (fp32-equivalent; NOT the default, NOT `value`); "
                             "parity_max_rel = its frame against the oracle's"}
+            except Exception as e:                      # an experiment must not take the metric's line down with it
+                extra["render_split_bf16x3"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                render_split_frame.clear()
             finally:
                 _bl.set_tuning("BMV_RENDER_SPLIT", None)
                 net._autograph.invalidate()
