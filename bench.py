@@ -719,10 +719,11 @@ def main():
                     getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
         if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
                 and cc.num_samples[-1] == 2 and batch["src_inps"].shape[1] == 3):
-            # EXPERIMENT, not the metric: the fused renderer's largest matrix chain (color.0's shared part, 88 of the MLP's
-            # 206 fp32 MFMAs per tile) on the bf16 matrix pipe with BOTH operands split into three bf16 pieces -- the fp32
-            # values exactly, products below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT)
+            # EXPERIMENT, not the metric: the fused renderer's two-tile MLP chains (lr0, color.0: 160 of the MLP's 206 fp32
+            # MFMAs per tile) on the bf16 matrix pipe with BOTH operands split into three bf16 pieces -- the fp32 values
+            # exactly, products below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT)
             from boostmvsnerfs_amd import _lib as _bl
+            rs_was = _bl.get_tuning("BMV_RENDER_SPLIT")        # (an environment / caller setting survives the experiment)
             _bl.set_tuning("BMV_RENDER_SPLIT", 1)
             net._autograph.invalidate()                  # (the captured frame has the fp32 renderer baked in)
             try:
@@ -736,14 +737,14 @@ def main():
                 extra["render_split_bf16x3"] = {
                     "value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
                     "parity_max_rel": None,        # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
-                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=1: the renderer's color.0 shared part as six bf16 "
+                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=1: the renderer's lr0 / color.0 chains as six bf16 "
                             "MFMAs per product group on three-piece operands (fp32-equivalent; NOT the default, NOT `value`); "
                             "parity_max_rel = its frame against the oracle's"}
             except Exception as e:                      # an experiment must not take the metric's line down with it
                 extra["render_split_bf16x3"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 render_split_frame.clear()
             finally:
-                _bl.set_tuning("BMV_RENDER_SPLIT", None)
+                _bl.set_tuning("BMV_RENDER_SPLIT", rs_was)
                 net._autograph.invalidate()
                 for _ in range(3):
                     step_plain()

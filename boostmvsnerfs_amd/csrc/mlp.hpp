@@ -56,13 +56,20 @@ struct MlpLayout {
   static constexpr int V_WC2 = V_BC + 64;                  // color.2 weight [2*16]
   static constexpr int V_SC = V_WC2 + 64;                  // scalars: agg_w bias, sigma bias, color.2 bias
   static constexpr int TOTAL = (V_SC + 4 + 3) / 4 * 4;
-  // Experiment (round 5, bmv_tuning BMV_RENDER_SPLIT): color.0's shared part on the bf16 matrix pipe with both operands
-  // split into THREE bf16 pieces (8 + 8 + 8 mantissa bits: the fp32 value exactly) -- the A tables of that chain a
-  // second time, behind the fp32 blob: [piece 3][k-step 6 (of 16)][tile 2][lane 64] x 8 bf16 (16 bytes)
-  static constexpr int SK = 6;                             // 44 fp32 k-steps of 2 = 88 inputs, padded to 96 = 6 x 16
-  static constexpr int S_CSH = TOTAL;
-  static constexpr int S_WORDS = 3 * SK * 2 * 64 * 4;
-  static constexpr int TOTAL_S = TOTAL + S_WORDS;
+  // Experiment (round 5, bmv_tuning BMV_RENDER_SPLIT): the two-tile chains -- lr0, color.0's shared and per-view parts: 160
+  // of the MLP's 206 fp32 MFMAs per tile -- on the bf16 matrix pipe with both operands split into THREE bf16 pieces (8 + 8
+  // + 8 mantissa bits: the fp32 value exactly).  Their A tables a second time, behind the fp32 blob, pre-split:
+  // [piece 3][bf16 k-step][tile 2][lane 64] x 8 bf16 (16 bytes); one bf16 k-step = 8 fp32 k-steps (zero padded).
+  static constexpr int SK_L0 = 2;                          // lr0: 12 fp32 k-steps
+  static constexpr int SK = 6;                             // color.0 shared: 44
+  static constexpr int SK_CV = (KF + 7) / 8;               // color.0 per view: KF
+  static constexpr int S_L0 = TOTAL;
+  static constexpr int S_CSH = S_L0 + 3 * SK_L0 * 2 * 64 * 4;
+  static constexpr int S_CV = S_CSH + 3 * SK * 2 * 64 * 4;
+  static constexpr int TOTAL_S = S_CV + 3 * SK_CV * 2 * 64 * 4;
+  // the split form keeps blob[0, A_L0) ++ blob[V_VF, TOTAL_S) in LDS: the fp32 tables of the three chains stay out
+  static constexpr int LDS_HOLE = V_VF - A_L0;
+  static constexpr int LDS_S = TOTAL_S - LDS_HOLE;
 };
 
 // --------------------------------------------------------------------------
@@ -77,24 +84,37 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L::TOTAL_S) return;
   if (idx >= L::TOTAL) {
-    // split tables of color.0's shared part: dword q of (piece, k-step T, tile, lane (i, h)) = pieces of the fp32 table's
-    // entries of fp32 k-steps t = 8 T + 2 q, 8 T + 2 q + 1 for this tile and lane (low | high half)
-    int e = idx - L::TOTAL;
+    // split tables: dword q of (piece, bf16 k-step T, tile, lane (i, h)) = that piece of the fp32 table's entries of fp32
+    // k-steps t = 8 T + 2 q, 8 T + 2 q + 1 for this tile and lane (low | high half), zero beyond the chain's length
+    const int which = idx >= L::S_CV ? 2 : idx >= L::S_CSH ? 1 : 0;
+    int e = idx - (which == 2 ? L::S_CV : which == 1 ? L::S_CSH : L::S_L0);
+    const int nk = which == 2 ? L::SK_CV : which == 1 ? L::SK : L::SK_L0;
     const int q = e & 3;
     e >>= 2;
     const int lane = e & 63;
     e >>= 6;
     const int tl = e & 1;
     e >>= 1;
-    const int T = e % L::SK, pc = e / L::SK;
+    const int T = e % nk, pc = e / nk;
     const int i = lane & 31, h = lane >> 5, n = 32 * tl + i;
     unsigned packed = 0;
     for (int jj = 0; jj < 2; ++jj) {
       const int t = 8 * T + 2 * q + jj;
       float w = 0.f;
-      if (t < 44) {
-        const int k = t < 32 ? 32 * (t >> 4) + n16(t & 15, h) : t < 36 ? 64 + 2 * (t - 32) + h : 72 + n16(t - 36, h);
-        w = p.color0_w[n * CW + k];
+      if (which == 0) {
+        if (t < 12) w = p.lr0_w[n * 24 + (t < 4 ? 2 * t + h : 8 + n16(t - 4, h))];
+      } else if (which == 1) {
+        if (t < 44) {
+          const int k = t < 32 ? 32 * (t >> 4) + n16(t & 15, h) : t < 36 ? 64 + 2 * (t - 32) + h : 72 + n16(t - 36, h);
+          w = p.color0_w[n * CW + k];
+        }
+      } else if (t < L::KF) {
+        if (t < KFC) {
+          const int c = 2 * t + h;
+          if (c < FC) w = p.color0_w[n * CW + 88 + c];
+        } else {
+          w = p.color0_w[n * CW + 88 + FC + 2 * (t - KFC) + h];
+        }
       }
       const float hi = __uint_as_float(__float_as_uint(w) & 0xffff0000u);
       const float r1 = w - hi;
@@ -246,6 +266,51 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
     }                                                                                              \
   }
 
+// A two-tile chain on v_mfma_f32_32x32x16_bf16 with three-piece operands (CSPLIT): 8 fp32 k-steps = one bf16 k-step -- a
+// lane's 8 B values are its own registers of those steps, as the fp32 chain takes them one by one; operands = hi + mid +
+// lo bf16 pieces (truncation: exact), products hi hi + hi mid + mid hi + hi lo + lo hi + mid mid (what is dropped is
+// below 2^-24 of the product), small terms first.  `t` is the fp32 k-step visible to BEXPR; steps >= NT are zeros.
+// SPTR: the chain's split table in LDS, [piece][k-step][tile][lane] x 16 bytes, already offset by the lane.
+using mlp_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using mlp_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#define BMV_SPLIT_CHAIN2(SPTR, NK, NT, BEXPR, ACC0, ACC1)                                          \
+  {                                                                                                \
+    _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_) {                                          \
+      mlp_u32x4 bh_, bm_, bl_;                                                                     \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                           \
+        unsigned ph_[2], pm_[2], pl_[2];                                                           \
+        _Pragma("unroll") for (int jj_ = 0; jj_ < 2; ++jj_) {                                      \
+          const int t = 8 * T_ + 2 * q_ + jj_;                                                     \
+          const float bv_ = t < (NT) ? (BEXPR) : 0.f;                                              \
+          const unsigned uh_ = __float_as_uint(bv_) & 0xffff0000u;                                 \
+          const float r1_ = bv_ - __uint_as_float(uh_);                                            \
+          const unsigned um_ = __float_as_uint(r1_) & 0xffff0000u;                                 \
+          const float r2_ = r1_ - __uint_as_float(um_);                                            \
+          ph_[jj_] = uh_, pm_[jj_] = um_, pl_[jj_] = __float_as_uint(r2_);                         \
+        }                                                                                          \
+        bh_[q_] = (ph_[0] >> 16) | ph_[1];                                                         \
+        bm_[q_] = (pm_[0] >> 16) | pm_[1];                                                         \
+        bl_[q_] = (pl_[0] >> 16) | (pl_[1] & 0xffff0000u);                                         \
+      }                                                                                            \
+      const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, bh_), Bm_ = __builtin_bit_cast(mlp_bf16x8, bm_),  \
+                       Bl_ = __builtin_bit_cast(mlp_bf16x8, bl_);                                  \
+      _Pragma("unroll") for (int tl_ = 0; tl_ < 2; ++tl_) {                                        \
+        const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((0 * (NK) + T_) * 2 + tl_) * 64]);  \
+        const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((1 * (NK) + T_) * 2 + tl_) * 64]);  \
+        const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((2 * (NK) + T_) * 2 + tl_) * 64]);  \
+        f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                        \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                       \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                       \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                       \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                       \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                       \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                       \
+        if (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                                   \
+        BMV_FENCE();   /* (one tile's 12 A registers at a time: the kernel sits at its register cap) */ \
+      }                                                                                            \
+    }                                                                                              \
+  }
+
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // ReLU as ONE instruction.  fmaxf(x, 0.f) on an MFMA result compiles to TWO v_max_f32: llvm.maxnum wants a
@@ -314,8 +379,11 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   using L = MlpLayout<FEAT_CH>;
   constexpr int KFC = L::KFC, KF = L::KF;
   const int h = lane >> 5;
+  // (CSPLIT: the LDS image is blob[0, A_L0) ++ blob[V_VF, TOTAL_S) -- everything from the vector tables on sits LDS_HOLE
+  // floats lower than in the blob)
+  constexpr int HOLE = CSPLIT ? L::LDS_HOLE : 0;
   const float* __restrict__ Wa = W + lane;
-  const float* __restrict__ Wv = W + h;
+  const float* __restrict__ Wv = W + h - HOLE;
 
   // Agg.view_fc + residual (nerf.py:77-79): f_i = in_i[:F] + relu(W_v dir_i + b).  f is
   // cheap, so it is recomputed where the per-view chain needs it instead of kept live.
@@ -366,7 +434,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   }
   // agg_w_fc + softmax over views + weighted sum (nerf.py:88-89)
   float aw[NV];
-  const float ba = W[L::V_SC + 0], bs = W[L::V_SC + 1], bc2 = W[L::V_SC + 2];
+  const float ba = W[L::V_SC - HOLE + 0], bs = W[L::V_SC - HOLE + 1], bc2 = W[L::V_SC - HOLE + 2];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     float s = 0.f;
@@ -389,7 +457,12 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[tl][r] = Wv[L::V_B0 + (tl * 16 + r) * 2];
-  BMV_CHAIN2(L::A_L0, 12, BMV_MLP_G2, (t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0]), x[0], x[1])
+  if constexpr (CSPLIT) {
+    const mlp_u32x4* sp = reinterpret_cast<const mlp_u32x4*>(W + L::S_L0 - HOLE) + lane;
+    BMV_SPLIT_CHAIN2(sp, L::SK_L0, 12, (t < 4 ? vox[t & 3] : im16[(t - 4) & 7]), x[0], x[1])
+  } else {
+    BMV_CHAIN2(L::A_L0, 12, BMV_MLP_G2, (t < 4 ? vox[t < 4 ? t : 0] : im16[t >= 4 ? t - 4 : 0]), x[0], x[1])
+  }
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
@@ -411,49 +484,8 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
     for (int r = 0; r < 16; ++r) csh[tl][r] = Wv[L::V_BC + (tl * 16 + r) * 2];
   if constexpr (CSPLIT) {
-    // the same sum on v_mfma_f32_32x32x16_bf16: 8 fp32 k-steps = one bf16 k-step (a lane's 8 B values are its own
-    // registers of those steps, as the fp32 chain takes them one by one); operands = hi + mid + lo bf16 pieces, products
-    // hi hi + hi mid + mid hi + hi lo + lo hi + mid mid (what is dropped is below 2^-24 of the product), small terms first
-    using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    const u32x4* Ws = reinterpret_cast<const u32x4*>(W + L::S_CSH) + lane;
-#pragma unroll
-    for (int T = 0; T < L::SK; ++T) {
-      u32x4 bh, bm, bl;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        unsigned ph[2], pm[2], pl[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int t = 8 * T + 2 * q4 + jj;
-          const float bv = t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : t < 44 ? im16[t >= 36 && t < 44 ? t - 36 : 0] : 0.f;
-          const unsigned uh = __float_as_uint(bv) & 0xffff0000u;
-          const float r1 = bv - __uint_as_float(uh);
-          const unsigned um = __float_as_uint(r1) & 0xffff0000u;
-          const float r2 = r1 - __uint_as_float(um);
-          ph[jj] = uh, pm[jj] = um, pl[jj] = __float_as_uint(r2);
-        }
-        bh[q4] = (ph[0] >> 16) | ph[1];
-        bm[q4] = (pm[0] >> 16) | pm[1];
-        bl[q4] = (pl[0] >> 16) | (pl[1] & 0xffff0000u);
-      }
-      const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) {
-        const bf16x8 Ah = __builtin_bit_cast(bf16x8, Ws[((0 * L::SK + T) * 2 + tl) * 64]);
-        const bf16x8 Am = __builtin_bit_cast(bf16x8, Ws[((1 * L::SK + T) * 2 + tl) * 64]);
-        const bf16x8 Al = __builtin_bit_cast(bf16x8, Ws[((2 * L::SK + T) * 2 + tl) * 64]);
-        f32x16 c = csh[tl];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, c, 0, 0, 0);
-        csh[tl] = c;
-      }
-      BMV_FENCE();
-    }
+    const mlp_u32x4* sp = reinterpret_cast<const mlp_u32x4*>(W + L::S_CSH - HOLE) + lane;
+    BMV_SPLIT_CHAIN2(sp, L::SK, 44, (t < 32 ? x[(t >> 4) & 1][t & 15] : t < 36 ? vox[t & 3] : im16[(t - 36) & 7]), csh[0], csh[1])
   } else {
   BMV_CHAIN2(L::A_CSH, 44, BMV_MLP_G2,
              (t < 32 ? x[t < 32 ? (t >> 4) : 0][t & 15] : t < 36 ? vox[t >= 32 && t < 36 ? t - 32 : 0] : im16[t >= 36 ? t - 36 : 0]),
@@ -464,7 +496,12 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lan
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     f32x16 hc[2] = {csh[0], csh[1]};
-    BMV_CHAIN2(L::A_CV, KF, BMV_MLP_G2, fin[i][t], hc[0], hc[1])
+    if constexpr (CSPLIT) {
+      const mlp_u32x4* sp = reinterpret_cast<const mlp_u32x4*>(W + L::S_CV - HOLE) + lane;
+      BMV_SPLIT_CHAIN2(sp, L::SK_CV, KF, fin[i][t < KF ? t : 0], hc[0], hc[1])
+    } else {
+      BMV_CHAIN2(L::A_CV, KF, BMV_MLP_G2, fin[i][t], hc[0], hc[1])
+    }
     float s = 0.f;
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)

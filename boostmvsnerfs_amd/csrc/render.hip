@@ -22,15 +22,30 @@ struct RenderCams {
   float tar_c[4];
 };
 
+// the weight blob into LDS; the split form (CS) keeps blob[0, A_L0) ++ blob[V_VF, TOTAL_S): the fp32 tables of the chains
+// that run on the bf16 pipe stay out (mlp.hpp)
+template <class L, bool CS>
+__device__ __forceinline__ void blob_to_lds(float* lds, const float* __restrict__ blob) {
+  if constexpr (CS) {
+    static_assert(L::A_L0 % 4 == 0 && L::V_VF % 4 == 0 && L::TOTAL_S % 4 == 0, "16-byte pieces");
+    for (int i = threadIdx.x; i < L::A_L0 / 4; i += blockDim.x)
+      reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(blob)[i];
+    for (int i = threadIdx.x; i < (L::TOTAL_S - L::V_VF) / 4; i += blockDim.x)
+      reinterpret_cast<float4*>(lds)[L::A_L0 / 4 + i] = reinterpret_cast<const float4*>(blob)[L::V_VF / 4 + i];
+  } else {
+    for (int i = threadIdx.x; i < L::TOTAL / 4; i += blockDim.x)
+      reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(blob)[i];
+  }
+}
+
 template <int FEAT_CH, int NV, bool CS = false>
-__global__ void __launch_bounds__(256, CS ? 1 : 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
+__global__ void __launch_bounds__(256, 2) nerf_mlp_kernel(const float* __restrict__ vox_feat,
                                                            const float* __restrict__ img,
                                                            const float* __restrict__ blob, long npts,
                                                            float* __restrict__ out) {
   using L = MlpLayout<FEAT_CH>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < (CS ? L::TOTAL_S : L::TOTAL) / 4; i += blockDim.x)
-    reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(blob)[i];
+  blob_to_lds<L, CS>(lds, blob);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 31, h = lane >> 5;
@@ -377,7 +392,7 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
   // mailbox rows: [0, 6 NV) fin, [6 NV, 10 NV) dir, then vox[4], z, visibility
   constexpr int kPcBox = pc_box(NV), B_DIR = 6 * NV, B_VOX = 10 * NV, B_Z = 10 * NV + 4, B_VIS = 10 * NV + 5;
   constexpr int RAYS_PER_TILE = 32 / NS;
-  constexpr int BLOB = CS ? L::TOTAL_S : L::TOTAL;
+  constexpr int BLOB = CS ? L::LDS_S : L::TOTAL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   RenderCams* rc = reinterpret_cast<RenderCams*>(lds + BLOB);
   // [kPcMlp] sequence words: 2 n = empty, waiting for this MLP wave's n-th job; 2 n + 1 = holds it (with more gather
@@ -385,8 +400,7 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
   int* flags = reinterpret_cast<int*>(rc + 1);
   float* boxes = reinterpret_cast<float*>(flags + 16);              // [kPcMlp][kPcBox][64 MLP lanes]
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < BLOB / 4; i += blockDim.x)
-    reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(a.blob)[i];
+  blob_to_lds<L, CS>(lds, a.blob);
   if (threadIdx.x < NV)
     load_cam(a.src_exts + ((size_t)b * NV + threadIdx.x) * 16, a.src_ixts + ((size_t)b * NV + threadIdx.x) * 9,
              a.render_scale, rc->cam[threadIdx.x]);
@@ -696,7 +710,7 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
     BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
   }
   if (feat_ch == 8 && S == 3 && bmv::tuning("BMV_RENDER_SPLIT", 0)) {   // the experiment's MLP by itself (accuracy probes)
-    size_t lds = MlpLayout<8>::TOTAL_S * 4;
+    size_t lds = MlpLayout<8>::LDS_S * 4;
     BMV_REQUIRE(set_lds(nerf_mlp_kernel<8, 3, true>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL((nerf_mlp_kernel<8, 3, true>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts, out);
     BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
@@ -761,8 +775,8 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   }
   if (use_pc && bmv::tuning("BMV_RENDER_SPLIT", 0) && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == 2 &&
       a->depth_inv == 0 && a->S == 3) {
-    // experiment: color.0's shared part on the bf16 pipe with three-piece operands (the headline shape only)
-    size_t lds = MlpLayout<8>::TOTAL_S * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(3) * 64 * 4;
+    // experiment: the MLP's two-tile chains on the bf16 pipe with three-piece operands (the headline shape only)
+    size_t lds = MlpLayout<8>::LDS_S * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(3) * 64 * 4;
     BMV_REQUIRE(set_lds(render_pc_kernel<2, false, 3, true>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");
     int ntiles = (nrays + 15) / 16;
     const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u));

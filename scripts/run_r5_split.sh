@@ -1,7 +1,8 @@
 #!/bin/bash
-R=$(pwd); O=$R/gpurun_out/r5_split; mkdir -p $O
-python3 tests/tools/mlp_split_accuracy.py 2>&1 | grep -v amdgpu.ids | tee $O/mlp_split_accuracy.txt
-python3 -m pytest tests/test_gpu_parity.py tests/test_cabi.py -q -x 2>&1 | tail -3
-python3 bench.py --steps 400 > $O/bench_with_split_extra.json 2> $O/b.err
-python3 -c "
-import json; d=json.loads(open('$O/bench_with_split_extra.json').read().strip().splitlines()[-1]); print('value', round(d['value'],2), 'parity', d['parity_max_rel']['max']); print(json.dumps(d['value_extra'].get('render_split_bf16x3'), indent=1))"
+R=$(pwd); O=$R/gpurun_out/r5_split; mkdir -p $O; rm -f $O/ab5.txt
+for v in 0 1 0 1 0 1; do
+  BMV_RENDER_SPLIT=$v python3 bench.py --no-cpu-baseline --steps 400 > $O/b.json 2> $O/b.err
+  python3 -c "
+import json; d=json.loads(open('$O/b.json').read().strip().splitlines()[-1]); m=d.get('roofline_mfma',{}); x=d['value_extra']
+print('render split $v', round(d['value'],2), round(d['ms_per_step'],4), 'resident', round(x['resident_batch']['value'],2), 'pipelined', round(x.get('pipelined_replay',{}).get('value',0),1), 'renderer us', round(m.get('avg_us'),1), 'steps', x.get('step_ms'))" | tee -a $O/ab5.txt
+done

@@ -41,7 +41,7 @@ def main():
                 outs[split] = ops.nerf_mlp(vox.cuda(), img.cuda(), netd.packed_weights(), 8).cpu()
         _lib.set_tuning("BMV_RENDER_SPLIT", None)
         print(f"trial {trial} (weights x {wscale}): {P} samples, 3 views; |sigma| up to {float(want[..., 3].abs().max()):.2f}")
-        for name, got in (("torch CPU fp32 (the oracle)", ref32), ("HIP, fp32 MFMAs (default)", outs[0]), ("HIP, color.0 shared part split bf16 x 3", outs[1])):
+        for name, got in (("torch CPU fp32 (the oracle)", ref32), ("HIP, fp32 MFMAs (default)", outs[0]), ("HIP, two-tile chains split bf16 x 3", outs[1])):
             e = (got.double() - want).abs()
             print(f"    {name:42s} rgb max {float(e[..., :3].max()):.3e} mean {float(e[..., :3].mean()):.3e}   "
                   f"sigma max {float(e[..., 3].max()):.3e} mean {float(e[..., 3].mean()):.3e}")
