@@ -647,3 +647,40 @@ def test_renderer_split_bf16_experiment_is_fp32_equivalent():
         d = float((got[k] - ref[k]).abs().max())
         scale = float(ref[k].abs().max())
         assert d <= 2e-6 * scale, f"{k}: {d:.3e} against scale {scale:.3e}"
+
+
+def test_split_mlp_is_as_accurate_as_the_fp32_mlp_against_float64():
+    """The experiment's arithmetic claim, as a test: on the same fp32 inputs and weights the MLP with its two-tile chains
+    on the bf16 pipe (three-piece operands) is no farther from a float64 evaluation of the network
+    (oracle/enerf.py nerf_mlp, lib/networks/enerf/nerf.py:29-43, 74-89) than the fp32-MFMA form is."""
+    from boostmvsnerfs_amd import _lib, ops
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from oracle import enerf as O
+    set_cfg(make_cfg("enerf_eval"))
+    from boostmvsnerfs_amd.networks.enerf.nerf import NeRF
+    torch.manual_seed(11)
+    P = 1 << 14
+    net = NeRF(feat_ch=8 + 3)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.dim() == 1:
+                p_.normal_(0, 0.1)
+    sd = {("nerf." + k): v.detach().double() for k, v in net.state_dict().items()}
+    vox = torch.randn(1, P, 8)
+    img = torch.cat([torch.randn(1, P, 3, 8), torch.rand(1, P, 3, 3), torch.randn(1, P, 3, 4) * 0.5], -1)
+    want = O.nerf_mlp(sd, "nerf.", vox.double(), img.double())
+    netd = net.to(DEV).eval()
+    err = {}
+    with torch.no_grad():
+        for split in (0, 1):
+            _lib.set_tuning("BMV_RENDER_SPLIT", split)
+            try:
+                got = ops.nerf_mlp(vox.to(DEV), img.to(DEV), netd.packed_weights(), 8).cpu().double()
+            finally:
+                _lib.set_tuning("BMV_RENDER_SPLIT", None)
+            err[split] = (got - want).abs()
+    assert float((err[1] - err[0]).abs().max()) > 0, "the split path did not run"
+    for name, sl in (("rgb", slice(0, 3)), ("sigma", slice(3, 4))):
+        e0, e1 = err[0][..., sl], err[1][..., sl]
+        assert float(e1.mean()) <= 1.5 * float(e0.mean()) + 1e-9, (name, float(e1.mean()), float(e0.mean()))
+        assert float(e1.max()) <= 2.0 * float(e0.max()) + 1e-8, (name, float(e1.max()), float(e0.max()))
