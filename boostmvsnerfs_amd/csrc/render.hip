@@ -709,11 +709,19 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
                        npts, out);                                                                                   \
     BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
   }
-  if (feat_ch == 8 && S == 3 && bmv::tuning("BMV_RENDER_SPLIT", 0)) {   // the experiment's MLP by itself (accuracy probes)
+  if (feat_ch == 8 && bmv::tuning("BMV_RENDER_SPLIT", 0)) {   // the experiment's MLP by itself (accuracy probes)
     size_t lds = MlpLayout<8>::LDS_S * 4;
-    BMV_REQUIRE(set_lds(nerf_mlp_kernel<8, 3, true>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((nerf_mlp_kernel<8, 3, true>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, npts, out);
-    BMV_LAUNCH_END("bmv_nerf_mlp_fwd");
+#define MLP_SPLIT_CASE(NVV)                                                                                          \
+  if (S == NVV) {                                                                                                    \
+    BMV_REQUIRE(set_lds(nerf_mlp_kernel<8, NVV, true>, lds) == 0, "bmv_nerf_mlp_fwd: cannot reserve %zu B of LDS", lds); \
+    hipLaunchKernelGGL((nerf_mlp_kernel<8, NVV, true>), dim3(grid), dim3(256), lds, as_stream(stream), vox_feat, img, blob, \
+                       npts, out);                                                                                   \
+    BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
+  }
+    MLP_SPLIT_CASE(3)
+    MLP_SPLIT_CASE(2)
+    MLP_SPLIT_CASE(4)
+#undef MLP_SPLIT_CASE
   }
   MLP_CASE(8, 3)
   MLP_CASE(32, 3)
@@ -762,28 +770,24 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   }
   // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
   const bool use_pc = bmv::tuning("BMV_RENDER_PC", 1) != 0;
+  // experiment (BMV_RENDER_SPLIT): the MLP's two-tile chains on the bf16 pipe with three-piece operands (mlp.hpp CSPLIT)
+  const bool split = bmv::tuning("BMV_RENDER_SPLIT", 0) != 0;
 #define RENDER_CASE_PC(NSV, NVV)                                                                                     \
   if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0 && a->S == NVV) { \
-    size_t lds = MlpLayout<8>::TOTAL * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(NVV) * 64 * 4;          \
-    BMV_REQUIRE(set_lds(render_pc_kernel<NSV, false, NVV>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");    \
+    size_t lds = (split ? MlpLayout<8>::LDS_S : MlpLayout<8>::TOTAL) * 4 + sizeof(RenderCams) + 64 +                \
+                 (size_t)kPcMlp * pc_box(NVV) * 64 * 4;                                                             \
+    BMV_REQUIRE((split ? set_lds(render_pc_kernel<NSV, false, NVV, true>, lds) : set_lds(render_pc_kernel<NSV, false, NVV>, lds)) == 0, \
+                "bmv_render_rays_fwd: cannot reserve LDS");                                                         \
     int ntiles = (nrays + (32 / NSV) - 1) / (32 / NSV);                                                             \
     const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u)); \
     unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;                                        \
-    hipLaunchKernelGGL((render_pc_kernel<NSV, false, NVV>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds, \
-                       as_stream(stream), dev);                                                                      \
+    if (split)                                                                                                       \
+      hipLaunchKernelGGL((render_pc_kernel<NSV, false, NVV, true>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds, \
+                         as_stream(stream), dev);                                                                    \
+    else                                                                                                             \
+      hipLaunchKernelGGL((render_pc_kernel<NSV, false, NVV>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds, \
+                         as_stream(stream), dev);                                                                    \
     BMV_LAUNCH_END("bmv_render_rays_fwd");                                                                          \
-  }
-  if (use_pc && bmv::tuning("BMV_RENDER_SPLIT", 0) && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == 2 &&
-      a->depth_inv == 0 && a->S == 3) {
-    // experiment: the MLP's two-tile chains on the bf16 pipe with three-piece operands (the headline shape only)
-    size_t lds = MlpLayout<8>::LDS_S * 4 + sizeof(RenderCams) + 64 + (size_t)kPcMlp * pc_box(3) * 64 * 4;
-    BMV_REQUIRE(set_lds(render_pc_kernel<2, false, 3, true>, lds) == 0, "bmv_render_rays_fwd: cannot reserve LDS");
-    int ntiles = (nrays + 15) / 16;
-    const unsigned pc_grid = (unsigned)bmv::tuning("BMV_RENDER_PC_GRID", (int)(256u));
-    unsigned grid = (unsigned)ntiles < pc_grid ? (unsigned)ntiles : pc_grid;
-    hipLaunchKernelGGL((render_pc_kernel<2, false, 3, true>), dim3(grid, a->B), dim3(64 * (kPcMlp + kPcGather)), lds,
-                       as_stream(stream), dev);
-    BMV_LAUNCH_END("bmv_render_rays_fwd");
   }
   RENDER_CASE_PC(2, 3)
   RENDER_CASE_PC(1, 3)

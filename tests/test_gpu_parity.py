@@ -620,7 +620,8 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
     assert not gemms, f"S={S}: GEMM launches on the path: {gemms}"
 
 
-def test_renderer_split_bf16_experiment_is_fp32_equivalent():
+@pytest.mark.parametrize("n_views", [3, 2, 4])
+def test_renderer_split_bf16_experiment_is_fp32_equivalent(n_views):
     """bmv_tuning BMV_RENDER_SPLIT (experiment, off by default): color.0's shared part -- 43 % of the MLP's matrix
     instructions -- on the bf16 matrix pipe with BOTH operands split into three bf16 pieces (the fp32 values exactly; the
     product terms dropped are below 2^-24 of a product).  The frame it renders must agree with the fp32-MFMA frame to fp32
@@ -634,14 +635,16 @@ def test_renderer_split_bf16_experiment_is_fp32_equivalent():
     set_cfg(cfg)
     torch.manual_seed(3)
     net = Network().eval().to(DEV)
-    batch = clone_batch(make_batch(128, 160, n_views=3, seed=3), DEV)
+    batch = clone_batch(make_batch(128, 160, n_views=n_views, seed=3), DEV)
+    was = _lib.get_tuning("BMV_RENDER_SPLIT")      # (the suite may be running with the experiment switched on)
     with torch.no_grad():
-        ref = net._forward_checked(dict(batch))
-        _lib.set_tuning("BMV_RENDER_SPLIT", 1)
         try:
+            _lib.set_tuning("BMV_RENDER_SPLIT", 0)
+            ref = net._forward_checked(dict(batch))
+            _lib.set_tuning("BMV_RENDER_SPLIT", 1)
             got = net._forward_checked(dict(batch))
         finally:
-            _lib.set_tuning("BMV_RENDER_SPLIT", None)
+            _lib.set_tuning("BMV_RENDER_SPLIT", was)
     assert not torch.equal(got["rgb_level1"], ref["rgb_level1"]), "the split path did not run"
     for k in ("rgb_level1", "depth_level1", "weights_level1"):
         d = float((got[k] - ref[k]).abs().max())
@@ -672,12 +675,13 @@ def test_split_mlp_is_as_accurate_as_the_fp32_mlp_against_float64():
     netd = net.to(DEV).eval()
     err = {}
     with torch.no_grad():
+        was = _lib.get_tuning("BMV_RENDER_SPLIT")
         for split in (0, 1):
             _lib.set_tuning("BMV_RENDER_SPLIT", split)
             try:
                 got = ops.nerf_mlp(vox.to(DEV), img.to(DEV), netd.packed_weights(), 8).cpu().double()
             finally:
-                _lib.set_tuning("BMV_RENDER_SPLIT", None)
+                _lib.set_tuning("BMV_RENDER_SPLIT", was)
             err[split] = (got - want).abs()
     assert float((err[1] - err[0]).abs().max()) > 0, "the split path did not run"
     for name, sl in (("rgb", slice(0, 3)), ("sigma", slice(3, 4))):
