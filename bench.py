@@ -717,15 +717,17 @@ def main():
             finally:
                 for i in range(cc.num):
                     getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
+        from boostmvsnerfs_amd import _lib as _bl
         if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
-                and cc.num_samples[-1] == 2 and batch["src_inps"].shape[1] == 3):
-            # EXPERIMENT, not the metric: the fused renderer's two-tile MLP chains (lr0, color.0: 160 of the MLP's 206 fp32
-            # MFMAs per tile) on the bf16 matrix pipe with BOTH operands split into three bf16 pieces -- the fp32 values
-            # exactly, products below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT)
-            from boostmvsnerfs_amd import _lib as _bl
-            rs_was = _bl.get_tuning("BMV_RENDER_SPLIT")        # (an environment / caller setting survives the experiment)
-            _bl.set_tuning("BMV_RENDER_SPLIT", 1)
-            net._autograph.invalidate()                  # (the captured frame has the fp32 renderer baked in)
+                and _bl.get_tuning("BMV_RENDER_SPLIT") != 0):
+            # The same frame with EVERY chain of the renderer's MLP on fp32 MFMAs (bmv_tuning BMV_RENDER_SPLIT=0: the form of
+            # rounds 1-5).  `value` runs the default: the MLP's two-tile chains (lr0, color.0: 160 of its 206 matrix
+            # instructions per tile) as bf16 MFMAs on three-piece fp32 operands -- the fp32 values exactly, product terms
+            # below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT; accuracy against float64:
+            # profiles/r5/mlp_split_accuracy.txt)
+            rs_was = _bl.get_tuning("BMV_RENDER_SPLIT")        # (an environment / caller setting survives)
+            _bl.set_tuning("BMV_RENDER_SPLIT", 0)
+            net._autograph.invalidate()                  # (the captured frame has the other renderer baked in)
             try:
                 for _ in range(4):                      # eager, capture, first replays of the new configuration
                     step_plain()
@@ -734,14 +736,13 @@ def main():
                 with torch.no_grad():
                     rs_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
                 render_split_frame.update(rs_frame)
-                extra["render_split_bf16x3"] = {
+                extra["renderer_fp32_mfma"] = {
                     "value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
                     "parity_max_rel": None,        # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
-                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=1: the renderer's lr0 / color.0 chains as six bf16 "
-                            "MFMAs per product group on three-piece operands (fp32-equivalent; NOT the default, NOT `value`); "
-                            "parity_max_rel = its frame against the oracle's"}
-            except Exception as e:                      # an experiment must not take the metric's line down with it
-                extra["render_split_bf16x3"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the renderer's MLP on fp32 MFMAs "
+                            "(what `value` measured up to the end of round 5); parity_max_rel = its frame against the oracle's"}
+            except Exception as e:                      # a side measurement must not take the metric's line down with it
+                extra["renderer_fp32_mfma"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 render_split_frame.clear()
             finally:
                 _bl.set_tuning("BMV_RENDER_SPLIT", rs_was)
@@ -913,8 +914,12 @@ def main():
                 # roofline share because work was REMOVED, not because the pipe is full)
                 ex = 26.2e3 * rays_launch * cc.num_samples[1] / kernels[rname]["avg_us"] / 1e6
                 alg = 50.9e3 * rays_launch * cc.num_samples[1] / kernels[rname]["avg_us"] / 1e6
-                mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused, fp32 MFMA MLP)", "achieved": ex,
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / FP32_MFMA_PEAK_TFLOPS,
+                mfma = {"bound": "mfma", "kernel": "render_rays (a6-a12 fused; MLP: 160 of 206 matrix instructions per tile as "
+                                                   "bf16 MFMAs on three-piece fp32 operands, the rest fp32 MFMAs; BMV_RENDER_SPLIT=0: all fp32)",
+                        "achieved": ex,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "peak_is": "the fp32 MFMA peak (the rate the same fp32 FLOPs would be bound by on "
+                                                                  "fp32 matrix instructions; `frac` can pass it only through the bf16 pipe)",
+                        "unit": "TFLOP/s", "frac": ex / FP32_MFMA_PEAK_TFLOPS,
                         "flops_counted": "executed (26.2 kFLOP / sample)", "algorithmic_tflops": alg,
                         "algorithmic_over_peak": alg / FP32_MFMA_PEAK_TFLOPS,
                         "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
@@ -967,10 +972,10 @@ def main():
                 line["cpu_baseline"] = cb
             line.update(parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev))
             ref_frame = getattr(cpu_baseline, "last_frame", None)
-            if render_split_frame and ref_frame and "render_split_bf16x3" in extra:
+            if render_split_frame and ref_frame and "renderer_fp32_mfma" in extra:
                 rs_par = {k: _rel_err(render_split_frame[k], want)[0] for k, want in ref_frame.items()
                           if k in render_split_frame and torch.is_tensor(want)}
-                extra["render_split_bf16x3"]["parity_max_rel"] = max(rs_par.values()) if rs_par else None
+                extra["renderer_fp32_mfma"]["parity_max_rel"] = max(rs_par.values()) if rs_par else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -380,7 +380,8 @@ __device__ __forceinline__ bool pc_wait(volatile int* flag, int want) {
   return false;
 }
 
-// CS: color.0's shared part on the bf16 matrix pipe with three-piece operands (mlp.hpp, CSPLIT; experiment, BMV_RENDER_SPLIT)
+// CS: the MLP's two-tile chains on the bf16 matrix pipe with three-piece fp32 operands (mlp.hpp, CSPLIT): the default since
+// the end of round 5; bmv_tuning BMV_RENDER_SPLIT=0 puts every chain back on fp32 MFMAs
 template <int NS, bool INV, int NV, bool CS = false>
 __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel(RenderArgsDev a) {
   resolve_deferred(a);
@@ -671,7 +672,7 @@ int bmv_debug_fetch_stamps(float* dst) {
 #endif
 
 int bmv_nerf_blob_size(int feat_ch) {
-  if (feat_ch == 8) return MlpLayout<8>::TOTAL_S;       // (the fp32 tables + the split tables of the BMV_RENDER_SPLIT experiment)
+  if (feat_ch == 8) return MlpLayout<8>::TOTAL_S;       // (the fp32 tables + the pre-split tables of the bf16 x 3 chains)
   if (feat_ch == 32) return MlpLayout<32>::TOTAL_S;
   set_error("bmv_nerf_blob_size: feat_ch=%d unsupported (8 or 32)", feat_ch);
   return BMV_ERR_UNSUPPORTED;
@@ -709,7 +710,7 @@ int bmv_nerf_mlp_fwd(const float* vox_feat, const float* img, const float* blob,
                        npts, out);                                                                                   \
     BMV_LAUNCH_END("bmv_nerf_mlp_fwd");                                                                              \
   }
-  if (feat_ch == 8 && bmv::tuning("BMV_RENDER_SPLIT", 0)) {   // the experiment's MLP by itself (accuracy probes)
+  if (feat_ch == 8 && bmv::tuning("BMV_RENDER_SPLIT", 1)) {   // the two-tile chains as bf16 x 3, as in the fused renderer
     size_t lds = MlpLayout<8>::LDS_S * 4;
 #define MLP_SPLIT_CASE(NVV)                                                                                          \
   if (S == NVV) {                                                                                                    \
@@ -770,8 +771,9 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   }
   // producer / consumer form (lookup records for image and volume, feat_ch 8): BMV_RENDER_PC=0 keeps the kernel above
   const bool use_pc = bmv::tuning("BMV_RENDER_PC", 1) != 0;
-  // experiment (BMV_RENDER_SPLIT): the MLP's two-tile chains on the bf16 pipe with three-piece operands (mlp.hpp CSPLIT)
-  const bool split = bmv::tuning("BMV_RENDER_SPLIT", 0) != 0;
+  // the MLP's two-tile chains on the bf16 pipe with three-piece fp32 operands (mlp.hpp CSPLIT; fp32 accuracy: tests,
+  // profiles/r5/mlp_split_accuracy.txt); BMV_RENDER_SPLIT=0: every chain on fp32 MFMAs
+  const bool split = bmv::tuning("BMV_RENDER_SPLIT", 1) != 0;
 #define RENDER_CASE_PC(NSV, NVV)                                                                                     \
   if (use_pc && a->im_packed && a->vol_packed && a->feat_ch == 8 && a->Ns == NSV && a->depth_inv == 0 && a->S == NVV) { \
     size_t lds = (split ? MlpLayout<8>::LDS_S : MlpLayout<8>::TOTAL) * 4 + sizeof(RenderCams) + 64 +                \

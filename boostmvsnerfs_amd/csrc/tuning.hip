@@ -22,7 +22,7 @@ Knob g_knobs[] = {
     {"BMV_SWEEP_WIN_FLAGS", "windowed sweep ablations: 1 no fill, 2 no blend, 4 no store, 64 stamps"},
     {"BMV_RENDER_GRID", "fused renderer: workgroups (default 256 x waves per SIMD)"},
     {"BMV_RENDER_PC", "0 = fused renderer instead of the producer / consumer one"},
-    {"BMV_RENDER_SPLIT", "experiment: 1 = the fused renderer's two-tile MLP chains on the bf16 matrix pipe with three-piece fp32 operands, fp32 accuracy (the producer / consumer renderer and the stand-alone feat_ch 8 MLP)"},
+    {"BMV_RENDER_SPLIT", "0 = every chain of the fused MLP on fp32 MFMAs; default 1: its two-tile chains on the bf16 matrix pipe with three-piece fp32 operands at fp32 accuracy (the producer / consumer renderer and the stand-alone feat_ch 8 MLP)"},
     {"BMV_RENDER_PC_GRID", "producer / consumer renderer: workgroups (default 256: one per CU, all resident)"},
     {"BMV_MVS_SWEEP_AUX", "MVS padded sweep: cache-policy bits of its stores (default 0x102)"},
     {"BMV_CONV_SPLIT_TZ", "split-bf16 convolution: tile depth"},
