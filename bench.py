@@ -21,8 +21,12 @@ with the rays built on the device, and through `net(batch)` with new device tens
 per frame as an unchanged run.py loop hands them over), and
 `split_bf16_first_last_layers` (an opt-in EXPERIMENT, not the metric: four
 convolutions on the bf16 matrix cores with split fp32 operands; its frame's
-distance to the oracle is `parity_max_rel_split`).  `parity_max_rel`: the frame the
-timed steps render against the oracle's frame of the `cpu_baseline` leg.
+distance to the oracle is `parity_max_rel_split`), and `renderer_fp32_mfma` (the same
+bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the fused renderer's MLP on
+fp32 MFMAs -- `value` runs the default, whose two-tile chains are bf16 MFMAs on
+three-piece fp32 operands at fp32 accuracy -- with that frame's own distance to the
+oracle).  `parity_max_rel`: the frame the timed steps render against the oracle's
+frame of the `cpu_baseline` leg.
 
 N > 1 (one process per GPU, torch.distributed over RCCL): independent target
 views are sharded across ranks -- every rank renders its own target frame of the
