@@ -116,11 +116,16 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
           w = p.color0_w[n * CW + 88 + FC + 2 * (t - KFC) + h];
         }
       }
-      const float hi = __uint_as_float(__float_as_uint(w) & 0xffff0000u);
+      // round to nearest even, as v_cvt_pk_bf16_f32 does for the activations (finite weights)
+      auto rn = [](float v) {
+        const unsigned u = __float_as_uint(v);
+        return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+      };
+      const float hi = rn(w);
       const float r1 = w - hi;
-      const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-      const float r2 = r1 - mid;
-      const float piece = pc == 0 ? hi : pc == 1 ? mid : r2;        // (the last piece: truncated below)
+      const float mid = rn(r1);
+      const float r2 = r1 - mid;                                    // (exact: at most 8 significant bits are left)
+      const float piece = pc == 0 ? hi : pc == 1 ? mid : r2;
       packed |= (__float_as_uint(piece) >> 16) << (16 * jj);
     }
     blob[idx] = __uint_as_float(packed);
@@ -268,9 +273,15 @@ __global__ void nerf_pack_kernel(bmv_nerf_params p, float* __restrict__ blob) {
 
 // A two-tile chain on v_mfma_f32_32x32x16_bf16 with three-piece operands (CSPLIT): 8 fp32 k-steps = one bf16 k-step -- a
 // lane's 8 B values are its own registers of those steps, as the fp32 chain takes them one by one; operands = hi + mid +
-// lo bf16 pieces (truncation: exact), products hi hi + hi mid + mid hi + hi lo + lo hi + mid mid (what is dropped is
-// below 2^-24 of the product), small terms first.  `t` is the fp32 k-step visible to BEXPR; steps >= NT are zeros.
+// lo bf16 pieces by ROUND TO NEAREST (hi = rn(x), mid = rn(x - hi), lo = x - hi - mid: exact, |mid| <= 2^-8 |x|, |lo| <= 2^-16
+// |x|), products hi hi + hi mid + mid hi + hi lo + lo hi + mid mid (what is dropped -- mid lo, lo mid, lo lo -- is at
+// most 2^-23 of the product: one fp32 rounding), small terms first.  `t` is the fp32 k-step visible to BEXPR; steps >= NT are zeros.
 // SPTR: the chain's split table in LDS, [piece][k-step][tile][lane] x 16 bytes, already offset by the lane.
+__device__ __forceinline__ unsigned mlp_cvt_pk_bf16(float a, float b) {   // [rn_bf16(a) | rn_bf16(b) << 16]
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 using mlp_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using mlp_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #define BMV_SPLIT_CHAIN2(SPTR, NK, NT, BEXPR, ACC0, ACC1)                                          \
@@ -278,19 +289,16 @@ using mlp_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_) {                                          \
       mlp_u32x4 bh_, bm_, bl_;                                                                     \
       _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                           \
-        unsigned ph_[2], pm_[2], pl_[2];                                                           \
+        float bv_[2];                                                                              \
         _Pragma("unroll") for (int jj_ = 0; jj_ < 2; ++jj_) {                                      \
           const int t = 8 * T_ + 2 * q_ + jj_;                                                     \
-          const float bv_ = t < (NT) ? (BEXPR) : 0.f;                                              \
-          const unsigned uh_ = __float_as_uint(bv_) & 0xffff0000u;                                 \
-          const float r1_ = bv_ - __uint_as_float(uh_);                                            \
-          const unsigned um_ = __float_as_uint(r1_) & 0xffff0000u;                                 \
-          const float r2_ = r1_ - __uint_as_float(um_);                                            \
-          ph_[jj_] = uh_, pm_[jj_] = um_, pl_[jj_] = __float_as_uint(r2_);                         \
+          bv_[jj_] = t < (NT) ? (BEXPR) : 0.f;                                                     \
         }                                                                                          \
-        bh_[q_] = (ph_[0] >> 16) | ph_[1];                                                         \
-        bm_[q_] = (pm_[0] >> 16) | pm_[1];                                                         \
-        bl_[q_] = (pl_[0] >> 16) | (pl_[1] & 0xffff0000u);                                         \
+        const unsigned ph_ = mlp_cvt_pk_bf16(bv_[0], bv_[1]);                                      \
+        const float r10_ = bv_[0] - __uint_as_float(ph_ << 16), r11_ = bv_[1] - __uint_as_float(ph_ & 0xffff0000u); \
+        const unsigned pm_ = mlp_cvt_pk_bf16(r10_, r11_);                                          \
+        const float r20_ = r10_ - __uint_as_float(pm_ << 16), r21_ = r11_ - __uint_as_float(pm_ & 0xffff0000u);     \
+        bh_[q_] = ph_, bm_[q_] = pm_, bl_[q_] = mlp_cvt_pk_bf16(r20_, r21_);                       \
       }                                                                                            \
       const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, bh_), Bm_ = __builtin_bit_cast(mlp_bf16x8, bm_),  \
                        Bl_ = __builtin_bit_cast(mlp_bf16x8, bl_);                                  \

@@ -1,0 +1,49 @@
+"""The arithmetic of the renderer's bf16 x 3 chains (csrc/mlp.hpp, BMV_SPLIT_CHAIN2), restated in numpy on the CPU: an fp32
+value is cut by ROUND TO NEAREST EVEN (v_cvt_pk_bf16_f32) into hi = rn(x), mid = rn(x - hi), lo = x - hi - mid; a product
+keeps hi hi + hi mid + mid hi + hi lo + lo hi + mid mid and drops mid lo + lo mid + lo lo.  Checked here: the three
+pieces are bf16 numbers and reproduce the fp32 value EXACTLY, every kept partial product is exact in fp32, and what is
+dropped is at most 2^-23 of the product -- one fp32 rounding of it."""
+import numpy as np
+
+
+def _rn_bf16(x):
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _pieces(x):
+    hi = _rn_bf16(x)
+    r1 = x - hi
+    mid = _rn_bf16(r1)
+    lo = r1 - mid
+    return hi, mid, lo
+
+
+def _values(seed, n):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+
+
+def test_three_bf16_pieces_are_the_fp32_value():
+    x = np.concatenate([_values(0, 1 << 16), np.array([0.0, -0.0, 1.0, -1.0, np.pi, 1.0 + 2.0 ** -23, 255.0 / 256.0, 1e30, -1e-30], np.float32)])
+    hi, mid, lo = _pieces(x)
+    for p in (hi, mid, lo):                      # every piece is a bf16 number (low 16 bits clear): lo needs no rounding
+        assert not np.any(p.view(np.uint32) & np.uint32(0xFFFF))
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    nz = x != 0
+    assert float((np.abs(mid[nz]) / np.abs(x[nz])).max()) <= 2.0 ** -8 and float((np.abs(lo[nz]) / np.abs(x[nz])).max()) <= 2.0 ** -16
+
+
+def test_kept_products_are_exact_and_the_dropped_ones_are_one_fp32_rounding():
+    a, b = _values(1, 1 << 16), _values(2, 1 << 16)
+    ah, am, al = _pieces(a)
+    bh, bm, bl = _pieces(b)
+    kept = [(ah, bh), (ah, bm), (am, bh), (ah, bl), (al, bh), (am, bm)]
+    for u, v in kept:                            # 8-bit x 8-bit significands: 16 bits, exact in fp32 (the MFMA's products)
+        assert np.array_equal((u * v).astype(np.float64), u.astype(np.float64) * v.astype(np.float64))
+    full = a.astype(np.float64) * b.astype(np.float64)
+    got = sum(u.astype(np.float64) * v.astype(np.float64) for u, v in kept)
+    rel = np.abs(full - got) / np.abs(full)
+    assert float(rel.max()) <= 2.0 ** -23 * 1.01, float(rel.max())
+    assert float(np.median(rel)) < 2.0 ** -26
