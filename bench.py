@@ -727,7 +727,7 @@ def main():
             # The same frame with EVERY chain of the renderer's MLP on fp32 MFMAs (bmv_tuning BMV_RENDER_SPLIT=0: the form of
             # rounds 1-5).  `value` runs the default: the MLP's two-tile chains (lr0, color.0: 160 of its 206 matrix
             # instructions per tile) as bf16 MFMAs on three-piece fp32 operands -- the fp32 values exactly, product terms
-            # below 2^-24 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT; accuracy against float64:
+            # of at most 2^-23 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT; accuracy against float64:
             # profiles/r5/mlp_split_accuracy.txt)
             rs_was = _bl.get_tuning("BMV_RENDER_SPLIT")        # (an environment / caller setting survives)
             _bl.set_tuning("BMV_RENDER_SPLIT", 0)

@@ -624,7 +624,7 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
 def test_renderer_split_bf16_experiment_is_fp32_equivalent(n_views):
     """bmv_tuning BMV_RENDER_SPLIT (default 1 since the end of round 5; 0 = every chain on fp32 MFMAs): the MLP's two-tile
     chains -- 160 of its 206 matrix instructions per tile -- on the bf16 matrix pipe with BOTH operands split into three
-    bf16 pieces (the fp32 values exactly; the product terms dropped are below 2^-24 of a product).  The frame it renders
+    bf16 pieces (the fp32 values exactly; the product terms dropped are at most 2^-23 of a product).  The frame it renders
     must agree with the all-fp32-MFMA frame to fp32 rounding (not bit for bit: the summation order differs), far inside
     the 1e-3 bar of the parity tests."""
     from boostmvsnerfs_amd import _lib
