@@ -350,7 +350,18 @@ struct MvsMlp {
   static constexpr int S_SC = S_WRGB + 3 * 64;        // alpha bias, rgb bias x3
   static constexpr int S_TOTAL = S_SC + 4;
   static constexpr int TOTAL = A_TOTAL + S_TOTAL;
+  // Round 5: the ten 128 -> 128 chunks (pts_linears.1-4, feature_linear: 64 k-steps x 2 tiles each, 1280 of the MLP's 1964
+  // fp32 MFMAs per tile) a second time behind the blob, pre-split into three bf16 pieces for v_mfma_f32_32x32x16_bf16 (the
+  // bf16 x 3 form of mlp.hpp's BMV_SPLIT_CHAIN2): [piece 3][bf16 k-step 8][tile 2][lane 64] x 16 bytes = 48 KB per chunk
+  // = CHUNK_MAX, so the two LDS buffers and the DMA pipeline are unchanged.
+  __host__ __device__ static constexpr bool is_split(int c) { return (c >= 4 && c < 12) || c == 14 || c == 15; }
+  __host__ __device__ static constexpr int split_index(int c) { return c < 12 ? c - 4 : c - 6; }
+  static constexpr int N_SPLIT = 10;
+  static constexpr int SPLIT_CHUNK = 3 * 8 * 2 * 64 * 4;          // floats (dwords)
+  static constexpr int S_SPLIT = (TOTAL + 255) / 256 * 256;
+  static constexpr int TOTAL_S = S_SPLIT + N_SPLIT * SPLIT_CHUNK;
 };
+static_assert(MvsMlp::SPLIT_CHUNK == MvsMlp::CHUNK_MAX, "a split chunk takes a whole LDS buffer");
 static_assert(MvsMlp::offset(MvsMlp::N_CHUNKS) == MvsMlp::A_TOTAL, "chunk table");
 static constexpr int kMvsSmall = ((MvsMlp::S_TOTAL + 255) / 256) * 256;   // floats of LDS in front of the chunk buffers
 
@@ -358,7 +369,42 @@ __device__ __forceinline__ int hid_index(int u, int h) { return 32 * (u >> 4) + 
 
 __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ blob) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= MvsMlp::TOTAL) return;
+  if (idx >= MvsMlp::TOTAL_S) return;
+  if (idx >= MvsMlp::TOTAL) {
+    if (idx < MvsMlp::S_SPLIT) {
+      blob[idx] = 0.f;
+      return;
+    }
+    // split chunks: dword q of (piece, bf16 k-step T, tile, lane (i, h)) = that piece (round to nearest; the last one is
+    // exact) of the fp32 A entries of fp32 k-steps t = 8 T + 2 q, 8 T + 2 q + 1 for this tile and lane (low | high half)
+    int e = idx - MvsMlp::S_SPLIT;
+    const int ci = e / MvsMlp::SPLIT_CHUNK;
+    e -= ci * MvsMlp::SPLIT_CHUNK;
+    const int c = ci < 8 ? 4 + ci : 6 + ci;
+    const int q = e & 3, lane = (e >> 2) & 63, tl = (e >> 8) & 1, T = (e >> 9) & 7, pc = e >> 12;
+    const int i = lane & 31, h = lane >> 5;
+    auto rn = [](float v) {
+      const unsigned u = __float_as_uint(v);
+      return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+    };
+    unsigned packed = 0;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = 8 * T + 2 * q + jj;
+      float w;
+      if (c < 12) {
+        const int l = 1 + (c - 4) / 2, n = 64 * ((c - 4) & 1) + 32 * tl + i;
+        w = p.pts_w[l][n * 128 + hid_index(t, h)];
+      } else {
+        const int n = 64 * (c - 14) + 32 * tl + i;
+        w = p.feature_w[n * 128 + hid_index(t, h)];
+      }
+      const float hi = rn(w), r1 = w - hi, mid = rn(r1), r2 = r1 - mid;
+      const float piece = pc == 0 ? hi : pc == 1 ? mid : r2;
+      packed |= (__float_as_uint(piece) >> 16) << (16 * jj);
+    }
+    blob[idx] = __uint_as_float(packed);
+    return;
+  }
   float v = 0.f;
   if (idx < MvsMlp::A_TOTAL) {
     int c = 0, base = 0;
@@ -433,11 +479,14 @@ struct ChunkPipe {
   bool more;   // another tile follows this one: prefetch its chunk 0
 };
 
+template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ buf2, int c, int parity) {
-  const char* src = reinterpret_cast<const char*>(blob + MvsMlp::offset(c));
+  const bool sp = SPLIT && MvsMlp::is_split(c);      // (the bf16 x 3 form of the chunk: 48 KB)
+  const char* src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_index(c) * MvsMlp::SPLIT_CHUNK
+                                                     : blob + MvsMlp::offset(c));
   char* dst = reinterpret_cast<char*>(buf2 + parity * MvsMlp::CHUNK_MAX);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int npieces = MvsMlp::steps(c) / 2;          // 128 floats per k-step = 512 B; a piece is 1 KB
+  const int npieces = sp ? MvsMlp::SPLIT_CHUNK / 256 : MvsMlp::steps(c) / 2;   // 128 floats per k-step = 512 B; a piece is 1 KB
   for (int p = wave; p < npieces; p += 4)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
@@ -475,6 +524,44 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
 // e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
 // Must be called by all 4 waves of the workgroup together (chunk staging uses __syncthreads).
 // Chunk 0 of this tile must already be in flight (issue_chunk(blob, buf2, 0, pipe.count & 1) by every wave).
+// a 128 -> 64 product of a split chunk on the B pieces of the layer's input (computed once per layer: both output halves
+// use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
+#define MVS_GEMM_SPLIT(buf, BH, BM, BL, ACC0, ACC1)                                                     \
+  {                                                                                                     \
+    const mlp_u32x4* sp_ = reinterpret_cast<const mlp_u32x4*>(buf) + lane;                              \
+    _Pragma("unroll") for (int T_ = 0; T_ < 8; ++T_) {                                                  \
+      const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, BH[T_]), Bm_ = __builtin_bit_cast(mlp_bf16x8, BM[T_]), \
+                       Bl_ = __builtin_bit_cast(mlp_bf16x8, BL[T_]);                                    \
+      _Pragma("unroll") for (int tl_ = 0; tl_ < 2; ++tl_) {                                             \
+        const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, sp_[((0 * 8 + T_) * 2 + tl_) * 64]);      \
+        const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, sp_[((1 * 8 + T_) * 2 + tl_) * 64]);      \
+        const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, sp_[((2 * 8 + T_) * 2 + tl_) * 64]);      \
+        f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                             \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                            \
+        if (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                                        \
+        BMV_FENCE();                                                                                    \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+// the three bf16 pieces of a layer's 128-wide input (this lane's 64 values: hcur[t >> 4][t & 15] for fp32 k-step t)
+#define MVS_SPLIT_INPUT(H, BH, BM, BL)                                                                  \
+  _Pragma("unroll") for (int T_ = 0; T_ < 8; ++T_)                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+      const int t0_ = 8 * T_ + 2 * q_;                                                                  \
+      const float v0_ = H[t0_ >> 4][t0_ & 15], v1_ = H[(t0_ + 1) >> 4][(t0_ + 1) & 15];                 \
+      const unsigned ph_ = mlp_cvt_pk_bf16(v0_, v1_);                                                   \
+      const float r10_ = v0_ - __uint_as_float(ph_ << 16), r11_ = v1_ - __uint_as_float(ph_ & 0xffff0000u); \
+      const unsigned pm_ = mlp_cvt_pk_bf16(r10_, r11_);                                                 \
+      const float r20_ = r10_ - __uint_as_float(pm_ << 16), r21_ = r11_ - __uint_as_float(pm_ & 0xffff0000u); \
+      BH[T_][q_] = ph_, BM[T_][q_] = pm_, BL[T_][q_] = mlp_cvt_pk_bf16(r20_, r21_);                     \
+    }
+
+template <bool SPLIT = false>
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
                                                 float* __restrict__ buf2, ChunkPipe& pipe, int lane,
                                                 const float (&e)[32], const float (&f)[10], const float (&dv)[2],
@@ -489,8 +576,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     __syncthreads();                                   // everyone's have; everyone is done with the previous chunk
     const int par = pipe.count & 1;
     buf = buf2 + par * MvsMlp::CHUNK_MAX;
-    if (chunk + 1 < MvsMlp::N_CHUNKS) issue_chunk(blob, buf2, chunk + 1, par ^ 1);
-    else if (pipe.more) issue_chunk(blob, buf2, 0, par ^ 1);
+    if (chunk + 1 < MvsMlp::N_CHUNKS) issue_chunk<SPLIT>(blob, buf2, chunk + 1, par ^ 1);
+    else if (pipe.more) issue_chunk<SPLIT>(blob, buf2, 0, par ^ 1);
     ++chunk, ++pipe.count;
   };
   // pts_bias (network.py:210): bias = W_b feat + b_b
@@ -507,6 +594,9 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4
 #pragma unroll
   for (int layer = 0; layer < 6; ++layer) {
+    mlp_u32x4 bh[8], bm[8], bl[8];
+    if constexpr (SPLIT)
+      if (layer >= 1 && layer <= 4) { MVS_SPLIT_INPUT(hcur, bh, bm, bl) }
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -520,6 +610,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       } else if (layer == 5) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
         MVS_GEMM(buf, 32, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+      } else if constexpr (SPLIT) {
+        MVS_GEMM_SPLIT(buf, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
       } else {
         MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
       }
@@ -540,6 +632,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     out[3] = fmaxf(xhalf_sum(s) + small[MvsMlp::S_SC], 0.f);
   }
   // feature_linear (network.py:221), no activation
+  mlp_u32x4 fh[8], fm[8], fl[8];
+  if constexpr (SPLIT) { MVS_SPLIT_INPUT(hcur, fh, fm, fl) }
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -548,7 +642,11 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BF / 2 + (2 * tp + 1) * 16 + r) * 2];
     }
     next_chunk();
-    MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+    if constexpr (SPLIT) {
+      MVS_GEMM_SPLIT(buf, fh, fm, fl, hnew[2 * tp], hnew[2 * tp + 1]);
+    } else {
+      MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
+    }
   }
   // views_linears.0 (network.py:222-226): relu(W_v [feature, dir] + b_v), 131 -> 64
   f32x16 hv[2];
@@ -664,7 +762,7 @@ __device__ __forceinline__ void mvs_point_inputs(const bmv_mvs_render_args& a, c
   }
 }
 
-template <int S>
+template <int S, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 1 KB for the DMA buffers)
@@ -684,7 +782,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
-  if (a.blob) issue_chunk(a.blob, buf, 0, 0);   // under the gathers / sincos of the first tile
+  if (a.blob) issue_chunk<SPLIT>(a.blob, buf, 0, 0);   // under the gathers / sincos of the first tile
   for (long round = 0; round * per_round < ntiles; ++round) {   // uniform trip count across the workgroup
     pipe.more = (round + 1) * per_round < ntiles;
     long tile = round * per_round + (long)blockIdx.x * 4 + wave;
@@ -706,7 +804,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
       else row[84] = dv[0];
     }
     if (a.blob) {
-      mvs_mlp_forward(a.blob, small, buf, pipe, lane, e, f, dv, res);
+      mvs_mlp_forward<SPLIT>(a.blob, small, buf, pipe, lane, e, f, dv, res);
       if (valid && h == 0) {
         float4 o4 = {res[0], res[1], res[2], res[3]};
         reinterpret_cast<float4*>(a.raw)[gi] = o4;
@@ -719,6 +817,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
   }
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict__ x, const float* __restrict__ blob,
                                                           long npts, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -731,7 +830,7 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
-  issue_chunk(blob, buf, 0, 0);
+  issue_chunk<SPLIT>(blob, buf, 0, 0);
   for (long round = 0; round * per_round < ntiles; ++round) {
     pipe.more = (round + 1) * per_round < ntiles;
     long pt = (round * per_round + (long)blockIdx.x * 4 + wave) * 32 + s;
@@ -744,7 +843,7 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
     for (int t = 0; t < 10; ++t) f[t] = row[63 + 2 * t + h];
     dv[0] = row[83 + h];
     dv[1] = h ? 0.f : row[85];
-    mvs_mlp_forward(blob, small, buf, pipe, lane, e, f, dv, res);
+    mvs_mlp_forward<SPLIT>(blob, small, buf, pipe, lane, e, f, dv, res);
     if (valid && h == 0) {
       float4 o4 = {res[0], res[1], res[2], res[3]};
       reinterpret_cast<float4*>(out)[pt] = o4;
@@ -969,13 +1068,13 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
   BMV_LAUNCH_END("bmv_mvs_march_mask");
 }
 
-int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL; }
+int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL_S; }   // (fp32 chunks + small tables + the ten bf16 x 3 chunks)
 
 int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* p, float* blob, bmv_stream_t stream) {
   BMV_REQUIRE(p && blob, "bmv_mvs_mlp_pack_weights: null pointer");
   const float* const* pp = reinterpret_cast<const float* const*>(p);
   for (int i = 0; i < 22; ++i) BMV_REQUIRE(pp[i], "bmv_mvs_mlp_pack_weights: parameter %d is null", i);
-  hipLaunchKernelGGL(mvs_mlp_pack_kernel, dim3(cdiv(MvsMlp::TOTAL, 256)), dim3(256), 0, as_stream(stream), *p, blob);
+  hipLaunchKernelGGL(mvs_mlp_pack_kernel, dim3(cdiv(MvsMlp::TOTAL_S, 256)), dim3(256), 0, as_stream(stream), *p, blob);
   BMV_LAUNCH_END("bmv_mvs_mlp_pack_weights");
 }
 
@@ -987,10 +1086,14 @@ int bmv_mvs_mlp_fwd(const float* x, const float* blob, long npts, float* out, bm
   BMV_REQUIRE(x && blob && out, "bmv_mvs_mlp_fwd: null pointer");
   BMV_REQUIRE(npts >= 0, "bmv_mvs_mlp_fwd: npts=%ld", npts);
   if (npts == 0) return BMV_OK;
-  BMV_REQUIRE(mvs_lds_ok(reinterpret_cast<const void*>(mvs_mlp_kernel)), "bmv_mvs_mlp_fwd: cannot reserve LDS");
+  // BMV_MVS_SPLIT (default 1): the ten 128 -> 128 chunks as bf16 MFMAs on three-piece fp32 operands (fp32 accuracy); 0: all fp32
+  const bool split = bmv::tuning("BMV_MVS_SPLIT", 1) != 0;
+  BMV_REQUIRE(mvs_lds_ok(split ? reinterpret_cast<const void*>(mvs_mlp_kernel<true>) : reinterpret_cast<const void*>(mvs_mlp_kernel<false>)),
+              "bmv_mvs_mlp_fwd: cannot reserve LDS");
   long ntiles = (npts + 31) / 32;
   unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
-  hipLaunchKernelGGL(mvs_mlp_kernel, dim3(grid), dim3(256), kMvsLds, as_stream(stream), x, blob, npts, out);
+  if (split) hipLaunchKernelGGL(mvs_mlp_kernel<true>, dim3(grid), dim3(256), kMvsLds, as_stream(stream), x, blob, npts, out);
+  else hipLaunchKernelGGL(mvs_mlp_kernel<false>, dim3(grid), dim3(256), kMvsLds, as_stream(stream), x, blob, npts, out);
   BMV_LAUNCH_END("bmv_mvs_mlp_fwd");
 }
 
@@ -1005,10 +1108,13 @@ int bmv_mvs_render_fwd(const bmv_mvs_render_args* a, bmv_stream_t stream) {
               "bmv_mvs_render_fwd: bad shape");
   BMV_REQUIRE(a->ray_begin >= 0 && a->ray_end <= a->N && a->ray_begin <= a->ray_end, "bmv_mvs_render_fwd: ray range");
   if (a->ray_begin == a->ray_end) return BMV_OK;
-  BMV_REQUIRE(mvs_lds_ok(reinterpret_cast<const void*>(mvs_render_kernel<3>)), "bmv_mvs_render_fwd: cannot reserve LDS");
+  const bool split = bmv::tuning("BMV_MVS_SPLIT", 1) != 0;
+  BMV_REQUIRE(mvs_lds_ok(split ? reinterpret_cast<const void*>(mvs_render_kernel<3, true>) : reinterpret_cast<const void*>(mvs_render_kernel<3, false>)),
+              "bmv_mvs_render_fwd: cannot reserve LDS");
   long ntiles = ((long)(a->ray_end - a->ray_begin) * a->Ns + 31) / 32;
   unsigned grid = (unsigned)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
-  hipLaunchKernelGGL(mvs_render_kernel<3>, dim3(grid), dim3(256), kMvsLds, as_stream(stream), *a);
+  if (split) hipLaunchKernelGGL((mvs_render_kernel<3, true>), dim3(grid), dim3(256), kMvsLds, as_stream(stream), *a);
+  else hipLaunchKernelGGL((mvs_render_kernel<3, false>), dim3(grid), dim3(256), kMvsLds, as_stream(stream), *a);
   BMV_LAUNCH_END("bmv_mvs_render_fwd");
 }
 

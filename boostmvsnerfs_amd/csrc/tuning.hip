@@ -23,6 +23,7 @@ Knob g_knobs[] = {
     {"BMV_RENDER_GRID", "fused renderer: workgroups (default 256 x waves per SIMD)"},
     {"BMV_RENDER_PC", "0 = fused renderer instead of the producer / consumer one"},
     {"BMV_RENDER_SPLIT", "0 = every chain of the fused MLP on fp32 MFMAs; default 1: its two-tile chains on the bf16 matrix pipe with three-piece fp32 operands at fp32 accuracy (the producer / consumer renderer and the stand-alone feat_ch 8 MLP)"},
+    {"BMV_MVS_SPLIT", "0 = every layer of MVSNeRF's 6 x 128 MLP on fp32 MFMAs; default 1: its ten 128 -> 128 weight chunks (pts_linears.1-4, feature_linear) as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy"},
     {"BMV_RENDER_PC_GRID", "producer / consumer renderer: workgroups (default 256: one per CU, all resident)"},
     {"BMV_MVS_SWEEP_AUX", "MVS padded sweep: cache-policy bits of its stores (default 0x102)"},
     {"BMV_CONV_SPLIT_TZ", "split-bf16 convolution: tile depth"},
