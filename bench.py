@@ -933,8 +933,12 @@ def main():
             if rname in kernels:
                 flops = 251e3 * N * Ns                                 # a25, per launch (one volume)
                 tf = flops / kernels[rname]["avg_us"] / 1e6
-                mfma = {"bound": "mfma", "kernel": "mvs_render (a21-a25 fused, 6x128 fp32 MFMA MLP)", "achieved": tf,
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                mfma = {"bound": "mfma", "kernel": "mvs_render (a21-a25 fused, 6x128 MLP: the ten 128 -> 128 weight chunks as bf16 MFMAs on "
+                                                   "three-piece fp32 operands, the rest fp32 MFMAs; BMV_MVS_SPLIT=0: all fp32)",
+                        "achieved": tf,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "peak_is": "the fp32 MFMA peak (the rate the same fp32 FLOPs would be bound by on "
+                                                                  "fp32 matrix instructions)",
+                        "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                         "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
             sname = next((n for n in kernels if n.startswith("mvs_sweep[")), None)
             if sname:
