@@ -46,10 +46,10 @@ from . import _lib, ops, switches
 
 _version_of = attrgetter("_version")
 
-ENABLED = switches.get("BMV_AUTOGRAPH") != 0
-DEFER = switches.get("BMV_AUTOGRAPH_DEFER") != 0    # large inputs / outputs through a pointer table (no copies)
-RING = switches.get("BMV_AUTOGRAPH_RING") != 0      # ... fed by the frame's own first node from a host ring (no launch)
-MAX_GRAPHS = switches.get("BMV_AUTOGRAPH_MAX")
+# BMV_AUTOGRAPH (self-capturing forward), BMV_AUTOGRAPH_DEFER (large inputs / outputs through a pointer table, no
+# copies), BMV_AUTOGRAPH_RING (the table fed by the frame's own first node from a host ring, no launch) and
+# BMV_AUTOGRAPH_MAX (graphs kept per network) are read when a call / a capture needs them: `switches.set()` after import
+# takes effect on the next call (entries captured before keep the form they were captured in)
 
 
 def _built(v):
@@ -138,7 +138,7 @@ class AutoGraph:
                      if torch.is_tensor(v) and not _built(v))
 
     def usable(self, batch):
-        if not ENABLED or self.net.training:
+        if switches.get("BMV_AUTOGRAPH") == 0 or self.net.training:
             return False
         probe = None
         grad = torch.is_grad_enabled()
@@ -397,7 +397,7 @@ class AutoGraph:
 
     def _capture(self, key, batch, version, resident):
         from .framegraph import FrameGraph
-        if len(self.entries) >= MAX_GRAPHS:          # every graph owns a private memory pool: keep a few
+        if len(self.entries) >= max(1, int(switches.get("BMV_AUTOGRAPH_MAX"))):          # every graph owns a private memory pool: keep a few
             victim = min(self.entries, key=lambda k: self.entries[k]["hits"])
             del self.entries[victim]
         # static inputs of the graph: private copies (default), or -- declared resident -- the caller's own tensors, kept
@@ -436,12 +436,12 @@ class AutoGraph:
         # the large inputs the network says its kernels can read through a pointer table (ops.PtrTable): registered
         # BEFORE the capture so that the wrappers defer them while the frame is captured
         tb = None
-        want = () if (resident or not DEFER) else getattr(self.net, "_autograph_deferrable", lambda b: ())(batch)
+        want = () if (resident or switches.get("BMV_AUTOGRAPH_DEFER") == 0) else getattr(self.net, "_autograph_deferrable", lambda b: ())(batch)
         def_in = []
         if want:
             probe = next(v for v in static.values() if torch.is_tensor(v))
             tb = ops.PtrTable(probe.device)
-            if RING:
+            if switches.get("BMV_AUTOGRAPH_RING") != 0:
                 tb.ring = ops.FeedRing(probe.device)
             for k in want:
                 v = static.get(k)

@@ -207,12 +207,15 @@ def conv3d_split_heads_records(x, wsplit, bias, parts):
 #           frame only -7 us of 881: the level-0 first layer runs beside FeatureNet's top-down path and is no faster
 #           there -- all 183 GPU tests pass unchanged with it, but it is not worth a default);
 #   "3" / "2": all four layers with three / two pieces (two = 2^-16 per product: the opt-in experiment, +7 % of the frame).
-_split_env = str(switches.get("BMV_CONV_SPLIT"))
-SPLIT_BF16 = _split_env if _split_env == "auto" else int(_split_env)
+def split_bf16_default():
+    """The policy a regulariser module is constructed with (`_CostReg.split_bf16`): read from the switch WHEN the module
+    is built, so `switches.set("BMV_CONV_SPLIT", ...)` after import counts (module constants froze it)."""
+    raw = str(switches.get("BMV_CONV_SPLIT")).strip()
+    return raw if raw == "auto" else int(raw)
 
 
-# The regularisers' first layers and heads on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip): BMV_CONV_C4=1 / 0
-CONV_C4 = switches.on("BMV_CONV_C4")
+# The regularisers' first layers and heads on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip): BMV_CONV_C4=1 / 0, read by the
+# modules at construction (`switches.on("BMV_CONV_C4")`)
 
 
 def split_parts(policy, kind, cin):

@@ -795,7 +795,13 @@ static int vox_feat_bwd_impl(const float* uvd01, const float* volume, const floa
                              bmv_stream_t stream, const char* name) {
   BMV_REQUIRE(uvd01 && volume && d_out && d_volume && d_d01, "%s: null pointer", name);
   BMV_REQUIRE(B > 0 && P >= 0 && C > 0 && D > 0 && h > 0 && w > 0, "%s: bad shape", name);
-  if (P == 0) return BMV_OK;
+  if (P == 0) {      // the float form adds into a caller-zeroed buffer; the fixed-point form WRITES its output
+    if (fixed.ws) {
+      fixed_zero(d_volume, (size_t)B * C * D * h * w, as_stream(stream));
+      BMV_LAUNCH_END(name);
+    }
+    return BMV_OK;
+  }
   int tw, th, tiles_x, nblocks;
   ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
   launch_modes(fixed, as_stream(stream), [&](auto mode) {
@@ -825,7 +831,13 @@ static int img_feat_bwd_impl(const float* xyz, const float* img_feat_rgb, const 
   BMV_REQUIRE(xyz && img_feat_rgb && src_exts && src_ixts && tar_ext && d_out && d_img && d_xyz, "%s: null pointer", name);
   BMV_REQUIRE(B > 0 && P >= 0 && S > 0 && S <= 16 && C > 0 && H > 1 && W > 1, "%s: bad shape", name);
   BMV_REQUIRE(c_grad >= 0 && c_grad <= C, "%s: c_grad=%d outside [0, %d]", name, c_grad, C);
-  if (P == 0) return BMV_OK;
+  if (P == 0) {
+    if (fixed.ws) {
+      fixed_zero(d_img, (size_t)B * S * C * H * W, as_stream(stream));
+      BMV_LAUNCH_END(name);
+    }
+    return BMV_OK;
+  }
   int tw, th, tiles_x, nblocks;
   ray_tiles(P, ray_w, Ns, tw, th, tiles_x, nblocks);
   launch_modes(fixed, as_stream(stream), [&](auto mode) {
@@ -867,8 +879,15 @@ static int build_rays_bwd_impl(const float* rays, const float* depth, const floa
                                float* d_depth, float* d_std, FixedWs fixed, bmv_stream_t stream, const char* name) {
   BMV_REQUIRE(rays && depth && std_ && near_far && d_near_far && d_depth && d_std, "%s: null pointer", name);
   BMV_REQUIRE(B > 0 && N >= 0 && hv > 0 && wv > 0 && Hr > 0 && Wr > 0, "%s: bad shape", name);
-  if (N == 0) return BMV_OK;
   const size_t n_out = (size_t)B * hv * wv;
+  if (N == 0) {
+    if (fixed.ws) {
+      fixed_zero(d_depth, n_out, as_stream(stream));
+      fixed_zero(d_std, n_out, as_stream(stream));
+      BMV_LAUNCH_END(name);
+    }
+    return BMV_OK;
+  }
   launch_modes(fixed, as_stream(stream), [&](auto mode) {
     hipLaunchKernelGGL(build_rays_bwd_kernel<decltype(mode)::value>, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream),
                        rays, depth, std_, near_far, d_near_far, N, hv, wv, Hr, Wr, depth_inv, d_depth, d_std, n_out, fixed);

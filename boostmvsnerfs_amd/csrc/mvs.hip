@@ -1153,7 +1153,13 @@ static int mvs_vol_feat_bwd_impl(const float* rays, const float* src_ext0, const
                                  float* d_volume, FixedWs fixed, bmv_stream_t stream, const char* name) {
   BMV_REQUIRE(rays && src_ext0 && src_ixt0 && near_far && d_feat && d_volume, "%s: null pointer", name);
   BMV_REQUIRE(N >= 0 && Ns > 0 && H > 1 && W > 1 && D > 0 && hp > 0 && wp > 0, "%s: bad shape", name);
-  if (N == 0) return BMV_OK;
+  if (N == 0) {      // the float form adds into a caller-zeroed buffer; the fixed-point form WRITES its output
+    if (fixed.ws) {
+      fixed_zero(d_volume, (size_t)8 * D * hp * wp, as_stream(stream));
+      BMV_LAUNCH_END(name);
+    }
+    return BMV_OK;
+  }
   const long npts = N * Ns;
   launch_modes(fixed, as_stream(stream), [&](auto mode) {
     hipLaunchKernelGGL(mvs_vol_feat_bwd_kernel<decltype(mode)::value>, dim3(cdiv(npts, 256)), dim3(256), 0,

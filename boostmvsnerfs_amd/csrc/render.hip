@@ -795,8 +795,14 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   RENDER_CASE_PC(1, 3)
   RENDER_CASE_PC(4, 3)
   RENDER_CASE_PC(8, 3)
-  RENDER_CASE_PC(2, 2)      // 2 / 4 source views (ENeRF pre-training, dtu_pretrain.yaml:22-23): the shipped sample counts
+  RENDER_CASE_PC(2, 2)      // 2 / 4 source views (ENeRF pre-training, dtu_pretrain.yaml:22-23; test_input_views)
   RENDER_CASE_PC(2, 4)
+  RENDER_CASE_PC(1, 2)      // ... at every sample count the 3-view form has (S = 2 / 4 x Ns = 1 / 4 / 8 failed)
+  RENDER_CASE_PC(4, 2)
+  RENDER_CASE_PC(8, 2)
+  RENDER_CASE_PC(1, 4)
+  RENDER_CASE_PC(4, 4)
+  RENDER_CASE_PC(8, 4)
 #undef RENDER_CASE_PC
 #define RENDER_CASE_PK(FC, NSV, INVV, PKV, NVV)                                                                     \
   if (a->im_packed && (a->vol_packed ? 3 : 1) == PKV && a->feat_ch == FC && a->Ns == NSV && (a->depth_inv != 0) == INVV && \
@@ -820,6 +826,18 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   RENDER_CASE_PK(8, 2, false, 3, 2)
   RENDER_CASE_PK(8, 2, false, 1, 4)
   RENDER_CASE_PK(8, 2, false, 3, 4)
+  RENDER_CASE_PK(8, 1, false, 1, 2)
+  RENDER_CASE_PK(8, 1, false, 3, 2)
+  RENDER_CASE_PK(8, 4, false, 1, 2)
+  RENDER_CASE_PK(8, 4, false, 3, 2)
+  RENDER_CASE_PK(8, 8, false, 1, 2)
+  RENDER_CASE_PK(8, 8, false, 3, 2)
+  RENDER_CASE_PK(8, 1, false, 1, 4)
+  RENDER_CASE_PK(8, 1, false, 3, 4)
+  RENDER_CASE_PK(8, 4, false, 1, 4)
+  RENDER_CASE_PK(8, 4, false, 3, 4)
+  RENDER_CASE_PK(8, 8, false, 1, 4)
+  RENDER_CASE_PK(8, 8, false, 3, 4)
 #undef RENDER_CASE_PK
   BMV_REQUIRE(!a->im_packed && !a->vol_packed,
               "bmv_render_rays_fwd: no lookup-record kernel for feat_ch=%d Ns=%d depth_inv=%d S=%d (volume records: %d)",
@@ -844,8 +862,19 @@ int bmv_render_rays_fwd(const bmv_render_args* a, bmv_stream_t stream) {
   RENDER_CASE(32, 8, true, 2)
   RENDER_CASE(8, 2, false, 4)
   RENDER_CASE(32, 8, true, 4)
+  RENDER_CASE(8, 1, false, 2)
+  RENDER_CASE(8, 4, false, 2)
+  RENDER_CASE(8, 8, false, 2)
+  RENDER_CASE(32, 2, true, 2)
+  RENDER_CASE(32, 4, true, 2)
+  RENDER_CASE(8, 1, false, 4)
+  RENDER_CASE(8, 4, false, 4)
+  RENDER_CASE(8, 8, false, 4)
+  RENDER_CASE(32, 2, true, 4)
+  RENDER_CASE(32, 4, true, 4)
 #undef RENDER_CASE
-  set_error("bmv_render_rays_fwd: no kernel for feat_ch=%d Ns=%d depth_inv=%d S=%d", a->feat_ch, a->Ns, a->depth_inv, a->S);
+  set_error("bmv_render_rays_fwd: no kernel for feat_ch=%d Ns=%d depth_inv=%d S=%d (built: feat_ch 8 / linear depth with Ns 1, 2, 4, 8; "
+            "feat_ch 32 / inverse depth with Ns 2, 4, 8; S 2, 3, 4 each)", a->feat_ch, a->Ns, a->depth_inv, a->S);
   return BMV_ERR_UNSUPPORTED;
 }
 

@@ -95,6 +95,17 @@ static inline void fixed_finish(FixedWs f, size_t offset, size_t n, float* dst, 
   if (n) hipLaunchKernelGGL(fixed_finish_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, f.acc(offset), f.scale2(), n, dst);
 }
 
+// An EMPTY input (no rays / samples): the float forms add nothing into their caller-zeroed outputs and return; the
+// fixed-point forms WRITE their outputs (callers hand them uninitialised memory), so they write zeros.  A kernel, not
+// hipMemsetAsync: a memset node did not reliably clear its buffer on later replays of a captured step.
+static __global__ void fixed_zero_kernel(float* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = 0.f;
+}
+static inline void fixed_zero(float* dst, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(fixed_zero_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, dst, n);
+}
+
 // the passes of a launch: float atomics, or (fixed.ws set) magnitude pass -> scale -> fixed-point pass (scatter.hpp);
 // `launch(mode)` issues the kernel with MODE = decltype(mode)::value
 template <class L>

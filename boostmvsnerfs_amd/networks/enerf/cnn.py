@@ -35,9 +35,8 @@ def _engine_ok(module, x):
             and switches.get("BMV_CNN") != "torch")
 
 
-FUSE_FPN_SMOOTH = switches.on("BMV_FPN_FUSE")
-FUSE_CONV0 = switches.on("BMV_CONV0_FUSE")
-FUSE_TOP = switches.on("BMV_TOP_FUSE")
+# (BMV_FPN_FUSE / BMV_CONV0_FUSE / BMV_TOP_FUSE are read where FeatureNet's engine path runs: `switches.set()` /
+# `override()` after import take effect on the next forward)
 
 class _Packed:
     """Folded + packed weights of a module, rebuilt when any parameter / buffer changes (in-place updates
@@ -155,7 +154,7 @@ class FeatureNet(nn.Module):
         sweep reads.  The coarsest map is all the level-0 cost volume needs, so a caller can start that cascade level
         while `engine_top_down` is still running."""
         P = self._blobs()
-        if FUSE_CONV0:    # the 3-channel first layer is computed in the second layer's tile producer: one launch
+        if switches.on("BMV_CONV0_FUSE"):    # the 3-channel first layer is computed in the second layer's tile producer: one launch
             c0 = convnet.conv0_fused(x, *P["conv0.0_raw"], *P["conv0.1"], 8)
         else:
             c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
@@ -165,7 +164,7 @@ class FeatureNet(nn.Module):
         c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
         # the coarsest map is written once, channel-last (the level-0 sweep's layout); the top-down step reads it so
         quad = self.quad_out      # the plane sweep's quad-planar layout (inference default) or channel-last
-        if FUSE_TOP:      # conv2.1 + toplayer: the 1x1 layer is a second stage of the 3x3 layer's workgroups
+        if switches.on("BMV_TOP_FUSE"):      # conv2.1 + toplayer: the 1x1 layer is a second stage of the 3x3 layer's workgroups
             p2 = convnet.conv_top(c2, *P["conv2.1"], *P["toplayer"], quad=quad)
         else:
             c2 = convnet.conv_fwd(c2, *P["conv2.1"], 32, 1, 3, relu=True)
@@ -181,7 +180,7 @@ class FeatureNet(nn.Module):
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
         if rgb is not None:
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
-        elif FUSE_FPN_SMOOTH:
+        elif switches.on("BMV_FPN_FUSE"):
             # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0"], 8)
         else:
@@ -232,10 +231,10 @@ class _CostReg(nn.Module):
         self.volume_records = False   # engine path: emit the feature volume as the renderer's voxel records
         # first layer and heads on the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip): 0 = fp32 MFMA
         # engine (default), "auto" = three pieces (fp32-equivalent) where faster stand-alone, 3 / 2 = all with 3 / 2 pieces
-        self.split_bf16 = convnet.SPLIT_BF16
+        self.split_bf16 = convnet.split_bf16_default()
         # first layer (32 | 16 -> 8) and heads (8 -> 8 + 1) on v_mfma_f32_4x4x1 (csrc/conv_c4.hip: every matrix row useful
         # for 8 output channels; the 16-row kernels of conv.hip reach 75 % / 56 %): same fp32 FMA chains per output
-        self.conv_c4 = convnet.CONV_C4
+        self.conv_c4 = switches.on("BMV_CONV_C4")
         self.quad_volume = switches.on("BMV_QUAD_VOLUME")
         self.quad_s0 = switches.on("BMV_QUAD_S0")
 

@@ -37,6 +37,20 @@ class LevelState:
         self.keep = None      # tensors a side stream still reads: kept alive until the level state dies
 
 
+def _check_renderer_case(S, Ns, feat_ch, depth_inv):
+    """The fused renderer (bmv_render_rays_fwd) is instantiated for S in {2, 3, 4} source views x (feat_ch 8, linear
+    depth, Ns in {1, 2, 4, 8}) and (feat_ch 32, inverse depth, Ns in {2, 4, 8}): the cascade levels of every shipped
+    config and their `num_samples` / `test_input_views` variations.  Anything else is refused HERE, by name, before a
+    launch (the reference's torch ops take any combination, lib/networks/enerf/network.py:24-43)."""
+    ok = (2 <= S <= 4) and ((feat_ch == 8 and not depth_inv and Ns in (1, 2, 4, 8)) or
+                            (feat_ch == 32 and depth_inv and Ns in (2, 4, 8)))
+    if not ok:
+        raise NotImplementedError(
+            f"fused renderer: no kernel for {S} source views, {Ns} samples per ray, {feat_ch} feature channels, "
+            f"depth_inv={depth_inv}.  Built: S in (2, 3, 4) with (feat_ch 8, depth_inv False, Ns in 1/2/4/8) or "
+            "(feat_ch 32, depth_inv True, Ns in 2/4/8) -- INTEGRATION.md, 'Limits'")
+
+
 class Network(nn.Module):
     def __init__(self):
         super().__init__()
@@ -199,6 +213,9 @@ class Network(nn.Module):
                                                       align_corners=True, mode="bilinear")
             im_feat = im_feat.view(b_, s_, c_, int(h_ * up), int(w_ * up))
         Ns, inv = cc.num_samples[i], cc.depth_inv[i]
+        if not 2 <= src_exts.shape[1] <= 4:
+            raise NotImplementedError(f"{src_exts.shape[1]} source views per cost volume: the fused MLP kernels (forward and "
+                                      "backward) are built for 2, 3 or 4 (INTEGRATION.md, 'Limits')")
         xyz, uvd, z = A.SampleAlongDepth.apply(rays12.contiguous(), Ns, inv)
         uvd01 = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1).reshape(B, -1, 3)
         full = xyz.shape[1] == Hr * Wr          # a whole frame of rays (train_img): the scatter kernels tile it in 2-D
@@ -253,6 +270,7 @@ class Network(nn.Module):
                 raise ValueError("view_ids need render_scale 1 (the resized colour maps are per cost volume)")
             rgb_src, affine = ops.unpreprocess(src_inps, Hr, Wr), False
         nerf = getattr(self, f"nerf_{i}")
+        _check_renderer_case(src_exts.shape[1], int(cc.num_samples[i]), nerf.feat_ch - 3, bool(cc.depth_inv[i]))
         rays = batch[f"rays_{i}"]
         N = rays.shape[1]
         begin, end = self.ray_range if self.ray_range is not None else (0, N)

@@ -1075,6 +1075,8 @@ def vox_feat_bwd(uvd01, volume, d_out, ray_w=0, Ns=0):
     _, C_, D, h, w = volume.shape
     d_d = torch.empty(B, P, device=volume.device, dtype=torch.float32)
     lib = _lib.load()
+    if P == 0:          # an empty ray shard / chunk: no sample, zero gradient (an empty tensor has no device pointer)
+        return torch.zeros_like(volume, memory_format=torch.contiguous_format), d_d
     if deterministic():
         d_vol = torch.empty_like(volume, memory_format=torch.contiguous_format)
         ws = _fixed_ws(d_vol.numel(), volume.device)
@@ -1098,6 +1100,8 @@ def img_feat_bwd(xyz, img_feat_rgb, src_exts, src_ixts, tar_ext, render_scale, d
     P = pts.shape[1]
     d_xyz = torch.empty(B, P, 3, device=xyz.device, dtype=torch.float32)
     lib = _lib.load()
+    if P == 0:
+        return torch.zeros_like(img_feat_rgb, memory_format=torch.contiguous_format), d_xyz.reshape(xyz.shape)
     if deterministic():
         d_img = torch.empty_like(img_feat_rgb, memory_format=torch.contiguous_format)
         ws = _fixed_ws(d_img.numel(), xyz.device)
@@ -1131,6 +1135,9 @@ def build_rays_bwd(rays, depth, std, near_far, d_nf, Hr, Wr, depth_inv):
     B, N = rays.shape[:2]
     hv, wv = depth.shape[-2:]
     lib = _lib.load()
+    if N == 0:
+        return (torch.zeros_like(depth, memory_format=torch.contiguous_format),
+                torch.zeros_like(std, memory_format=torch.contiguous_format))
     if deterministic():
         d_depth = torch.empty_like(depth, memory_format=torch.contiguous_format)
         d_std = torch.empty_like(std, memory_format=torch.contiguous_format)
@@ -1365,6 +1372,8 @@ def mvs_vol_feat_bwd(rays, src_ext0, src_ixt0, near_far, d_feat, H, W, vol_shape
     N, Ns = d_feat.shape[:2]
     _, D, hp, wp = vol_shape
     lib = _lib.load()
+    if N == 0:
+        return torch.zeros(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
     if deterministic():
         d_vol = torch.empty(8, D, hp, wp, device=d_feat.device, dtype=torch.float32)
         ws = _fixed_ws(d_vol.numel(), d_feat.device)

@@ -154,18 +154,33 @@ class VolumeShard:
         G, sub = self.G, self.sub
         if G == 1:
             return raws, zs, ms
-        pack = torch.zeros(kl, G * sub, Ns, 6, device=raws.device, dtype=torch.float32)
+        # persistent buffers (torch.zeros / .contiguous() / torch.cat on every step are a visible cost at
+        # 0.8 ms frames): the padded pack (its padding rows are zeroed once and never written), the peer-major send and
+        # receive blocks and the three outputs live as long as the shapes do; the returned tensors are valid until the
+        # next exchange() of this object (the blend consumes them inside the step)
+        key = (kl, n_r, Ns, raws.device)
+        if getattr(self, "_xbuf", None) is None or self._xbuf[0] != key:
+            dev = raws.device
+            pack = torch.zeros(kl, G * sub, Ns, 6, device=dev, dtype=torch.float32)
+            send = torch.empty(G, kl, sub, Ns, 6, device=dev, dtype=torch.float32)
+            b, e = self.sub_range()
+            outs = (torch.empty(1, self.K, e - b, Ns, 4, device=dev), torch.empty(1, self.K, e - b, Ns, device=dev),
+                    torch.empty(1, self.K, e - b, Ns, device=dev))
+            self._xbuf = (key, pack, send, torch.empty_like(send), outs)
+        _, pack, send, recv, outs = self._xbuf
         pack[:, :n_r, :, :4] = raws[0]
         pack[:, :n_r, :, 4] = zs[0]
         pack[:, :n_r, :, 5] = ms[0]
-        send = pack.view(kl, G, sub, Ns, 6).transpose(0, 1).contiguous()      # (G peers, kl, sub, Ns, 6)
-        recv = torch.empty_like(send)
+        send.copy_(pack.view(kl, G, sub, Ns, 6).transpose(0, 1))              # (G peers, kl, sub, Ns, 6)
         dist.all_to_all_single(recv, send, group=self.group)
         # recv[g'] = volumes {g', g' + G, ...} of peer g' for my sub-slice -> volume order k = j * G + g'
-        full = recv.permute(1, 0, 2, 3, 4).reshape(self.K, sub, Ns, 6)
-        b, e = self.sub_range()
-        full = full[:, : e - b]
-        return (full[None, ..., :4].contiguous(), full[None, ..., 4].contiguous(), full[None, ..., 5].contiguous())
+        # ((kl, G, sub, Ns, 6) view of the receive block: row (j, g') is volume k = j * G + g')
+        n_sub = outs[0].shape[2]
+        v = recv.permute(1, 0, 2, 3, 4)[:, :, :n_sub]
+        outs[0][0].view(kl, G, n_sub, Ns, 4).copy_(v[..., :4])
+        outs[1][0].view(kl, G, n_sub, Ns).copy_(v[..., 4])
+        outs[2][0].view(kl, G, n_sub, Ns).copy_(v[..., 5])
+        return outs
 
     def gather_tiles(self, rgb, depth):
         """Fused (1, n_sub, 3), (1, n_sub) of every rank's sub-slice -> the frame (n_rays, 4)."""
@@ -177,11 +192,23 @@ class VolumeShard:
         send[:n, 3] = depth.reshape(n)
         dist.all_gather_into_tensor(recv, send)
         parts = recv.view(self.world, self.sub_max, 4)
-        out = []
-        for r in range(self.R):
-            b, e = ray_slice(self.n_rays, self.R, r)
-            sub = -(-(e - b) // self.G)
-            for g in range(self.G):
-                lo, hi = min(b + g * sub, e), min(b + (g + 1) * sub, e)
-                out.append(parts[r * self.G + g, : hi - lo])
-        return torch.cat(out, 0)
+        # the frame buffer is persistent too: valid until the next gather_tiles() of this object
+        if getattr(self, "_frame", None) is None or self._frame.device != rgb.device:
+            self._frame = torch.empty(self.n_rays, 4, device=rgb.device)
+            self._spans = []
+            at = 0
+            for r in range(self.R):
+                b, e = ray_slice(self.n_rays, self.R, r)
+                sub = -(-(e - b) // self.G)
+                for g in range(self.G):
+                    lo, hi = min(b + g * sub, e), min(b + (g + 1) * sub, e)
+                    self._spans.append((r * self.G + g, at, hi - lo))
+                    at += hi - lo
+            assert at == self.n_rays
+            self._even = all(n_ == self.sub_max for _, _, n_ in self._spans)
+        if self._even:                       # every sub-slice is full: the gathered block IS the frame
+            return parts.reshape(self.n_rays, 4)
+        for rank_, at, n_ in self._spans:
+            if n_:
+                self._frame[at:at + n_].copy_(parts[rank_, :n_])
+        return self._frame

@@ -61,6 +61,10 @@ def _parse(name, raw):
         try:
             return int(raw, 0)
         except ValueError:
+            try:
+                return int(raw)           # "08" and the like, as `_lib.load` reads the library's tuning switches
+            except ValueError:
+                pass
             low = raw.lower()
             if low in ("true", "on", "yes"):
                 return 1

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Per-round evidence (PFX=r5 by default) for profiles/: per workload a bench line (bench.py, cpu_baseline included) and the rocprofv3
+# Per-round evidence (PFX=r6 by default) for profiles/: per workload a bench line (bench.py, cpu_baseline included) and the rocprofv3
 # --kernel-trace summary of the same command reduced to its steady-state steps (scripts/rocprof_steady.py).
 # Run on the MI355X box from the repo root:  bash scripts/collect_profiles.sh <outdir> [workload ...]
 set -u
-OUT=${1:-gpurun_out/r5_profiles}; shift || true
-PFX=${PFX:-r5}
+OUT=${1:-gpurun_out/r6_profiles}; shift || true
+PFX=${PFX:-r6}
 RM=${RENDER_MARKER:-render_pc_kernel}
 R=$(pwd); mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp

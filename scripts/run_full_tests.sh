@@ -1,7 +1,8 @@
 #!/bin/bash
-# the whole GPU suite + the entry point's smoke + the default bench line, timed
-R=$(pwd); O=$R/gpurun_out/r5_tests; mkdir -p $O
-N=${1:-2}
+# the whole GPU suite + the entry point's smoke + the default bench line, timed.   bash scripts/run_full_tests.sh [tag]
+PFX=${PFX:-r6}
+R=$(pwd); O=$R/gpurun_out/${PFX}_tests; mkdir -p $O
+N=${1:-1}
 python3 -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/pytest_gpu_$N.txt
 cat $O/pytest_gpu_$N.txt
 ( time python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) 2>&1 | tail -5 | tee $O/smoke_$N.txt

@@ -88,3 +88,18 @@ def test_view_ids_are_range_checked_on_the_host():
     with pytest.raises(ValueError, match="view_ids must lie"):
         ops.sweep_variance_views(cl, torch.tensor([[0, 1, 6]], dtype=torch.int32), torch.zeros(1, 3, 3, 4),
                                  torch.zeros(1, 2, 4, 4))
+
+
+def test_unsupported_renderer_cases_are_refused_by_name():
+    """view / sample counts outside the instantiated fused kernels fail BEFORE a launch with an error that
+    names the supported set (the reference's torch path takes any combination)."""
+    import pytest
+    from boostmvsnerfs_amd.networks.enerf.network import _check_renderer_case
+    for S in (2, 3, 4):
+        for Ns in (1, 2, 4, 8):
+            _check_renderer_case(S, Ns, 8, False)
+        for Ns in (2, 4, 8):
+            _check_renderer_case(S, Ns, 32, True)
+    for bad in ((5, 2, 8, False), (1, 2, 8, False), (3, 3, 8, False), (3, 16, 8, False), (3, 1, 32, True), (3, 2, 8, True)):
+        with pytest.raises(NotImplementedError, match="Built: S in"):
+            _check_renderer_case(*bad)

@@ -191,3 +191,38 @@ def test_fixed_point_scatter_is_bit_reproducible_and_as_accurate(enerf_fx):
         assert float(ops.vox_feat_bwd(uvd, vol, torch.zeros_like(go))[0].abs().max()) == 0.0
     finally:
         _lib.set_tuning("BMV_DETERMINISTIC", before)
+
+
+def test_empty_inputs_give_zero_scatter_gradients(enerf_fx, scatter_mode):
+    """An empty ray shard / chunk (P = 0 samples, N = 0 rays): the scatter gradients are ZERO in both modes -- through
+    the Python wrappers (an empty tensor has no device pointer: they answer without a launch) and through the C ABI
+    with valid pointers, where the *_fixed entry points WRITE their outputs (the float forms add into caller-zeroed
+    buffers) and used to return before writing anything."""
+    import ctypes as C
+    from boostmvsnerfs_amd import _lib, ops
+    vol = enerf_fx.t("cap/cost_reg_1#0.0").to(DEV)
+    d_vol, d_d = ops.vox_feat_bwd(torch.empty(1, 0, 3, device=DEV), vol, torch.empty(1, 0, 8, device=DEV))
+    assert d_vol.shape == vol.shape and float(d_vol.abs().max()) == 0.0 and d_d.shape == (1, 0)
+    img = torch.randn(1, 3, 11, 16, 24, device=DEV)
+    cam = torch.eye(4, device=DEV)[None, None].repeat(1, 3, 1, 1)
+    ixt = torch.eye(3, device=DEV)[None, None].repeat(1, 3, 1, 1)
+    d_img, d_xyz = ops.img_feat_bwd(torch.empty(1, 0, 3, device=DEV), img, cam, ixt, cam[:, 0], 1.0,
+                                    torch.empty(1, 0, 3, 11, device=DEV))
+    assert d_img.shape == img.shape and float(d_img.abs().max()) == 0.0 and d_xyz.numel() == 0
+    depth = torch.rand(1, 1, 8, 12, device=DEV)
+    d_depth, d_std = ops.build_rays_bwd(torch.empty(1, 0, 8, device=DEV), depth, depth.clone(), torch.tensor([[2.0, 6.0]], device=DEV),
+                                        torch.empty(1, 0, 2, device=DEV), 8, 12, False)
+    assert float(d_depth.abs().max()) == 0.0 and float(d_std.abs().max()) == 0.0
+    assert float(ops.mvs_vol_feat_bwd(torch.empty(0, 8, device=DEV), cam[0, 0], ixt[0, 0], torch.tensor([2.0, 6.0], device=DEV),
+                                      torch.empty(0, 4, 8, device=DEV), 16, 24, (8, 4, 6, 8), 2).abs().max()) == 0.0
+    # the C ABI with valid pointers and P = 0: the fixed-point twin overwrites a poisoned output with zeros
+    lib = _lib.load()
+    dummy = torch.zeros(16, device=DEV)
+    out = torch.full_like(vol, float("nan")).contiguous()
+    ws = ops._fixed_ws(out.numel(), vol.device)
+    B, C_, D, h, w = vol.shape
+    p = lambda t: C.c_void_p(t.data_ptr())       # noqa: E731
+    rc = lib.bmv_vox_feat_bwd_fixed(p(dummy), p(vol.contiguous()), p(dummy), B, 0, C_, D, h, w, 0, 0, p(out), p(dummy), p(ws), _lib.stream())
+    _lib.check(rc, "vox_feat_bwd_fixed")
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0

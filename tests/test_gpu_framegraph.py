@@ -434,3 +434,47 @@ def test_forward_resident_opt_in():
     assert ag.stats["captures"] == 1 and ag.stats["copies"] > 0
     for k in want3:
         assert torch.equal(got3[k], want3[k]), k
+
+
+def test_run_py_loop_with_new_device_tensors_every_frame_stays_on_the_fast_path():
+    """run.py:113-123 as the reference runs it: every frame the loader's HOST batch is moved into NEW device tensors
+    (`batch[k] = batch[k].cuda()`) and handed to `network(batch)`.  VERDICT r5 item 4 (bench's `host_batch_sync` read
+    2.6x slower than the eager leg): the probe (profiles/r6/host_batch_sync_probe.txt) shows one eager + one capturing
+    call and then nothing but replays fed through the host ring's fast path -- asserted here by the counters: 20 frames
+    on never-seen addresses = 1 eager call, 1 capture, 18 replays, every replay through `post_fast` (no copy launch, no
+    slow `post`), no ring fault, and every frame bit-equal to the eager frame of the same host batch."""
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    net, eager = _small_net()
+    ag = net._autograph
+    hosts = [make_batch(128, 160, n_views=3, seed=s) for s in (0, 1)]
+    reads = net._autograph_inputs(clone_batch(hosts[0], DEV))
+    pinned = [{k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in h.items()
+               if not torch.is_tensor(v) or reads is None or k in reads} for h in hosts]
+    want = [eager(clone_batch(h, DEV)) for h in pinned]
+    seen_ptrs = set()
+    slow_posts = []
+    frames = []
+    for i in range(20):
+        fresh = {k: (v.to(DEV, non_blocking=True) if torch.is_tensor(v) else v) for k, v in pinned[i % 2].items()}
+        seen_ptrs.add(fresh["src_inps"].data_ptr())
+        with torch.no_grad():
+            out = net(fresh)
+        torch.cuda.synchronize()                     # run.py's bracket
+        frames.append(out)
+        if i == 1:                                   # from the capture on: the slow post must never run again
+            ring = ag._hot["ring"]
+            real_post = ring.post
+
+            def post(*a, **k):
+                slow_posts.append(a)
+                return real_post(*a, **k)
+            ring.post = post
+    assert ag.stats["eager"] == 1 and ag.stats["captures"] == 1 and ag.stats["replays"] == 19, ag.stats
+    assert "defer_rejected" not in ag.stats
+    ring = ag._hot["ring"]
+    assert ring.fast is not None and not slow_posts
+    assert ring.faults() == 0 and int(ring.state[0].item()) == ring.posted
+    for i, f in enumerate(frames):
+        for k in want[i % 2]:
+            assert torch.equal(f[k], want[i % 2][k]), (i, k)
+    assert len({f["rgb_level1"].data_ptr() for f in frames[2:]}) > 1           # (outputs are not one recycled buffer)

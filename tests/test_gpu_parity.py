@@ -620,6 +620,43 @@ def test_enerf_with_2_and_4_source_views(enerf_fx, S):
     assert not gemms, f"S={S}: GEMM launches on the path: {gemms}"
 
 
+@pytest.mark.parametrize("n_views,num_samples,render_if", [(2, [8, 1], [False, True]), (2, [8, 4], [False, True]),
+                                                          (2, [4, 8], [True, True]), (4, [8, 1], [False, True]),
+                                                          (4, [8, 4], [False, True]), (4, [2, 8], [True, True])])
+@pytest.mark.parametrize("records", [True, False])
+def test_two_and_four_views_at_every_sample_count(n_views, num_samples, render_if, records):
+    """with S = 2 / 4 source views only the shipped sample counts (2 at level 1, 8 at level 0) had fused
+    renderer kernels; users vary `test_input_views` and `num_samples` independently (lib/networks/enerf/network.py:24-43
+    works for any combination).  Whole frames of `Network.forward` at S in {2, 4} x Ns in {1, 4, 8} (level 1: feat_ch 8)
+    and Ns in {2, 4} (level 0: feat_ch 32, inverse depth), through the lookup-record (producer / consumer) and the
+    planar-lookup renderers, against the oracle's frame on the same weights and batch."""
+    from boostmvsnerfs_amd.config import make_cfg, set_cfg
+    from boostmvsnerfs_amd.networks.enerf.network import Network
+    from boostmvsnerfs_amd.synthetic import clone_batch, make_batch
+    from oracle import enerf as O
+    cfg = make_cfg("enerf_eval")
+    cfg.enerf.cas_config.volume_planes = [16, 8]
+    cfg.enerf.cas_config.num_samples = list(num_samples)
+    cfg.enerf.cas_config.render_if = list(render_if)
+    set_cfg(cfg)
+    torch.manual_seed(0)
+    net = Network().eval()
+    with torch.no_grad():
+        for i in range(2):
+            getattr(net, f"cost_reg_{i}").depth_conv[0].weight.mul_(40.0)
+    batch = make_batch(64, 96, n_views=n_views, seed=5)
+    with torch.no_grad():
+        want = O.enerf_forward({k: v.clone() for k, v in net.state_dict().items()}, clone_batch(batch), cfg)
+        net = net.to(DEV)
+        net.lookup_records = records
+        got = net._forward_checked(clone_batch(batch, DEV))
+    levels = [i for i in range(2) if render_if[i]]
+    assert levels and all(f"rgb_level{i}" in got for i in levels)
+    for i in levels:
+        for k in (f"rgb_level{i}", f"depth_level{i}"):
+            assert_close(got[k], want[k], name=f"S={n_views} Ns={num_samples} records={records} {k}")
+
+
 @pytest.mark.parametrize("n_views", [3, 2, 4])
 def test_renderer_split_bf16_experiment_is_fp32_equivalent(n_views):
     """bmv_tuning BMV_RENDER_SPLIT (default 1 since the end of round 5; 0 = every chain on fp32 MFMAs): the MLP's two-tile

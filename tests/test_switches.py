@@ -46,3 +46,34 @@ def test_quad_volume_is_a_view_of_the_reference_layout():
     assert torch.equal(q.to_planar(), x)
     with pytest.raises(ValueError):
         ops.QuadVolume(x)
+
+
+def test_switches_set_after_import_are_honoured():
+    """several switches were read once into module constants (convnet.CONV_C4 / SPLIT_BF16, cnn.FUSE_*,
+    autograph.ENABLED / DEFER / RING / MAX_GRAPHS), so `switches.set()` / `override()` after import silently changed
+    nothing.  They are read at construction / call time now; "08" parses as `_lib.load` parses the library's switches."""
+    from boostmvsnerfs_amd import autograph, convnet
+    from boostmvsnerfs_amd.networks.enerf import cnn
+    for mod, names in ((convnet, ("CONV_C4", "SPLIT_BF16")), (cnn, ("FUSE_FPN_SMOOTH", "FUSE_CONV0", "FUSE_TOP")),
+                       (autograph, ("ENABLED", "DEFER", "RING", "MAX_GRAPHS"))):
+        for n in names:
+            assert not hasattr(mod, n), f"{mod.__name__}.{n} is an import-time copy of a switch again"
+    assert convnet.split_bf16_default() == 0
+    with switches.override(BMV_CONV_SPLIT="auto"):
+        assert convnet.split_bf16_default() == "auto"
+    with switches.override(BMV_CONV_SPLIT="3", BMV_CONV_C4=0):
+        assert convnet.split_bf16_default() == 3
+        reg = cnn.MinCostRegNet(8)
+        assert reg.split_bf16 == 3 and reg.conv_c4 is False
+    assert cnn.MinCostRegNet(8).conv_c4 is True
+
+    class _Net:
+        training = False
+
+        def parameters(self):
+            return iter(())
+    import torch
+    ag = autograph.AutoGraph(_Net())
+    with switches.override(BMV_AUTOGRAPH=0):
+        assert ag.usable({"x": torch.zeros(1)}) is False
+    assert switches._parse("BMV_AUTOGRAPH_MAX", "08") == 8
