@@ -186,6 +186,83 @@ def conv3d_split_fwd(x, wsplit, bias, parts, Cout, relu=False, slope=None, out=N
     return out
 
 
+def _split3_words(w):
+    """float32 tensor (..., 8) -> three int32 tensors (..., 4): the hi / mid / lo bf16 pieces of every value (hi = the upper
+    16 bits, mid = the upper 16 bits of w - hi, lo = w - hi - mid, which has at most 8 significant bits left: hi + mid + lo
+    == w EXACTLY), packed in pairs [even | odd << 16] -- the arithmetic of csrc/conv_c4s.hip's staging, on the host."""
+    trunc = lambda t: (t.view(torch.int32) & -65536).view(torch.float32)      # noqa: E731
+    top16 = lambda t: (t.view(torch.int32) >> 16) & 0xFFFF                       # noqa: E731
+    hi = trunc(w)
+    r = w - hi
+    mid = trunc(r)
+    lo = (r - mid).to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+    pack = lambda t: t[..., 0::2] | (t[..., 1::2] << 16)                         # noqa: E731
+    return pack(top16(hi)), pack(top16(mid)), pack(lo)
+
+
+def pack_conv_c4s(weight, bias, pair=None):
+    """weight (Cout, Cin % 8 == 0, 3, 3, 3), bias (Cout) or None -> (wsplit, bias16, pair) of bmv_conv_c4s_fwd
+    (csrc/conv_c4s.hip; include/bmv.h has the layout): int32 [octet][step][piece 3][lane 64][4].  pair (default: Cout == 8):
+    the row-paired form -- matrix row m = (output row m // 8, channel m % 8), 36 tap slots (kz, j, kx) over the 4 input
+    rows j a row pair touches -- else row m = channel m and 27 + 1 slots."""
+    Cout, Cin = weight.shape[:2]
+    assert weight.shape[2:] == (3, 3, 3) and Cin % 8 == 0 and Cout <= 16
+    pair = (Cout == 8) if pair is None else bool(pair)
+    assert not pair or Cout == 8
+    dev = weight.device
+    w5 = weight.detach().float()
+    if pair:
+        w = torch.zeros(2, 8, Cin, 3, 4, 3, device=dev, dtype=torch.float32)       # (r, c, cin, kz, j, kx)
+        w[0, :, :, :, 0:3] = w5
+        w[1, :, :, :, 1:4] = w5
+        w = w.reshape(16, Cin, 36)
+        steps = 9
+    else:
+        w = torch.zeros(16, Cin, 28, device=dev, dtype=torch.float32)
+        w[:Cout, :, :27] = w5.reshape(Cout, Cin, 27)
+        steps = 7
+    # (m, o, c, g, kk) -> (o, g, kk, m, c): lane = 16 kk + m, the lane's 8 values = the octet's channels at slot 4 g + kk
+    w = w.view(16, Cin // 8, 8, steps, 4).permute(1, 3, 4, 0, 2).reshape(Cin // 8, steps, 64, 8).contiguous()
+    wsplit = torch.stack(_split3_words(w), 2).contiguous()                         # (o, g, 3, 64, 4)
+    b = torch.zeros(16, device=dev, dtype=torch.float32)
+    if bias is not None:
+        b[:Cout] = bias.detach().float()
+    return wsplit, b, pair
+
+
+def conv_c4s_fwd(x, wsplit, bias, pair, Cout, relu=False, slope=None, records=False, quad_out=False):
+    """x = ops.QuadVolume (B,Cin/4,D,H,W,4), Cin % 8 == 0 -> act(conv3d(x, 3x3x3, stride 1, padding 1) + bias) on the bf16
+    matrix cores with three-piece fp32 operands (csrc/conv_c4s.hip: fp32 accuracy).  records: the renderer's volume
+    records (VolumeRecords of channels 0..7 + the planar channel 8 when Cout == 9); quad_out (Cout % 4 == 0): the result
+    as an ops.QuadVolume; else the planar tensor."""
+    assert isinstance(x, ops.QuadVolume), "conv_c4s_fwd stages quad records (ops.QuadVolume)"
+    xd = x.data
+    B, Q, D, H, W, _ = xd.shape
+    Cin = 4 * Q
+    lib = _lib.load()
+    assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_conv_c4s_wsplit_ints(Cin, int(pair))
+    xd = xd if xd.is_contiguous() else xd.contiguous()
+    out2 = None
+    quad_out = bool(quad_out) and Cout % 4 == 0 and not records
+    if records:
+        assert Cout in (8, 9)
+        out = torch.empty(B, D, H, W, 8, device=xd.device, dtype=torch.float32)
+        if Cout == 9:
+            out2 = torch.empty(B, D, H, W, device=xd.device, dtype=torch.float32)
+    elif quad_out:
+        out = torch.empty(B, Cout // 4, D, H, W, 4, device=xd.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Cout, D, H, W, device=xd.device, dtype=torch.float32)
+    with ktimer.region(f"conv_c4s[{Cin}->{Cout},{D}x{H}x{W}]"):
+        rc = lib.bmv_conv_c4s_fwd(dptr(xd, "conv input"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out),
+                                  dptr(out2) if out2 is not None else None, B, Cin, D, H, W, Cout, int(pair),
+                                  _slope(relu, slope), 2 if records else 8 if quad_out else 0, stream())
+    _lib.check(rc, "conv_c4s_fwd")
+    if records:
+        return VolumeRecords(out), out2
+    return ops.QuadVolume(out) if quad_out else out
+
+
 def conv3d_split_heads_records(x, wsplit, bias, parts):
     """conv_heads_records on the split-bf16 path (weights packed with pack_conv_split in VolumeRecords.ORDER)."""
     B, Cin, D, H, W = x.shape

@@ -235,6 +235,9 @@ class _CostReg(nn.Module):
         # first layer (32 | 16 -> 8) and heads (8 -> 8 + 1) on v_mfma_f32_4x4x1 (csrc/conv_c4.hip: every matrix row useful
         # for 8 output channels; the 16-row kernels of conv.hip reach 75 % / 56 %): same fp32 FMA chains per output
         self.conv_c4 = switches.on("BMV_CONV_C4")
+        # ... and on the bf16 matrix cores with three-piece fp32 operands where the input arrives as quad records
+        # (csrc/conv_c4s.hip: the sums of the fp32 kernel to fp32 rounding, 3.4 x the matrix rate)
+        self.conv_c4s = switches.on("BMV_CONV_C4S")
         self.quad_volume = switches.on("BMV_QUAD_VOLUME")
         self.quad_s0 = switches.on("BMV_QUAD_S0")
 
@@ -266,6 +269,10 @@ class _CostReg(nn.Module):
             P["heads_c4"] = convnet.pack_conv_c4(heads, None)
             P["heads_rec_c4"] = convnet.pack_conv_c4(heads[list(convnet.VolumeRecords.ORDER)], None)
             P["conv11_c4"] = convnet.pack_convT_c4(*convnet.fold_bn(self.conv11[0].weight, self.conv11[1], out_dim=1))
+            if self.conv0.conv.weight.shape[1] % 8 == 0:      # (csrc/conv_c4s.hip; used when self.conv_c4s)
+                P["conv0_c4s"] = convnet.pack_conv_c4s(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn))
+            P["heads_c4s"] = convnet.pack_conv_c4s(heads, None)
+            P["heads_rec_c4s"] = convnet.pack_conv_c4s(heads[list(convnet.VolumeRecords.ORDER)], None)
             for parts in (2, 3):     # (csrc/conv_split.hip; used when self.split_bf16 == parts; < 100 KB per regulariser)
                 P[f"conv0_split{parts}"] = convnet.pack_conv_split(*convnet.fold_bn(self.conv0.conv.weight, self.conv0.bn), parts=parts)
                 P[f"heads_split{parts}"] = convnet.pack_conv_split(heads, None, parts=parts)
@@ -281,6 +288,8 @@ class _CostReg(nn.Module):
             x = x.to_planar()
         if split:
             s0 = convnet.conv3d_split_fwd(x, *P[f"conv0_split{split}"], 8, relu=True)
+        elif self.conv_c4 and self.conv_c4s and isinstance(x, ops.QuadVolume) and "conv0_c4s" in P:
+            s0 = convnet.conv_c4s_fwd(x, *P["conv0_c4s"], 8, relu=True, quad_out=self.quad_volume and self.quad_s0)
         elif self.conv_c4:
             # (quad records out as well: the stride-2 layer and conv11's skip add stage them with 16-byte loads)
             s0 = convnet.conv_c4_fwd(x, *P["conv0_c4"], 8, relu=True, quad_out=self.quad_volume and self.quad_s0)
@@ -302,11 +311,16 @@ class _CostReg(nn.Module):
         if self.volume_records:      # the feature volume as the fused renderer's 32-byte voxel records
             if split:
                 return convnet.conv3d_split_heads_records(y, *P[f"heads_rec_split{split}"])
+            if self.conv_c4 and self.conv_c4s and isinstance(y, ops.QuadVolume):
+                return convnet.conv_c4s_fwd(y, *P["heads_rec_c4s"], 9, records=True)
             if self.conv_c4:
                 return convnet.conv_c4_fwd(y, *P["heads_rec_c4"], 9, records=True)
             return convnet.conv_heads_records(y, *P["heads_rec"])
         if split:
             heads = convnet.conv3d_split_fwd(y, *P[f"heads_split{split}"], 9)
+            return heads[:, :8], heads[:, 8]
+        if self.conv_c4 and self.conv_c4s and isinstance(y, ops.QuadVolume):
+            heads = convnet.conv_c4s_fwd(y, *P["heads_c4s"], 9)
             return heads[:, :8], heads[:, 8]
         if self.conv_c4:
             heads = convnet.conv_c4_fwd(y, *P["heads_c4"], 9)

@@ -61,6 +61,15 @@ def main():
             qv = ops.QuadVolume(x.view(B, Cin // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
             t4 = timed(lambda: convnet.conv_c4_fwd(qv, wp4, bp4, Cout, relu=True))
             line += f"  c4 v0, quad-record input {t4:6.1f} us ({flops / t4 / 1e6:5.1f})"
+            if Cin % 8 == 0:                # ... and the bf16 x 3 form of the same layer (csrc/conv_c4s.hip)
+                ws, bs, pr = convnet.pack_conv_c4s(w, b)
+                ts = timed(lambda: convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, relu=True, quad_out=Cout % 4 == 0))
+                line += f"  c4s (bf16 x 3{', paired' if pr else ''}) {ts:6.1f} us ({flops / ts / 1e6:5.1f})"
+                if Cout == 9:
+                    ws, bs, pr = convnet.pack_conv_c4s(w, None)
+                    ts = timed(lambda: convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, records=True))
+                    t4 = timed(lambda: convnet.conv_c4_fwd(qv, wp4, bp4, Cout, records=True))
+                    line += f"  records: c4 {t4:6.1f} / c4s {ts:6.1f} us"
         print(line, flush=True)
 
 

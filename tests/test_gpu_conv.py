@@ -484,6 +484,55 @@ def test_conv_c4(nd, B, Cin, Cout, sp):
             _close(logit, want[:, 8], tol=2e-5)
 
 
+C4S_CASES = [  # B, Cin, Cout, pair, spatial: ragged tiles in every axis, one plane, the frame's four layers at full size
+    (1, 16, 8, True, (4, 32, 48)), (2, 32, 8, True, (3, 17, 33)), (1, 8, 9, False, (5, 9, 19)), (1, 8, 8, False, (2, 16, 16)),
+    (1, 8, 8, True, (1, 5, 7)), (1, 16, 12, False, (2, 20, 18)), (1, 24, 16, False, (2, 7, 40)),
+    (1, 32, 8, True, (64, 64, 80)), (1, 16, 8, True, (8, 256, 320)), (1, 8, 9, False, (8, 256, 320)), (1, 8, 9, False, (64, 64, 80)),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,pair,sp", C4S_CASES)
+def test_conv_c4s(B, Cin, Cout, pair, sp):
+    """csrc/conv_c4s.hip: the regularisers' first layers / heads on the bf16 matrix cores with three-piece fp32 operands,
+    staged from quad records, against a FLOAT64 convolution: no farther from it than the fp32 kernel it replaces
+    (csrc/conv_c4.hip) -- the claim 'fp32 accuracy' as a test -- and not bit-equal to that kernel (the split path ran);
+    bias / ReLU / leaky slope; the three output forms (planar, quad records, the renderer's volume records) bit-equal."""
+    from boostmvsnerfs_amd import convnet, ops
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + sp[0])
+    x = torch.randn(B, Cin, *sp, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    D_, H_, W_ = sp
+    qv = ops.QuadVolume(x.view(B, Cin // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
+    ws, bs, pr = convnet.pack_conv_c4s(w, b, pair)
+    assert pr == pair
+    want64 = F.conv3d(x.double(), w.double(), b.double(), 1, 1)
+    got = convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout)
+    if Cout <= 12:
+        ref32 = convnet.conv_c4_fwd(qv, *convnet.pack_conv_c4(w, b), Cout)
+    else:
+        ref32 = convnet.conv_fwd(x, *convnet.pack_conv(w, b, 1), Cout, 3, 3, 1)
+    scale = float(want64.abs().max())
+    err, err32 = float((got.double() - want64).abs().max()), float((ref32.double() - want64).abs().max())
+    mean, mean32 = float((got.double() - want64).abs().mean()), float((ref32.double() - want64).abs().mean())
+    print(f"[conv_c4s] {Cin}->{Cout} pair={pair} {sp}: max err {err:.3e} (fp32 kernel {err32:.3e}), mean {mean:.3e} ({mean32:.3e}), scale {scale:.3e}")
+    assert err <= max(2.0 * err32, 1e-6 * scale) and mean <= 1.5 * mean32 + 1e-9 * scale
+    assert not torch.equal(got, ref32), "the split path did not run"
+    _close(convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, relu=True), F.relu(want64).float(), tol=2e-6)
+    _close(convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, slope=0.01), F.leaky_relu(want64, 0.01).float(), tol=2e-6)
+    if Cout % 4 == 0:
+        qo = convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, relu=True, quad_out=True)
+        assert isinstance(qo, ops.QuadVolume) and torch.equal(qo.to_planar(), convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, relu=True))
+    if Cout in (8, 9):
+        rec, logit = convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, records=True)
+        assert torch.equal(rec.t.permute(0, 4, 1, 2, 3), got[:, :8])            # (channels in the order they were packed)
+        assert (logit is None) == (Cout == 8) and (logit is None or torch.equal(logit, got[:, 8]))
+    if Cout == 8 and not pair or Cout == 8 and Cin == 16 and sp[0] == 4:
+        # the paired and the unpaired form of an 8-channel layer are the same sums in another order
+        other = convnet.conv_c4s_fwd(qv, *convnet.pack_conv_c4s(w, b, not pair), Cout)
+        _close(other, got, tol=2e-6)
+
+
 @pytest.mark.parametrize("Cin,Cout,D,H,W", [(16, 8, 2, 8, 12), (16, 8, 3, 9, 19), (6, 5, 1, 4, 33), (32, 4, 2, 5, 16),
                                             (16, 8, 4, 128, 160), (16, 8, 32, 32, 40)])
 def test_convT_c4(Cin, Cout, D, H, W):

@@ -690,6 +690,43 @@ def test_renderer_split_bf16_experiment_is_fp32_equivalent(n_views):
         assert d <= 2e-6 * scale, f"{k}: {d:.3e} against scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("records", [True, False])
+def test_regulariser_first_layers_and_heads_on_the_bf16_pipe_are_fp32_equivalent(enerf_fx, records):
+    """BMV_CONV_C4S (csrc/conv_c4s.hip): the regularisers' first layers and heads -- the four matrix-bound layers of a
+    frame -- as bf16 MFMAs on three-piece fp32 operands.  The frame must (i) match the reference's output dict at the
+    project tolerance in both forms, (ii) agree with the fp32-block form to fp32 rounding (2e-6 of an output's scale), and
+    (iii) not be bit-equal to it (the split kernels ran: four launches per frame are counted)."""
+    from boostmvsnerfs_amd import convnet
+    net = _network(enerf_fx)
+    net.lookup_records = records
+    want = enerf_fx.group("out")
+    frames, calls = {}, []
+    real = convnet.conv_c4s_fwd
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    convnet.conv_c4s_fwd = spy
+    try:
+        for on in (False, True):
+            for i in range(2):
+                getattr(net, f"cost_reg_{i}").conv_c4s = on
+            with torch.no_grad():
+                frames[on] = net._forward_checked(enerf_fx.batch(DEV))
+            for k in want:
+                assert_close(frames[on][k], want[k], name=f"{k}, conv_c4s={on}")
+    finally:
+        convnet.conv_c4s_fwd = real
+    assert len(calls) == 4, calls          # conv0 + heads of both regularisers, in the split form's frame only
+    differs = False
+    for k in want:
+        a, b_ = frames[False][k], frames[True][k]
+        differs |= not torch.equal(a, b_)
+        d, scale = float((a - b_).abs().max()), float(a.abs().max())
+        assert d <= 2e-6 * scale, f"{k}: {d:.3e} against scale {scale:.3e}"
+    assert differs, "the split path did not run"
+
+
 def test_split_mlp_is_as_accurate_as_the_fp32_mlp_against_float64():
     """The experiment's arithmetic claim, as a test: on the same fp32 inputs and weights the MLP with its two-tile chains
     on the bf16 pipe (three-piece operands) is no farther from a float64 evaluation of the network
