@@ -19,13 +19,11 @@ started after 50 ms of idle, no spin-up), the PCIe-inclusive legs
 (`host_batch_sync*`: the batch copied from pinned host memory every frame -- eager,
 with the rays built on the device, and through `net(batch)` with new device tensors
 per frame as an unchanged run.py loop hands them over), and
-`split_bf16_first_last_layers` (an opt-in EXPERIMENT, not the metric: four
-convolutions on the bf16 matrix cores with split fp32 operands; its frame's
-distance to the oracle is `parity_max_rel_split`), and `renderer_fp32_mfma` (the same
-bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the fused renderer's MLP on
-fp32 MFMAs -- `value` runs the default, whose two-tile chains are bf16 MFMAs on
-three-piece fp32 operands at fp32 accuracy -- with that frame's own distance to the
-oracle).  `parity_max_rel`: the frame the timed steps render against the oracle's
+`renderer_fp32_mfma` / `all_fp32_mfma` (the same bracket with the frame's bf16 x 3
+kernels switched back to fp32 matrix instructions: bmv_tuning BMV_RENDER_SPLIT=0, and
+that plus the regularisers' first layers / heads on the fp32 4-row blocks -- `value`
+runs the defaults, bf16 MFMAs on three-piece fp32 operands at fp32 accuracy -- each
+with that frame's own distance to the oracle).  `parity_max_rel`: the frame the timed steps render against the oracle's
 frame of the `cpu_baseline` leg.
 
 N > 1 (one process per GPU, torch.distributed over RCCL): independent target
@@ -565,7 +563,7 @@ def main():
     # of `roofline` time them inside the timed region.  Falls back to eager launches if capture fails.
     graph_note = "off"
     split_frame = None
-    render_split_frame = {}
+    side_frames = {}
     if not wl.get("train"):
         graphed_train = None
     eager_step = step
@@ -717,64 +715,58 @@ def main():
                                                 "tensors every frame, net(batch) = pointer-table feed + graph replay (steady "
                                                 "state: `first_frames_ms` are the untimed eager / capturing / first replayed "
                                                 "frames of this batch structure; `autograph` counts all of the leg's calls)"}
-        if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
-                and all(hasattr(net, f"cost_reg_{i}") for i in range(cc.num))):
-            # EXPERIMENT, not the metric: the regularisers' first layers and heads (4 of the frame's 30 convolutions) on
-            # the bf16 matrix cores with split fp32 operands (csrc/conv_split.hip; 2^-16 per product, fp32 accumulation)
-            split_was = [getattr(net, f"cost_reg_{i}").split_bf16 for i in range(cc.num)]
-            for i in range(cc.num):
-                getattr(net, f"cost_reg_{i}").split_bf16 = 2
-            try:
-                for _ in range(3):                      # eager, capture, first replay of the new configuration
-                    step_plain()
-                torch.cuda.synchronize()
-                t_s = bracketed(step_plain, max(n_x, 50))
-                with torch.no_grad():
-                    split_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
-                extra["split_bf16_first_last_layers"] = {
-                    "value": N / t_s / 1e6, "ms_per_step": t_s * 1e3,
-                    "what": "same bracket, cost_reg_{0,1}.conv0 and the heads ALL as THREE bf16 MFMAs per product group "
-                            "(two-piece split, 2^-16 per product: BMV_CONV_SPLIT=2); `parity_max_rel_split` below is its frame "
-                            "against the oracle's"}
-            finally:
-                for i in range(cc.num):
-                    getattr(net, f"cost_reg_{i}").split_bf16 = split_was[i]
         from boostmvsnerfs_amd import _lib as _bl
-        if (args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf"
-                and _bl.get_tuning("BMV_RENDER_SPLIT") != 0):
-            # The same frame with EVERY chain of the renderer's MLP on fp32 MFMAs (bmv_tuning BMV_RENDER_SPLIT=0: the form of
-            # rounds 1-5).  `value` runs the default: the MLP's two-tile chains (lr0, color.0: 160 of its 206 matrix
-            # instructions per tile) as bf16 MFMAs on three-piece fp32 operands -- the fp32 values exactly, product terms
-            # of at most 2^-23 of a product dropped, fp32 accumulation (csrc/mlp.hpp CSPLIT; accuracy against float64:
-            # profiles/r5/mlp_split_accuracy.txt)
+        if args.graph and hasattr(net, "_autograph") and not args.all_kernel_events and wl["net"] == "enerf":
+            # The same frame with its bf16 x 3 kernels switched back to fp32 matrix instructions.  `value` runs the defaults:
+            # the renderer MLP's two-tile chains (csrc/mlp.hpp CSPLIT, round 5) and the regularisers' first layers and
+            # heads (csrc/conv_c4s.hip, round 6) as bf16 MFMAs on three-piece fp32 operands -- the fp32 values exactly,
+            # product terms of at most 2^-23 of a product dropped, fp32 accumulation; accuracy against float64:
+            # profiles/r5/mlp_split_accuracy.txt, tests/test_gpu_conv.py::test_conv_c4s.
+            #   renderer_fp32_mfma: bmv_tuning BMV_RENDER_SPLIT=0 (every chain of the MLP on fp32 MFMAs);
+            #   all_fp32_mfma: that AND cost_reg_i.conv_c4s = False (the fp32 4-row blocks of csrc/conv_c4.hip): no bf16
+            #   matrix instruction in the frame -- what `value` measured in rounds 1-4.
+            regs = [getattr(net, f"cost_reg_{i}") for i in range(cc.num) if hasattr(net, f"cost_reg_{i}")]
+            c4s_was = [r.conv_c4s for r in regs]
             rs_was = _bl.get_tuning("BMV_RENDER_SPLIT")        # (an environment / caller setting survives)
-            _bl.set_tuning("BMV_RENDER_SPLIT", 0)
-            net._autograph.invalidate()                  # (the captured frame has the other renderer baked in)
-            try:
-                for _ in range(4):                      # eager, capture, first replays of the new configuration
-                    step_plain()
-                torch.cuda.synchronize()
-                t_r = bracketed(step_plain, max(n_x, 50))
-                with torch.no_grad():
-                    rs_frame = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
-                render_split_frame.update(rs_frame)
-                extra["renderer_fp32_mfma"] = {
-                    "value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
-                    "parity_max_rel": None,        # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
-                    "what": "same bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the renderer's MLP on fp32 MFMAs "
-                            "(what `value` measured up to the end of round 5); parity_max_rel = its frame against the oracle's"}
-            except Exception as e:                      # a side measurement must not take the metric's line down with it
-                extra["renderer_fp32_mfma"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                render_split_frame.clear()
-            finally:
-                _bl.set_tuning("BMV_RENDER_SPLIT", rs_was)
+            legs = []
+            if rs_was != 0:
+                legs.append(("renderer_fp32_mfma", 0, None,
+                             "same bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the renderer's MLP on fp32 MFMAs"))
+            if rs_was != 0 or any(c4s_was):
+                legs.append(("all_fp32_mfma", 0, False,
+                             "same bracket with NO bf16 matrix instruction in the frame: BMV_RENDER_SPLIT=0 and the regularisers' "
+                             "first layers / heads on the fp32 4-row blocks (cost_reg_i.conv_c4s = False; what `value` measured in "
+                             "rounds 1-4)"))
+            for name, rsplit, c4s, what in legs:
+                _bl.set_tuning("BMV_RENDER_SPLIT", rsplit)
+                if c4s is not None:
+                    for r in regs:
+                        r.conv_c4s = c4s
+                net._autograph.invalidate()              # (the captured frame has the other renderer baked in)
+                try:
+                    for _ in range(4):                  # eager, capture, first replays of the new configuration
+                        step_plain()
+                    torch.cuda.synchronize()
+                    t_r = bracketed(step_plain, max(n_x, 50))
+                    with torch.no_grad():
+                        side_frames[name] = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
+                    extra[name] = {"value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
+                                   "parity_max_rel": None,     # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
+                                   "what": what + "; parity_max_rel = its frame against the oracle's"}
+                except Exception as e:                  # a side measurement must not take the metric's line down with it
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    side_frames.pop(name, None)
+            _bl.set_tuning("BMV_RENDER_SPLIT", rs_was)
+            for r, w_ in zip(regs, c4s_was):
+                r.conv_c4s = w_
+            if legs:
                 try:                                    # (back to the default configuration: its own failure is recorded,
                     net._autograph.invalidate()         # not raised -- the metric's timed region warms up again anyway)
                     for _ in range(3):
                         step_plain()
                     torch.cuda.synchronize()
                 except Exception as e:
-                    extra.setdefault("renderer_fp32_mfma", {})["rewarm_error"] = f"{type(e).__name__}: {e}"[:300]
+                    extra["side_frames_rewarm_error"] = f"{type(e).__name__}: {e}"[:300]
         if args.graph and hasattr(net, "_autograph") and not args.all_kernel_events:
             # the opt-in a serving loop with a resident batch can make (autograph.py): captured on the caller's own
             # tensors, no input copies, the graph's static outputs handed out.  NOT `value`: run.py hands over other
@@ -1001,10 +993,10 @@ def main():
                 line["cpu_baseline"] = cb
             line.update(parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev))
             ref_frame = getattr(cpu_baseline, "last_frame", None)
-            if render_split_frame and ref_frame and "renderer_fp32_mfma" in extra:
-                rs_par = {k: _rel_err(render_split_frame[k], want)[0] for k, want in ref_frame.items()
-                          if k in render_split_frame and torch.is_tensor(want)}
-                extra["renderer_fp32_mfma"]["parity_max_rel"] = max(rs_par.values()) if rs_par else None
+            for name, fr in side_frames.items():
+                if ref_frame and name in extra and "error" not in extra[name]:
+                    par = {k: _rel_err(fr[k], want)[0] for k, want in ref_frame.items() if k in fr and torch.is_tensor(want)}
+                    extra[name]["parity_max_rel"] = max(par.values()) if par else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -34,6 +34,8 @@ if os.environ.get("BMV_MVS_DEFS"):
     EXTRA_FLAGS["mvs.hip"] = os.environ["BMV_MVS_DEFS"].split()
 if os.environ.get("BMV_C4_DEFS"):   # ablation builds of the 4-row-block convolutions (scripts/ablate_conv_c4.py)
     EXTRA_FLAGS["conv_c4.hip"] = os.environ["BMV_C4_DEFS"].split()
+if os.environ.get("BMV_C4S_DEFS"):  # ablation builds of the bf16 x 3 first layers / heads (scripts/ablate_conv_c4s.py)
+    EXTRA_FLAGS["conv_c4s.hip"] = os.environ["BMV_C4S_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

@@ -202,39 +202,39 @@ def _split3_words(w):
 
 def pack_conv_c4s(weight, bias, pair=None):
     """weight (Cout, Cin % 8 == 0, 3, 3, 3), bias (Cout) or None -> (wsplit, bias16, pair) of bmv_conv_c4s_fwd
-    (csrc/conv_c4s.hip; include/bmv.h has the layout): int32 [octet][step][piece 3][lane 64][4].  pair (default: Cout == 8):
-    the row-paired form -- matrix row m = (output row m // 8, channel m % 8), 36 tap slots (kz, j, kx) over the 4 input
-    rows j a row pair touches -- else row m = channel m and 27 + 1 slots."""
+    (csrc/conv_c4s.hip; include/bmv.h has the layout): int32 [octet][step 3][kz 3][piece 3][lane 64][4]; lane = 16 kk + m
+    holds, as 8 bf16 per piece, the octet's 8 input channels of matrix row m at in-plane slot t = 4 step + kk.  pair
+    (default: Cout == 8): the row-paired form -- row m = (output row m // 8, channel m % 8), slot t = (j, kx) = (t // 3,
+    t % 3) over the 4 input rows j a row pair touches -- else row m = channel m, slots t < 9 = (ky, kx), 9..11 zero."""
     Cout, Cin = weight.shape[:2]
     assert weight.shape[2:] == (3, 3, 3) and Cin % 8 == 0 and Cout <= 16
     pair = (Cout == 8) if pair is None else bool(pair)
     assert not pair or Cout == 8
     dev = weight.device
     w5 = weight.detach().float()
+    w = torch.zeros(16, Cin, 3, 12, device=dev, dtype=torch.float32)                # (m, cin, kz, slot)
     if pair:
-        w = torch.zeros(2, 8, Cin, 3, 4, 3, device=dev, dtype=torch.float32)       # (r, c, cin, kz, j, kx)
-        w[0, :, :, :, 0:3] = w5
-        w[1, :, :, :, 1:4] = w5
-        w = w.reshape(16, Cin, 36)
-        steps = 9
+        wp = torch.zeros(2, 8, Cin, 3, 4, 3, device=dev, dtype=torch.float32)      # (r, c, cin, kz, j, kx)
+        wp[0, :, :, :, 0:3] = w5
+        wp[1, :, :, :, 1:4] = w5
+        w[:] = wp.reshape(16, Cin, 3, 12)
     else:
-        w = torch.zeros(16, Cin, 28, device=dev, dtype=torch.float32)
-        w[:Cout, :, :27] = w5.reshape(Cout, Cin, 27)
-        steps = 7
-    # (m, o, c, g, kk) -> (o, g, kk, m, c): lane = 16 kk + m, the lane's 8 values = the octet's channels at slot 4 g + kk
-    w = w.view(16, Cin // 8, 8, steps, 4).permute(1, 3, 4, 0, 2).reshape(Cin // 8, steps, 64, 8).contiguous()
-    wsplit = torch.stack(_split3_words(w), 2).contiguous()                         # (o, g, 3, 64, 4)
+        w[:Cout, :, :, :9] = w5.reshape(Cout, Cin, 3, 9)
+    # (m, o, c, kz, g, kk) -> (o, g, kz, kk, m, c): the order the kernel uses (and therefore loads) them in
+    w = w.view(16, Cin // 8, 8, 3, 3, 4).permute(1, 4, 3, 5, 0, 2).reshape(Cin // 8, 3, 3, 64, 8).contiguous()
+    wsplit = torch.stack(_split3_words(w), 3).contiguous()                          # (o, g, kz, 3, 64, 4)
     b = torch.zeros(16, device=dev, dtype=torch.float32)
     if bias is not None:
         b[:Cout] = bias.detach().float()
     return wsplit, b, pair
 
 
-def conv_c4s_fwd(x, wsplit, bias, pair, Cout, relu=False, slope=None, records=False, quad_out=False):
+def conv_c4s_fwd(x, wsplit, bias, pair, Cout, relu=False, slope=None, records=False, quad_out=False, split_heads=False):
     """x = ops.QuadVolume (B,Cin/4,D,H,W,4), Cin % 8 == 0 -> act(conv3d(x, 3x3x3, stride 1, padding 1) + bias) on the bf16
     matrix cores with three-piece fp32 operands (csrc/conv_c4s.hip: fp32 accuracy).  records: the renderer's volume
     records (VolumeRecords of channels 0..7 + the planar channel 8 when Cout == 9); quad_out (Cout % 4 == 0): the result
-    as an ops.QuadVolume; else the planar tensor."""
+    as an ops.QuadVolume; else the planar tensor (split_heads with Cout == 9: the pair (channels 0..7, channel 8) as
+    strided views of the kernel's two outputs instead of one concatenated copy)."""
     assert isinstance(x, ops.QuadVolume), "conv_c4s_fwd stages quad records (ops.QuadVolume)"
     xd = x.data
     B, Q, D, H, W, _ = xd.shape
@@ -243,24 +243,32 @@ def conv_c4s_fwd(x, wsplit, bias, pair, Cout, relu=False, slope=None, records=Fa
     assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_conv_c4s_wsplit_ints(Cin, int(pair))
     xd = xd if xd.is_contiguous() else xd.contiguous()
     out2 = None
-    quad_out = bool(quad_out) and Cout % 4 == 0 and not records
-    if records:
+    want_planar = not records and not (quad_out and Cout % 4 == 0)
+    # the kernel writes 16-byte records only: a planar result is a strided VIEW of quad records (Cout % 4 == 0) or of the
+    # volume records + the planar ninth channel (Cout == 9), made contiguous where a caller needs that
+    as_records = records or (want_planar and Cout == 9)
+    if as_records:
         assert Cout in (8, 9)
         out = torch.empty(B, D, H, W, 8, device=xd.device, dtype=torch.float32)
         if Cout == 9:
             out2 = torch.empty(B, D, H, W, device=xd.device, dtype=torch.float32)
-    elif quad_out:
-        out = torch.empty(B, Cout // 4, D, H, W, 4, device=xd.device, dtype=torch.float32)
     else:
-        out = torch.empty(B, Cout, D, H, W, device=xd.device, dtype=torch.float32)
+        assert Cout % 4 == 0, "conv_c4s_fwd: planar / quad output needs Cout % 4 == 0 (or the 8 + 1 heads)"
+        out = torch.empty(B, Cout // 4, D, H, W, 4, device=xd.device, dtype=torch.float32)
     with ktimer.region(f"conv_c4s[{Cin}->{Cout},{D}x{H}x{W}]"):
         rc = lib.bmv_conv_c4s_fwd(dptr(xd, "conv input"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out),
                                   dptr(out2) if out2 is not None else None, B, Cin, D, H, W, Cout, int(pair),
-                                  _slope(relu, slope), 2 if records else 8 if quad_out else 0, stream())
+                                  _slope(relu, slope), 2 if as_records else 8, stream())
     _lib.check(rc, "conv_c4s_fwd")
     if records:
         return VolumeRecords(out), out2
-    return ops.QuadVolume(out) if quad_out else out
+    if want_planar:
+        if Cout == 9:
+            if split_heads:      # (feat_conv, depth_conv) as the reference returns them: views, no copy
+                return out.permute(0, 4, 1, 2, 3), out2
+            return torch.cat([out.permute(0, 4, 1, 2, 3), out2[:, None]], 1)
+        return ops.QuadVolume(out).to_planar()
+    return ops.QuadVolume(out)
 
 
 def conv3d_split_heads_records(x, wsplit, bias, parts):

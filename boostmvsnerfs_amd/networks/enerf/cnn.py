@@ -320,8 +320,7 @@ class _CostReg(nn.Module):
             heads = convnet.conv3d_split_fwd(y, *P[f"heads_split{split}"], 9)
             return heads[:, :8], heads[:, 8]
         if self.conv_c4 and self.conv_c4s and isinstance(y, ops.QuadVolume):
-            heads = convnet.conv_c4s_fwd(y, *P["heads_c4s"], 9)
-            return heads[:, :8], heads[:, 8]
+            return convnet.conv_c4s_fwd(y, *P["heads_c4s"], 9, split_heads=True)
         if self.conv_c4:
             heads = convnet.conv_c4_fwd(y, *P["heads_c4"], 9)
             return heads[:, :8], heads[:, 8]

@@ -38,7 +38,7 @@ DECLARED = {
     "BMV_QUAD_VOLUME": (1, "the inference sweep hands the regulariser's first layer its cost volume as 16-byte quad records"),
     "BMV_QUAD_S0": (1, "... and the first layer's output (stride-2 layer input, conv11's skip) as quad records too"),
     "BMV_CONV_C4": (1, "<= 9-output-channel layers on v_mfma_f32_4x4x1_16b_f32 (csrc/conv_c4.hip)"),
-    "BMV_CONV_C4S": (0, "... and, where their input arrives as quad records, as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy (csrc/conv_c4s.hip); 0 = the fp32 blocks"),
+    "BMV_CONV_C4S": (1, "... and, where their input arrives as quad records, as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy (csrc/conv_c4s.hip; the default since round 6); 0 = the fp32 blocks"),
     "BMV_TRAIN_CONV": ("engine", "'torch' = MIOpen for the training convolutions"),
     "BMV_TRAIN_DGRAD5": (1, "stride-2 5x5 data gradients as one 3x3 engine convolution"),
     # ops.py

@@ -538,13 +538,15 @@ int bmv_conv3d_transpose_c4_fwd(const float* in, const float* wpack, const float
  * weight is split into hi + mid + lo bf16 pieces (the fp32 value exactly), a product is the six piece products hh, hm, mh,
  * hl, mm, lh accumulated in fp32 (v_mfma_f32_16x16x32_bf16), what is dropped is <= 3 x 2^-24 of a product.
  * in: QUAD RECORDS (B, Cin/4, D, H, W, 4), Cin % 8 == 0 (bmv_sweep_variance_quad_fwd flags bit 24, bmv_conv3d_transpose_c4_fwd
- * variant | 16).  wsplit: bmv_conv_c4s_wsplit_ints(Cin, pair) int32 words [octet][step][piece 3][lane 64][4]: lane =
- * 16 (slot % 4) + m holds, as 8 bf16, the octet's 8 input channels of matrix row m at tap slot 4 step + lane / 16.
- *   pair = 0 (Cout <= 16, 7 steps): row m = output channel m, slot t < 27 = tap (kz, ky, kx) = (t / 9, t / 3 % 3, t % 3), slot 27 zero;
- *   pair = 1 (Cout == 8, 9 steps): row m = (output row r = m / 8, channel m % 8), slot t = (kz, j, kx) = (t / 12, t / 3 % 4, t % 3)
- *            walks the 4 input rows j the row pair touches: weight[channel][cin][kz][j - r][kx] where 0 <= j - r <= 2, else zero.
- * bias (16); act(v) = v > 0 ? v : slope v.  mode 0: out planar (B,Cout,D,H,W); 8: quad records (B,Cout/4,D,H,W,4); 2: the
- * renderer's volume records (B,D,H,W,8) of channels 0..7 + out2 (B,D,H,W) = channel 8 (as bmv_conv_c4_fwd). */
+ * variant | 16).  wsplit: bmv_conv_c4s_wsplit_ints(Cin, pair) int32 words [octet][step 3][kz 3][piece 3][lane 64][4]: lane =
+ * 16 (slot % 4) + m holds, as 8 bf16, the octet's 8 input channels of matrix row m at IN-PLANE tap slot t = 4 step + lane / 16
+ * of filter plane kz (a workgroup walks the input planes of its tile and keeps an octet's 27 operand quads in registers):
+ *   pair = 0 (Cout <= 16): row m = output channel m, slot t < 9 = (ky, kx) = (t / 3, t % 3), slots 9..11 zero;
+ *   pair = 1 (Cout == 8): row m = (output row r = m / 8, channel m % 8), slot t = (j, kx) = (t / 3, t % 3) walks the 4 input
+ *            rows j the row pair touches: weight[channel][cin][kz][j - r][kx] where 0 <= j - r <= 2, else zero.
+ * bias (16); act(v) = v > 0 ? v : slope v.  mode 8: out = quad records (B,Cout/4,D,H,W,4), Cout % 4 == 0; mode 2: the
+ * renderer's volume records (B,D,H,W,8) of channels 0..7 + out2 (B,D,H,W) = channel 8 (as bmv_conv_c4_fwd; Cout 8 | 9).
+ * (No planar form: both are 16-byte stores, and the reference layout is a strided view of either.) */
 int bmv_conv_c4s_wsplit_ints(int Cin, int pair);
 int bmv_conv_c4s_fwd(const float* in, const int* wsplit, const float* bias, float* out, float* out2, int B, int Cin, int D,
                      int H, int W, int Cout, int pair, float slope, int mode, bmv_stream_t stream);

@@ -527,6 +527,17 @@ def test_conv_c4s(B, Cin, Cout, pair, sp):
         rec, logit = convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout, records=True)
         assert torch.equal(rec.t.permute(0, 4, 1, 2, 3), got[:, :8])            # (channels in the order they were packed)
         assert (logit is None) == (Cout == 8) and (logit is None or torch.equal(logit, got[:, 8]))
+    # every tiling (rows per wave x planes per workgroup; bmv_tuning BMV_CONV_C4S_RW / _TZ) computes the same sums
+    from boostmvsnerfs_amd import _lib
+    try:
+        for rw in (4, 2):
+            for tz in (4, 2):
+                _lib.set_tuning("BMV_CONV_C4S_RW", rw), _lib.set_tuning("BMV_CONV_C4S_TZ", tz)
+                other = convnet.conv_c4s_fwd(qv, ws, bs, pr, Cout)
+                e = float((other.double() - want64).abs().max())
+                assert e <= max(2.0 * err32, 1e-6 * scale), f"tiling RW={rw} TZ={tz}: max err {e:.3e} (fp32 kernel {err32:.3e})"
+    finally:
+        _lib.set_tuning("BMV_CONV_C4S_RW", None), _lib.set_tuning("BMV_CONV_C4S_TZ", None)
     if Cout == 8 and not pair or Cout == 8 and Cin == 16 and sp[0] == 4:
         # the paired and the unpaired form of an 8-channel layer are the same sums in another order
         other = convnet.conv_c4s_fwd(qv, *convnet.pack_conv_c4s(w, b, not pair), Cout)

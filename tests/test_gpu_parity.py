@@ -723,6 +723,7 @@ def test_regulariser_first_layers_and_heads_on_the_bf16_pipe_are_fp32_equivalent
         a, b_ = frames[False][k], frames[True][k]
         differs |= not torch.equal(a, b_)
         d, scale = float((a - b_).abs().max()), float(a.abs().max())
+        print(f"[conv_c4s frame, records={records}] {k}: max |d| {d:.3e} (scale {scale:.3e})")
         assert d <= 2e-6 * scale, f"{k}: {d:.3e} against scale {scale:.3e}"
     assert differs, "the split path did not run"
 
