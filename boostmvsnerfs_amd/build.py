@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbmv.so")
-SOURCES = ["sweep.hip", "sweep_win.hip", "sweep_quad.hip", "tuning.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_c4.hip", "conv_c4s.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
+SOURCES = ["sweep.hip", "sweep_win.hip", "sweep_quad.hip", "tuning.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_c4.hip", "conv_c4s.hip", "fpn_s.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
 HEADERS = ["bmv_common.hpp", "scatter.hpp", "sweep_util.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}    # per-file flags
@@ -36,6 +36,8 @@ if os.environ.get("BMV_C4_DEFS"):   # ablation builds of the 4-row-block convolu
     EXTRA_FLAGS["conv_c4.hip"] = os.environ["BMV_C4_DEFS"].split()
 if os.environ.get("BMV_C4S_DEFS"):  # ablation builds of the bf16 x 3 first layers / heads (scripts/ablate_conv_c4s.py)
     EXTRA_FLAGS["conv_c4s.hip"] = os.environ["BMV_C4S_DEFS"].split()
+if os.environ.get("BMV_FPN_S_DEFS"):  # ablation builds of the bf16 x 3 top-down + smooth0 kernel (scripts/ablate_fpn_s.py)
+    EXTRA_FLAGS["fpn_s.hip"] = os.environ["BMV_FPN_S_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"
     EXTRA_FLAGS["sweep_win.hip"] = os.environ["BMV_WIN_DEFS"].split()
 

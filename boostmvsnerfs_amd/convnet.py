@@ -514,6 +514,64 @@ def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, 
     return LookupRecords(packed) if packed is not None else out
 
 
+def pack_fpn_smooth_s(smooth_weight, smooth_bias, lat_weight, lat_bias, order=None):
+    """(wsplit, btab) of bmv_fpn_smooth_s_fwd (csrc/fpn_s.hip, include/bmv.h): smooth0 (8, 32, 3, 3) + bias (8) or None,
+    lat0 (32, 8, 1, 1) + bias (32).  The lateral 1x1 convolution is folded into the 3x3 weights in float64 (smooth0 is
+    linear): octets 0..3 = smooth0 on bilinear_x2(p1), octet 4 = smooth0 . lat0 on c0, btab[row case][column case] =
+    smooth0's bias + smooth0 applied to the lateral bias through the taps INSIDE the image (cases: first / interior / last
+    row resp. column).  `order`: output-channel permutation (LookupRecords.EVEN_ODD for the renderer's records)."""
+    Ws = smooth_weight.detach().double()
+    bs = smooth_bias.detach().double() if smooth_bias is not None else torch.zeros(Ws.shape[0], dtype=torch.float64, device=Ws.device)
+    assert tuple(Ws.shape) == (8, 32, 3, 3) and tuple(lat_weight.shape[:2]) == (32, 8)
+    if order is not None:
+        Ws, bs = Ws[list(order)], bs[list(order)]
+    Wl = lat_weight.detach().double().reshape(32, 8)
+    bl = lat_bias.detach().double()
+    # (broadcast products + sums, not einsum / matmul: the pack runs on the parameters' device, and the GPU suite asserts
+    # that no GEMM library kernel is launched on the path)
+    Wc = (Ws[:, :, None] * Wl[None, :, :, None, None]).sum(1)        # (8, 8, 3, 3): smooth0 . lat0
+    T = (Ws * bl[None, :, None, None]).sum(1)                        # (8, 3, 3): what a tap adds through the lateral bias
+    Wfull = torch.cat([Ws, Wc], 1).float()                           # (8, 40, 3, 3)
+    dev = Wfull.device
+    w16 = torch.zeros(2, 8, 40, 3, 4, device=dev, dtype=torch.float32)   # (r, c, ch, ky, slot kk): kx = kk - r
+    w16[0, :, :, :, 0:3] = Wfull
+    w16[1, :, :, :, 1:4] = Wfull
+    # (m, o, i, ky, kk) -> (o, ky, kk, m, i): lane = 16 kk + m, the lane's 8 values = the octet's channels
+    w = w16.reshape(16, 5, 8, 3, 4).permute(1, 3, 4, 0, 2).reshape(5, 3, 64, 8).contiguous()
+    wsplit = torch.stack(_split3_words(w), 2).contiguous()            # (5, 3, 3, 64, 4)
+    valid = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}                      # taps inside the image by case (first, interior, last)
+    btab = torch.stack([torch.stack([bs + T[:, list(valid[yc])][:, :, list(valid[xc])].sum((1, 2)) for xc in range(3)])
+                        for yc in range(3)]).float().contiguous()     # (3, 3, 8)
+    return wsplit, btab
+
+
+def fpn_smooth_s(fine, coarse, wsplit, btab, rgb=None):
+    """smooth0(bilinear_x2(coarse, align_corners=True) + lat0(fine)) on the bf16 matrix cores with three-piece fp32
+    operands and the lateral convolution folded into the weights (csrc/fpn_s.hip; `pack_fpn_smooth_s`): fine (B,8,H,W),
+    coarse (B,32,H/2,W/2) -> (B,8,H,W), or with `rgb` (B,3,H,W) the renderer's LookupRecords (weights packed with
+    order=LookupRecords.EVEN_ODD)."""
+    B, Cf, H, W = fine.shape
+    assert Cf == 8 and tuple(coarse.shape) == (B, 32, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+    lib = _lib.load()
+    assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_fpn_smooth_s_wsplit_ints() and btab.numel() == 72
+    packed = out = None
+    if rgb is not None:
+        assert tuple(rgb.shape) == (B, 3, H, W)
+        packed = torch.empty(B, H, W, 12, device=fine.device, dtype=torch.float32)
+        rgb = rgb.contiguous()
+        if ops.defer_table is not None:
+            ops.defer_input(rgb)
+    else:
+        out = torch.empty(B, 8, H, W, device=fine.device, dtype=torch.float32)
+    with ktimer.region(f"fpn_smooth_s[8+32->8,{H}x{W}]"):
+        rc = lib.bmv_fpn_smooth_s_fwd(dptr(fine.contiguous(), "fine"), dptr(coarse.contiguous(), "coarse"),
+                                      dptr(wsplit, "wsplit", torch.int32), dptr(btab, "btab"),
+                                      dptr(out) if out is not None else None, dptr(rgb, "rgb") if packed is not None else None,
+                                      dptr(packed) if packed is not None else None, B, H, W, 1.0, stream())
+    _lib.check(rc, "fpn_smooth_s_fwd")
+    return LookupRecords(packed) if packed is not None else out
+
+
 def conv_fwd(x, wpack, bias, Cout, kd, k, stride=1, relu=False, skip=None, channels_last=False, out=None, slope=None):
     """x (B,Cin,H,W) or (B,Cin,D,H,W) planar -> act(conv(x) + bias) + skip, planar or channel-last
     ((B,Ho,Wo,Cout) / (B,Do,Ho,Wo,Cout)), or -- channels_last="quad" -- quad-planar (B,Cout/4,[Do,]Ho,Wo,4)."""

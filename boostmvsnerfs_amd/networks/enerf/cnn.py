@@ -147,7 +147,11 @@ class FeatureNet(nn.Module):
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias),
             # the same layer with its output channels in the order of the renderer's lookup records
             "smooth0_eo": convnet.pack_conv(self.smooth0.weight[list(convnet.LookupRecords.EVEN_ODD)],
-                                            self.smooth0.bias[list(convnet.LookupRecords.EVEN_ODD)])})
+                                            self.smooth0.bias[list(convnet.LookupRecords.EVEN_ODD)]),
+            # smooth0 with lat0 folded in, split for the bf16 matrix cores (csrc/fpn_s.hip; BMV_FPN_S)
+            "smooth0_s": convnet.pack_fpn_smooth_s(self.smooth0.weight, self.smooth0.bias, self.lat0.weight, self.lat0.bias),
+            "smooth0_s_eo": convnet.pack_fpn_smooth_s(self.smooth0.weight, self.smooth0.bias, self.lat0.weight, self.lat0.bias,
+                                                      order=convnet.LookupRecords.EVEN_ODD)})
 
     def engine_bottom_up(self, x):
         """Encoder + top layer: (c0, c1, p2, p2) with p2 a (N,32,H/4,W/4) view of the channel-last buffer the level-0
@@ -178,7 +182,10 @@ class FeatureNet(nn.Module):
         (convnet.LookupRecords: feature channels + colours of a pixel in one 48-byte record)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
-        if rgb is not None:
+        fpn_s = switches.on("BMV_FPN_S") and switches.on("BMV_FPN_FUSE") and c0.shape[1] == 8 and p1.shape[1] == 32
+        if fpn_s:       # one launch on the bf16 matrix cores, lat0 folded into smooth0's weights (csrc/fpn_s.hip)
+            f0 = convnet.fpn_smooth_s(c0, p1, *P["smooth0_s_eo" if rgb is not None else "smooth0_s"], rgb=rgb)
+        elif rgb is not None:
             f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
         elif switches.on("BMV_FPN_FUSE"):
             # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written

@@ -32,6 +32,7 @@ DECLARED = {
     "BMV_CNN": ("engine", "'torch' = the torch modules instead of the convolution engine (tests compare the two)"),
     "BMV_BN": ("hip", "'torch' = torch's batch norm in training mode"),
     "BMV_FPN_FUSE": (1, "fused FPN top-down + smooth0"),
+    "BMV_FPN_S": (1, "... on the bf16 matrix cores with three-piece fp32 operands and lat0 folded into smooth0's weights (csrc/fpn_s.hip; the default since round 6); 0 = the fp32 kernel of csrc/conv.hip"),
     "BMV_CONV0_FUSE": (1, "fused first FeatureNet block"),
     "BMV_TOP_FUSE": (1, "fused conv2 tail + top layer"),
     "BMV_CONV_SPLIT": ("0", "split-bf16 first layers / heads: '0' fp32 engine, 'auto' / '3' three pieces, '2' two pieces (opt-in experiment)"),

@@ -551,6 +551,22 @@ int bmv_conv_c4s_wsplit_ints(int Cin, int pair);
 int bmv_conv_c4s_fwd(const float* in, const int* wsplit, const float* bias, float* out, float* out2, int B, int Cin, int D,
                      int H, int W, int Cout, int pair, float slope, int mode, bmv_stream_t stream);
 
+/* bmv_fpn_smooth_fwd on the BF16 matrix cores with three-piece fp32 operands (round 6, csrc/fpn_s.hip; the inference
+ * default): out = act(smooth0(bilinear_x2(coarse, align_corners) + lat0(fine))), feature_net.py:24-36, with the 1x1 lateral
+ * convolution FOLDED into the 3x3 weights on the host (smooth0 is linear): 32 channels of up(coarse) + 8 channels of
+ * `fine` = five octets for the matrix cores, no 32-channel full-resolution map anywhere.
+ * fine (B,8,H,W), coarse (B,32,H/2,W/2), H and W even.  wsplit: bmv_fpn_smooth_s_wsplit_ints() int32 words
+ * [octet 5][filter row ky 3][piece 3][lane 64][4]: lane = 16 kk + m holds, as 8 bf16 per piece (hi, mid, lo: the fp32
+ * value exactly), the octet's 8 input channels of matrix row m = (output column parity r = m / 8, output channel m % 8) at
+ * input column slot kk of a column pair: weight[channel][input channel][ky][kk - r] where 0 <= kk - r <= 2, else zero;
+ * octets 0..3 = smooth0's weights on up(coarse), octet 4 = smooth0 . lat0 on fine.  btab (3, 3, 8): the bias by (row case,
+ * column case) = (first / interior / last): smooth0's bias + the lateral bias through the taps that lie inside the image.
+ * out (B,8,H,W) or, with rgb (B,3,H,W; may be registered with bmv_defer_pointer), packed_out (B,H,W,12) = the renderer's
+ * lookup records as bmv_fpn_smooth_fwd writes them. */
+int bmv_fpn_smooth_s_wsplit_ints(void);
+int bmv_fpn_smooth_s_fwd(const float* fine, const float* coarse, const int* wsplit, const float* btab, float* out,
+                         const float* rgb, float* packed_out, int B, int H, int W, float act_slope, bmv_stream_t stream);
+
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =
  * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights

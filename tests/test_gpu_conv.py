@@ -134,6 +134,45 @@ def test_fpn_smooth_fused_equals_the_two_launches(H, W, rows, monkeypatch):
     assert float((got - two).abs().max()) <= 1e-5 * float(two.abs().max())
 
 
+@pytest.mark.parametrize("H,W,rows", [(64, 96, 0), (34, 50, 9), (6, 8, 10), (18, 130, 12), (40, 124, 6), (30, 62, 8), (512, 640, 0)])
+def test_fpn_smooth_s_matches_float64_like_the_fp32_kernel(H, W, rows):
+    """bmv_fpn_smooth_s_fwd (csrc/fpn_s.hip): smooth0(bilinear_x2(p1) + lat0(c0)) with lat0 folded into the weights, on the
+    bf16 matrix cores with three-piece fp32 operands -- against a FLOAT64 evaluation of the reference's graph
+    (feature_net.py:24-36): no farther from it than the fp32 kernel it replaces (bmv_fpn_smooth_fwd), within 1e-5 of
+    that kernel, not bit-equal to it; planar output and the renderer's lookup records; every row tiling; ragged strips."""
+    from boostmvsnerfs_amd import _lib, convnet
+    g = torch.Generator().manual_seed(H + W)
+    B = 2 if H < 100 else 3
+    fine = torch.randn(B, 8, H, W, generator=g).to(DEV)
+    coarse = torch.randn(B, 32, H // 2, W // 2, generator=g).to(DEV)
+    wl = torch.randn(32, 8, 1, 1, generator=g).to(DEV)
+    bl = torch.randn(32, generator=g).to(DEV)
+    ws = (torch.randn(8, 32, 3, 3, generator=g) / (32 * 9 / 8) ** 0.5).to(DEV)
+    bs = torch.randn(8, generator=g).to(DEV)
+    rgb = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    p0 = F.interpolate(coarse.double(), scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(fine.double(), wl.double(), bl.double())
+    want = F.conv2d(p0, ws.double(), bs.double(), padding=1)
+    ref32 = convnet.fpn_smooth(fine, coarse, wl, bl, *convnet.pack_conv(ws, bs), 8)
+    _lib.set_tuning("BMV_FPN_S_ROWS", rows)
+    try:
+        got = convnet.fpn_smooth_s(fine, coarse, *convnet.pack_fpn_smooth_s(ws, bs, wl, bl))
+        rec = convnet.fpn_smooth_s(fine, coarse, *convnet.pack_fpn_smooth_s(ws, bs, wl, bl, order=convnet.LookupRecords.EVEN_ODD), rgb=rgb)
+    finally:
+        _lib.set_tuning("BMV_FPN_S_ROWS", None)
+    scale = float(want.abs().max())
+    err, err32 = float((got.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+    mean, mean32 = float((got.double() - want).abs().mean()), float((ref32.double() - want).abs().mean())
+    print(f"[fpn_smooth_s] {H}x{W} rows={rows}: max err {err:.3e} (fp32 kernel {err32:.3e}), mean {mean:.3e} ({mean32:.3e}), scale {scale:.3e}")
+    assert err <= max(2.0 * err32, 1e-6 * scale) and mean <= 1.5 * mean32 + 1e-9 * scale
+    assert float((got - ref32).abs().max()) <= 1e-5 * scale and not torch.equal(got, ref32)
+    # the lookup records: [ch 0 2 4 6 | ch 1 3 5 7 | r b | g 0] per pixel, the same values as the planar map
+    t = rec.t
+    eo = list(convnet.LookupRecords.EVEN_ODD)
+    assert torch.equal(t[..., :8].permute(0, 3, 1, 2), got[:, eo])
+    assert torch.equal(t[..., 8], rgb[:, 0]) and torch.equal(t[..., 9], rgb[:, 2]) and torch.equal(t[..., 10], rgb[:, 1])
+    assert float(t[..., 11].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("H,W", [(64, 96), (34, 50), (5, 7), (18, 130)])
 def test_conv0_fused_equals_the_two_launches(H, W):
     """bmv_conv0_fused_fwd = relu(conv(relu(conv(x)))) of FeatureNet's first block in one launch, against torch and
