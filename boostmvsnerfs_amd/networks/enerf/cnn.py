@@ -176,23 +176,27 @@ class FeatureNet(nn.Module):
         p2 = ops.QuadFeats(p2) if quad else p2.permute(0, 3, 1, 2)
         return c0, c1, p2, p2
 
-    def engine_top_down(self, c0, c1, p2, rgb=None):
+    def engine_top_down(self, c0, c1, p2, rgb=None, defer_f0=False):
         """Top-down path + smoothing: (16 ch @ 1/2 channel-last view, 8 ch @ 1 planar).  With `rgb` (the source images
         (N,3,H,W)) the full-resolution map comes out as the fused renderer's lookup records instead
         (convnet.LookupRecords: feature channels + colours of a pixel in one 48-byte record)."""
         P = self._blobs()
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
-        fpn_s = switches.on("BMV_FPN_S") and switches.on("BMV_FPN_FUSE") and c0.shape[1] == 8 and p1.shape[1] == 32
-        if fpn_s:       # one launch on the bf16 matrix cores, lat0 folded into smooth0's weights (csrc/fpn_s.hip)
-            f0 = convnet.fpn_smooth_s(c0, p1, *P["smooth0_s_eo" if rgb is not None else "smooth0_s"], rgb=rgb)
-        elif rgb is not None:
-            f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
-        elif switches.on("BMV_FPN_FUSE"):
-            # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written
-            f0 = convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0"], 8)
-        else:
+
+        def full_resolution():
+            fpn_s = switches.on("BMV_FPN_S") and switches.on("BMV_FPN_FUSE") and c0.shape[1] == 8 and p1.shape[1] == 32
+            if fpn_s:       # one launch on the bf16 matrix cores, lat0 folded into smooth0's weights (csrc/fpn_s.hip)
+                return convnet.fpn_smooth_s(c0, p1, *P["smooth0_s_eo" if rgb is not None else "smooth0_s"], rgb=rgb)
+            if rgb is not None:
+                return convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0_eo"], 8, rgb=rgb)
+            if switches.on("BMV_FPN_FUSE"):
+                # the full-resolution 32-channel map exists only between lat0 / upsample and smooth0: one launch, never written
+                return convnet.fpn_smooth(c0, p1, self.lat0.weight, self.lat0.bias, *P["smooth0"], 8)
             p0 = convnet.fpn_topdown(c0, p1, self.lat0.weight, self.lat0.bias)
-            f0 = convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
+            return convnet.conv_fwd(p0, *P["smooth0"], 8, 1, 3)
+        # (defer_f0: the full-resolution map -- only the renderer reads it -- is left to the caller, who may run it beside
+        # the level-1 chain: `f0` comes back as the function that launches it)
+        f0 = full_resolution if defer_f0 else full_resolution()
         # the level-1 sweep's source map LAST: it then sits in the L2s (rows band k in XCD k's, conv.hip's band map) when
         # that sweep starts instead of being pushed out by the 23 MB the full-resolution map writes
         f1 = convnet.conv_fwd(p1, *P["smooth1"], 16, 1, 3, channels_last="quad" if self.quad_out else True)

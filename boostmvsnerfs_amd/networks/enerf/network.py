@@ -77,6 +77,10 @@ class Network(nn.Module):
         self._pre = None
         self.volume_records = switches.on("BMV_VOLUME_RECORDS")
         self.overlap_eager = switches.on("BMV_OVERLAP_EAGER")
+        # the renderer's full-resolution feature map (FeatureNet's last launch) beside the level-1 chain instead of inside
+        # the level-0 window (round 6: that window is bound by the level-0 regulariser since csrc/fpn_s.hip)
+        self.defer_f0 = switches.on("BMV_DEFER_F0")
+        self._f0_pending = None
         from ...autograph import AutoGraph
         object.__setattr__(self, "_autograph", AutoGraph(self))
         # autograph opt-ins (autograph.py): the caller declares its batch resident / accepts outputs that the next
@@ -327,8 +331,16 @@ class Network(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 st0 = self.level_front(0, level0, views, batch, None)
-        f1, f0 = fn.engine_top_down(c0, c1, p2, rgb=x.reshape(B * V, C, H, W) if fn.pack_lookup else None)
+        defer = bool(self.defer_f0)
+        f1, f0 = fn.engine_top_down(c0, c1, p2, rgb=x.reshape(B * V, C, H, W) if fn.pack_lookup else None, defer_f0=defer)
         main.wait_stream(side)
+        if defer:       # the side stream is free again: the full-resolution map runs there under the level-1 chain
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                f0 = f0()
+            self._f0_pending = side
+            if not torch.cuda.is_current_stream_capturing():
+                (f0.t if isinstance(f0, convnet.LookupRecords) else f0).record_stream(main)
         if not torch.cuda.is_current_stream_capturing():   # (a graph capture owns its memory pool)
             for name in ("depth", "std", "near_far", "feature_volume", "depth_values"):
                 t = getattr(st0, name)           # allocated under the side stream, consumed on the main one
@@ -370,6 +382,10 @@ class Network(nn.Module):
             return self._forward(batch)
         finally:
             self.set_volume_records(False)       # the modules go back to planar outputs for any other caller
+            if self._f0_pending is not None:     # (a level that is not rendered, an exception: join before leaving)
+                if torch.cuda.is_available():
+                    torch.cuda.current_stream().wait_stream(self._f0_pending)
+                self._f0_pending = None
 
     def _autograph_inputs(self, batch):
         """The batch tensors an inference frame of THIS network reads (autograph copies only these into its captured
@@ -391,7 +407,7 @@ class Network(nn.Module):
         return (self.sweep_algo, self.overlap_front, self.lookup_records, self.frame_setup, self.volume_records,
                 self.overlap_eager, self.cost_reg_0.split_bf16, self.cost_reg_1.split_bf16,
                 self.cost_reg_0.conv_c4, self.cost_reg_1.conv_c4, self.cost_reg_0.quad_volume, self.cost_reg_1.quad_volume,
-                self.cost_reg_0.conv_c4s, self.cost_reg_1.conv_c4s)
+                self.cost_reg_0.conv_c4s, self.cost_reg_1.conv_c4s, self.defer_f0, switches.get("BMV_FPN_S"))
 
     def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() replace storage: captured graphs are stale
         ag = self.__dict__.get("_autograph")
@@ -428,6 +444,9 @@ class Network(nn.Module):
                                                                            pre=self._pre)
             if not cc.render_if[i]:
                 continue
+            if self._f0_pending is not None:        # (the deferred full-resolution map: the renderer is its first reader)
+                torch.cuda.current_stream().wait_stream(self._f0_pending)
+                self._f0_pending = None
             rgb, depth, weights = render(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch)
             ret_i = {"rgb": rgb, "depth": depth, "weights": weights,
                      "depth_mvs": torch.reciprocal(st.depth) if cc.depth_inv[i] else st.depth, "std": st.std}

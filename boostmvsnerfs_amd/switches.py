@@ -18,6 +18,7 @@ DECLARED = {
     # networks/enerf/network.py
     "BMV_OVERLAP": (2, "level-0 chain under FeatureNet's top-down path: 0 one stream, 1 whole chain forked, 2 what follows the sweep"),
     "BMV_OVERLAP_EAGER": (0, "1 = fork outside HIP-graph capture too"),
+    "BMV_DEFER_F0": (0, "1 = FeatureNet's full-resolution map (only the renderer reads it) on the side stream beside the level-1 chain"),
     "BMV_LOOKUP_RECORDS": (1, "FeatureNet writes the renderer's image lookup records in its epilogue"),
     "BMV_VOLUME_RECORDS": (1, "the regularisers' heads write the renderer's volume records"),
     "BMV_FRAME_SETUP": (1, "cameras, projections and level-0 hypotheses of a frame in one launch"),
