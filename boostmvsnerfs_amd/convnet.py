@@ -514,6 +514,46 @@ def fpn_smooth(fine, coarse, lat_weight, lat_bias, wpack, bias, Cout, out=None, 
     return LookupRecords(packed) if packed is not None else out
 
 
+def _xpair_octets(w):
+    """weight (8, 8 n, 3, 3) float32 -> int32 [octet n][filter row 3][piece 3][lane 64][4]: the x-paired A operands of
+    csrc/fpn_s.hip (lane = 16 kk + m: matrix row m = (output column parity r = m // 8, channel m % 8), input column slot kk
+    of a column pair: weight[.., ky, kk - r] where 0 <= kk - r <= 2, else zero), every value split into three bf16 pieces."""
+    nch = w.shape[1]
+    w16 = torch.zeros(2, 8, nch, 3, 4, device=w.device, dtype=torch.float32)     # (r, c, ch, ky, slot kk): kx = kk - r
+    w16[0, :, :, :, 0:3] = w
+    w16[1, :, :, :, 1:4] = w
+    # (m, o, i, ky, kk) -> (o, ky, kk, m, i): lane = 16 kk + m, the lane's 8 values = the octet's channels
+    t = w16.reshape(16, nch // 8, 8, 3, 4).permute(1, 3, 4, 0, 2).reshape(nch // 8, 3, 64, 8).contiguous()
+    return torch.stack(_split3_words(t), 2).contiguous()                          # (n, 3, 3, 64, 4)
+
+
+def pack_conv0_s(w0, b0, w1, b1):
+    """(w0b0, wsplit, bias) of bmv_conv0_s_fwd (csrc/fpn_s.hip): FeatureNet's first block, batch norm folded -- w0 (8,3,3,3),
+    b0 (8): the first layer as [channel][27 weights | bias]; w1 (8,8,3,3), b1 (8): the second layer as one x-paired octet."""
+    assert tuple(w0.shape) == (8, 3, 3, 3) and tuple(w1.shape) == (8, 8, 3, 3)
+    w0b0 = torch.cat([w0.detach().float().reshape(8, 27), b0.detach().float().reshape(8, 1)], 1).contiguous()
+    return w0b0, _xpair_octets(w1.detach().float())[0].contiguous(), b1.detach().float().contiguous()
+
+
+def conv0_s(x, w0b0, wsplit, bias, out=None):
+    """relu(conv3x3(relu(conv3x3(x (B,3,H,W)) + b0)) + bias) -> (B,8,H,W): FeatureNet's first block with the second layer on
+    the bf16 matrix cores with three-piece fp32 operands (csrc/fpn_s.hip conv0_s_kernel; `pack_conv0_s`)."""
+    B, _, H, W = x.shape
+    assert x.shape[1] == 3
+    if out is None:
+        out = torch.empty(B, 8, H, W, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_conv0_s_wsplit_ints() and w0b0.numel() == 224
+    x = x.contiguous()
+    if ops.defer_table is not None:
+        ops.defer_input(x)
+    with ktimer.region(f"conv0_s[3->8->8,{H}x{W}]"):
+        rc = lib.bmv_conv0_s_fwd(dptr(x, "x"), dptr(w0b0, "w0b0"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"),
+                                 dptr(out), B, H, W, 0.0, stream())
+    _lib.check(rc, "conv0_s_fwd")
+    return out
+
+
 def pack_fpn_smooth_s(smooth_weight, smooth_bias, lat_weight, lat_bias, order=None):
     """(wsplit, btab) of bmv_fpn_smooth_s_fwd (csrc/fpn_s.hip, include/bmv.h): smooth0 (8, 32, 3, 3) + bias (8) or None,
     lat0 (32, 8, 1, 1) + bias (32).  The lateral 1x1 convolution is folded into the 3x3 weights in float64 (smooth0 is
@@ -532,13 +572,7 @@ def pack_fpn_smooth_s(smooth_weight, smooth_bias, lat_weight, lat_bias, order=No
     Wc = (Ws[:, :, None] * Wl[None, :, :, None, None]).sum(1)        # (8, 8, 3, 3): smooth0 . lat0
     T = (Ws * bl[None, :, None, None]).sum(1)                        # (8, 3, 3): what a tap adds through the lateral bias
     Wfull = torch.cat([Ws, Wc], 1).float()                           # (8, 40, 3, 3)
-    dev = Wfull.device
-    w16 = torch.zeros(2, 8, 40, 3, 4, device=dev, dtype=torch.float32)   # (r, c, ch, ky, slot kk): kx = kk - r
-    w16[0, :, :, :, 0:3] = Wfull
-    w16[1, :, :, :, 1:4] = Wfull
-    # (m, o, i, ky, kk) -> (o, ky, kk, m, i): lane = 16 kk + m, the lane's 8 values = the octet's channels
-    w = w16.reshape(16, 5, 8, 3, 4).permute(1, 3, 4, 0, 2).reshape(5, 3, 64, 8).contiguous()
-    wsplit = torch.stack(_split3_words(w), 2).contiguous()            # (5, 3, 3, 64, 4)
+    wsplit = _xpair_octets(Wfull)                                     # (5, 3, 3, 64, 4)
     valid = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}                      # taps inside the image by case (first, interior, last)
     btab = torch.stack([torch.stack([bs + T[:, list(valid[yc])][:, :, list(valid[xc])].sum((1, 2)) for xc in range(3)])
                         for yc in range(3)]).float().contiguous()     # (3, 3, 8)

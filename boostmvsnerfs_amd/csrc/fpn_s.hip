@@ -282,6 +282,178 @@ __global__ void __launch_bounds__(256, (TY <= 6 ? 3 : 2)) fpn_smooth_s_kernel(Fp
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FeatureNet's first block (feature_net.py:8-10: conv0 = ConvBnReLU(3, 8) + ConvBnReLU(8, 8), batch norm folded) in the
+// same form: independent waves walk strips of 62 columns; the producer computes the FIRST layer (3 input channels: 27
+// FMAs per value, weights wave-uniform) at its position from a rolling window of image rows kept in registers, splits the
+// 8 values into three bf16 pieces and parks them; the second layer is ONE octet on the bf16 matrix cores (x-paired rows,
+// 18 matrix instructions per staged row and tile).  Replaces csrc/conv.hip's conv0_fused_kernel (fp32 MFMAs, image tile
+// in LDS, two barriers per 4-channel chunk: 37 us at the head of the frame, where nothing runs beside it).
+// ---------------------------------------------------------------------------------------------------------------
+struct Conv0SArgs {
+  const float* in;       // (B, 3, H, W)
+  const float* w0b0;     // first layer, batch norm folded: [channel 8][28] = the 27 weights (ci, ky, kx) + the bias
+  const int* wsplit;     // second layer: [filter row 3][piece 3][lane 64][4] (one octet, x-paired rows as fpn_smooth_s)
+  const float* bias;     // (8)
+  float* out;            // (B, 8, H, W)
+  int B, H, W;
+  float slope1;
+  int strips, tiles_y, ntiles;
+  const void* const* table;   // deferred `in` (bmv_defer_pointer)
+  int in_slot;
+};
+
+template <int TY>
+__global__ void __launch_bounds__(256, 2) conv0_s_kernel(Conv0SArgs a) {
+  constexpr int NP = TY + 2;
+  extern __shared__ i32x4p fs_lds[];                       // [wave 4][buffer 2][piece 3][64 positions]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= a.ntiles) return;
+  const int strip = tile % a.strips, ty = (tile / a.strips) % a.tiles_y, b = tile / (a.strips * a.tiles_y);
+  const int x0 = strip * kFS_STRIP, y0 = ty * TY;
+  const int H = a.H, W = a.W, hw = H * W;
+  i32x4p* my = fs_lds + wave * (2 * 3 * 64 + 56);
+  // the first layer's 8 x 28 weights in this wave's LDS (wave-uniform 16-byte reads broadcast: through a pointer hipcc
+  // fetched them with 442 uniform VECTOR loads per strip -- it cannot prove nobody stores there --, as kernel arguments
+  // it parked all 216 in SGPRs spilled to lanes: one v_readlane per FMA)
+  f32x4p* wl = reinterpret_cast<f32x4p*>(my + 2 * 3 * 64);
+  if (lane < 56) wl[lane] = reinterpret_cast<const f32x4p*>(a.w0b0)[lane];
+  const int n = lane & 15, kk = lane >> 4;
+  const int gx = x0 - 1 + lane;                             // column of this lane's intermediate position
+  const bool xin = (gx >= 0) & (gx < W);
+  const int wpos = (lane & 1) * 32 + (lane >> 1), rpos = (kk & 1) * 32 + n + (kk >> 1);
+  // the three image columns under the position (zero padding of the FIRST layer: out of range -> 0)
+  int voff[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) voff[dx] = ((gx + dx - 1 >= 0) & (gx + dx - 1 < W)) ? 4 * (gx + dx - 1) : (int)0x80000000u;
+  const float* in = deferred_load(a.table, a.in_slot, a.in);
+  __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)b * 3 * hw), 0,
+                                                                 (int)(4u * 3u * (unsigned)hw), 0x00020000);
+  // image row q of the window is image row y0 - 2 + q; intermediate row p (image row y0 - 1 + p) reads q = p, p + 1, p + 2
+  auto rowok = [&](int p) { return (y0 - 1 + p >= 0) & (y0 - 1 + p < H); };
+  auto load_row = [&](int q, float (&t)[3][3]) {
+    const int gy = y0 - 2 + q;
+    const int dead = ((gy >= 0) & (gy < H)) ? 0 : (int)0x80000000u;
+    const int gyc = min(max(gy, 0), H - 1);
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        t[ci][dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, voff[dx] | dead, 4 * ((ci * H + gyc) * W), 0));
+  };
+  // zero padding of the SECOND layer: an intermediate position outside the image is 0, not relu(b0 + ...): its bias is
+  // -1e30 there (ReLU then gives 0; rows outside the image are skipped altogether)
+  const float xmask = xin ? 0.f : -1e30f;
+
+  f32x4p acc[TY][2];
+#pragma unroll
+  for (int z = 0; z < TY; ++z) acc[z][0] = acc[z][1] = f32x4p{0.f, 0.f, 0.f, 0.f};
+  i32x4p A[3][3];
+  const i32x4p* __restrict__ wp = reinterpret_cast<const i32x4p*>(a.wsplit) + lane;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) A[i / 3][i % 3] = wp[(size_t)i * 64];
+
+  auto park = [&](const float* v, int buf) {
+    i32x4p pc[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = v[2 * e], v1 = v[2 * e + 1];
+      pc[0][e] = (int)fs_pack_hi(v0, v1);
+      const float r0 = v0 - fs_trunc(v0), r1 = v1 - fs_trunc(v1);
+      pc[1][e] = (int)fs_pack_hi(r0, r1);
+      pc[2][e] = (int)fs_pack_rne(r0 - fs_trunc(r0), r1 - fs_trunc(r1));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) my[(buf * 3 + q) * 64 + wpos] = pc[q];
+  };
+  auto multiply = [&](int p) {
+    const i32x4p* bp = my + (p & 1) * 3 * 64 + rpos;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bf16x8p bx[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) bx[r] = __builtin_bit_cast(bf16x8p, bp[r * 64 + 15 * q]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int zo = p - ky;
+        if (zo < 0 || zo >= TY) continue;
+#pragma unroll
+        for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+            acc[zo][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8p, A[ky][i]), bx[sum - i], acc[zo][q], 0, 0, 0);
+      }
+    }
+  };
+  // first layer at this lane's position from window rows r0, r1, r2 (filter rows 0, 1, 2)
+  auto first_layer = [&](const float (&r0)[3][3], const float (&r1)[3][3], const float (&r2)[3][3], float (&v)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {          // (channel by channel: 28 wave-uniform values = seven broadcast LDS reads)
+      float w[28];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const f32x4p t = wl[c * 7 + i];
+        w[4 * i] = t[0], w[4 * i + 1] = t[1], w[4 * i + 2] = t[2], w[4 * i + 3] = t[3];
+      }
+      float s = w[27] + xmask;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          s = fmaf(w[ci * 9 + kx], r0[ci][kx], s);
+          s = fmaf(w[ci * 9 + 3 + kx], r1[ci][kx], s);
+          s = fmaf(w[ci * 9 + 6 + kx], r2[ci][kx], s);
+        }
+      v[c] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+  };
+  const int cgq = kk & 1, rr = kk >> 1;
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bs[j] = a.bias[4 * cgq + j];
+  auto store_row = [&](int zo) {
+    const int y = y0 + zo;
+    if (y >= H) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int x = x0 + 30 * q + 2 * n + rr;
+      if (x >= W || (q == 1 && n == 0)) continue;
+      float* o = a.out + ((size_t)b * 8 + 4 * cgq) * hw + (size_t)y * W + x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = acc[zo][q][j] + bs[j];
+        o[(size_t)j * hw] = fmaxf(t, 0.f) + a.slope1 * fminf(t, 0.f);
+      }
+    }
+  };
+
+  // window ring of 4 image rows: intermediate row p + 1 is produced in iteration p from rows p + 1, p + 2, p + 3; row
+  // p + 4 is requested at the top of iteration p into the slot of row p (last read when row p was produced, one
+  // iteration ago): one iteration = 216 FMAs + 36 matrix instructions ahead of its use
+  float R[4][3][3];
+  load_row(0, R[0]), load_row(1, R[1]), load_row(2, R[2]), load_row(3, R[3]);
+  {
+    float v[8];
+    first_layer(R[0], R[1], R[2], v);
+    park(v, 0);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (p + 1 < NP) load_row(p + 4, R[p % 4]);
+    if (rowok(p)) multiply(p);
+    if (p >= 2) store_row(p - 2);
+    if (p + 1 < NP) {
+      float v[8];
+      first_layer(R[(p + 1) % 4], R[(p + 2) % 4], R[(p + 3) % 4], v);
+      park(v, (p + 1) & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace bmv
 
 using namespace bmv;
@@ -333,6 +505,43 @@ int bmv_fpn_smooth_s_fwd(const float* fine, const float* coarse, const int* wspl
   else if (rows == 8) hipLaunchKernelGGL(fpn_smooth_s_kernel<8>, grid, block, lds, st, a);
   else hipLaunchKernelGGL(fpn_smooth_s_kernel<6>, grid, block, lds, st, a);
   BMV_LAUNCH_END("bmv_fpn_smooth_s_fwd");
+}
+
+// int32 words of bmv_conv0_s_fwd's split second-layer weights: [filter row 3][piece 3][lane 64][4]
+int bmv_conv0_s_wsplit_ints(void) { return 9 * 64 * 4; }
+
+// relu(conv3x3(relu(conv3x3(in (B,3,H,W); w0 (8,3,3,3)) + b0); second layer) + bias) -> out (B,8,H,W): FeatureNet's first block
+// with the second layer on the bf16 matrix cores (three-piece fp32 operands); wsplit: convnet.py pack_conv0_s.
+// w0b0: the first layer as [channel 8][28] floats = 27 weights (ci, ky, kx) + the bias, batch norm folded
+int bmv_conv0_s_fwd(const float* in, const float* w0b0, const int* wsplit, const float* bias, float* out,
+                    int B, int H, int W, float slope1, bmv_stream_t stream) {
+  BMV_REQUIRE(in && w0b0 && wsplit && bias && out, "conv0_s: null pointer");
+  BMV_REQUIRE(B > 0 && H > 0 && W > 0 && (size_t)3 * H * W * 4 < ((size_t)1 << 31), "conv0_s: bad shape");
+  Conv0SArgs a;
+  a.in = in, a.w0b0 = w0b0, a.wsplit = wsplit, a.bias = bias, a.out = out, a.B = B, a.H = H, a.W = W, a.slope1 = slope1;
+  const DeferredPtr din = deferred_for(in);
+  a.table = din.table, a.in_slot = din.slot;
+  a.strips = (W + kFS_STRIP - 1) / kFS_STRIP;
+  int rows = bmv::tuning("BMV_CONV0_S_ROWS", 0);
+  const int cand[3] = {12, 10, 9};
+  if (rows != 12 && rows != 10 && rows != 9) {
+    long best = -1;
+    for (int i = 0; i < 3; ++i) {
+      const long waves = (long)a.strips * ((H + cand[i] - 1) / cand[i]) * B, occ = 2;
+      const long per_simd = (waves + 1023) / 1024;
+      const long cost = (per_simd <= occ ? per_simd : ((waves + 1024 * occ - 1) / (1024 * occ)) * occ) * (cand[i] + 2);
+      if (best < 0 || cost < best) best = cost, rows = cand[i];
+    }
+  }
+  a.tiles_y = (H + rows - 1) / rows;
+  a.ntiles = a.strips * a.tiles_y * B;
+  const size_t lds = (size_t)4 * (2 * 3 * 64 + 56) * sizeof(i32x4p);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((a.ntiles + 3) / 4), block(256);
+  if (rows == 12) hipLaunchKernelGGL(conv0_s_kernel<12>, grid, block, lds, st, a);
+  else if (rows == 10) hipLaunchKernelGGL(conv0_s_kernel<10>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(conv0_s_kernel<9>, grid, block, lds, st, a);
+  BMV_LAUNCH_END("bmv_conv0_s_fwd");
 }
 
 }  // extern "C"

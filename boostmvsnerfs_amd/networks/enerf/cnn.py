@@ -111,6 +111,9 @@ def up3(cin, cout):
     return _Up3(ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(cout))
 
 
+_S_KERNELS_MIN_PIXELS = 600_000     # views x H x W from which csrc/fpn_s.hip's kernels beat the fp32 ones (see engine_bottom_up)
+
+
 class FeatureNet(nn.Module):
     """3 -> (32 ch @ 1/4, 16 ch @ 1/2, 8 ch @ 1) feature pyramid with top-down path."""
 
@@ -142,6 +145,9 @@ class FeatureNet(nn.Module):
             **{f"conv{i}.{j}": _pack_cbr(getattr(self, f"conv{i}")[j]) for i in range(3) for j in range(2)},
             # first layer of the first block, folded, as the fused kernel's producer reads it ((8,3,3,3), (8))
             "conv0.0_raw": tuple(t.float().contiguous() for t in convnet.fold_bn(self.conv0[0].conv.weight, self.conv0[0].bn)),
+            # the whole first block for csrc/fpn_s.hip's conv0_s_kernel (second layer on the bf16 matrix cores; BMV_CONV0_S)
+            "conv0_s": convnet.pack_conv0_s(*convnet.fold_bn(self.conv0[0].conv.weight, self.conv0[0].bn),
+                                            *convnet.fold_bn(self.conv0[1].conv.weight, self.conv0[1].bn)),
             "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
             "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias),
@@ -158,7 +164,12 @@ class FeatureNet(nn.Module):
         sweep reads.  The coarsest map is all the level-0 cost volume needs, so a caller can start that cascade level
         while `engine_top_down` is still running."""
         P = self._blobs()
-        if switches.on("BMV_CONV0_FUSE"):    # the 3-channel first layer is computed in the second layer's tile producer: one launch
+        # (the strip-walking bf16 kernels need ~1500 waves to fill the chip: 3 x 512 x 640 has 1881, 3 x 256 x 320 only 435
+        # and runs the fp32 kernels faster -- 12.7 against 18.0 us, profiles/r6/fpn_s_rows.txt)
+        big = x.shape[0] * x.shape[-2] * x.shape[-1] >= _S_KERNELS_MIN_PIXELS
+        if switches.on("BMV_CONV0_FUSE") and switches.on("BMV_CONV0_S") and big:
+            c0 = convnet.conv0_s(x, *P["conv0_s"])      # ... with the second layer on the bf16 matrix cores (csrc/fpn_s.hip)
+        elif switches.on("BMV_CONV0_FUSE"):    # the 3-channel first layer is computed in the second layer's tile producer: one launch
             c0 = convnet.conv0_fused(x, *P["conv0.0_raw"], *P["conv0.1"], 8)
         else:
             c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
@@ -184,7 +195,8 @@ class FeatureNet(nn.Module):
         p1 = convnet.fpn_topdown(c1, p2, self.lat1.weight, self.lat1.bias)
 
         def full_resolution():
-            fpn_s = switches.on("BMV_FPN_S") and switches.on("BMV_FPN_FUSE") and c0.shape[1] == 8 and p1.shape[1] == 32
+            fpn_s = (switches.on("BMV_FPN_S") and switches.on("BMV_FPN_FUSE") and c0.shape[1] == 8 and p1.shape[1] == 32
+                     and c0.shape[0] * c0.shape[-2] * c0.shape[-1] >= _S_KERNELS_MIN_PIXELS)
             if fpn_s:       # one launch on the bf16 matrix cores, lat0 folded into smooth0's weights (csrc/fpn_s.hip)
                 return convnet.fpn_smooth_s(c0, p1, *P["smooth0_s_eo" if rgb is not None else "smooth0_s"], rgb=rgb)
             if rgb is not None:

@@ -567,6 +567,15 @@ int bmv_fpn_smooth_s_wsplit_ints(void);
 int bmv_fpn_smooth_s_fwd(const float* fine, const float* coarse, const int* wsplit, const float* btab, float* out,
                          const float* rgb, float* packed_out, int B, int H, int W, float act_slope, bmv_stream_t stream);
 
+/* bmv_conv0_fused_fwd with the second layer on the BF16 matrix cores (round 6, csrc/fpn_s.hip; the inference default):
+ * out (B,8,H,W) = act1(conv3x3(relu(conv3x3(in (B,3,H,W); first layer) + b0); second layer) + bias), feature_net.py:8-10, batch norm
+ * folded.  w0b0: the first layer as [channel 8][28] floats = its 27 weights (ci, ky, kx) + the bias (computed on the vector
+ * ALU from a rolling window of image rows, ReLU).  wsplit: bmv_conv0_s_wsplit_ints() int32 words [filter row ky 3][piece 3]
+ * [lane 64][4], one octet in bmv_fpn_smooth_s_fwd's x-paired layout.  bias (8).  `in` may be registered with bmv_defer_pointer. */
+int bmv_conv0_s_wsplit_ints(void);
+int bmv_conv0_s_fwd(const float* in, const float* w0b0, const int* wsplit, const float* bias, float* out, int B, int H, int W,
+                    float slope1, bmv_stream_t stream);
+
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =
  * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights

@@ -31,6 +31,19 @@ def main():
             line += f"  rows {rows}: {timed(lambda: convnet.fpn_smooth_s(fine, coarse, wsp, bt, rgb=rgb)):6.1f}"
         _lib.set_tuning("BMV_FPN_S_ROWS", None)
         print(line, flush=True)
+        # FeatureNet's first block: the fp32 fused kernel against conv0_s (second layer on the bf16 matrix cores)
+        x = torch.randn(B, 3, H, W, generator=g).cuda()
+        w0, b0 = (torch.randn(8, 3, 3, 3, generator=g) / 3).cuda(), torch.randn(8, generator=g).cuda()
+        w1, b1 = (torch.randn(8, 8, 3, 3, generator=g) / 6).cuda(), torch.randn(8, generator=g).cuda()
+        wp1, bp1 = convnet.pack_conv(w1, b1)
+        t32 = timed(lambda: convnet.conv0_fused(x, w0, b0, wp1, bp1, 8))
+        pk = convnet.pack_conv0_s(w0, b0, w1, b1)
+        line = f"{B} x {H} x {W}: conv0 block, fp32 kernel {t32:6.1f} us | conv0_s:"
+        for rows in (0, 9, 10, 12):
+            _lib.set_tuning("BMV_CONV0_S_ROWS", rows)
+            line += f"  rows {rows}: {timed(lambda: convnet.conv0_s(x, *pk)):6.1f}"
+        _lib.set_tuning("BMV_CONV0_S_ROWS", None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -173,6 +173,34 @@ def test_fpn_smooth_s_matches_float64_like_the_fp32_kernel(H, W, rows):
     assert float(t[..., 11].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("H,W,rows", [(64, 96, 0), (34, 50, 9), (5, 7, 10), (18, 130, 12), (512, 640, 0)])
+def test_conv0_s_matches_float64_like_the_fp32_kernel(H, W, rows):
+    """bmv_conv0_s_fwd (csrc/fpn_s.hip): FeatureNet's first block with the second layer as bf16 MFMAs on three-piece fp32
+    operands, against a FLOAT64 evaluation of the two ConvBnReLU layers: no farther from it than the fp32 fused kernel
+    (bmv_conv0_fused_fwd), within 1e-5 of that kernel, not bit-equal; ragged sizes, every row tiling."""
+    from boostmvsnerfs_amd import _lib, convnet
+    g = torch.Generator().manual_seed(H * W)
+    B = 2 if H < 100 else 3
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w0 = (torch.randn(8, 3, 3, 3, generator=g) / 3).to(DEV)
+    b0 = torch.randn(8, generator=g).to(DEV) * 0.3
+    w1 = (torch.randn(8, 8, 3, 3, generator=g) / 6).to(DEV)
+    b1 = torch.randn(8, generator=g).to(DEV) * 0.3
+    want = F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1)), w1.double(), b1.double(), padding=1))
+    ref32 = convnet.conv0_fused(x, w0.contiguous(), b0.contiguous(), *convnet.pack_conv(w1, b1), 8)
+    _lib.set_tuning("BMV_CONV0_S_ROWS", rows)
+    try:
+        got = convnet.conv0_s(x, *convnet.pack_conv0_s(w0, b0, w1, b1))
+    finally:
+        _lib.set_tuning("BMV_CONV0_S_ROWS", None)
+    scale = float(want.abs().max())
+    err, err32 = float((got.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+    mean, mean32 = float((got.double() - want).abs().mean()), float((ref32.double() - want).abs().mean())
+    print(f"[conv0_s] {H}x{W} rows={rows}: max err {err:.3e} (fp32 kernel {err32:.3e}), mean {mean:.3e} ({mean32:.3e}), scale {scale:.3e}")
+    assert err <= max(2.0 * err32, 1e-6 * scale) and mean <= 1.5 * mean32 + 1e-9 * scale
+    assert float((got - ref32).abs().max()) <= 1e-5 * scale and not torch.equal(got, ref32)
+
+
 @pytest.mark.parametrize("H,W", [(64, 96), (34, 50), (5, 7), (18, 130)])
 def test_conv0_fused_equals_the_two_launches(H, W):
     """bmv_conv0_fused_fwd = relu(conv(relu(conv(x)))) of FeatureNet's first block in one launch, against torch and
