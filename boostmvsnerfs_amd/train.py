@@ -186,11 +186,14 @@ class GraphedTrainStep:
         from . import ktimer
         graph = torch.cuda.CUDAGraph()
         was, ktimer.enabled = ktimer.enabled, False       # per-kernel event brackets are host-side objects: not in a graph
+        from . import convnet
+        convnet.clear_pack_cache()       # (weight packs cached by an earlier capture live in THAT graph's pool)
         try:
             with torch.cuda.graph(graph):
                 loss, stats = self._fwd_bwd(dict(static))
         finally:
             ktimer.enabled = was
+            convnet.clear_pack_cache()   # ... and this capture's must not be handed to an eager step or another capture
         # the gradient tensors this graph writes (allocations of ITS pool).  Any other step -- an eager one, another key's
         # graph -- rebinds p.grad (zero_grad(set_to_none=True)): every replay binds these back before clip + Adam read
         # p.grad, and un-binds the parameters this graph leaves without a gradient
