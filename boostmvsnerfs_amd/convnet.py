@@ -8,6 +8,8 @@ state-dict names (networks/enerf/cnn.py) and are re-packed only when one of them
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib, ktimer, ops, switches
@@ -338,12 +340,16 @@ def pack_conv_dev(weight, bias, stride=1, transposed=False, flip=False, for_conv
     lib = _lib.load()
     # One pack per (parameter version, form) and step: the K cost volumes of a boost step run the same regulariser K
     # times (and forward + the data gradient of a layer ask for different forms): config 5 launched 173 pack kernels
-    # per step.  Keyed by storage + version: an optimiser step bumps the version and the entry is replaced.
+    # per step.  Keyed by storage + version: an optimiser step bumps the version and the entry is replaced
+    # (a graph REPLAY updates parameters without touching the counter: train.GraphedTrainStep clears the cache after one).
     key = (weight.data_ptr(), tuple(weight.shape), stride, bool(transposed), bool(flip), bool(for_convT),
            None if bias is None else bias.data_ptr(), torch.cuda.is_current_stream_capturing() if weight.is_cuda else False)
     ver = (weight._version, None if bias is None else bias._version)
     hit = _PACK_DEV_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    # (the entry remembers the tensor OBJECTS, weakly: a temporary -- the parity sub-filters of conv_train's 5x5 data
+    # gradient -- or the parameter of a network that went away leaves a dead reference, and a new tensor that the caching
+    # allocator puts at the same address with the same version counter is not taken for it)
+    if hit is not None and hit[0] == ver and hit[3]() is weight and (bias is None or hit[4]() is bias):
         return hit[1], hit[2]
     w = weight.detach()
     w = w if w.is_contiguous() else w.contiguous()
@@ -362,7 +368,7 @@ def pack_conv_dev(weight, bias, stride=1, transposed=False, flip=False, for_conv
         b[:Cout] = bias.detach()
     if len(_PACK_DEV_CACHE) > 512:       # (parameters that went away: storage addresses are not reused as keys for ever)
         _PACK_DEV_CACHE.clear()
-    _PACK_DEV_CACHE[key] = (ver, wpack, b)
+    _PACK_DEV_CACHE[key] = (ver, wpack, b, weakref.ref(weight), None if bias is None else weakref.ref(bias))
     return wpack, b
 
 

@@ -353,7 +353,7 @@ struct MvsMlp {
   // Round 5: the ten 128 -> 128 chunks (pts_linears.1-4, feature_linear: 64 k-steps x 2 tiles each, 1280 of the MLP's 1964
   // fp32 MFMAs per tile) a second time behind the blob, pre-split into three bf16 pieces for v_mfma_f32_32x32x16_bf16 (the
   // bf16 x 3 form of mlp.hpp's BMV_SPLIT_CHAIN2): [piece 3][bf16 k-step 8][tile 2][lane 64] x 16 bytes = 48 KB per chunk
-  // = CHUNK_MAX, so the two LDS buffers and the DMA pipeline are unchanged.
+  // = CHUNK_MAX, so the LDS buffers and the DMA pipeline are unchanged.
   __host__ __device__ static constexpr bool is_split(int c) { return (c >= 4 && c < 12) || c == 14 || c == 15; }
   __host__ __device__ static constexpr int split_index(int c) { return c < 12 ? c - 4 : c - 6; }
   static constexpr int N_SPLIT = 10;
@@ -468,28 +468,57 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
   blob[idx] = v;
 }
 
-// Weight streaming.  The chunks go through TWO LDS buffers by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
-// instruction, no VGPR round trip): chunk c + 1 is in flight while the MFMAs of chunk c run, so a chunk costs one
-// workgroup barrier and no exposed load latency (one buffer + a register-staged copy between two barriers per chunk
-// left the matrix pipe idle half of the time: 51 % of the fp32 MFMA peak at 1 wave per SIMD).  The buffer parity is a
-// running count over chunks AND tiles (17 chunks per tile is odd: chunk 0 of the next tile takes the other buffer and
-// is fetched under the last chunk of this one).
+// Weight streaming.  The chunks go through THREE LDS buffers by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
+// instruction, no VGPR round trip) with a prefetch distance of TWO chunks: chunks c + 1 and c + 2 are in flight while
+// the MFMAs of chunk c run, so a chunk costs one workgroup barrier and no exposed load latency.  (History: one buffer
+// + a register-staged copy between two barriers per chunk left the matrix pipe idle half of the time, 51 % of the fp32
+// MFMA peak at 1 wave per SIMD; two buffers hid the stream under the 3.5 us of fp32 MFMAs of a chunk but not under the
+// 1.3 us of a bf16 x 3 chunk.)  The wait in front of a chunk is COUNTED: vmcnt may keep this wave's pieces of the next
+// chunk outstanding (memory operations retire in order, so everything older -- this chunk -- has landed), and the
+// workgroup barrier is a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. the prefetch.
+// The buffer slot is a running count over chunks AND tiles (17 chunks per tile: the first two chunks of the next tile
+// are fetched under the last two of this one).
 struct ChunkPipe {
-  int count;   // chunks consumed so far by this workgroup (buffer = count & 1)
-  bool more;   // another tile follows this one: prefetch its chunk 0
+  int slot;    // LDS buffer (0..2) of the next chunk this workgroup consumes
+  bool more;   // another tile follows this one: prefetch its first chunks
 };
+#ifndef BMV_MVS_BUFFERS
+#define BMV_MVS_BUFFERS 2     // 3 measured 3 % SLOWER than 2 on config 4 (profiles/r6/mvs_pipeline.txt): the stream was never the stall
+#endif
+static constexpr int kMvsBuffers = BMV_MVS_BUFFERS;
+static_assert(kMvsBuffers == 2 || kMvsBuffers == 3, "prefetch distance 1 or 2");
 
 template <bool SPLIT = false>
-__device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ buf2, int c, int parity) {
+__device__ __forceinline__ int chunk_pieces(int c) {   // 1 KB pieces of chunk c (128 floats per k-step = 512 B)
+  return (SPLIT && MvsMlp::is_split(c)) ? MvsMlp::SPLIT_CHUNK / 256 : MvsMlp::steps(c) / 2;
+}
+
+template <bool SPLIT = false>
+__device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ bufs, int c, int slot) {
   const bool sp = SPLIT && MvsMlp::is_split(c);      // (the bf16 x 3 form of the chunk: 48 KB)
   const char* src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_index(c) * MvsMlp::SPLIT_CHUNK
                                                      : blob + MvsMlp::offset(c));
-  char* dst = reinterpret_cast<char*>(buf2 + parity * MvsMlp::CHUNK_MAX);
+  char* dst = reinterpret_cast<char*>(bufs + slot * MvsMlp::CHUNK_MAX);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int npieces = sp ? MvsMlp::SPLIT_CHUNK / 256 : MvsMlp::steps(c) / 2;   // 128 floats per k-step = 512 B; a piece is 1 KB
+  const int npieces = chunk_pieces<SPLIT>(c);
   for (int p = wave; p < npieces; p += 4)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+}
+// the first two chunks of a launch (every wave, before the first tile's gathers)
+template <bool SPLIT = false>
+__device__ __forceinline__ void start_chunks(const float* __restrict__ blob, float* __restrict__ bufs) {
+  issue_chunk<SPLIT>(blob, bufs, 0, 0);
+  if constexpr (kMvsBuffers == 3) issue_chunk<SPLIT>(blob, bufs, 1, 1);
+}
+// wait until at most `keep` of this wave's vector-memory operations are outstanding (keep: wave-uniform; the piece
+// counts of a wave are 1-2, 4, 8-9 or 12 -- rounded down, which only waits for one piece more on wave 0)
+__device__ __forceinline__ void wait_vm_keep(int keep) {
+  if (keep >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (keep >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (keep >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // acc{0,1} += W_chunk[:, steps T0..T0+NT) * B, B given by `bval(t)` for the chunk-local step t
@@ -522,30 +551,39 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
   }
 
 // e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
-// Must be called by all 4 waves of the workgroup together (chunk staging uses __syncthreads).
-// Chunk 0 of this tile must already be in flight (issue_chunk(blob, buf2, 0, pipe.count & 1) by every wave).
+// Must be called by all 4 waves of the workgroup together (chunk staging uses workgroup barriers).
+// Chunks 0 and 1 of this tile must already be in flight (start_chunks at the top of the launch; afterwards the last two
+// chunks of the previous tile issue them).
 // a 128 -> 64 product of a split chunk on the B pieces of the layer's input (computed once per layer: both output halves
 // use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
 #define MVS_GEMM_SPLIT(buf, BH, BM, BL, ACC0, ACC1)                                                     \
   {                                                                                                     \
+    /* 16 groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + 1 are read from LDS  \
+       under the MFMAs of group g (as MVS_GEMM does: read + use inside one group left the 192 matrix cycles of a     \
+       group waiting ~200 cycles for its three ds_read_b128 -- 32 k of the 137 k cycles of a tile) */              \
     const mlp_u32x4* sp_ = reinterpret_cast<const mlp_u32x4*>(buf) + lane;                              \
-    _Pragma("unroll") for (int T_ = 0; T_ < 8; ++T_) {                                                  \
+    mlp_u32x4 as_[2][3];                                                                                \
+    _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[0][pc_] = sp_[(pc_ * 8 * 2) * 64];          \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                 \
+      const int T_ = g_ >> 1, tl_ = g_ & 1;                                                             \
+      if (g_ + 1 < 16) {                                                                                \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[(g_ + 1) & 1][pc_] = sp_[(pc_ * 16 + g_ + 1) * 64]; \
+      }                                                                                                 \
+      BMV_FENCE();                                                                                      \
       const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, BH[T_]), Bm_ = __builtin_bit_cast(mlp_bf16x8, BM[T_]), \
                        Bl_ = __builtin_bit_cast(mlp_bf16x8, BL[T_]);                                    \
-      _Pragma("unroll") for (int tl_ = 0; tl_ < 2; ++tl_) {                                             \
-        const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, sp_[((0 * 8 + T_) * 2 + tl_) * 64]);      \
-        const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, sp_[((1 * 8 + T_) * 2 + tl_) * 64]);      \
-        const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, sp_[((2 * 8 + T_) * 2 + tl_) * 64]);      \
-        f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                             \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                            \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                            \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                            \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                            \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                            \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                            \
-        if (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                                        \
-        BMV_FENCE();                                                                                    \
-      }                                                                                                 \
+      const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][0]);                            \
+      const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][1]);                            \
+      const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][2]);                            \
+      f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                               \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                              \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                              \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                              \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                              \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                              \
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                              \
+      if (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                                          \
+      BMV_FENCE();                                                                                      \
     }                                                                                                   \
   }
 // the three bf16 pieces of a layer's 128-wide input (this lane's 64 values: hcur[t >> 4][t & 15] for fp32 k-step t)
@@ -572,13 +610,17 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   int chunk = 0;
   const float* buf = buf2;
   auto next_chunk = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this chunk have landed
-    __syncthreads();                                   // everyone's have; everyone is done with the previous chunk
-    const int par = pipe.count & 1;
-    buf = buf2 + par * MvsMlp::CHUNK_MAX;
-    if (chunk + 1 < MvsMlp::N_CHUNKS) issue_chunk<SPLIT>(blob, buf2, chunk + 1, par ^ 1);
-    else if (pipe.more) issue_chunk<SPLIT>(blob, buf2, 0, par ^ 1);
-    ++chunk, ++pipe.count;
+    constexpr int DIST = kMvsBuffers - 1;              // prefetch distance in chunks
+    // my pieces of this chunk have landed (distance 2: those of the next one may still be in flight) ...
+    const int nxt = chunk + 1 < MvsMlp::N_CHUNKS ? chunk + 1 : pipe.more ? 0 : -1;
+    wait_vm_keep(DIST == 1 || nxt < 0 ? 0 : chunk_pieces<SPLIT>(nxt) / 4);
+    asm volatile("s_barrier" ::: "memory");            // ... everyone's have; everyone is done with the previous chunk
+    buf = buf2 + pipe.slot * MvsMlp::CHUNK_MAX;
+    const int free_slot = pipe.slot == 0 ? kMvsBuffers - 1 : pipe.slot - 1;   // the previous chunk's buffer
+    if (chunk + DIST < MvsMlp::N_CHUNKS) issue_chunk<SPLIT>(blob, buf2, chunk + DIST, free_slot);
+    else if (pipe.more) issue_chunk<SPLIT>(blob, buf2, chunk + DIST - MvsMlp::N_CHUNKS, free_slot);
+    pipe.slot = pipe.slot == kMvsBuffers - 1 ? 0 : pipe.slot + 1;
+    ++chunk;
   };
   // pts_bias (network.py:210): bias = W_b feat + b_b
 #pragma unroll
@@ -766,8 +808,8 @@ template <int S, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 1 KB for the DMA buffers)
-  float* buf = lds + kMvsSmall;                         // two weight-chunk buffers
-  MvsCams* mc = reinterpret_cast<MvsCams*>(buf + 2 * MvsMlp::CHUNK_MAX);
+  float* buf = lds + kMvsSmall;                         // three weight-chunk buffers
+  MvsCams* mc = reinterpret_cast<MvsCams*>(buf + kMvsBuffers * MvsMlp::CHUNK_MAX);
   if (a.blob)
     for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = a.blob[MvsMlp::A_TOTAL + i];
   if ((int)threadIdx.x < S) load_cam(a.src_exts + threadIdx.x * 16, a.src_ixts + threadIdx.x * 9, 1.f, mc->cam[threadIdx.x]);
@@ -782,7 +824,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
-  if (a.blob) issue_chunk<SPLIT>(a.blob, buf, 0, 0);   // under the gathers / sincos of the first tile
+  if (a.blob) start_chunks<SPLIT>(a.blob, buf);   // under the gathers / sincos of the first tile
   for (long round = 0; round * per_round < ntiles; ++round) {   // uniform trip count across the workgroup
     pipe.more = (round + 1) * per_round < ntiles;
     long tile = round * per_round + (long)blockIdx.x * 4 + wave;
@@ -830,7 +872,7 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
-  issue_chunk<SPLIT>(blob, buf, 0, 0);
+  start_chunks<SPLIT>(blob, buf);
   for (long round = 0; round * per_round < ntiles; ++round) {
     pipe.more = (round + 1) * per_round < ntiles;
     long pt = (round * per_round + (long)blockIdx.x * 4 + wave) * 32 + s;
@@ -843,6 +885,13 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
     for (int t = 0; t < 10; ++t) f[t] = row[63 + 2 * t + h];
     dv[0] = row[83 + h];
     dv[1] = h ? 0.f : row[85];
+    // the row is in registers BEFORE the next weight chunk is requested: a wait for these loads behind that request
+    // would have to be vmcnt(0), i.e. would drain the prefetch
+#pragma unroll
+    for (int t = 0; t < 32; ++t) asm volatile("" ::"v"(e[t]));
+#pragma unroll
+    for (int t = 0; t < 10; ++t) asm volatile("" ::"v"(f[t]));
+    asm volatile("" ::"v"(dv[0]), "v"(dv[1]));
     mvs_mlp_forward<SPLIT>(blob, small, buf, pipe, lane, e, f, dv, res);
     if (valid && h == 0) {
       float4 o4 = {res[0], res[1], res[2], res[3]};
@@ -873,7 +922,8 @@ __global__ void mvs_march_mask_kernel(const float* __restrict__ rays, const floa
   mask[i] = acc / (float)V;
 }
 
-static constexpr size_t kMvsLds = (kMvsSmall + 2 * MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
+static constexpr size_t kMvsLds = (kMvsSmall + kMvsBuffers * MvsMlp::CHUNK_MAX) * sizeof(float) + sizeof(MvsCams);
+static_assert(kMvsLds <= 160 * 1024, "LDS of a gfx950 CU");
 
 // ---------------------------------------------------------------------------
 // Backward of the MVSNeRF path (training).  Gradient reaches the network only through the masked variance channels of

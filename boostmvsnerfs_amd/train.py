@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 from torch.optim._functional import adam as _adam_update
 
+from . import convnet
 from .config import cfg
 
 
@@ -186,7 +187,6 @@ class GraphedTrainStep:
         from . import ktimer
         graph = torch.cuda.CUDAGraph()
         was, ktimer.enabled = ktimer.enabled, False       # per-kernel event brackets are host-side objects: not in a graph
-        from . import convnet
         convnet.clear_pack_cache()       # (weight packs cached by an earlier capture live in THAT graph's pool)
         try:
             with torch.cuda.graph(graph):
@@ -231,6 +231,7 @@ class GraphedTrainStep:
                     s.copy_(v)
                     self.stats["copies"] += 1
         e["graph"].replay()
+        convnet.clear_pack_cache()       # the replay stepped the parameters without bumping their version counters
         for p, g in e["grads"]:
             p.grad = g
         e["hits"] += 1

@@ -477,6 +477,34 @@ def test_conv2d_training_module(cin, cout, k, stride, bias, hw):
         _close(m.bias.grad.double(), bd.grad, 1e-4)
 
 
+def test_weight_pack_cache_is_per_tensor_object_and_version():
+    """convnet.pack_conv_dev keeps one device-side pack per weight and version.  A tensor that went away must not lend
+    its pack to a new one the caching allocator puts at the same address (both with version counter 0: the temporaries
+    of the 5x5 stride-2 data gradient, the parameters of the next network of a process), an in-place update must
+    replace the pack, and an unchanged parameter must be packed once."""
+    from boostmvsnerfs_amd import convnet
+    convnet.clear_pack_cache()
+    torch.manual_seed(3)
+    x = torch.randn(1, 8, 24, 40, device=DEV)
+    ptrs = set()
+    for seed in range(4):                          # temporaries: same size, freed before the next one is made
+        w = torch.randn(8, 8, 3, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(seed))
+        ptrs.add(w.data_ptr())
+        y = convnet.conv_fwd(x, *convnet.pack_conv_dev(w, None, 1), 8, 1, 3, 1)
+        _close(y.double(), F.conv2d(x.double(), w.double(), None, 1, 1), 2e-5)
+        del w, y
+    assert len(ptrs) < 4                           # (the allocator did hand an address out again: the case is exercised)
+    w = torch.randn(8, 8, 3, 3, device=DEV)
+    p1, _ = convnet.pack_conv_dev(w, None, 1)
+    p2, _ = convnet.pack_conv_dev(w, None, 1)
+    assert p1 is p2                                # unchanged: one pack
+    w.mul_(2.0)                                    # (what an optimiser step does: in place, version + 1)
+    p3, b3 = convnet.pack_conv_dev(w, None, 1)
+    assert p3 is not p1
+    _close(convnet.conv_fwd(x, p3, b3, 8, 1, 3, 1).double(), F.conv2d(x.double(), w.double(), None, 1, 1), 2e-5)
+    convnet.clear_pack_cache()
+
+
 @pytest.mark.parametrize("parts", [3, 2])
 @pytest.mark.parametrize("cin,cout,dhw", [(16, 8, (8, 40, 72)), (32, 8, (5, 19, 52)), (8, 9, (3, 16, 36)), (16, 16, (2, 8, 32))])
 def test_conv3d_split_bf16(cin, cout, dhw, parts):
