@@ -468,18 +468,19 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
   blob[idx] = v;
 }
 
-// Weight streaming.  The chunks go through THREE LDS buffers by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
-// instruction, no VGPR round trip) with a prefetch distance of TWO chunks: chunks c + 1 and c + 2 are in flight while
-// the MFMAs of chunk c run, so a chunk costs one workgroup barrier and no exposed load latency.  (History: one buffer
-// + a register-staged copy between two barriers per chunk left the matrix pipe idle half of the time, 51 % of the fp32
-// MFMA peak at 1 wave per SIMD; two buffers hid the stream under the 3.5 us of fp32 MFMAs of a chunk but not under the
-// 1.3 us of a bf16 x 3 chunk.)  The wait in front of a chunk is COUNTED: vmcnt may keep this wave's pieces of the next
-// chunk outstanding (memory operations retire in order, so everything older -- this chunk -- has landed), and the
-// workgroup barrier is a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. the prefetch.
-// The buffer slot is a running count over chunks AND tiles (17 chunks per tile: the first two chunks of the next tile
-// are fetched under the last two of this one).
+// Weight streaming.  The chunks go through kMvsBuffers (2; build option 3) LDS buffers by LDS-DMA
+// (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR round trip) with a prefetch distance of kMvsBuffers - 1
+// chunks: the next chunk(s) are in flight while the MFMAs of chunk c run, so a chunk costs one workgroup barrier and no
+// exposed load latency.  (History: one buffer + a register-staged copy between two barriers per chunk left the matrix
+// pipe idle half of the time, 51 % of the fp32 MFMA peak at 1 wave per SIMD.  Round 6 measured the three-buffer /
+// distance-2 form 3 % slower than two buffers, also for the 1.3 us bf16 x 3 chunks: the stream is not what the split
+// form waits for -- profiles/r6/mvs_pipeline.txt.)  The wait in front of a chunk is COUNTED: with distance 2, vmcnt may
+// keep this wave's pieces of the next chunk outstanding (memory operations retire in order, so everything older --
+// this chunk -- has landed), and the workgroup barrier is a bare s_barrier: __syncthreads() carries a fence that drains
+// vmcnt to 0, i.e. the prefetch.  The buffer slot is a running count over chunks AND tiles (17 chunks per tile: the
+// first chunk(s) of the next tile are fetched under the last one(s) of this one).
 struct ChunkPipe {
-  int slot;    // LDS buffer (0..2) of the next chunk this workgroup consumes
+  int slot;    // LDS buffer (0 .. kMvsBuffers - 1) of the next chunk this workgroup consumes
   bool more;   // another tile follows this one: prefetch its first chunks
 };
 #ifndef BMV_MVS_BUFFERS
@@ -505,7 +506,7 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
 }
-// the first two chunks of a launch (every wave, before the first tile's gathers)
+// the first chunk(s) of a launch (every wave, before the first tile's gathers)
 template <bool SPLIT = false>
 __device__ __forceinline__ void start_chunks(const float* __restrict__ blob, float* __restrict__ bufs) {
   issue_chunk<SPLIT>(blob, bufs, 0, 0);
@@ -552,8 +553,8 @@ __device__ __forceinline__ void wait_vm_keep(int keep) {
 
 // e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
 // Must be called by all 4 waves of the workgroup together (chunk staging uses workgroup barriers).
-// Chunks 0 and 1 of this tile must already be in flight (start_chunks at the top of the launch; afterwards the last two
-// chunks of the previous tile issue them).
+// The first kMvsBuffers - 1 chunks of this tile must already be in flight (start_chunks at the top of the launch;
+// afterwards the last chunks of the previous tile issue them).
 // a 128 -> 64 product of a split chunk on the B pieces of the layer's input (computed once per layer: both output halves
 // use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
 #define MVS_GEMM_SPLIT(buf, BH, BM, BL, ACC0, ACC1)                                                     \
@@ -808,7 +809,7 @@ template <int S, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* small = lds;                                   // MvsMlp::S_TOTAL floats (padded to 1 KB for the DMA buffers)
-  float* buf = lds + kMvsSmall;                         // three weight-chunk buffers
+  float* buf = lds + kMvsSmall;                         // kMvsBuffers weight-chunk buffers
   MvsCams* mc = reinterpret_cast<MvsCams*>(buf + kMvsBuffers * MvsMlp::CHUNK_MAX);
   if (a.blob)
     for (int i = threadIdx.x; i < MvsMlp::S_TOTAL; i += blockDim.x) small[i] = a.blob[MvsMlp::A_TOTAL + i];
