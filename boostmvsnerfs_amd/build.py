@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbmv.so")
-SOURCES = ["sweep.hip", "sweep_win.hip", "sweep_quad.hip", "tuning.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_c4.hip", "conv_c4s.hip", "fpn_s.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
+SOURCES = ["sweep.hip", "sweep_win.hip", "sweep_quad.hip", "tuning.hip", "sample.hip", "render.hip", "mvs.hip", "mvs_mlp_train.hip", "backward.hip", "sweep_bwd_cl.hip", "mlp_bwd.hip", "conv.hip", "conv_c4.hip", "conv_c4s.hip", "fpn_s.hip", "conv2d_s.hip", "conv_split.hip", "conv_wgrad.hip", "bn.hip", "rays.hip", "timing.hip"]
 HEADERS = ["bmv_common.hpp", "scatter.hpp", "sweep_util.hpp", "render_geom.hpp", "mlp.hpp", os.path.join("..", "..", "include", "bmv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}    # per-file flags

@@ -581,6 +581,44 @@ def conv0_s(x, w0b0, wsplit, bias, out=None):
     return out
 
 
+def pack_conv2d_s(weight, bias):
+    """(wsplit, bias) of bmv_conv2d_s_fwd (csrc/conv2d_s.hip; include/bmv.h has the layout): weight (Cout % 16 == 0, Cin % 8 == 0,
+    ks, ks) -> int32 [M tile][filter row][step][piece 3][lane 64][4]; lane = 16 kg + m holds the 8 channels of input octet o at
+    filter column kx for output channel 16 tile + m, (o, kx) = divmod(4 step + kg, ks), every value as three bf16 pieces."""
+    Cout, Cin, ks, ks2 = weight.shape
+    lib = _lib.load()
+    assert ks == ks2 and lib.bmv_conv2d_s_wsplit_ints(Cin, Cout, ks, 2 if ks == 5 else 1) > 0, "shape not covered by conv2d_s"
+    noct, nmt = Cin // 8, Cout // 16
+    npair = noct * ks
+    nstep = (npair + 3) // 4
+    w = weight.detach().float().reshape(nmt, 16, noct, 8, ks, ks)                     # (tile, m, octet, c, ky, kx)
+    w = w.permute(0, 1, 4, 2, 5, 3).reshape(nmt, 16, ks, npair, 8)                    # (tile, m, ky, pair, c)
+    wz = torch.zeros(nmt, 16, ks, nstep * 4, 8, device=w.device, dtype=torch.float32)
+    wz[:, :, :, :npair] = w
+    t = wz.reshape(nmt, 16, ks, nstep, 4, 8).permute(0, 2, 3, 4, 1, 5).reshape(nmt, ks, nstep, 64, 8).contiguous()
+    wsplit = torch.stack(_split3_words(t), 3).contiguous()                            # (tile, ky, step, 3, 64, 4)
+    assert wsplit.numel() == lib.bmv_conv2d_s_wsplit_ints(Cin, Cout, ks, 2 if ks == 5 else 1)
+    b = bias.detach().float().contiguous() if bias is not None else torch.zeros(Cout, device=w.device, dtype=torch.float32)
+    return wsplit, b
+
+
+def conv2d_s(x, wsplit, bias, Cout, ks, stride, relu=False, slope=None, out=None):
+    """act(conv2d(x (B,Cin,H,W), k = ks, stride, padding ks // 2) + bias) -> (B,Cout,H/stride,W/stride) on the bf16 matrix cores
+    with three-piece fp32 operands (csrc/conv2d_s.hip; `pack_conv2d_s`): FeatureNet's 5x5 stride-2 and 3x3 encoder layers."""
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, Cout, H // stride, W // stride, device=x.device, dtype=torch.float32)
+    assert out.shape == (B, Cout, H // stride, W // stride) and out.is_contiguous()
+    lib = _lib.load()
+    assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_conv2d_s_wsplit_ints(Cin, Cout, ks, stride)
+    x = x if x.is_contiguous() else x.contiguous()
+    with ktimer.region(f"conv2d_s[{Cin}->{Cout},k{ks}s{stride},{H}x{W}]"):
+        rc = lib.bmv_conv2d_s_fwd(dptr(x, "x"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out), B, Cin, H, W,
+                                  Cout, ks, stride, _slope(relu, slope), stream())
+    _lib.check(rc, "conv2d_s_fwd")
+    return out
+
+
 def pack_fpn_smooth_s(smooth_weight, smooth_bias, lat_weight, lat_bias, order=None):
     """(wsplit, btab) of bmv_fpn_smooth_s_fwd (csrc/fpn_s.hip, include/bmv.h): smooth0 (8, 32, 3, 3) + bias (8) or None,
     lat0 (32, 8, 1, 1) + bias (32).  The lateral 1x1 convolution is folded into the 3x3 weights in float64 (smooth0 is

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256, (TY <= 6 ? 3 : 2)) fpn_smooth_s_kernel(Fp
   constexpr int NP = TY + 2;
   extern __shared__ i32x4p fs_lds[];                       // [wave 4][buffer 2][piece 3][64 positions]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;   // an XCD = a band of rows: the chain reads what it left in its L2
   if (tile >= a.ntiles) return;                             // (no barrier in this kernel: a wave may leave)
   const int strip = tile % a.strips, ty = (tile / a.strips) % a.tiles_y, b = tile / (a.strips * a.tiles_y);
   const int x0 = strip * kFS_STRIP, y0 = ty * TY;
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256, 2) conv0_s_kernel(Conv0SArgs a) {
   constexpr int NP = TY + 2;
   extern __shared__ i32x4p fs_lds[];                       // [wave 4][buffer 2][piece 3][64 positions]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;   // an XCD = a band of rows: the chain reads what it left in its L2
   if (tile >= a.ntiles) return;
   const int strip = tile % a.strips, ty = (tile / a.strips) % a.tiles_y, b = tile / (a.strips * a.tiles_y);
   const int x0 = strip * kFS_STRIP, y0 = ty * TY;

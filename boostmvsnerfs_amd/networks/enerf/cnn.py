@@ -148,6 +148,10 @@ class FeatureNet(nn.Module):
             # the whole first block for csrc/fpn_s.hip's conv0_s_kernel (second layer on the bf16 matrix cores; BMV_CONV0_S)
             "conv0_s": convnet.pack_conv0_s(*convnet.fold_bn(self.conv0[0].conv.weight, self.conv0[0].bn),
                                             *convnet.fold_bn(self.conv0[1].conv.weight, self.conv0[1].bn)),
+            # the encoder's 5x5 stride-2 / 3x3 layers for csrc/conv2d_s.hip (bf16 matrix cores; BMV_CONV2D_S)
+            **{f"conv{i}.{j}_s": convnet.pack_conv2d_s(*convnet.fold_bn(getattr(self, f"conv{i}")[j].conv.weight,
+                                                                         getattr(self, f"conv{i}")[j].bn))
+               for i in (1, 2) for j in range(2)},
             "toplayer": convnet.pack_conv(self.toplayer.weight, self.toplayer.bias),
             "smooth1": convnet.pack_conv(self.smooth1.weight, self.smooth1.bias),
             "smooth0": convnet.pack_conv(self.smooth0.weight, self.smooth0.bias),
@@ -174,9 +178,15 @@ class FeatureNet(nn.Module):
         else:
             c0 = convnet.conv_fwd(x, *P["conv0.0"], 8, 1, 3, relu=True)
             c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
-        c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
-        c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
-        c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
+        if switches.on("BMV_CONV2D_S") and big and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0:
+            # conv1, conv2.0 on the bf16 matrix cores (csrc/conv2d_s.hip: weights stationary, independent strip-walking waves)
+            c1 = convnet.conv2d_s(c0, *P["conv1.0_s"], 16, 5, 2, relu=True)
+            c1 = convnet.conv2d_s(c1, *P["conv1.1_s"], 16, 3, 1, relu=True)
+            c2 = convnet.conv2d_s(c1, *P["conv2.0_s"], 32, 5, 2, relu=True)
+        else:
+            c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
+            c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)
+            c2 = convnet.conv_fwd(c1, *P["conv2.0"], 32, 1, 5, 2, relu=True)
         # the coarsest map is written once, channel-last (the level-0 sweep's layout); the top-down step reads it so
         quad = self.quad_out      # the plane sweep's quad-planar layout (inference default) or channel-last
         if switches.on("BMV_TOP_FUSE"):      # conv2.1 + toplayer: the 1x1 layer is a second stage of the 3x3 layer's workgroups

@@ -576,6 +576,18 @@ int bmv_conv0_s_wsplit_ints(void);
 int bmv_conv0_s_fwd(const float* in, const float* w0b0, const int* wsplit, const float* bias, float* out, int B, int H, int W,
                     float slope1, bmv_stream_t stream);
 
+/* FeatureNet's encoder convolutions on the BF16 matrix cores (round 6, csrc/conv2d_s.hip; feature_net.py:11-19, batch norm
+ * folded): out (B,Cout,H/stride,W/stride) = act(conv2d(in (B,Cin,H,W); k = ks, stride, zero padding ks / 2) + bias) with
+ * three-piece fp32 operands (six v_mfma_f32_16x16x32_bf16 per product group, fp32 accumulation: fp32 accuracy).  Covered:
+ * (ks, stride, Cin) = (5, 2, 8 | 16) | (3, 1, 16 | 32); Cout in {16, 32}; H, W even.  Replaces bmv_conv_fwd (nd = 2) for
+ * these layers.  wsplit: bmv_conv2d_s_wsplit_ints() int32 words [M tile = Cout / 16][filter row ky][step][piece 3][lane 64][4]:
+ * lane = 16 kg + m holds, as 8 bf16 per piece (hi | mid | lo of the fp32 value, exactly), the 8 input channels of octet o
+ * at filter column kx for output channel 16 tile + m, where (o, kx) = divmod(4 step + kg, ks) enumerates the (octet,
+ * column) pairs of a filter row four to a step (pairs past Cin / 8 * ks: zeros).  bmv_conv2d_s_wsplit_ints: 0 = not covered. */
+int bmv_conv2d_s_wsplit_ints(int Cin, int Cout, int ks, int stride);
+int bmv_conv2d_s_fwd(const float* in, const int* wsplit, const float* bias, float* out, int B, int Cin, int H, int W,
+                     int Cout, int ks, int stride, float act_slope, bmv_stream_t stream);
+
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =
  * conv1x1(act(conv3x3(in (B,32,H,W); wpack) + bias); wpack_top) + bias_top; both packs in the bmv_conv_pack_weights

@@ -201,6 +201,45 @@ def test_conv0_s_matches_float64_like_the_fp32_kernel(H, W, rows):
     assert float((got - ref32).abs().max()) <= 1e-5 * scale and not torch.equal(got, ref32)
 
 
+C2S_CASES = [(8, 16, 5, 2, 2, 64, 96, 0), (16, 32, 5, 2, 2, 64, 96, 0), (16, 16, 3, 1, 2, 32, 48, 0), (32, 32, 3, 1, 2, 32, 48, 0),
+             (8, 16, 5, 2, 1, 34, 50, 8), (16, 32, 5, 2, 1, 6, 70, 4), (16, 16, 3, 1, 1, 18, 130, 8), (32, 32, 3, 1, 1, 2, 2, 4),
+             (8, 32, 5, 2, 1, 20, 36, 8), (32, 16, 3, 1, 1, 10, 34, 4),
+             (8, 16, 5, 2, 3, 512, 640, 0), (16, 16, 3, 1, 3, 256, 320, 0), (16, 32, 5, 2, 3, 256, 320, 0),
+             (32, 32, 3, 1, 3, 128, 160, 0)]
+
+
+@pytest.mark.parametrize("Cin,Cout,ks,stride,B,H,W,rows", C2S_CASES)
+def test_conv2d_s_matches_float64_like_the_fp32_kernel(Cin, Cout, ks, stride, B, H, W, rows):
+    """bmv_conv2d_s_fwd (csrc/conv2d_s.hip): FeatureNet's encoder layers as bf16 MFMAs on three-piece fp32 operands, against
+    a FLOAT64 convolution: no farther from it than the fp32 engine (bmv_conv_fwd), within 1e-5 of that kernel, not
+    bit-equal; ragged sizes (strips and row blocks that end inside a tile, a 2 x 2 image), both row tilings, the frame's
+    own layer shapes."""
+    from boostmvsnerfs_amd import _lib, convnet
+    g = torch.Generator().manual_seed(Cin * 1000 + H * W)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2))
+    ref32 = convnet.conv_fwd(x, *convnet.pack_conv(w, b, stride=stride), Cout, 1, ks, stride, relu=True)
+    _lib.set_tuning("BMV_CONV2D_S_ROWS", rows)
+    try:
+        got = convnet.conv2d_s(x, *convnet.pack_conv2d_s(w, b), Cout, ks, stride, relu=True)
+    finally:
+        _lib.set_tuning("BMV_CONV2D_S_ROWS", None)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    err, err32 = float((got.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+    mean, mean32 = float((got.double() - want).abs().mean()), float((ref32.double() - want).abs().mean())
+    print(f"[conv2d_s] {Cin}->{Cout} k{ks}s{stride} {B}x{H}x{W} rows={rows}: max err {err:.3e} (fp32 kernel {err32:.3e}), "
+          f"mean {mean:.3e} ({mean32:.3e}), scale {scale:.3e}")
+    assert err <= max(2.0 * err32, 1e-6 * scale) and mean <= 1.5 * mean32 + 1e-9 * scale
+    assert float((got - ref32).abs().max()) <= 1e-5 * scale and not torch.equal(got, ref32)
+    # leaky slope, no bias
+    got = convnet.conv2d_s(x, *convnet.pack_conv2d_s(w, None), Cout, ks, stride, slope=0.1)
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=stride, padding=ks // 2), 0.1)
+    assert float((got.double() - want).abs().max()) <= 4e-6 * scale
+
+
 @pytest.mark.parametrize("H,W", [(64, 96), (34, 50), (5, 7), (18, 130)])
 def test_conv0_fused_equals_the_two_launches(H, W):
     """bmv_conv0_fused_fwd = relu(conv(relu(conv(x)))) of FeatureNet's first block in one launch, against torch and
@@ -283,6 +322,40 @@ def test_feature_net_engine_matches_torch_modules(monkeypatch):
     with torch.no_grad():
         net.smooth0.bias.add_(1.0)
         _close(net(x)[2], want[2] + 1.0)
+
+
+def test_feature_net_at_frame_size_bf16_kernels_on_and_off(monkeypatch):
+    """At BASELINE configs[1]'s size (3 x 512 x 640) FeatureNet's default forward runs its first block, the encoder's 5x5
+    stride-2 / 3x3 layers and the last top-down step on the bf16 matrix cores (BMV_CONV0_S, BMV_CONV2D_S, BMV_FPN_S:
+    three-piece fp32 operands; the small fixtures of the other tests are below the size gate).  Both forms against the
+    torch modules, and against each other to fp32 rounding -- not bit-equal, and the switch counts its launches."""
+    from boostmvsnerfs_amd import convnet
+    from boostmvsnerfs_amd.networks.enerf.cnn import FeatureNet
+    torch.manual_seed(0)
+    net = FeatureNet()
+    _randomise_bn(net, 1)
+    net = net.to(DEV).eval()
+    x = torch.rand(3, 3, 512, 640, device=DEV)
+    calls = []
+    real = convnet.conv2d_s
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(convnet, "conv2d_s", spy)
+    with torch.no_grad():
+        got_s = [t.contiguous() if torch.is_tensor(t) else t.to_nchw() for t in net(x)]
+        assert len(calls) == 3, calls                           # conv1.0, conv1.1, conv2.0
+        for name in ("BMV_CONV0_S", "BMV_CONV2D_S", "BMV_FPN_S"):
+            monkeypatch.setitem(switches.VALUES, name, "0")
+        got_f = [t.contiguous() if torch.is_tensor(t) else t.to_nchw() for t in net(x)]
+        assert len(calls) == 3
+        monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
+        want = net(x)
+    for a, b_, w_ in zip(got_s, got_f, want):
+        _close(a, w_), _close(b_, w_)
+        scale = float(w_.abs().max())
+        assert float((a - b_).abs().max()) <= 1e-5 * scale and not torch.equal(a, b_)
 
 
 @pytest.mark.parametrize("cls,cin,shape", [("MinCostRegNet", 32, (8, 8, 12)), ("CostRegNet", 16, (8, 32, 48))])
