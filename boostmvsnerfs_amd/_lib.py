@@ -99,7 +99,7 @@ SIGNATURES = {
     "bmv_conv_c4_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_i, c_f],
     "bmv_conv0_s_wsplit_ints": [],
     "bmv_conv2d_s_wsplit_ints": [c_i, c_i, c_i, c_i],
-    "bmv_conv2d_s_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "bmv_conv2d_s_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "bmv_conv0_s_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f],
     "bmv_fpn_smooth_s_wsplit_ints": [],
     "bmv_fpn_smooth_s_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f],

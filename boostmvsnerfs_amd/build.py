@@ -36,6 +36,8 @@ if os.environ.get("BMV_C4_DEFS"):   # ablation builds of the 4-row-block convolu
     EXTRA_FLAGS["conv_c4.hip"] = os.environ["BMV_C4_DEFS"].split()
 if os.environ.get("BMV_C4S_DEFS"):  # ablation builds of the bf16 x 3 first layers / heads (scripts/ablate_conv_c4s.py)
     EXTRA_FLAGS["conv_c4s.hip"] = os.environ["BMV_C4S_DEFS"].split()
+if os.environ.get("BMV_C2S_DEFS"):    # ablation builds of the bf16 x 3 encoder convolutions (scripts/ablate_conv2d_s.py)
+    EXTRA_FLAGS["conv2d_s.hip"] = os.environ["BMV_C2S_DEFS"].split()
 if os.environ.get("BMV_FPN_S_DEFS"):  # ablation builds of the bf16 x 3 top-down + smooth0 kernel (scripts/ablate_fpn_s.py)
     EXTRA_FLAGS["fpn_s.hip"] = os.environ["BMV_FPN_S_DEFS"].split()
 if os.environ.get("BMV_WIN_DEFS"):   # kernel-tuning builds of the windowed sweep, e.g. "-DBMV_WIN_WPE=5 -DBMV_WIN_TAPBUF=1"

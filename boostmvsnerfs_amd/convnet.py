@@ -602,21 +602,72 @@ def pack_conv2d_s(weight, bias):
     return wsplit, b
 
 
-def conv2d_s(x, wsplit, bias, Cout, ks, stride, relu=False, slope=None, out=None):
+class SplitRecords:
+    """A feature map as SPLIT RECORDS (csrc/conv2d_s.hip, include/bmv.h): `data` (B, C/8, 3, H, W, 4) int32 -- the 8 channels
+    of an octet at a pixel as 8 bf16 (16 bytes) per piece, hi + mid + lo = the fp32 value exactly.  Written by the producing
+    layer's epilogue and staged by the consuming layer with LDS-DMA.  `shape` is the logical planar shape, `to_planar()` the
+    fp32 tensor (exact)."""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        assert data.dtype == torch.int32 and data.dim() == 6 and data.shape[2] == 3 and data.shape[-1] == 4 and data.is_contiguous()
+        self.data = data
+
+    @staticmethod
+    def empty(B, C, H, W, device):
+        assert C % 8 == 0
+        return SplitRecords(torch.empty(B, C // 8, 3, H, W, 4, device=device, dtype=torch.int32))
+
+    @staticmethod
+    def from_planar(x):
+        """(B, C % 8 == 0, H, W) float32 -> records (the arithmetic of the kernels' epilogue; tests and first layers)."""
+        B, C, H, W = x.shape
+        t = x.float().reshape(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()        # (B, octet, H, W, 8)
+        return SplitRecords(torch.stack(_split3_words(t), 2).contiguous())
+
+    @property
+    def shape(self):
+        B, O, _, H, W, _ = self.data.shape
+        return torch.Size((B, O * 8, H, W))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def to_planar(self):
+        B, O, _, H, W, _ = self.data.shape
+        w = self.data.view(torch.int16).reshape(B, O, 3, H, W, 8).to(torch.int32) << 16      # bf16 -> the fp32 bit pattern
+        f = w.view(torch.float32)
+        return ((f[:, :, 2] + f[:, :, 1]) + f[:, :, 0]).permute(0, 1, 4, 2, 3).reshape(B, O * 8, H, W)
+
+
+def conv2d_s(x, wsplit, bias, Cout, ks, stride, relu=False, slope=None, out=None, records=False):
     """act(conv2d(x (B,Cin,H,W), k = ks, stride, padding ks // 2) + bias) -> (B,Cout,H/stride,W/stride) on the bf16 matrix cores
-    with three-piece fp32 operands (csrc/conv2d_s.hip; `pack_conv2d_s`): FeatureNet's 5x5 stride-2 and 3x3 encoder layers."""
+    with three-piece fp32 operands (csrc/conv2d_s.hip; `pack_conv2d_s`): FeatureNet's 5x5 stride-2 and 3x3 encoder layers.
+    `x` may be a SplitRecords (staged by LDS-DMA: no split in this layer); records=True: the result as SplitRecords,
+    records="both": (planar, SplitRecords)."""
+    rin = isinstance(x, SplitRecords)
     B, Cin, H, W = x.shape
-    if out is None:
-        out = torch.empty(B, Cout, H // stride, W // stride, device=x.device, dtype=torch.float32)
-    assert out.shape == (B, Cout, H // stride, W // stride) and out.is_contiguous()
+    Ho, Wo = H // stride, W // stride
+    dev = x.device
+    want_planar = records is False or records == "both"
+    if want_planar and out is None:
+        out = torch.empty(B, Cout, Ho, Wo, device=dev, dtype=torch.float32)
+    assert out is None or (out.shape == (B, Cout, Ho, Wo) and out.is_contiguous())
+    rec = SplitRecords.empty(B, Cout, Ho, Wo, dev) if records else None
     lib = _lib.load()
     assert wsplit.dtype == torch.int32 and wsplit.numel() == lib.bmv_conv2d_s_wsplit_ints(Cin, Cout, ks, stride)
-    x = x if x.is_contiguous() else x.contiguous()
-    with ktimer.region(f"conv2d_s[{Cin}->{Cout},k{ks}s{stride},{H}x{W}]"):
-        rc = lib.bmv_conv2d_s_fwd(dptr(x, "x"), dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out), B, Cin, H, W,
-                                  Cout, ks, stride, _slope(relu, slope), stream())
+    if not rin:
+        x = x if x.is_contiguous() else x.contiguous()
+    with ktimer.region(f"conv2d_s[{Cin}->{Cout},k{ks}s{stride},{H}x{W}{',rec' if rin else ''}]"):
+        rc = lib.bmv_conv2d_s_fwd(None if rin else dptr(x, "x"), dptr(x.data, "x records", torch.int32) if rin else None,
+                                  dptr(wsplit, "wsplit", torch.int32), dptr(bias, "bias"), dptr(out) if want_planar else None,
+                                  dptr(rec.data, "out records", torch.int32) if rec is not None else None, B, Cin, H, W, Cout, ks, stride,
+                                  _slope(relu, slope), stream())
     _lib.check(rc, "conv2d_s_fwd")
-    return out
+    if records == "both":
+        return out, rec
+    return rec if records else out
 
 
 def pack_fpn_smooth_s(smooth_weight, smooth_bias, lat_weight, lat_bias, order=None):

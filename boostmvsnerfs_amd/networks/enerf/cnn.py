@@ -180,9 +180,16 @@ class FeatureNet(nn.Module):
             c0 = convnet.conv_fwd(c0, *P["conv0.1"], 8, 1, 3, relu=True)
         if switches.on("BMV_CONV2D_S") and big and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0:
             # conv1, conv2.0 on the bf16 matrix cores (csrc/conv2d_s.hip: weights stationary, independent strip-walking waves)
-            c1 = convnet.conv2d_s(c0, *P["conv1.0_s"], 16, 5, 2, relu=True)
-            c1 = convnet.conv2d_s(c1, *P["conv1.1_s"], 16, 3, 1, relu=True)
-            c2 = convnet.conv2d_s(c1, *P["conv2.0_s"], 32, 5, 2, relu=True)
+            if switches.on("BMV_CONV2D_S_REC"):
+                # ... the maps BETWEEN them as split records (convnet.SplitRecords: split once by the producer's epilogue, staged
+                # by LDS-DMA; bit-identical results); c1 also planar for the top-down step
+                c1 = convnet.conv2d_s(c0, *P["conv1.0_s"], 16, 5, 2, relu=True, records=True)
+                c1, c1r = convnet.conv2d_s(c1, *P["conv1.1_s"], 16, 3, 1, relu=True, records="both")
+                c2 = convnet.conv2d_s(c1r, *P["conv2.0_s"], 32, 5, 2, relu=True)
+            else:
+                c1 = convnet.conv2d_s(c0, *P["conv1.0_s"], 16, 5, 2, relu=True)
+                c1 = convnet.conv2d_s(c1, *P["conv1.1_s"], 16, 3, 1, relu=True)
+                c2 = convnet.conv2d_s(c1, *P["conv2.0_s"], 32, 5, 2, relu=True)
         else:
             c1 = convnet.conv_fwd(c0, *P["conv1.0"], 16, 1, 5, 2, relu=True)
             c1 = convnet.conv_fwd(c1, *P["conv1.1"], 16, 1, 3, relu=True)

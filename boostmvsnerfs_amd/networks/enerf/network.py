@@ -407,7 +407,7 @@ class Network(nn.Module):
         return (self.sweep_algo, self.overlap_front, self.lookup_records, self.frame_setup, self.volume_records,
                 self.overlap_eager, self.cost_reg_0.split_bf16, self.cost_reg_1.split_bf16,
                 self.cost_reg_0.conv_c4, self.cost_reg_1.conv_c4, self.cost_reg_0.quad_volume, self.cost_reg_1.quad_volume,
-                self.cost_reg_0.conv_c4s, self.cost_reg_1.conv_c4s, self.defer_f0, switches.get("BMV_FPN_S"), switches.get("BMV_CONV0_S"), switches.get("BMV_CONV2D_S"))
+                self.cost_reg_0.conv_c4s, self.cost_reg_1.conv_c4s, self.defer_f0, switches.get("BMV_FPN_S"), switches.get("BMV_CONV0_S"), switches.get("BMV_CONV2D_S"), switches.get("BMV_CONV2D_S_REC"))
 
     def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() replace storage: captured graphs are stale
         ag = self.__dict__.get("_autograph")

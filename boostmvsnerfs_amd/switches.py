@@ -36,6 +36,7 @@ DECLARED = {
     "BMV_FPN_S": (1, "... on the bf16 matrix cores with three-piece fp32 operands and lat0 folded into smooth0's weights (csrc/fpn_s.hip; the default since round 6); 0 = the fp32 kernel of csrc/conv.hip"),
     "BMV_CONV0_FUSE": (1, "fused first FeatureNet block"),
     "BMV_CONV2D_S": (1, "FeatureNet's conv1.0 / conv1.1 / conv2.0 (5x5 stride 2, 3x3) on the bf16 matrix cores, three-piece fp32 operands (csrc/conv2d_s.hip; round 6); 0 = the fp32 engine of csrc/conv.hip"),
+    "BMV_CONV2D_S_REC": (1, "... with the maps between those layers as split records (three bf16 pieces per value, written by the producing layer's epilogue, staged by LDS-DMA: convnet.SplitRecords; bit-identical results); 0 = planar fp32 maps, every consuming wave splits"),
     "BMV_CONV0_S": (1, "... with its second layer on the bf16 matrix cores, three-piece fp32 operands (csrc/fpn_s.hip conv0_s_kernel; the default since round 6); 0 = the fp32 kernel of csrc/conv.hip"),
     "BMV_TOP_FUSE": (1, "fused conv2 tail + top layer"),
     "BMV_CONV_SPLIT": ("0", "split-bf16 first layers / heads: '0' fp32 engine, 'auto' / '3' three pieces, '2' two pieces (opt-in experiment)"),

@@ -583,10 +583,15 @@ int bmv_conv0_s_fwd(const float* in, const float* w0b0, const int* wsplit, const
  * these layers.  wsplit: bmv_conv2d_s_wsplit_ints() int32 words [M tile = Cout / 16][filter row ky][step][piece 3][lane 64][4]:
  * lane = 16 kg + m holds, as 8 bf16 per piece (hi | mid | lo of the fp32 value, exactly), the 8 input channels of octet o
  * at filter column kx for output channel 16 tile + m, where (o, kx) = divmod(4 step + kg, ks) enumerates the (octet,
- * column) pairs of a filter row four to a step (pairs past Cin / 8 * ks: zeros).  bmv_conv2d_s_wsplit_ints: 0 = not covered. */
+ * column) pairs of a filter row four to a step (pairs past Cin / 8 * ks: zeros).  bmv_conv2d_s_wsplit_ints: 0 = not covered.
+ * SPLIT RECORDS: between two layers of the chain a map may travel as (B, C / 8, piece 3, H, W, 4) int32 -- the 8 channels of an
+ * octet at a pixel as 8 bf16 (16 bytes) per piece, hi + mid + lo = the fp32 value exactly -- written by the producing
+ * layer's epilogue (`out_records`) and staged by the consuming layer with LDS-DMA (`in_records`; `in` null): the split is
+ * paid once per value instead of once per consuming wave, and the result is BIT-IDENTICAL to the planar path.  Exactly one
+ * of in / in_records; out and / or out_records. */
 int bmv_conv2d_s_wsplit_ints(int Cin, int Cout, int ks, int stride);
-int bmv_conv2d_s_fwd(const float* in, const int* wsplit, const float* bias, float* out, int B, int Cin, int H, int W,
-                     int Cout, int ks, int stride, float act_slope, bmv_stream_t stream);
+int bmv_conv2d_s_fwd(const float* in, const int* in_records, const int* wsplit, const float* bias, float* out, int* out_records,
+                     int B, int Cin, int H, int W, int Cout, int ks, int stride, float act_slope, bmv_stream_t stream);
 
 /* FeatureNet's conv2.1 + toplayer as one launch (feature_net.py:14-16): out (B,H,W,32) channel-last (out_layout 1)
  * or (B,8,H,W,4) quad-planar (out_layout 3) =

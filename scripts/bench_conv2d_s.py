@@ -16,7 +16,7 @@ LAYERS = [("conv1.0", 8, 16, 5, 2, 1), ("conv1.1", 16, 16, 3, 1, 2), ("conv2.0",
 
 
 def main():
-    for B, H, W in ((3, 512, 640), (6, 480, 736), (3, 256, 320)):
+    for B, H, W in ((3, 512, 640), (6, 480, 736)):
         for name, cin, cout, ks, stride, div in LAYERS:
             g = torch.Generator().manual_seed(0)
             x = torch.randn(B, cin, H // div, W // div, generator=g).cuda()
@@ -29,6 +29,15 @@ def main():
             for rows in (0, 4, 8):
                 _lib.set_tuning("BMV_CONV2D_S_ROWS", rows)
                 line += f"  rows {rows}: {timed(lambda: convnet.conv2d_s(x, ws, bs, cout, ks, stride, relu=True)):6.1f}"
+            xr = convnet.SplitRecords.from_planar(x)
+            line += " | records in:"
+            for rows in (4, 8):
+                _lib.set_tuning("BMV_CONV2D_S_ROWS", rows)
+                line += f"  rows {rows}: {timed(lambda: convnet.conv2d_s(xr, ws, bs, cout, ks, stride, relu=True)):6.1f}"
+            _lib.set_tuning("BMV_CONV2D_S_ROWS", 4)
+            line += f" | rows 4, records in + out: {timed(lambda: convnet.conv2d_s(xr, ws, bs, cout, ks, stride, relu=True, records=True)):6.1f}"
+            line += f", in + both: {timed(lambda: convnet.conv2d_s(xr, ws, bs, cout, ks, stride, relu=True, records='both')):6.1f}"
+            line += f", planar in, records out: {timed(lambda: convnet.conv2d_s(x, ws, bs, cout, ks, stride, relu=True, records=True)):6.1f}"
             _lib.set_tuning("BMV_CONV2D_S_ROWS", None)
             print(line, flush=True)
 

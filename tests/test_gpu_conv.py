@@ -240,6 +240,33 @@ def test_conv2d_s_matches_float64_like_the_fp32_kernel(Cin, Cout, ks, stride, B,
     assert float((got.double() - want).abs().max()) <= 4e-6 * scale
 
 
+@pytest.mark.parametrize("Cin,Cout,ks,stride,B,H,W,rows", [c for c in C2S_CASES if c[4] < 3 or c[0] != 32])
+def test_conv2d_s_split_records_are_bit_identical_to_the_planar_path(Cin, Cout, ks, stride, B, H, W, rows):
+    """The split-record form of a map between two layers (convnet.SplitRecords: written by the producer's epilogue, staged by
+    the consumer with LDS-DMA) changes WHERE a value is split, not the arithmetic: records in -> the planar result bit for
+    bit; records out -> exactly the records of the planar result; both at once; ragged sizes (image borders = the zero
+    record, rows outside the image requested and never multiplied), both row tilings."""
+    from boostmvsnerfs_amd import _lib, convnet
+    g = torch.Generator().manual_seed(Cin * 1000 + H * W + 1)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    pk = convnet.pack_conv2d_s(w, b)
+    _lib.set_tuning("BMV_CONV2D_S_ROWS", rows)
+    try:
+        want = convnet.conv2d_s(x, *pk, Cout, ks, stride, relu=True)
+        xr = convnet.SplitRecords.from_planar(x)
+        assert torch.equal(xr.to_planar(), x)
+        got = convnet.conv2d_s(xr, *pk, Cout, ks, stride, relu=True)
+        assert torch.equal(got, want)
+        rec = convnet.conv2d_s(x, *pk, Cout, ks, stride, relu=True, records=True)
+        assert torch.equal(rec.data, convnet.SplitRecords.from_planar(want).data) and torch.equal(rec.to_planar(), want)
+        both, rec2 = convnet.conv2d_s(xr, *pk, Cout, ks, stride, relu=True, records="both")
+        assert torch.equal(both, want) and torch.equal(rec2.data, rec.data)
+    finally:
+        _lib.set_tuning("BMV_CONV2D_S_ROWS", None)
+
+
 @pytest.mark.parametrize("H,W", [(64, 96), (34, 50), (5, 7), (18, 130)])
 def test_conv0_fused_equals_the_two_launches(H, W):
     """bmv_conv0_fused_fwd = relu(conv(relu(conv(x)))) of FeatureNet's first block in one launch, against torch and
@@ -346,10 +373,13 @@ def test_feature_net_at_frame_size_bf16_kernels_on_and_off(monkeypatch):
     with torch.no_grad():
         got_s = [t.contiguous() if torch.is_tensor(t) else t.to_nchw() for t in net(x)]
         assert len(calls) == 3, calls                           # conv1.0, conv1.1, conv2.0
+        monkeypatch.setitem(switches.VALUES, "BMV_CONV2D_S_REC", "0")     # planar maps between the layers: the same bits
+        got_p = [t.contiguous() if torch.is_tensor(t) else t.to_nchw() for t in net(x)]
+        assert len(calls) == 6 and all(torch.equal(a, b_) for a, b_ in zip(got_s, got_p))
         for name in ("BMV_CONV0_S", "BMV_CONV2D_S", "BMV_FPN_S"):
             monkeypatch.setitem(switches.VALUES, name, "0")
         got_f = [t.contiguous() if torch.is_tensor(t) else t.to_nchw() for t in net(x)]
-        assert len(calls) == 3
+        assert len(calls) == 6
         monkeypatch.setitem(switches.VALUES, "BMV_CNN", "torch")
         want = net(x)
     for a, b_, w_ in zip(got_s, got_f, want):

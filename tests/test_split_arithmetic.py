@@ -47,3 +47,21 @@ def test_kept_products_are_exact_and_the_dropped_ones_are_one_fp32_rounding():
     rel = np.abs(full - got) / np.abs(full)
     assert float(rel.max()) <= 2.0 ** -23 * 1.01, float(rel.max())
     assert float(np.median(rel)) < 2.0 ** -26
+
+
+def test_split_records_round_trip_is_exact():
+    """convnet.SplitRecords (the activation format between two bf16 x 3 encoder layers, csrc/conv2d_s.hip): hi / mid by
+    TRUNCATION, lo = the rest rounded to bf16 (at most 8 bits are left: exact) -- from_planar -> to_planar returns the fp32
+    tensor bit for bit, and the records are laid out (B, C/8, piece, H, W, 8 bf16)."""
+    import torch
+    from boostmvsnerfs_amd.convnet import SplitRecords
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 6, 10, generator=g) * 10.0 ** torch.randint(-6, 6, (2, 16, 6, 10), generator=g).float()
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0 + 2.0 ** -23, -255.0 / 256.0])
+    r = SplitRecords.from_planar(x)
+    assert tuple(r.data.shape) == (2, 2, 3, 6, 10, 4) and r.shape == x.shape
+    assert torch.equal(r.to_planar(), x)
+    # channel 8 o + 2 i (+ 1) of pixel (y, x) sits in the low (high) half of word i of record (o, piece, y, x)
+    hi = r.data[1, 1, 0, 3, 7, 2]
+    assert (int(hi) & 0xFFFF) == (int(x[1, 8 + 4, 3, 7].view(torch.int32)) >> 16) & 0xFFFF
+    assert ((int(hi) >> 16) & 0xFFFF) == (int(x[1, 8 + 5, 3, 7].view(torch.int32)) >> 16) & 0xFFFF
