@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from ... import ops, switches
+from ... import convnet, ops, switches
 from ...config import cfg
 from ..enerf import network as enerf_network
 
@@ -83,6 +83,13 @@ class Network(enerf_network.Network):
         """ids: (B,S) long tensor of view indices -> the S views of every batch item."""
         bi = torch.arange(ids.shape[0], device=ids.device)[:, None]
         return (batch["all_src_inps"][bi, ids], batch["all_src_exts"][bi, ids], batch["all_src_ixts"][bi, ids])
+
+    @staticmethod
+    def _pick_host(batch, ids):
+        """_pick for ONE batch item with the view numbers known on the host (the triplets of view_selection.json): three
+        concatenations instead of an arange + three index kernels + their index arithmetic (8 launches, 19 us for the
+        12.7 MB of images alone at 6 x 480 x 736: the tail of every K-volume frame)."""
+        return tuple(torch.stack([batch[k][:, i] for i in ids], 1) for k in ("all_src_inps", "all_src_exts", "all_src_ixts"))
 
     @staticmethod
     def _pick_feats(f, bi, ids):
@@ -164,7 +171,7 @@ class Network(enerf_network.Network):
             rgb, depth, weights = ops.blend(raws, masks, z_vals, normalise=True)
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
-    def _forward_parallel(self, batch, feats, sel, sel32, cams, K):
+    def _forward_parallel(self, batch, feats, sel, sel32, cams, K, late=None):
         """The K cost volumes are independent until the fusion: each one's chain (sweeps, regularisers, depth
         regression, render in MLP-only mode) runs on its own HIP stream; the deep U-Net levels are launches of a few
         dozen workgroups that fill the chip only together.  The main stream joins them before the blend."""
@@ -189,16 +196,30 @@ class Network(enerf_network.Network):
                 getattr(self, f"nerf_{i}").packed_weights()
         pre = getattr(self, "_cam_pre", None)      # per volume: projection matrices + level-0 hypotheses (_forward_boost)
         first = {}
+        fronts = {}
+        if late is not None:
+            # FeatureNet's coarsest map is all the level-0 cost volumes need (enerf.Network._front_overlapped, K times): the K
+            # level-0 chains -- sweep, 3-D regulariser, depth regression: short launches that fill the chip only together --
+            # run on their streams UNDER FeatureNet's top-down path (3 large launches on the main stream, 0.23 of a 2.2 ms
+            # frame at 6 x 480 x 736), instead of behind it
+            for j, k in enumerate(ks):
+                s = self._streams[j]
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    fronts[j] = self.level_front(0, feats["level_0"], (batch["all_src_inps"], *cams[k]), batch, None,
+                                                 view_ids=sel32[k], pre=pre[k] if pre is not None else None)
+            feats.update(late())
         for j, k in enumerate(ks):
             s = self._streams[j]
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 vid = sel32[k]
                 views = (batch["all_src_inps"], *cams[k])
-                st = None
+                st = fronts.get(j)
                 for i in range(cc.num):
-                    st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid,
-                                          pre=pre[k] if pre is not None else None)
+                    if not (i == 0 and st is not None):
+                        st = self.level_front(i, feats[f"level_{i}"], views, batch, st, view_ids=vid,
+                                              pre=pre[k] if pre is not None else None)
                     if cc.render_if[i]:
                         self.render_level(i, st, feats[f"level_{cc.render_im_feat_level[i]}"], views, batch, mode=1,
                                           outs=tuple(t[:, j] for t in stacks[i]), view_ids=vid)
@@ -224,7 +245,10 @@ class Network(enerf_network.Network):
                 out["depth_mvs"] = torch.reciprocal(depth0) if cc.depth_inv[i] else depth0
                 out["std"] = std0
             ret.update({f"{k_}_level{i}": v for k_, v in out.items()})
-        batch["src_inps"], batch["src_exts"], batch["src_ixts"] = self._pick(batch, sel[:, K - 1])
+        # the reference leaves the last triplet in batch['src_*'] (network.py:196-198)
+        last = getattr(self, "_last_triplet", None)
+        batch["src_inps"], batch["src_exts"], batch["src_ixts"] = (self._pick_host(batch, last) if last is not None
+                                                                    else self._pick(batch, sel[:, K - 1]))
         return ret
 
     def _forward_batched(self, batch, feats, sel, sel32, cams, K):
@@ -307,7 +331,8 @@ class Network(enerf_network.Network):
     def _autograph_key(self, batch):
         """A captured K-volume frame is specialised to the cost-volume triplets view_selection.json selects for the
         batch's targets (they are baked into the graph as device constants) and to the capture hook of the tests."""
-        base = super()._autograph_key(batch) + (self.parallel_volumes, self.batched_volumes, self.by_index, self.capture is not None)
+        base = super()._autograph_key(batch) + (self.parallel_volumes, self.batched_volumes, self.by_index, self.capture is not None,
+                                                 switches.get("BMV_BOOST_OVERLAP"))
         if self.view_selection_outputs is None:
             return base
         meta = batch["meta"]
@@ -338,7 +363,10 @@ class Network(enerf_network.Network):
             sel = trip[k_best[:, :K]]                               # (B,K,3)
             if len(self._sel_cache) > 64:
                 self._sel_cache.clear()
-            self._sel_cache[key] = sel
+            # (+ the last volume's view numbers as Python ints, for the batch['src_*'] the reference leaves behind)
+            self._sel_cache[key] = sel = (sel, [int(v) for v in view_triplets(N, cfg.enerf.cost_volume_input_views)[int(picks[0][K - 1])]]
+                                          if B == 1 else None)
+        sel, self._last_triplet = sel
         # what the K chains need from the cameras alone -- the K triplets' camera matrices, K x S projection matrices per
         # cascade level and level 0's hypotheses -- on a side stream UNDER FeatureNet: one gather per camera tensor and
         # ONE launch (ops.frame_setup, the triplets as batch items) instead of 2 K + K latency-bound launches and ~20 index
@@ -370,10 +398,33 @@ class Network(enerf_network.Network):
         self.feature_net.pack_lookup = (self.wants_lookup_records()
                                         and enerf_network.engine_ok(self.feature_net, batch["all_src_inps"]))
         self.set_volume_records(self.feature_net.pack_lookup)
-        try:
-            feats = self.forward_feat(batch["all_src_inps"])
-        finally:
-            self.feature_net.pack_lookup = False
+        late = None
+        x_all = batch["all_src_inps"]
+        fn = self.feature_net
+        if (switches.on("BMV_BOOST_OVERLAP") and B == 1 and dev.type == "cuda" and not self.wants_grad() and self.by_index
+                and (self.parallel_volumes or self.volume_ids is not None) and not self.batched_volumes
+                and cc.num == 2 and not cc.render_if[0] and cc.render_if[1] and cc.render_scale[1] == 1.0
+                and enerf_network.engine_ok(fn, x_all)):
+            # two phases: the encoder + top layer now, the top-down path (`late`) once the K level-0 chains are on their streams
+            _, V, C_, H_, W_ = x_all.shape
+            fn.quad_out = self.sweep_algo == 0 or self.sweep_algo >= 500
+            xf = x_all.reshape(V, C_, H_, W_)
+            pack = fn.pack_lookup
+            try:
+                c0, c1, p2, p2_cl = fn.engine_bottom_up(xf)
+            finally:
+                fn.pack_lookup = False
+            feats = {"level_0": enerf_network._views(p2_cl, 1, V, H_ // 4, W_ // 4)}
+
+            def late():
+                f1, f0 = fn.engine_top_down(c0, c1, p2, rgb=xf if pack else None)
+                return {"level_1": enerf_network._views(f1, 1, V, H_ // 2, W_ // 2),
+                        "level_2": f0.reshape_views(1, V) if isinstance(f0, convnet.LookupRecords) else f0.reshape(1, V, -1, H_, W_)}
+        else:
+            try:
+                feats = self.forward_feat(x_all)
+            finally:
+                self.feature_net.pack_lookup = False
         if cam is not None:
             # (long done: FeatureNet took 100x its time.  The tensors allocated on the side stream are read on the main
             # and the volume streams and released when this function returns; the side stream's next allocation comes
@@ -390,7 +441,9 @@ class Network(enerf_network.Network):
         by_index = (self.by_index and not train and all(cc.render_scale[i] == 1.0 for i in range(cc.num) if cc.render_if[i])
                     and all(isinstance(feats[f"level_{i}"], ops.QuadFeats)
                             or (not feats[f"level_{i}"].is_contiguous()
-                                and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous()) for i in range(cc.num)))
+                                and feats[f"level_{i}"].permute(0, 1, 3, 4, 2).is_contiguous())
+                            for i in range(cc.num) if f"level_{i}" in feats))   # (two-phase FeatureNet: the engine's layouts)
+        assert late is None or by_index
         if by_index:
             # (B,K,3) -> K tensors (B,3); in range by construction: rows of combinations(range(N), 3) picked by the
             # triplet numbers validated above, so no device read is spent on ops.check_view_ids
@@ -409,7 +462,7 @@ class Network(enerf_network.Network):
                 return self._forward_batched(batch, feats, sel, sel32, cams, K)
             if (self.parallel_volumes or self.volume_ids is not None) and B == 1:
                 try:
-                    return self._forward_parallel(batch, feats, sel, sel32, cams, K)
+                    return self._forward_parallel(batch, feats, sel, sel32, cams, K, late=late)
                 finally:
                     self._cam_pre = None      # (tensors of this frame / this capture's pool: not kept across calls)
         if self.volume_ids is not None:

@@ -35,6 +35,7 @@ DECLARED = {
     "BMV_FPN_FUSE": (1, "fused FPN top-down + smooth0"),
     "BMV_FPN_S": (1, "... on the bf16 matrix cores with three-piece fp32 operands and lat0 folded into smooth0's weights (csrc/fpn_s.hip; the default since round 6); 0 = the fp32 kernel of csrc/conv.hip"),
     "BMV_CONV0_FUSE": (1, "fused first FeatureNet block"),
+    "BMV_BOOST_OVERLAP": (0, "1 = K-volume ENeRF (boost_enerf) inference with the K level-0 chains on their streams UNDER FeatureNet's top-down path (which only the level-1 sweeps and the renderer need) instead of behind it.  Measured round 6: 2.235 -> 2.21 ms at 6 x 480 x 736, K = 4 -- and hipGraphLaunch of that topology (every volume stream joins the main stream twice) SEGFAULTS on ROCm 7.2 in a process that captured other graphs before (tests/test_gpu_framegraph.py in file order): off by default"),
     "BMV_CONV2D_S": (1, "FeatureNet's conv1.0 / conv1.1 / conv2.0 (5x5 stride 2, 3x3) on the bf16 matrix cores, three-piece fp32 operands (csrc/conv2d_s.hip; round 6); 0 = the fp32 engine of csrc/conv.hip"),
     "BMV_CONV2D_S_REC": (1, "... with the maps between those layers as split records (three bf16 pieces per value, written by the producing layer's epilogue, staged by LDS-DMA: convnet.SplitRecords; bit-identical results); 0 = planar fp32 maps, every consuming wave splits"),
     "BMV_CONV0_S": (1, "... with its second layer on the bf16 matrix cores, three-piece fp32 operands (csrc/fpn_s.hip conv0_s_kernel; the default since round 6); 0 = the fp32 kernel of csrc/conv.hip"),
