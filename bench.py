@@ -734,25 +734,31 @@ def main():
                              "same bracket with bmv_tuning BMV_RENDER_SPLIT=0: every chain of the renderer's MLP on fp32 MFMAs"))
             if rs_was != 0 or any(c4s_was):
                 legs.append(("all_fp32_mfma", 0, False,
-                             "same bracket with NO bf16 matrix instruction in the frame: BMV_RENDER_SPLIT=0 and the regularisers' "
-                             "first layers / heads on the fp32 4-row blocks (cost_reg_i.conv_c4s = False; what `value` measured in "
-                             "rounds 1-4)"))
+                             "same bracket with NO bf16 matrix instruction in the frame: BMV_RENDER_SPLIT=0, the regularisers' "
+                             "first layers / heads on the fp32 4-row blocks (cost_reg_i.conv_c4s = False) and FeatureNet on the fp32 "
+                             "engine (BMV_CONV0_S = BMV_CONV2D_S = BMV_FPN_S = 0): what `value` measured in rounds 1-4"))
+            import contextlib
+
+            from boostmvsnerfs_amd import switches as _sw
             for name, rsplit, c4s, what in legs:
                 _bl.set_tuning("BMV_RENDER_SPLIT", rsplit)
                 if c4s is not None:
                     for r in regs:
                         r.conv_c4s = c4s
                 net._autograph.invalidate()              # (the captured frame has the other renderer baked in)
+                # (... and FeatureNet's bf16 x 3 kernels of round 6 -- first block, encoder, last top-down step -- back on fp32 MFMAs)
+                fp32_cnn = _sw.override(BMV_CONV0_S=0, BMV_CONV2D_S=0, BMV_FPN_S=0) if c4s is False else contextlib.nullcontext()
                 try:
-                    for _ in range(4):                  # eager, capture, first replays of the new configuration
-                        step_plain()
-                    torch.cuda.synchronize()
-                    t_r = bracketed(step_plain, max(n_x, 50))
-                    with torch.no_grad():
-                        side_frames[name] = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
-                    extra[name] = {"value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
-                                   "parity_max_rel": None,     # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
-                                   "what": what + "; parity_max_rel = its frame against the oracle's"}
+                    with fp32_cnn:
+                        for _ in range(4):                  # eager, capture, first replays of the new configuration
+                            step_plain()
+                        torch.cuda.synchronize()
+                        t_r = bracketed(step_plain, max(n_x, 50))
+                        with torch.no_grad():
+                            side_frames[name] = {k: v.detach().float().cpu() for k, v in net(batch).items() if torch.is_tensor(v)}
+                        extra[name] = {"value": N / t_r / 1e6, "ms_per_step": t_r * 1e3,
+                                       "parity_max_rel": None,     # (filled in behind the cpu_baseline leg, which renders the oracle's frame)
+                                       "what": what + "; parity_max_rel = its frame against the oracle's"}
                 except Exception as e:                  # a side measurement must not take the metric's line down with it
                     extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                     side_frames.pop(name, None)
