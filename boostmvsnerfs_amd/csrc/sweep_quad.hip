@@ -112,6 +112,8 @@ struct QuadArgs {
   long long dv_bs;
   int flags;                                  // tuning: 1 no fill, 2 no blend, 4 no store
   int qsplit;                                 // the C/4 channel quads of a tile are shared by qsplit workgroups
+  int lds_pieces;                             // 1 KB pieces of LDS the launch gives a workgroup (>= budget): a workgroup whose S windows
+                                              // fit TWICE runs its channel quads double-buffered (round 6)
 };
 
 // PU: plane-uniform hypotheses (one depth per plane).  OQ: the variance leaves as QUAD RECORDS (B, C/4, D, h, w, 4) -- one
@@ -233,8 +235,8 @@ sweep_quad_kernel(const QuadArgs a) {
     }
   }
   int wbase[S];   // LDS byte offset of each view's window
+  int used = 0;   // 1 KB pieces of the S windows together
   {
-    int used = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const bool staged = (wmode[s] == 1) | (wmode[s] == 2);
@@ -282,14 +284,21 @@ sweep_quad_kernel(const QuadArgs a) {
       foff[s][i] = ok ? vb + (unsigned)(__mul24(gy, Ws) + gx) * 16u : 0x80000000u;
     }
   }
-  auto issue_fill = [&](int q) {
+  // Round 6: TWO window sets when they fit the workgroup's LDS (wave-uniform: level 0's 8 planes x 32 x 2 voxels need ~23 KB
+  // per set, the launch gives 53 = 160 / 3 resident workgroups): fill(q + 1) goes out BEFORE blend(q) instead of behind it,
+  // into the other set, and a quad costs one workgroup barrier instead of two.  (hipcc 7.2 does not put a vmcnt(0) in
+  // front of the LDS reads of a blend while a `buffer_load ... lds` is in flight -- checked in the ISA; round 4's
+  // compiler did, which is what stopped this then.)
+  const unsigned set_bytes = (unsigned)used * 1024u;
+  const bool dbl_fits = NPG == 1 && used > 0 && 2 * used <= a.lds_pieces && !(a.flags & 0x40);
+  auto issue_fill = [&](int q, unsigned set_off = 0u) {
     // (the range check of the resource is against the whole feature tensor from the moved base on: in-image offsets stay
     // inside, the out-of-range marker stays outside)
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(fbytes) + (size_t)q * qstride, 0, (int)(fsize - (size_t)q * qstride), 0x00020000);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      char* dst = win + wbase[s] + wave * 1024;
+      char* dst = win + set_off + wbase[s] + wave * 1024;
 #pragma unroll
       for (int i = 0; i < MAXP; ++i)
         if (i < fnp[s])
@@ -384,17 +393,26 @@ sweep_quad_kernel(const QuadArgs a) {
 #pragma unroll
   for (int sv = 0; sv < S; ++sv) all_staged &= (wmode[sv] == 1) | (wmode[sv] == 2);
   // two copies of the quad loop: the common one (every view staged) carries none of the gather path's live values
-  auto run_quads = [&](auto fast_tag) {
-  constexpr bool FAST = decltype(fast_tag)::value;
+  auto run_quads = [&](auto fast_tag, auto dbl_tag) {
+  constexpr bool FAST = decltype(fast_tag)::value, DBL = decltype(dbl_tag)::value;
+  static_assert(!DBL || FAST, "two window sets: every view staged");
   for (int q = q_begin; q < q_end; ++q) {
     // fills of quad q landed in this wave's pieces: everything older than the last 4 stores of quad q - 1
     // (a raw s_barrier: __syncthreads() carries a workgroup-scope fence that would wait for the stores as well)
     if (q == q_begin)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (DBL)   // fill(q) went out BEFORE quad q - 1's stores: all PG (x 4 planar) of them may still be in flight
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(OQ ? PG : 4 * PG) : "memory");
     else if (OQ)
       asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");   // (quad records: the last plane is ONE store)
     else
       asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // ... and in every wave's
+    // (DBL: every wave is past blend(q - 1) too, whose window set fill(q + 1) now overwrites under blend(q))
+    const char* winq = win + (DBL ? (unsigned)((q - q_begin) & 1) * set_bytes : 0u);
+    // (the windows start at LDS address 0 -- the kernel has no static LDS --: tap offsets are LDS addresses)
+    const unsigned setq = DBL ? (unsigned)((q - q_begin) & 1) * set_bytes : 0u;
+    (void)setq;
+    if (DBL && q + 1 < q_end) issue_fill(q + 1, (unsigned)((q + 1 - q_begin) & 1) * set_bytes);
     float4 V[PG];
     const unsigned soff = (unsigned)(4 * q) * cstride;    // (quad records: quad q's block of D planes starts at the same byte)
     // lanes outside the volume store too, out of range (dropped by the buffer's bounds check): the vmcnt count is exact
@@ -451,7 +469,7 @@ sweep_quad_kernel(const QuadArgs a) {
       float4 t00, t01, t10, t11;
       {
         const unsigned a0 = tadr[0][0], a1 = a0 + (unsigned)wc[0] * 16u;
-        t00 = lds4(win, a0), t01 = lds4(win, a0 + 16u), t10 = lds4(win, a1), t11 = lds4(win, a1 + 16u);
+        t00 = lds4(winq, a0), t01 = lds4(winq, a0 + 16u), t10 = lds4(winq, a1), t11 = lds4(winq, a1 + 16u);
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -460,7 +478,7 @@ sweep_quad_kernel(const QuadArgs a) {
         if (u + 1 < NU) {
           const int pn = (u + 1) / S, sn = (u + 1) % S;
           const unsigned a0 = tadr[pn][sn], a1 = a0 + (unsigned)wc[sn] * 16u;
-          n00 = lds4(win, a0), n01 = lds4(win, a0 + 16u), n10 = lds4(win, a1), n11 = lds4(win, a1 + 16u);
+          n00 = lds4(winq, a0), n01 = lds4(winq, a0 + 16u), n10 = lds4(winq, a1), n11 = lds4(winq, a1 + 16u);
         }
         BMV_QUAD_SB;
         blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv], sv == 0);
@@ -476,8 +494,26 @@ sweep_quad_kernel(const QuadArgs a) {
       for (int u = 0; u < NU; ++u) {
         const int pl = u / S, sv = u % S;
         const unsigned a0 = tadr[pl][sv], a1 = a0 + (unsigned)wc[sv] * 16u;
-        const float4 t00 = lds4(win, a0), t01 = lds4(win, a0 + 16u), t10 = lds4(win, a1), t11 = lds4(win, a1 + 16u);
+        if constexpr (DBL) {
+          // the four taps as hand-written ds_read_b128 with their own wait: the compiler puts s_waitcnt vmcnt(0..2) in front of
+          // every LDS read it sees while an LDS-DMA (the next quad's fill) is in flight -- it cannot tell the two window
+          // sets apart -- which serialised fill and blend (28 instead of 19 us with the reads left to it).  The wait is tied
+          // to the data registers so that no use is scheduled above it; lgkmcnt(0): scalar loads share the counter and
+          // return out of order, a counted wait would not be safe
+          using f4r = __attribute__((ext_vector_type(4))) float;
+          f4r r00, r01, r10, r11;
+          const unsigned l0 = setq + a0, l1 = setq + a1;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(r00) : "v"(l0) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(r01) : "v"(l0) : "memory");
+          asm volatile("ds_read_b128 %0, %1" : "=v"(r10) : "v"(l1) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(r11) : "v"(l1) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r00), "+v"(r01), "+v"(r10), "+v"(r11));
+          blend4(acc, acc2, make_float4(r00[0], r00[1], r00[2], r00[3]), make_float4(r01[0], r01[1], r01[2], r01[3]),
+                 make_float4(r10[0], r10[1], r10[2], r10[3]), make_float4(r11[0], r11[1], r11[2], r11[3]), tw[pl][sv], sv == 0);
+        } else {
+        const float4 t00 = lds4(winq, a0), t01 = lds4(winq, a0 + 16u), t10 = lds4(winq, a1), t11 = lds4(winq, a1 + 16u);
         blend4(acc, acc2, t00, t01, t10, t11, tw[pl][sv], sv == 0);
+        }
         if (sv == S - 1) {
           finish(pl, acc, acc2);
           if (pl + 1 < PG) store_plane(pl);   // (only the LAST plane's stores wait for the next fill to be issued)
@@ -495,7 +531,7 @@ sweep_quad_kernel(const QuadArgs a) {
           const int mode = wmode[sv];
           if (mode == 1 || mode == 2) {
             const unsigned a0 = tadr[pl][sv], a1 = a0 + (unsigned)wc[sv] * 16u;
-            blend4(acc, acc2, lds4(win, a0), lds4(win, a0 + 16u), lds4(win, a1), lds4(win, a1 + 16u), tw[pl][sv]);
+            blend4(acc, acc2, lds4(winq, a0), lds4(winq, a0 + 16u), lds4(winq, a1), lds4(winq, a1 + 16u), tw[pl][sv]);
           } else if (mode == 3) {
             gather4(sv, pl, q, acc, acc2);
           }
@@ -505,7 +541,7 @@ sweep_quad_kernel(const QuadArgs a) {
         if (pl + 1 < PG) store_plane(pl);
       }
     }
-    if (q + 1 < q_end) {
+    if (!DBL && q + 1 < q_end) {
       barrier_lds();       // every wave is done with the windows (its LDS reads have returned)
       issue_fill(q + 1);
     }
@@ -514,10 +550,12 @@ sweep_quad_kernel(const QuadArgs a) {
     store_plane(PG - 1);
   }
   };
-  if (all_staged)
-    run_quads(std::true_type{});
+  if (all_staged && dbl_fits)
+    run_quads(std::true_type{}, std::true_type{});
+  else if (all_staged)
+    run_quads(std::true_type{}, std::false_type{});
   else
-    run_quads(std::false_type{});
+    run_quads(std::false_type{}, std::false_type{});
   if (NPG > 1) barrier_lds();   // every wave is done with this group's windows before the next group plans its own
   }
 }
@@ -616,7 +654,7 @@ void fill_geom(QuadGeom& g, const QuVariant& v, int S, int Hs, int Ws, int D, in
 template <int TXW, int TYH, int DP, int PG, int S, int WPE, bool PU, bool OQ = false, int NPG = 1>
 int qu_launch_one(const QuadArgs& a, int B, hipStream_t stream) {
   auto kern = sweep_quad_kernel<TXW, TYH, DP, PG, S, WPE, PU, OQ, NPG>;
-  const size_t lds = (size_t)a.budget * 1024;
+  const size_t lds = (size_t)a.lds_pieces * 1024;
   static size_t allowed = 0;
   if (lds > allowed) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -704,6 +742,24 @@ int bmv_sweep_variance_quad_fwd(const float* feats_quad, const int* view_ids, in
   if ((flags >> 16) & 0xff) a.budget = (flags >> 16) & 0xff;   // tests: an LDS budget below the windows -> gather fallback
   a.qsplit = ((C >> 2) % v.qsplit) == 0 ? v.qsplit : 1;
   if (8 * a.pgroups * a.qsplit >= 65536) return BMV_ERR_UNSUPPORTED;
+  {
+    // LDS per workgroup: what the CU's LDS leaves each RESIDENT workgroup (the launch's workgroups over 256 CUs, at most the
+    // wpe x 4 / waves-per-workgroup the registers allow), at least the single-set budget, at most 64 KB; a workgroup whose
+    // windows fit twice pipelines its channel quads through two sets.  OPT-IN (BMV_SWEEP_QUAD_DBL=1), measured round 6
+    // (profiles/r6/sweep_double_buffer.txt): at the headline frame level 0's windows are ~27 KB per set and do not fit
+    // twice beside two other workgroups (3 resident per CU; at 53 KB each the third no longer fits: 28 us instead of 19),
+    // level 1 has 5 resident workgroups; where two sets do fit (256 x 320: one or two workgroups per CU) the sweep gains
+    // 5-10 % and the frame nothing; under the K streams of config 3 the larger allocation costs 2 % of the frame
+    const long wgs = (long)8 * ((a.pgroups + v.npg - 1) / v.npg) * a.qsplit * a.tiles_x * a.tyb * B;
+    const int waves = v.txw * v.tyh * v.dp / 64;
+    const int by_regs = (v.wpe * 4) / (waves > 0 ? waves : 1);
+    long resident = (wgs + 255) / 256;
+    if (resident > by_regs) resident = by_regs;
+    if (resident < 1) resident = 1;
+    int pieces = (int)(152 / resident);   // (152 of the CU's 160 KB: at 160 / n the n-th workgroup no longer fits beside the others -- measured, a second round)
+    if (pieces > 64) pieces = 64;
+    a.lds_pieces = (bmv::tuning("BMV_SWEEP_QUAD_DBL", 0) != 0 && (C >> 2) / a.qsplit > 1 && pieces > a.budget) ? pieces : a.budget;
+  }
   const bool pu = dv_plane_uniform != 0;
   int rc = BMV_ERR_UNSUPPORTED;
   if (v.npg > 1) {           // plane-walking tuning variants (S = 3, planar output)

@@ -26,6 +26,7 @@ Knob g_knobs[] = {
     {"BMV_MVS_SPLIT", "0 = every layer of MVSNeRF's 6 x 128 MLP on fp32 MFMAs; default 1: its ten 128 -> 128 weight chunks (pts_linears.1-4, feature_linear) as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy"},
     {"BMV_RENDER_PC_GRID", "producer / consumer renderer: workgroups (default 256: one per CU, all resident)"},
     {"BMV_MVS_SWEEP_AUX", "MVS padded sweep: cache-policy bits of its stores (default 0x102)"},
+    {"BMV_SWEEP_QUAD_DBL", "1 = a workgroup of the quad plane sweep whose windows fit its share of the CU's LDS twice requests the next channel quad's windows before it blends the current one (two window sets, hand-written LDS reads); default 0: one set (measured round 6: the headline frame's windows do not fit twice at its occupancy, profiles/r6/sweep_double_buffer.txt)"},
     {"BMV_CONV2D_S_ROWS", "bf16 x 3 FeatureNet encoder convolutions (csrc/conv2d_s.hip): output rows a wave walks (4, 8; default 0: 8 when that gives >= 1536 waves)"},
     {"BMV_CONV0_S_ROWS", "bf16 x 3 first FeatureNet block (csrc/fpn_s.hip conv0_s_kernel): output rows a wave walks (9, 10, 12; default 0: the cheapest)"},
     {"BMV_FPN_S_ROWS", "bf16 x 3 fused top-down + smooth0 (csrc/fpn_s.hip): output rows a wave walks (6, 8, 9, 10, 12; default 0: the cheapest by waves per SIMD x rows)"},
