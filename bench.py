@@ -57,6 +57,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2516.6 # v_mfma_f32_32x32x16_bf16 dense peak: 32 768 FLOP / 32 cycles x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
 
 HEADLINE = "enerf_512x640_3src_64planes"
 WORKLOADS = {
@@ -100,6 +101,7 @@ def parse():
     ap.add_argument("--sweep-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle for non-headline workloads")
+    ap.add_argument("--grad-f64", type=int, default=1, help="fine-tune workloads with a cpu_baseline: also run the oracle's step in float64 (parity_max_rel.grad_vs_float64)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the frame as HIP graphs (inference workloads)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N>1, views sharding: wait for each frame's all-gather before rendering the next frame")
@@ -212,30 +214,45 @@ def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
         from oracle import enerf as O   # checker / baseline only
         cc = cfg.enerf.cas_config
         k_best = list(sel)[: wl.get("k_best", 1)] if sel is not None else None
+        arbitrate = bool(getattr(args, "grad_f64", 1))
+        cpu_baseline.last_step64 = cpu_baseline.last_step_small = None
 
-        def step(stride):
+        def step(stride, f64=False):
             b = clone_batch(batch_cpu)
             g = torch.Generator().manual_seed(0)
             for i in range(cc.num):
                 b[f"rays_{i}"] = b[f"rays_{i}"][:, ::stride].contiguous()
                 b[f"rgb_{i}"] = torch.rand(1, b[f"rays_{i}"].shape[1], 3, generator=g)
-            leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in state_dict.items()}
+            if f64:     # the arbiter: the same step in float64 (an fp32-vs-fp32 distance of 0.09 says nothing by itself)
+                b = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+            leaves = {k: (v.detach().double() if f64 and v.is_floating_point() else v.detach().clone())
+                      .requires_grad_(v.is_floating_point() and "running" not in k) for k, v in state_dict.items()}
             t0 = time.perf_counter()
             out = (O.enerf_forward(leaves, b, cfg) if wl["net"] == "enerf" else O.boost_enerf_forward(leaves, b, cfg, k_best))
             loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - b[f"rgb_{i}"]) ** 2).mean()
                        for i in range(cc.num) if f"rgb_level{i}" in out)
             loss.backward()
             dt_ = time.perf_counter() - t0
-            # the checker's step: bench compares the HIP step on the same rays / targets with it (parity_max_rel)
-            cpu_baseline.last_step = {"stride": stride, "loss": float(loss.detach()),
-                                      "grads": {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}}
+            rec = {"stride": stride, "loss": float(loss.detach()),
+                   "grads": {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}}
+            if f64:
+                cpu_baseline.last_step64 = rec
+            else:
+                # the checker's step: bench compares the HIP step on the same rays / targets with it (parity_max_rel)
+                cpu_baseline.last_step = rec
             return dt_, b[f"rays_{cc.num - 1}"].shape[1]
         if wl["net"] == "enerf":
             timed(lambda: O.enerf_forward(state_dict, make_batch(64, 96), cfg))      # page-in / thread-pool warm-up
             dt, _ = step(1)
             sample = f"1 step at {H}x{W} (whole workload: forward + loss + backward), oracle/enerf.py torch-CPU fp32 autograd, {dt:.2f} s"
+            if arbitrate:
+                step(1, f64=True)
         else:
-            (t1, n1), (t2, n2) = step(8), step(4)
+            (t1, n1) = step(8)
+            if arbitrate:        # float64 twin of the SMALLER subset's step; its fp32 step is kept next to it
+                cpu_baseline.last_step_small = cpu_baseline.last_step
+                step(8, f64=True)
+            (t2, n2) = step(4)
             per_ray = max((t2 - t1) / (n2 - n1), 0.0)
             dt = t1 + per_ray * (N - n1)
             sample = (f"forward + loss + backward; front end in full + rays ::8 ({n1} rays, {t1:.2f} s) and ::4 ({n2} rays, "
@@ -307,36 +324,71 @@ def parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev):
     stp = getattr(cpu_baseline, "last_step", None)
     if wl.get("train") and stp is not None:
         from boostmvsnerfs_amd.train import NetworkWrapper
-        b = clone_batch(batch_cpu)
-        g = torch.Generator().manual_seed(0)
-        for i in range(cc.num):
-            b[f"rays_{i}"] = b[f"rays_{i}"][:, ::stp["stride"]].contiguous()
-            b[f"rgb_{i}"] = torch.rand(1, b[f"rays_{i}"].shape[1], 3, generator=g)
-        b = clone_batch(b, dev)
         was = net.training
         net.load_state_dict(sd_cpu)                 # the timed steps trained: back to the weights the oracle's step used
         net.eval()                                  # the oracle's step runs the batch norms in eval mode
-        net.zero_grad(set_to_none=True)
-        _, loss, _, _ = NetworkWrapper(net)(b)
-        loss.mean().backward()
+
+        def hip_step(stride):
+            b = clone_batch(batch_cpu)
+            g = torch.Generator().manual_seed(0)
+            for i in range(cc.num):
+                b[f"rays_{i}"] = b[f"rays_{i}"][:, ::stride].contiguous()
+                b[f"rgb_{i}"] = torch.rand(1, b[f"rays_{i}"].shape[1], 3, generator=g)
+            b = clone_batch(b, dev)
+            net.zero_grad(set_to_none=True)
+            _, loss_, _, _ = NetworkWrapper(net)(b)
+            loss_.mean().backward()
+            grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+            net.zero_grad(set_to_none=True)
+            return float(loss_), grads
+
+        loss, hip = hip_step(stp["stride"])
         worst, worst_name, n_tensors, rels = 0.0, None, 0, []
         gmax = max(float(v.abs().max()) for v in stp["grads"].values())
-        for k, p in net.named_parameters():
+        for k, gk in hip.items():
             want = stp["grads"].get(k)
-            if want is None or p.grad is None:
+            if want is None:
                 continue
-            num = float((p.grad.detach().cpu() - want).pow(2).sum().sqrt())
+            num = float((gk - want).pow(2).sum().sqrt())
             rel = num / (float(want.pow(2).sum().sqrt()) + 1e-6 * gmax)
             n_tensors += 1
             rels.append(rel)
             if rel > worst:
                 worst, worst_name = rel, k
+        # float64 arbitration: the same step in float64 on the CPU; HIP and the fp32 oracle each against it
+        arb = None
+        s64 = getattr(cpu_baseline, "last_step64", None)
+        if s64 is not None:
+            small = getattr(cpu_baseline, "last_step_small", None) or stp
+            hip64 = hip if s64["stride"] == stp["stride"] else hip_step(s64["stride"])[1]
+            g64max = max(float(v.abs().max()) for v in s64["grads"].values())
+            rows = []
+            for k, w64 in s64["grads"].items():
+                if k not in hip64 or k not in small["grads"]:
+                    continue
+                den = float(w64.pow(2).sum().sqrt()) + 1e-6 * g64max
+                rows.append((k, float((hip64[k].double() - w64).pow(2).sum().sqrt()) / den,
+                             float((small["grads"][k].double() - w64).pow(2).sum().sqrt()) / den,
+                             float((hip64[k] - small["grads"][k]).pow(2).sum().sqrt()) / den))
+            rows.sort(key=lambda r: -r[3])
+            arb = {"stride": s64["stride"], "tensors": len(rows),
+                   "hip_vs_f64_max": max(r[1] for r in rows), "oracle32_vs_f64_max": max(r[2] for r in rows),
+                   "hip_vs_f64_median": sorted(r[1] for r in rows)[len(rows) // 2],
+                   "oracle32_vs_f64_median": sorted(r[2] for r in rows)[len(rows) // 2],
+                   "hip_no_farther_than_oracle32_on": sum(r[1] <= r[2] for r in rows),
+                   "hip_within_1.5x_of_oracle32_on": sum(r[1] <= 1.5 * r[2] + 1e-7 for r in rows),
+                   "worst_five_by_hip_vs_oracle32": [{"tensor": r[0], "hip_vs_f64": r[1], "oracle32_vs_f64": r[2], "hip_vs_oracle32": r[3]}
+                                                     for r in rows[:5]],
+                   "what": "relative L2 distance of a parameter gradient to the SAME step evaluated in float64 on the CPU (oracle, "
+                           f"rays ::{s64['stride']}): the HIP step and the fp32 oracle step side by side.  An fp32-vs-fp32 distance is "
+                           "only as meaningful as the fp32 oracle's own distance to float64 on that tensor"}
         net.zero_grad(set_to_none=True)
         net.train(was)
         out["parity_max_rel"] = {
             "loss": abs(float(loss) - stp["loss"]) / abs(stp["loss"]), "grad_rel_l2_max": worst, "grad_worst_tensor": worst_name,
             "grad_tensors": n_tensors, "grad_rel_l2_median": sorted(rels)[len(rels) // 2] if rels else None,
             "grad_tensors_over_1e-2": sum(r > 1e-2 for r in rels),
+            "grad_vs_float64": arb,
             "max": max(worst, abs(float(loss) - stp["loss"]) / abs(stp["loss"])),
             "against": (f"oracle forward + MSE loss + torch.autograd backward (eval-mode batch norm) on rays ::{stp['stride']} of the "
                         "workload's frame, same weights and targets: relative loss difference and the worst per-tensor relative "
@@ -941,11 +993,34 @@ def main():
                                                    "bf16 MFMAs on three-piece fp32 operands, the rest fp32 MFMAs; BMV_RENDER_SPLIT=0: all fp32)",
                         "achieved": ex,
                         "peak": FP32_MFMA_PEAK_TFLOPS, "peak_is": "the fp32 MFMA peak (the rate the same fp32 FLOPs would be bound by on "
-                                                                  "fp32 matrix instructions; `frac` can pass it only through the bf16 pipe)",
-                        "unit": "TFLOP/s", "frac": ex / FP32_MFMA_PEAK_TFLOPS,
+                                                                  "fp32 matrix instructions)",
+                        "unit": "TFLOP/s", "fp32_equivalent_over_fp32_peak": ex / FP32_MFMA_PEAK_TFLOPS,
                         "flops_counted": "executed (26.2 kFLOP / sample)", "algorithmic_tflops": alg,
                         "algorithmic_over_peak": alg / FP32_MFMA_PEAK_TFLOPS,
                         "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
+                # `frac` = the share of the kernel's time its matrix pipe is BUSY, each instruction class against its own peak
+                # (fp32-equivalent FLOPs over the fp32 peak is not a roofline fraction once 160 of 206 instructions
+                # run on the bf16 pipe).  Instruction counts per 32-sample tile from the ISA of render_pc_kernel<2,false,3,true>
+                # (S = 3, 8 feature channels): 46 v_mfma_f32_32x32x2_f32 (4 096 FLOP, 64 cycles) + 132 v_mfma_f32_32x32x16_bf16
+                # (32 768 FLOP, 32 cycles); all-fp32 form: 206 x 64 cycles.  The rest of the time is vector work, which
+                # does not overlap with matrix work on a SIMD (profiles/r5/mfma_valu_coissue.txt).
+                if n_src == 3:
+                    from boostmvsnerfs_amd import _lib as _bl2
+                    split = (_bl2.get_tuning("BMV_RENDER_SPLIT") != 0)
+                    tiles = rays_launch * cc.num_samples[1] / 32.0
+                    t_s = kernels[rname]["avg_us"] * 1e-6
+                    n32, n16 = (46, 132) if split else (206, 0)
+                    tf32 = tiles * n32 * 4096 / t_s / 1e12
+                    tbf = tiles * n16 * 32768 / t_s / 1e12
+                    mfma.update({"frac": tf32 / FP32_MFMA_PEAK_TFLOPS + tbf / BF16_MFMA_PEAK_TFLOPS,
+                                 "frac_is": "matrix-pipe busy share of the kernel's time = fp32_pipe.frac + bf16_pipe.frac",
+                                 "fp32_pipe": {"achieved": tf32, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": tf32 / FP32_MFMA_PEAK_TFLOPS, "instructions_per_tile": n32},
+                                 "bf16_pipe": {"achieved": tbf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": tbf / BF16_MFMA_PEAK_TFLOPS, "instructions_per_tile": n16,
+                                               "what": "every one of the six bf16 products of a three-piece fp32 product counted"}})
+                else:
+                    mfma["frac"] = ex / FP32_MFMA_PEAK_TFLOPS
         else:
             Ns = cc.num_samples[0]
             rname = f"mvs_render[Ns={Ns}]"
