@@ -228,10 +228,15 @@ def cpu_baseline(args, cfg, wl, state_dict, batch_cpu, sel=None):
             leaves = {k: (v.detach().double() if f64 and v.is_floating_point() else v.detach().clone())
                       .requires_grad_(v.is_floating_point() and "running" not in k) for k, v in state_dict.items()}
             t0 = time.perf_counter()
-            out = (O.enerf_forward(leaves, b, cfg) if wl["net"] == "enerf" else O.boost_enerf_forward(leaves, b, cfg, k_best))
-            loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - b[f"rgb_{i}"]) ** 2).mean()
-                       for i in range(cc.num) if f"rgb_level{i}" in out)
-            loss.backward()
+            if f64:
+                torch.set_default_dtype(torch.float64)     # (the oracle builds its grids with the default dtype)
+            try:
+                out = (O.enerf_forward(leaves, b, cfg) if wl["net"] == "enerf" else O.boost_enerf_forward(leaves, b, cfg, k_best))
+                loss = sum(cc.loss_weight[i] * ((out[f"rgb_level{i}"] - b[f"rgb_{i}"]) ** 2).mean()
+                           for i in range(cc.num) if f"rgb_level{i}" in out)
+                loss.backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
             dt_ = time.perf_counter() - t0
             rec = {"stride": stride, "loss": float(loss.detach()),
                    "grads": {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}}
