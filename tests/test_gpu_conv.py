@@ -240,6 +240,26 @@ def test_conv2d_s_matches_float64_like_the_fp32_kernel(Cin, Cout, ks, stride, B,
     assert float((got.double() - want).abs().max()) <= 4e-6 * scale
 
 
+def test_conv2d_s_refuses_what_it_is_not_built_for():
+    """Shapes outside FeatureNet's encoder are errors by name, not another kernel: odd sizes, other channel counts, a 3x3
+    stride-2 layer; and the entry point wants exactly one input form."""
+    from boostmvsnerfs_amd import _lib, convnet
+    lib = _lib.load()
+    assert lib.bmv_conv2d_s_wsplit_ints(24, 16, 3, 1) == 0 and lib.bmv_conv2d_s_wsplit_ints(16, 16, 3, 2) == 0
+    assert lib.bmv_conv2d_s_wsplit_ints(8, 16, 3, 1) == 0 and lib.bmv_conv2d_s_wsplit_ints(16, 24, 5, 2) == 0
+    w = torch.randn(16, 16, 3, 3, device=DEV)
+    pk = convnet.pack_conv2d_s(w, None)
+    with pytest.raises(RuntimeError, match="not covered"):
+        convnet.conv2d_s(torch.randn(1, 16, 33, 48, device=DEV), *pk, 16, 3, 1)
+    with pytest.raises(AssertionError):
+        convnet.pack_conv2d_s(torch.randn(16, 24, 3, 3, device=DEV), None)
+    x = torch.randn(1, 16, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="exactly one of"):
+        _lib.check(lib.bmv_conv2d_s_fwd(_lib.dptr(x), _lib.dptr(convnet.SplitRecords.from_planar(x).data, "r", torch.int32),
+                                        _lib.dptr(pk[0], "w", torch.int32), _lib.dptr(pk[1]), _lib.dptr(torch.empty(1, 16, 8, 8, device=DEV)),
+                                        None, 1, 16, 8, 8, 16, 3, 1, 1.0, _lib.stream()), "conv2d_s_fwd")
+
+
 @pytest.mark.parametrize("Cin,Cout,ks,stride,B,H,W,rows", [c for c in C2S_CASES if c[4] < 3 or c[0] != 32])
 def test_conv2d_s_split_records_are_bit_identical_to_the_planar_path(Cin, Cout, ks, stride, B, H, W, rows):
     """The split-record form of a map between two layers (convnet.SplitRecords: written by the producer's epilogue, staged by
