@@ -345,7 +345,7 @@ def parity_objects(cfg, wl, net, sd_cpu, batch, batch_cpu, split_frame, dev):
             loss_.mean().backward()
             grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
             net.zero_grad(set_to_none=True)
-            return float(loss_), grads
+            return float(loss_.detach().mean()), grads
 
         loss, hip = hip_step(stp["stride"])
         worst, worst_name, n_tensors, rels = 0.0, None, 0, []
