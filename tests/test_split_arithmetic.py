@@ -65,3 +65,32 @@ def test_split_records_round_trip_is_exact():
     hi = r.data[1, 1, 0, 3, 7, 2]
     assert (int(hi) & 0xFFFF) == (int(x[1, 8 + 4, 3, 7].view(torch.int32)) >> 16) & 0xFFFF
     assert ((int(hi) >> 16) & 0xFFFF) == (int(x[1, 8 + 5, 3, 7].view(torch.int32)) >> 16) & 0xFFFF
+
+
+def test_conv2d_s_weight_pack_is_the_documented_layout():
+    """convnet.pack_conv2d_s (include/bmv.h, bmv_conv2d_s_fwd): int32 [M tile][filter row][step][piece 3][lane 64][4]; lane = 16 kg +
+    m holds the 8 channels of input octet o at filter column kx for output channel 16 tile + m, (o, kx) = divmod(4 step + kg,
+    ks); pairs past the end are zeros; hi + mid + lo of the three pieces is the fp32 weight exactly.  (Host logic: runs
+    without a GPU; the library is loaded for the word count only.)"""
+    import torch
+    from boostmvsnerfs_amd import convnet
+    g = torch.Generator().manual_seed(1)
+    for cout, cin, ks in ((16, 8, 5), (32, 16, 5), (16, 16, 3), (32, 32, 3)):
+        w = torch.randn(cout, cin, ks, ks, generator=g) * 10.0 ** torch.randint(-3, 3, (cout, cin, ks, ks), generator=g).float()
+        ws, b = convnet.pack_conv2d_s(w, None)
+        npair, nstep = (cin // 8) * ks, ((cin // 8) * ks + 3) // 4
+        assert tuple(ws.shape) == (cout // 16, ks, nstep, 3, 64, 4) and ws.dtype == torch.int32 and float(b.abs().max()) == 0.0
+        halves = ws.view(torch.int16).reshape(cout // 16, ks, nstep, 3, 64, 8).to(torch.int32) << 16      # bf16 -> fp32 bits
+        val = halves.view(torch.float32)
+        total = (val[:, :, :, 2] + val[:, :, :, 1]) + val[:, :, :, 0]                                      # (tile, ky, step, lane, c)
+        for tile in range(cout // 16):
+            for step in range(nstep):
+                for kg in range(4):
+                    pi = 4 * step + kg
+                    got = total[tile, :, step, 16 * kg:16 * kg + 16]                                        # (ky, m, c)
+                    if pi >= npair:
+                        assert float(got.abs().max()) == 0.0
+                        continue
+                    o, kx = divmod(pi, ks)
+                    want = w[16 * tile:16 * tile + 16, 8 * o:8 * o + 8, :, kx].permute(2, 0, 1)            # (ky, m, c)
+                    assert torch.equal(got, want), (cout, cin, ks, tile, step, kg)
