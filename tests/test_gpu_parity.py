@@ -431,16 +431,21 @@ def test_sweep_quad_channel_counts(ops, C, S):
     with pytest.raises(RuntimeError, match="not covered"):
         ops.sweep_variance_quad(torch.zeros(1, 5, 1, 8, 8, 4, device=DEV), torch.zeros(1, 5, 3, 4, device=DEV), dv.to(DEV))
     # BMV_SWEEP_QUAD_DBL=1 (round 6, opt-in): two window sets per workgroup, the next quad's fill under this quad's blend,
-    # hand-written LDS reads -- at this size the sets fit twice, so the path runs for every C > 4: the same bits
+    # hand-written LDS reads -- at this size the sets fit twice, so the path runs for every C > 4.  Equal to fp32 rounding,
+    # not bit for bit: the compiler contracts the blend's multiply-adds differently in the two copies of the quad loop
+    # (measured: <= 3e-7 of the volume's scale on ~1-2 % of the entries, every one of them in the second plane of a lane's
+    # pair, identical from run to run); against the oracle both forms pass the same bar
     from boostmvsnerfs_amd import _lib
     ref = {v: ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=v, quad_out=True).to_planar() for v in (-1, 0, 12)}
     _lib.set_tuning("BMV_SWEEP_QUAD_DBL", 1)
     try:
         for v, want_v in ref.items():
             got = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=v, quad_out=True).to_planar()
-            assert torch.equal(got, want_v), f"C {C} S {S} variant {v}: two window sets"
-            got = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=v)
-            assert torch.equal(got, want_v), f"C {C} S {S} variant {v}: two window sets, planar output"
+            scale = float(want_v.abs().max())
+            assert float((got - want_v).abs().max()) <= 1e-6 * scale, f"C {C} S {S} variant {v}: two window sets"
+            assert_close(got, want, name=f"C {C} S {S} variant {v}, two window sets")
+            got2 = ops.sweep_variance_quad(_quad(ops, feats.to(DEV)), P.to(DEV), dv.to(DEV), variant=v)
+            assert torch.equal(got2, got), f"C {C} S {S} variant {v}: two window sets, planar output = quad records"
     finally:
         _lib.set_tuning("BMV_SWEEP_QUAD_DBL", None)
 
