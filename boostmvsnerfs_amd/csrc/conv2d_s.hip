@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_s_kernel(Conv2dSArgs a) {
     c2_static_for<0, NP>([&](auto pc) {
       constexpr int p = decltype(pc)::value;
       if (p + DIST < NP) request(p + DIST);          // (into the buffer of row p - 1: its reads fed matrix instructions already issued)
-      if (p % STR == 0 && p / STR < TY) {
+      if constexpr (p % STR == 0 && p / STR < TY) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[p / STR][t] = f32x4s{0.f, 0.f, 0.f, 0.f};
       }
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_s_kernel(Conv2dSArgs a) {
   c2_static_for<0, NP>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     if (p + 2 < NP) fetch(p + 2, nx[p & 1]);       // (two rows ahead; row p's values were parked one iteration ago)
-    if (p % STR == 0 && p / STR < TY) {            // the first row output row p / STR reads
+    if constexpr (p % STR == 0 && p / STR < TY) {  // the first row output row p / STR reads
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[p / STR][t] = f32x4s{0.f, 0.f, 0.f, 0.f};
     }
