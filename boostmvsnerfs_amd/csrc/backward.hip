@@ -496,7 +496,7 @@ __global__ void build_rays_bwd_kernel(const float* __restrict__ rays, const floa
                                       const float* __restrict__ d_nf, int N, int hv, int wv, int Hr, int Wr,
                                       int depth_inv, float* __restrict__ d_depth, float* __restrict__ d_std, size_t n_out,
                                       FixedWs fixed) {
-  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out);
+  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out, 1);
   int b = blockIdx.y;
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -628,7 +628,7 @@ __global__ void depth_values_cascade_bwd_kernel(const float* __restrict__ depth,
                                                 const float* __restrict__ near_far, const float* __restrict__ g_dv,
                                                 int h0, int w0, int h, int w, int D, float* __restrict__ d_depth,
                                                 float* __restrict__ d_std, size_t n_out, FixedWs fixed) {
-  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out);
+  ScatterAcc<MODE> acc_d = make_acc<MODE>(d_depth, fixed, 0, 0), acc_s = make_acc<MODE>(d_std, fixed, n_out, 1);
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int hw = h * w;
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) sweep_bwd_kernel(const float* __restrict_
                                                          size_t n_feats, FixedWs fixed) {
   static_assert(CB <= kWinCh, "one window pass per channel block");
   __shared__ float win[kWinCh * kWinCap];
-  ScatterAcc<MODE> acc_f = make_acc<MODE>(d_feats, fixed, 0), acc_v = make_acc<MODE>(d_dv, fixed, n_feats);
+  ScatterAcc<MODE> acc_f = make_acc<MODE>(d_feats, fixed, 0, 0), acc_v = make_acc<MODE>(d_dv, fixed, n_feats, 1);
   __shared__ WinBox box;
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CB;
@@ -894,7 +894,7 @@ static int build_rays_bwd_impl(const float* rays, const float* depth, const floa
   });
   if (fixed.ws) {
     fixed_finish(fixed, 0, n_out, d_depth, as_stream(stream));
-    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream));
+    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream), 1);
   }
   BMV_LAUNCH_END(name);
 }
@@ -945,7 +945,7 @@ static int depth_values_cascade_bwd_impl(const float* depth, const float* std_, 
   });
   if (fixed.ws) {
     fixed_finish(fixed, 0, n_out, d_depth, as_stream(stream));
-    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream));
+    fixed_finish(fixed, n_out, n_out, d_std, as_stream(stream), 1);
   }
   BMV_LAUNCH_END(name);
 }
@@ -991,7 +991,7 @@ static int sweep_variance_bwd_impl(const float* feats, const float* proj, const 
   });
   if (fixed.ws) {
     fixed_finish(fixed, 0, n_feats, d_feats, as_stream(stream));
-    fixed_finish(fixed, n_feats, n_dv, d_depth_values, as_stream(stream));
+    fixed_finish(fixed, n_feats, n_dv, d_depth_values, as_stream(stream), 1);
   }
   BMV_LAUNCH_END(name);
 }

@@ -9,8 +9,8 @@
 //
 // A *_fixed launch is three passes of the same kernel code through ScatterAcc<MODE>:
 //   MODE 1  the largest |contribution| of the launch (atomicMax on the float's bits: max is order-independent too)
-//   scale   2^(38 - e) with max < 2^e: a contribution becomes an integer below 2^38 -- 38 bits under the largest one,
-//           2^24 of them fit a texel's int64 without overflow
+//   scale   2^(38 - e) with max < 2^e, PER OUTPUT tensor of the launch: a contribution becomes an integer below 2^38 -- 38 bits
+//           under the largest one of its tensor; 2^25 maximal contributions fit a texel's int64 without overflow (include/bmv.h)
 //   MODE 2  accumulate  llrint(v * scale)  with 64-bit integer atomics into the workspace
 //   finish  float(q * 2^-(38 - e)) into the caller's float gradient buffer
 // MODE 0 is the plain float-atomic form the default path runs.  Non-finite contributions make the scale NaN and with it
@@ -23,7 +23,10 @@
 namespace bmv {
 
 constexpr int kFixedSlots = 256;                    // spread of the magnitude pass over addresses
-constexpr int kFixedHeader = 2 + kFixedSlots / 2;   // int64 words in front of the accumulators: scale, 1/scale, slots
+constexpr int kFixedOuts = 2;                       // outputs of a launch with their OWN scale (d_feats + d_depth_values, d_depth + d_std:
+                                                    // tensors of different units -- with one scale for both the smaller one kept only
+                                                    // 38 - log2(ratio) bits: ADVICE r5)
+constexpr int kFixedHeader = kFixedOuts * (1 + kFixedSlots / 2);   // int64 words in front of the accumulators: per output [scale, 1 / scale], then per output the slots
 constexpr int kFixedBits = 38;
 
 template <int MODE>
@@ -51,37 +54,48 @@ struct ScatterAcc {
 // what a launcher hands its kernel: the workspace of a *_fixed call (null = float atomics)
 struct FixedWs {
   long long* ws = nullptr;
-  __host__ __device__ float* scale2() const { return reinterpret_cast<float*>(ws); }              // [scale, 1 / scale]
-  __host__ __device__ unsigned* slots() const { return reinterpret_cast<unsigned*>(ws + 2); }
+  __host__ __device__ float* scale2(int which = 0) const { return reinterpret_cast<float*>(ws + which); }              // [scale, 1 / scale] of output `which`
+  __host__ __device__ unsigned* slots(int which = 0) const { return reinterpret_cast<unsigned*>(ws + kFixedOuts + which * (kFixedSlots / 2)); }
   __host__ __device__ long long* acc(size_t offset) const { return ws + kFixedHeader + offset; }
 };
+// `which`: the launch's output this accumulator belongs to (0 or 1): its own magnitude slots and scale
 template <int MODE>
-__device__ __forceinline__ ScatterAcc<MODE> make_acc(const float* base, FixedWs f, size_t offset) {
+__device__ __forceinline__ ScatterAcc<MODE> make_acc(const float* base, FixedWs f, size_t offset, int which = 0) {
   ScatterAcc<MODE> a;
   a.base = base, a.q = nullptr, a.slots = nullptr, a.scale = 0.f, a.seen = 0u;
   if constexpr (MODE == 1) {
-    a.slots = f.slots();
+    a.slots = f.slots(which);
     a.seen = __atomic_load_n(a.slots + ((blockIdx.x * blockDim.x + threadIdx.x) & (kFixedSlots - 1)), __ATOMIC_RELAXED);
   }
-  if constexpr (MODE == 2) a.q = f.acc(offset), a.scale = f.scale2()[0];
+  if constexpr (MODE == 2) a.q = f.acc(offset), a.scale = f.scale2(which)[0];
   return a;
 }
 
 static __global__ void fixed_scale_kernel(FixedWs f) {
-  unsigned m = 0;
-  for (int i = threadIdx.x; i < kFixedSlots; i += 64) m = max(m, f.slots()[i]);
+  bool bad = false;
+  unsigned mm[kFixedOuts];
 #pragma unroll
-  for (int s = 1; s < 64; s <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, s, 64));
+  for (int w = 0; w < kFixedOuts; ++w) {
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < kFixedSlots; i += 64) m = max(m, f.slots(w)[i]);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, s, 64));
+    mm[w] = m;
+    bad |= m > 0x7f7fffffu;         // inf / NaN somewhere: EVERY output of the launch becomes NaN
+  }
   if (threadIdx.x == 0) {
-    float scale = 1.f, inv = 1.f;
-    if (m > 0x7f7fffffu) {          // inf / NaN somewhere: every output of the launch becomes NaN
-      scale = inv = __uint_as_float(0x7fc00000u);
-    } else if (m != 0u) {
-      int e;
-      (void)frexpf(__uint_as_float(m), &e);      // max = mant * 2^e, mant in [0.5, 1)
-      scale = ldexpf(1.f, kFixedBits - e), inv = ldexpf(1.f, e - kFixedBits);
+#pragma unroll
+    for (int w = 0; w < kFixedOuts; ++w) {
+      float scale = 1.f, inv = 1.f;
+      if (bad) {
+        scale = inv = __uint_as_float(0x7fc00000u);
+      } else if (mm[w] != 0u) {
+        int e;
+        (void)frexpf(__uint_as_float(mm[w]), &e);      // max = mant * 2^e, mant in [0.5, 1)
+        scale = ldexpf(1.f, kFixedBits - e), inv = ldexpf(1.f, e - kFixedBits);
+      }
+      f.scale2(w)[0] = scale, f.scale2(w)[1] = inv;
     }
-    f.scale2()[0] = scale, f.scale2()[1] = inv;
   }
 }
 
@@ -91,8 +105,8 @@ static __global__ void fixed_finish_kernel(const long long* __restrict__ q, cons
   if (i < n) dst[i] = (float)((double)q[i] * (double)scale2[1]);
 }
 
-static inline void fixed_finish(FixedWs f, size_t offset, size_t n, float* dst, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(fixed_finish_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, f.acc(offset), f.scale2(), n, dst);
+static inline void fixed_finish(FixedWs f, size_t offset, size_t n, float* dst, hipStream_t st, int which = 0) {
+  if (n) hipLaunchKernelGGL(fixed_finish_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, st, f.acc(offset), f.scale2(which), n, dst);
 }
 
 // An EMPTY input (no rays / samples): the float forms add nothing into their caller-zeroed outputs and return; the

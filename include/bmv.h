@@ -264,8 +264,11 @@ int bmv_sweep_variance_bwd_cl(const float* feats_cl, const float* proj, const fl
  * (csrc/scatter.hpp): one pass finds the largest |contribution| of the launch (an atomic max: order-independent), a
  * power-of-two scale puts it just under 2^38, a second pass of the same kernel adds llrint(v * scale) with 64-bit
  * INTEGER atomics (associative), and a finish kernel writes float(q / scale) to the float gradient buffers -- which
- * then need no zero-initialisation.  Every contribution is rounded once, 38 bits below the largest one of the launch:
- * at least as accurate as the float form.  Two runs on the same inputs give bit-identical outputs.
+ * then need no zero-initialisation.  Every contribution is rounded once, 38 bits below the largest one of ITS OUTPUT TENSOR
+ * (a launch with two scatter outputs of different units -- d_depth + d_std, d_feats + d_depth_values -- keeps a scale per
+ * output): at least as accurate as the float form.  Bound: 2^25 contributions of the largest magnitude fit a texel's int64
+ * accumulator (2^63 / 2^38); the kernels of this library add at most a few thousand per texel.  Two runs on the same inputs
+ * give bit-identical outputs.
  * `workspace`: bmv_fixed_workspace(n) 64-bit words, ZEROED by the caller, n = number of floats in the launch's
  * scatter outputs together (d_volume; d_img; d_depth + d_std; d_feats + d_depth_values (if not NULL); ...).
  * Reference semantics as the float twins (lib/networks/enerf/utils.py:57-95, 324-351, 392-460, 753-786 under

@@ -185,6 +185,18 @@ def test_fixed_point_scatter_is_bit_reproducible_and_as_accurate(enerf_fx):
             assert torch.equal(x, y)
             scale = float(r.abs().max())
             assert float((x - r).abs().max()) <= 1e-5 * scale, (float((x - r).abs().max()), scale)
+        # a launch with two outputs of different units keeps a fixed-point scale PER OUTPUT: with source maps of
+        # magnitude 1e-6 the hypothesis gradient is ~1e7 times smaller than the feature gradient of the same launch; under
+        # one common scale it kept 38 - 23 bits
+        tiny = feats * 1e-6
+        _lib.set_tuning("BMV_DETERMINISTIC", 0)
+        rf, rd = ops.sweep_variance_bwd(tiny, P, dv, g, True)
+        _lib.set_tuning("BMV_DETERMINISTIC", 1)
+        xf, xd = ops.sweep_variance_bwd(tiny, P, dv, g, True)
+        ratio = float(rf.abs().max()) / float(rd.abs().max())
+        assert ratio > 1e4, ratio
+        for x, r in ((xf, rf), (xd, rd)):
+            assert float((x - r).abs().max()) <= 1e-5 * float(r.abs().max()), (ratio, float((x - r).abs().max()), float(r.abs().max()))
         go2 = go.clone()
         go2[0, 17, 3] = float("nan")
         assert bool(ops.vox_feat_bwd(uvd, vol, go2)[0].isnan().all())          # loud, like the float form's NaN
