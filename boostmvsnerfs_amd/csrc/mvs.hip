@@ -338,7 +338,6 @@ struct MvsMlp {
     for (int i = 0; i < c; ++i) o += steps(i) * 128;
     return o;
   }
-  static constexpr int CHUNK_MAX = 96 * 128;  // floats (48 KB)
   static constexpr int A_TOTAL = 2 * 10 * 128 + 2 * 32 * 128 + 8 * 64 * 128 + 2 * 96 * 128 + 2 * 64 * 128 + 66 * 128;
   // resident small tables, [idx][half] with idx = tile*16 + reg
   static constexpr int S_BBIAS = 0;                   // pts_bias bias          [64]
@@ -350,22 +349,65 @@ struct MvsMlp {
   static constexpr int S_SC = S_WRGB + 3 * 64;        // alpha bias, rgb bias x3
   static constexpr int S_TOTAL = S_SC + 4;
   static constexpr int TOTAL = A_TOTAL + S_TOTAL;
-  // Round 5: the ten 128 -> 128 chunks (pts_linears.1-4, feature_linear: 64 k-steps x 2 tiles each, 1280 of the MLP's 1964
-  // fp32 MFMAs per tile) a second time behind the blob, pre-split into three bf16 pieces for v_mfma_f32_32x32x16_bf16 (the
-  // bf16 x 3 form of mlp.hpp's BMV_SPLIT_CHAIN2): [piece 3][bf16 k-step 8][tile 2][lane 64] x 16 bytes = 48 KB per chunk
-  // = CHUNK_MAX, so the LDS buffers and the DMA pipeline are unchanged.
-  __host__ __device__ static constexpr bool is_split(int c) { return (c >= 4 && c < 12) || c == 14 || c == 15; }
-  __host__ __device__ static constexpr int split_index(int c) { return c < 12 ? c - 4 : c - 6; }
-  static constexpr int N_SPLIT = 10;
-  static constexpr int SPLIT_CHUNK = 3 * 8 * 2 * 64 * 4;          // floats (dwords)
+  // The matrix chunks a second time behind the blob, pre-split into three bf16 pieces for v_mfma_f32_32x32x16_bf16 (the
+  // bf16 x 3 form of mlp.hpp's BMV_SPLIT_CHAIN2): [piece 3][bf16 k-step][tile 2][lane 64] x 16 bytes, one bf16 k-step =
+  // 8 fp32 k-steps.  Round 5 did this for the ten 128 -> 128 chunks (pts_linears.1-4, feature_linear: 8 k-steps, 48 KB);
+  // round 6 adds pts_linears.0 (4 k-steps), pts_linears.5 (12: the skip's 63 embedded values + 128) and views_linears.0
+  // (9: 128 + the 3 direction values; 66 -> 72 fp32 k-steps, zeros behind).  Only pts_bias (K = 20, 40 of the 1964 fp32
+  // MFMAs of a tile) stays fp32.  A pts_linears.5 chunk is 72 KB in this form: that sets CHUNK_MAX, two LDS buffers.
+  __host__ __device__ static constexpr int split_ks(int c) {          // bf16 k-steps of chunk c's split form (0: none)
+    return c < 2 ? 0 : c < 4 ? 4 : c < 12 ? 8 : c < 14 ? 12 : c < 16 ? 8 : 9;
+  }
+  __host__ __device__ static constexpr bool is_split(int c) { return split_ks(c) > 0; }
+  static constexpr int SPLIT_KSTEP = 3 * 2 * 64 * 4;                 // floats (dwords) of one bf16 k-step: 6 KB
+  __host__ __device__ static constexpr int split_size(int c) { return split_ks(c) * SPLIT_KSTEP; }
+  __host__ __device__ static constexpr int split_offset(int c) {
+    int o = 0;
+    for (int i = 0; i < c; ++i) o += split_size(i);
+    return o;
+  }
+  static constexpr int CHUNK_MAX = 12 * SPLIT_KSTEP;                 // floats: 72 KB (>= the 48 KB of a 96-step fp32 chunk)
   static constexpr int S_SPLIT = (TOTAL + 255) / 256 * 256;
-  static constexpr int TOTAL_S = S_SPLIT + N_SPLIT * SPLIT_CHUNK;
+  static constexpr int TOTAL_S = S_SPLIT + (2 * 4 + 8 * 8 + 2 * 12 + 2 * 8 + 9) * SPLIT_KSTEP;
 };
-static_assert(MvsMlp::SPLIT_CHUNK == MvsMlp::CHUNK_MAX, "a split chunk takes a whole LDS buffer");
+static_assert(MvsMlp::S_SPLIT + MvsMlp::split_offset(MvsMlp::N_CHUNKS) == MvsMlp::TOTAL_S, "split chunk table");
+static_assert(MvsMlp::split_size(12) == MvsMlp::CHUNK_MAX && MvsMlp::steps(12) * 128 <= MvsMlp::CHUNK_MAX, "largest chunk");
 static_assert(MvsMlp::offset(MvsMlp::N_CHUNKS) == MvsMlp::A_TOTAL, "chunk table");
 static constexpr int kMvsSmall = ((MvsMlp::S_TOTAL + 255) / 256) * 256;   // floats of LDS in front of the chunk buffers
 
 __device__ __forceinline__ int hid_index(int u, int h) { return 32 * (u >> 4) + n16(u & 15, h); }  // k-step u of a 128-wide input
+
+// A entry of chunk c for output 32 tl + i of the chunk's 64, fp32 k-step t, lane half h (zeros where the layer has no input)
+__device__ __forceinline__ float mvs_chunk_weight(const bmv_mvs_mlp_params& p, int c, int tl, int i, int h, int t) {
+  if (c < 2) {                                    // pts_bias: 20 -> 128
+    const int n = 64 * c + 32 * tl + i, k = 2 * t + h;
+    return k < 20 ? p.bias_w[n * 20 + k] : 0.f;
+  }
+  if (c < 4) {                                    // pts_linears.0: 63 -> 128
+    const int n = 64 * (c - 2) + 32 * tl + i, k = 2 * t + h;
+    return k < 63 ? p.pts_w[0][n * 63 + k] : 0.f;
+  }
+  if (c < 12) {                                   // pts_linears.1-4: 128 -> 128
+    const int l = 1 + (c - 4) / 2, n = 64 * ((c - 4) & 1) + 32 * tl + i;
+    return p.pts_w[l][n * 128 + hid_index(t, h)];
+  }
+  if (c < 14) {                                   // pts_linears.5: [pts 63 | h 128] -> 128
+    const int n = 64 * (c - 12) + 32 * tl + i;
+    if (t < 32) {
+      const int k = 2 * t + h;
+      return k < 63 ? p.pts_w[5][n * 191 + k] : 0.f;
+    }
+    return p.pts_w[5][n * 191 + 63 + hid_index(t - 32, h)];
+  }
+  if (c < 16) {                                   // feature_linear: 128 -> 128
+    const int n = 64 * (c - 14) + 32 * tl + i;
+    return p.feature_w[n * 128 + hid_index(t, h)];
+  }
+  const int n = 32 * tl + i;                      // views_linears.0: [feature 128 | dir 3] -> 64
+  if (t < 64) return p.views_w[n * 131 + hid_index(t, h)];
+  const int k = 2 * (t - 64) + h;
+  return k < 3 ? p.views_w[n * 131 + 128 + k] : 0.f;
+}
 
 __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ blob) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,10 +420,10 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
     // split chunks: dword q of (piece, bf16 k-step T, tile, lane (i, h)) = that piece (round to nearest; the last one is
     // exact) of the fp32 A entries of fp32 k-steps t = 8 T + 2 q, 8 T + 2 q + 1 for this tile and lane (low | high half)
     int e = idx - MvsMlp::S_SPLIT;
-    const int ci = e / MvsMlp::SPLIT_CHUNK;
-    e -= ci * MvsMlp::SPLIT_CHUNK;
-    const int c = ci < 8 ? 4 + ci : 6 + ci;
-    const int q = e & 3, lane = (e >> 2) & 63, tl = (e >> 8) & 1, T = (e >> 9) & 7, pc = e >> 12;
+    int c = 0;
+    while (e >= MvsMlp::split_size(c)) e -= MvsMlp::split_size(c), ++c;
+    const int ks = MvsMlp::split_ks(c);
+    const int q = e & 3, lane = (e >> 2) & 63, tl = (e >> 8) & 1, T = (e >> 9) % ks, pc = (e >> 9) / ks;
     const int i = lane & 31, h = lane >> 5;
     auto rn = [](float v) {
       const unsigned u = __float_as_uint(v);
@@ -390,14 +432,7 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
     unsigned packed = 0;
     for (int jj = 0; jj < 2; ++jj) {
       const int t = 8 * T + 2 * q + jj;
-      float w;
-      if (c < 12) {
-        const int l = 1 + (c - 4) / 2, n = 64 * ((c - 4) & 1) + 32 * tl + i;
-        w = p.pts_w[l][n * 128 + hid_index(t, h)];
-      } else {
-        const int n = 64 * (c - 14) + 32 * tl + i;
-        w = p.feature_w[n * 128 + hid_index(t, h)];
-      }
+      const float w = mvs_chunk_weight(p, c, tl, i, h, t);
       const float hi = rn(w), r1 = w - hi, mid = rn(r1), r2 = r1 - mid;
       const float piece = pc == 0 ? hi : pc == 1 ? mid : r2;
       packed |= (__float_as_uint(piece) >> 16) << (16 * jj);
@@ -409,38 +444,9 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
   if (idx < MvsMlp::A_TOTAL) {
     int c = 0, base = 0;
     while (idx >= base + MvsMlp::steps(c) * 128) base += MvsMlp::steps(c) * 128, ++c;
-    int rel = idx - base;
-    int lane = rel & 63, tl = (rel >> 6) & 1, t = rel >> 7;
-    int i = lane & 31, h = lane >> 5;
-    if (c < 2) {                                    // pts_bias: 20 -> 128
-      int n = 64 * c + 32 * tl + i, k = 2 * t + h;
-      if (k < 20) v = p.bias_w[n * 20 + k];
-    } else if (c < 4) {                             // pts_linears.0: 63 -> 128
-      int n = 64 * (c - 2) + 32 * tl + i, k = 2 * t + h;
-      if (k < 63) v = p.pts_w[0][n * 63 + k];
-    } else if (c < 12) {                            // pts_linears.1-4: 128 -> 128
-      int l = 1 + (c - 4) / 2, n = 64 * ((c - 4) & 1) + 32 * tl + i;
-      v = p.pts_w[l][n * 128 + hid_index(t, h)];
-    } else if (c < 14) {                            // pts_linears.5: [pts 63 | h 128] -> 128
-      int n = 64 * (c - 12) + 32 * tl + i;
-      if (t < 32) {
-        int k = 2 * t + h;
-        if (k < 63) v = p.pts_w[5][n * 191 + k];
-      } else {
-        v = p.pts_w[5][n * 191 + 63 + hid_index(t - 32, h)];
-      }
-    } else if (c < 16) {                            // feature_linear: 128 -> 128
-      int n = 64 * (c - 14) + 32 * tl + i;
-      v = p.feature_w[n * 128 + hid_index(t, h)];
-    } else {                                        // views_linears.0: [feature 128 | dir 3] -> 64
-      int n = 32 * tl + i;
-      if (t < 64) {
-        v = p.views_w[n * 131 + hid_index(t, h)];
-      } else {
-        int k = 2 * (t - 64) + h;
-        if (k < 3) v = p.views_w[n * 131 + 128 + k];
-      }
-    }
+    const int rel = idx - base;
+    const int lane = rel & 63, tl = (rel >> 6) & 1, t = rel >> 7;
+    v = mvs_chunk_weight(p, c, tl, lane & 31, lane >> 5, t);
   } else {
     int rel = idx - MvsMlp::A_TOTAL;
     if (rel >= MvsMlp::S_SC) {
@@ -491,13 +497,13 @@ static_assert(kMvsBuffers == 2 || kMvsBuffers == 3, "prefetch distance 1 or 2");
 
 template <bool SPLIT = false>
 __device__ __forceinline__ int chunk_pieces(int c) {   // 1 KB pieces of chunk c (128 floats per k-step = 512 B)
-  return (SPLIT && MvsMlp::is_split(c)) ? MvsMlp::SPLIT_CHUNK / 256 : MvsMlp::steps(c) / 2;
+  return (SPLIT && MvsMlp::is_split(c)) ? MvsMlp::split_size(c) / 256 : MvsMlp::steps(c) / 2;
 }
 
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ bufs, int c, int slot) {
-  const bool sp = SPLIT && MvsMlp::is_split(c);      // (the bf16 x 3 form of the chunk: 48 KB)
-  const char* src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_index(c) * MvsMlp::SPLIT_CHUNK
+  const bool sp = SPLIT && MvsMlp::is_split(c);      // (the bf16 x 3 form of the chunk: 24 - 72 KB)
+  const char* src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_offset(c)
                                                      : blob + MvsMlp::offset(c));
   char* dst = reinterpret_cast<char*>(bufs + slot * MvsMlp::CHUNK_MAX);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -555,20 +561,20 @@ __device__ __forceinline__ void wait_vm_keep(int keep) {
 // Must be called by all 4 waves of the workgroup together (chunk staging uses workgroup barriers).
 // The first kMvsBuffers - 1 chunks of this tile must already be in flight (start_chunks at the top of the launch;
 // afterwards the last chunks of the previous tile issue them).
-// a 128 -> 64 product of a split chunk on the B pieces of the layer's input (computed once per layer: both output halves
-// use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
-#define MVS_GEMM_SPLIT(buf, BH, BM, BL, ACC0, ACC1)                                                     \
+// a K -> 64 product of a split chunk of KS bf16 k-steps on the B pieces of the layer's input (computed once per layer:
+// both output halves use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
+#define MVS_GEMM_SPLIT(buf, KS, BH, BM, BL, ACC0, ACC1)                                                 \
   {                                                                                                     \
-    /* 16 groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + 1 are read from LDS  \
-       under the MFMAs of group g (as MVS_GEMM does: read + use inside one group left the 192 matrix cycles of a     \
+    /* 2 KS groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + 1 are read from   \
+       LDS under the MFMAs of group g (as MVS_GEMM does: read + use inside one group left the 192 matrix cycles of a \
        group waiting ~200 cycles for its three ds_read_b128 -- 32 k of the 137 k cycles of a tile) */              \
     const mlp_u32x4* sp_ = reinterpret_cast<const mlp_u32x4*>(buf) + lane;                              \
     mlp_u32x4 as_[2][3];                                                                                \
-    _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[0][pc_] = sp_[(pc_ * 8 * 2) * 64];          \
-    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                 \
+    _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[0][pc_] = sp_[(pc_ * (KS) * 2) * 64];       \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2 * (KS); ++g_) {                                           \
       const int T_ = g_ >> 1, tl_ = g_ & 1;                                                             \
-      if (g_ + 1 < 16) {                                                                                \
-        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[(g_ + 1) & 1][pc_] = sp_[(pc_ * 16 + g_ + 1) * 64]; \
+      if (g_ + 1 < 2 * (KS)) {                                                                          \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[(g_ + 1) & 1][pc_] = sp_[(pc_ * 2 * (KS) + g_ + 1) * 64]; \
       }                                                                                                 \
       BMV_FENCE();                                                                                      \
       const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, BH[T_]), Bm_ = __builtin_bit_cast(mlp_bf16x8, BM[T_]), \
@@ -587,17 +593,21 @@ __device__ __forceinline__ void wait_vm_keep(int keep) {
       BMV_FENCE();                                                                                      \
     }                                                                                                   \
   }
-// the three bf16 pieces of a layer's 128-wide input (this lane's 64 values: hcur[t >> 4][t & 15] for fp32 k-step t)
-#define MVS_SPLIT_INPUT(H, BH, BM, BL)                                                                  \
-  _Pragma("unroll") for (int T_ = 0; T_ < 8; ++T_)                                                      \
+// the three bf16 pieces of NK bf16 k-steps of a layer's input into B{H,M,L}[OFF ..): BEXPR is this lane's value for the
+// fp32 k-step `t` (0 .. 8 NK - 1) of that part of the input
+#define MVS_SPLIT_INPUT(NK, OFF, BEXPR, BH, BM, BL)                                                     \
+  _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_)                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
-      const int t0_ = 8 * T_ + 2 * q_;                                                                  \
-      const float v0_ = H[t0_ >> 4][t0_ & 15], v1_ = H[(t0_ + 1) >> 4][(t0_ + 1) & 15];                 \
-      const unsigned ph_ = mlp_cvt_pk_bf16(v0_, v1_);                                                   \
-      const float r10_ = v0_ - __uint_as_float(ph_ << 16), r11_ = v1_ - __uint_as_float(ph_ & 0xffff0000u); \
+      float v_[2];                                                                                      \
+      _Pragma("unroll") for (int jj_ = 0; jj_ < 2; ++jj_) {                                             \
+        const int t = 8 * T_ + 2 * q_ + jj_;                                                            \
+        v_[jj_] = (BEXPR);                                                                              \
+      }                                                                                                 \
+      const unsigned ph_ = mlp_cvt_pk_bf16(v_[0], v_[1]);                                               \
+      const float r10_ = v_[0] - __uint_as_float(ph_ << 16), r11_ = v_[1] - __uint_as_float(ph_ & 0xffff0000u); \
       const unsigned pm_ = mlp_cvt_pk_bf16(r10_, r11_);                                                 \
       const float r20_ = r10_ - __uint_as_float(pm_ << 16), r21_ = r11_ - __uint_as_float(pm_ & 0xffff0000u); \
-      BH[T_][q_] = ph_, BM[T_][q_] = pm_, BL[T_][q_] = mlp_cvt_pk_bf16(r20_, r21_);                     \
+      BH[(OFF) + T_][q_] = ph_, BM[(OFF) + T_][q_] = pm_, BL[(OFF) + T_][q_] = mlp_cvt_pk_bf16(r20_, r21_); \
     }
 
 template <bool SPLIT = false>
@@ -637,9 +647,12 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4
 #pragma unroll
   for (int layer = 0; layer < 6; ++layer) {
-    mlp_u32x4 bh[8], bm[8], bl[8];
-    if constexpr (SPLIT)
-      if (layer >= 1 && layer <= 4) { MVS_SPLIT_INPUT(hcur, bh, bm, bl) }
+    mlp_u32x4 bh[12], bm[12], bl[12];   // [embedded point 4 |] hidden 8 bf16 k-steps
+    if constexpr (SPLIT) {
+      if (layer == 0 || layer == 5) { MVS_SPLIT_INPUT(4, 0, e[t], bh, bm, bl) }
+      if (layer == 5) { MVS_SPLIT_INPUT(8, 4, hcur[t >> 4][t & 15], bh, bm, bl) }
+      if (layer >= 1 && layer <= 4) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], bh, bm, bl) }
+    }
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -648,13 +661,19 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
         hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BL / 2 + layer * 64 + (2 * tp + 1) * 16 + r) * 2];
       }
       next_chunk();
-      if (layer == 0) {
+      if constexpr (SPLIT) {
+        if (layer == 0) {
+          MVS_GEMM_SPLIT(buf, 4, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+        } else if (layer == 5) {
+          MVS_GEMM_SPLIT(buf, 12, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+        } else {
+          MVS_GEMM_SPLIT(buf, 8, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+        }
+      } else if (layer == 0) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
       } else if (layer == 5) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
         MVS_GEMM(buf, 32, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
-      } else if constexpr (SPLIT) {
-        MVS_GEMM_SPLIT(buf, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
       } else {
         MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
       }
@@ -676,7 +695,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   }
   // feature_linear (network.py:221), no activation
   mlp_u32x4 fh[8], fm[8], fl[8];
-  if constexpr (SPLIT) { MVS_SPLIT_INPUT(hcur, fh, fm, fl) }
+  if constexpr (SPLIT) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], fh, fm, fl) }
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -686,7 +705,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     }
     next_chunk();
     if constexpr (SPLIT) {
-      MVS_GEMM_SPLIT(buf, fh, fm, fl, hnew[2 * tp], hnew[2 * tp + 1]);
+      MVS_GEMM_SPLIT(buf, 8, fh, fm, fl, hnew[2 * tp], hnew[2 * tp + 1]);
     } else {
       MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
     }
@@ -698,8 +717,15 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[tl][r] = Sv[(MvsMlp::S_BV / 2 + tl * 16 + r) * 2];
   next_chunk();
-  MVS_GEMM(buf, 0, 64, hnew[t >> 4][t & 15], hv[0], hv[1]);
-  MVS_GEMM(buf, 64, 2, dv[t], hv[0], hv[1]);
+  if constexpr (SPLIT) {
+    mlp_u32x4 vh[9], vm[9], vl[9];      // feature 8 bf16 k-steps | direction (fp32 k-steps 64, 65; zeros behind)
+    MVS_SPLIT_INPUT(8, 0, hnew[t >> 4][t & 15], vh, vm, vl)
+    MVS_SPLIT_INPUT(1, 8, (t < 2 ? dv[t & 1] : 0.f), vh, vm, vl)
+    MVS_GEMM_SPLIT(buf, 9, vh, vm, vl, hv[0], hv[1]);
+  } else {
+    MVS_GEMM(buf, 0, 64, hnew[t >> 4][t & 15], hv[0], hv[1]);
+    MVS_GEMM(buf, 64, 2, dv[t], hv[0], hv[1]);
+  }
   // rgb head (network.py:228): sigmoid(W_rgb relu(hv) + b)
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -1119,7 +1145,7 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
   BMV_LAUNCH_END("bmv_mvs_march_mask");
 }
 
-int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL_S; }   // (fp32 chunks + small tables + the ten bf16 x 3 chunks)
+int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL_S; }   // (fp32 chunks + small tables + the fifteen bf16 x 3 chunks)
 
 int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* p, float* blob, bmv_stream_t stream) {
   BMV_REQUIRE(p && blob, "bmv_mvs_mlp_pack_weights: null pointer");
@@ -1137,7 +1163,7 @@ int bmv_mvs_mlp_fwd(const float* x, const float* blob, long npts, float* out, bm
   BMV_REQUIRE(x && blob && out, "bmv_mvs_mlp_fwd: null pointer");
   BMV_REQUIRE(npts >= 0, "bmv_mvs_mlp_fwd: npts=%ld", npts);
   if (npts == 0) return BMV_OK;
-  // BMV_MVS_SPLIT (default 1): the ten 128 -> 128 chunks as bf16 MFMAs on three-piece fp32 operands (fp32 accuracy); 0: all fp32
+  // BMV_MVS_SPLIT (default 1): all matrix chunks but pts_bias as bf16 MFMAs on three-piece fp32 operands (fp32 accuracy); 0: all fp32
   const bool split = bmv::tuning("BMV_MVS_SPLIT", 1) != 0;
   BMV_REQUIRE(mvs_lds_ok(split ? reinterpret_cast<const void*>(mvs_mlp_kernel<true>) : reinterpret_cast<const void*>(mvs_mlp_kernel<false>)),
               "bmv_mvs_mlp_fwd: cannot reserve LDS");
