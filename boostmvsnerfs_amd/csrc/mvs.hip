@@ -339,7 +339,7 @@ struct MvsMlp {
     return o;
   }
   static constexpr int A_TOTAL = 2 * 10 * 128 + 2 * 32 * 128 + 8 * 64 * 128 + 2 * 96 * 128 + 2 * 64 * 128 + 66 * 128;
-  // resident small tables, [idx][half] with idx = tile*16 + reg
+  // resident small tables, [tile][half][reg 16] (entry idx = tile * 16 + reg of a lane half: MVS_SMALL in the forward)
   static constexpr int S_BBIAS = 0;                   // pts_bias bias          [64]
   static constexpr int S_BL = S_BBIAS + 128;          // pts_linears.{0..5} bias [6][64]
   static constexpr int S_BF = S_BL + 6 * 128;         // feature_linear bias     [64]
@@ -453,7 +453,7 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
       int k = rel - MvsMlp::S_SC;
       v = k == 0 ? p.alpha_b[0] : p.rgb_b[k - 1];
     } else {
-      int h = rel & 1, e = rel >> 1;
+      int h = (rel >> 4) & 1, e = (rel >> 5) * 16 + (rel & 15);   // [tile][half][16]: a lane reads its 16 as 4 x 16 bytes
       if (rel < MvsMlp::S_BL) {
         v = p.bias_b[hid_index(e, h)];
       } else if (rel < MvsMlp::S_BF) {
@@ -563,60 +563,138 @@ __device__ __forceinline__ void wait_vm_keep(int keep) {
 // afterwards the last chunks of the previous tile issue them).
 // a K -> 64 product of a split chunk of KS bf16 k-steps on the B pieces of the layer's input (computed once per layer:
 // both output halves use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
+#ifndef BMV_MVS_ADIST
+#define BMV_MVS_ADIST 2     // groups the A pieces are read ahead of their MFMAs
+#endif
+#ifndef BMV_MVS_ASPREAD
+#define BMV_MVS_ASPREAD 1   // those reads between the group's first MFMAs instead of in front of them
+#endif
+// The A pieces are read by hand-written ds_read_b128 with COUNTED waits.  Left to the compiler, every wait in front of a
+// group's MFMAs is s_waitcnt lgkmcnt(0) -- with the next chunk's LDS-DMA in flight it does not count LDS reads -- which
+// also waits for the reads issued just before it for the NEXT group: the read-ahead was void in every second group and
+// the LDS latency of the four waves queueing at the pipe exposed (18.8 k of the 122 k cycles of a tile:
+// scripts/ablate_mvs_mlp.py, profiles/r6/mvs_pipeline.txt).  LDS operations complete in order, so "at most 3 n
+// outstanding" says the oldest are done whatever else the compiler has in flight; scalar loads share the counter and
+// return out of order -- none is issued between the drain at the top and the last group (the fences keep the
+// compiler's code out of the group regions).
+#define MVS_LDS_READ128(DST, ADDR, OFF)                                                                 \
+  {                                                                                                     \
+    mlp_u32x4& d_ = DST; /* (named outside the asm: operands alone do not capture in a generic lambda) */ \
+    const unsigned a_ = ADDR;                                                                           \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d_) : "v"(a_), "n"(OFF) : "memory");            \
+  }
+template <int I, int N, class F>
+__device__ __forceinline__ void mvs_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    mvs_static_for<I + 1, N>(f);
+  }
+}
 #define MVS_GEMM_SPLIT(buf, KS, BH, BM, BL, ACC0, ACC1)                                                 \
   {                                                                                                     \
-    /* 2 KS groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + 1 are read from   \
-       LDS under the MFMAs of group g (as MVS_GEMM does: read + use inside one group left the 192 matrix cycles of a \
-       group waiting ~200 cycles for its three ds_read_b128 -- 32 k of the 137 k cycles of a tile) */              \
-    const mlp_u32x4* sp_ = reinterpret_cast<const mlp_u32x4*>(buf) + lane;                              \
-    mlp_u32x4 as_[2][3];                                                                                \
-    _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[0][pc_] = sp_[(pc_ * (KS) * 2) * 64];       \
-    _Pragma("unroll") for (int g_ = 0; g_ < 2 * (KS); ++g_) {                                           \
-      const int T_ = g_ >> 1, tl_ = g_ & 1;                                                             \
-      if (g_ + 1 < 2 * (KS)) {                                                                          \
-        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) as_[(g_ + 1) & 1][pc_] = sp_[(pc_ * 2 * (KS) + g_ + 1) * 64]; \
+    /* 2 KS groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + BMV_MVS_ADIST are   \
+       read from LDS under the MFMAs of group g */                                                      \
+    constexpr int AD_ = BMV_MVS_ADIST, NG_ = 2 * (KS);                                                  \
+    unsigned ab_[3];   /* LDS byte address of this lane's 16 bytes of piece pc, group 0 */             \
+    _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_)                                                 \
+      ab_[pc_] = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(buf) + (unsigned)lane * 16u + pc_ * NG_ * 1024; \
+    mlp_u32x4 as_[AD_ + 1][3];                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+    mvs_static_for<0, (AD_ < NG_ ? AD_ : NG_) * 3>([&](auto I_) {                                       \
+      constexpr int g0_ = decltype(I_)::value / 3, pc_ = decltype(I_)::value % 3;                       \
+      if constexpr ((kMvsAblate & 16) != 0) as_[g0_][pc_] = mlp_u32x4{(unsigned)lane, 1u, 2u, 3u};      \
+      else MVS_LDS_READ128(as_[g0_][pc_], ab_[pc_], g0_ * 1024);                                        \
+    });                                                                                                 \
+    mvs_static_for<0, NG_>([&](auto G_) {                                                               \
+      constexpr int g_ = decltype(G_)::value, T_ = g_ >> 1, tl_ = g_ & 1, cur_ = g_ % (AD_ + 1);        \
+      constexpr int nxt_ = (g_ + AD_) % (AD_ + 1);                                                      \
+      constexpr bool more_ = g_ + AD_ < NG_;                                                            \
+      /* the reads of group g + AD between the first MFMAs of group g (BMV_MVS_ASPREAD), not in front of them: when   \
+         the four waves queue at the LDS pipe the issue of a read waits, and a wave issues in order -- behind an MFMA \
+         that wait is covered by its 32 cycles, in front of the group it is not */                                 \
+      auto read_ = [&](auto P_) {                                                                       \
+        constexpr int pc_ = decltype(P_)::value;                                                        \
+        if constexpr (more_) {                                                                          \
+          if constexpr ((kMvsAblate & 16) != 0) as_[nxt_][pc_] = as_[cur_][pc_];                        \
+          else MVS_LDS_READ128(as_[nxt_][pc_], ab_[pc_], (g_ + AD_) * 1024);                            \
+        }                                                                                               \
+      };                                                                                                \
+      if constexpr ((kMvsAblate & 16) == 0) {                                                           \
+        /* (with the reads spread, those of group g + AD are issued AFTER this wait: one group fewer is newer) */   \
+        constexpr int ahead_ = BMV_MVS_ASPREAD ? AD_ - 1 : AD_;                                         \
+        constexpr int newer_ = 3 * (NG_ - 1 - g_ < ahead_ ? NG_ - 1 - g_ : ahead_);                     \
+        if constexpr (!BMV_MVS_ASPREAD) { read_(std::integral_constant<int, 0>{}); read_(std::integral_constant<int, 1>{}); read_(std::integral_constant<int, 2>{}); } \
+        mlp_u32x4 &w0_ = as_[cur_][0], &w1_ = as_[cur_][1], &w2_ = as_[cur_][2];                        \
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w0_), "+v"(w1_), "+v"(w2_) : "n"(newer_));          \
       }                                                                                                 \
       BMV_FENCE();                                                                                      \
       const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, BH[T_]), Bm_ = __builtin_bit_cast(mlp_bf16x8, BM[T_]), \
                        Bl_ = __builtin_bit_cast(mlp_bf16x8, BL[T_]);                                    \
-      const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][0]);                            \
-      const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][1]);                            \
-      const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, as_[g_ & 1][2]);                            \
+      const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, as_[cur_][0]);                              \
+      const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, as_[cur_][1]);                              \
+      const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, as_[cur_][2]);                              \
       f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                               \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                              \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                              \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                              \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                              \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                              \
-      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                              \
-      if (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                                          \
+      if constexpr ((kMvsAblate & 8) != 0) {                                                            \
+        asm volatile("" :: "v"(Al_), "v"(Am_), "v"(Ah_), "v"(Bh_), "v"(Bm_), "v"(Bl_));                 \
+        if constexpr (BMV_MVS_ASPREAD) { read_(std::integral_constant<int, 0>{}); read_(std::integral_constant<int, 1>{}); read_(std::integral_constant<int, 2>{}); } \
+      } else {                                                                                          \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                            \
+        if constexpr (BMV_MVS_ASPREAD) { BMV_FENCE(); read_(std::integral_constant<int, 0>{}); BMV_FENCE(); } \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                            \
+        if constexpr (BMV_MVS_ASPREAD) { BMV_FENCE(); read_(std::integral_constant<int, 1>{}); BMV_FENCE(); } \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                            \
+        if constexpr (BMV_MVS_ASPREAD) { BMV_FENCE(); read_(std::integral_constant<int, 2>{}); BMV_FENCE(); } \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                            \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                            \
+        if constexpr (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                              \
+      }                                                                                                 \
       BMV_FENCE();                                                                                      \
-    }                                                                                                   \
+    });                                                                                                 \
   }
+typedef float mvs_f32x2 __attribute__((ext_vector_type(2)));
+// Timing ablations of the split form (WRONG results; scripts/ablate_mvs_mlp.py builds them beside the product library):
+// 1 no operand split (the pieces are the value's own bits), 2 no bias * relu epilogue, 4 no chunk barrier / wait,
+// 8 no matrix instructions, 16 no LDS reads of the A pieces, 32 accumulators start at zero instead of the layer's bias vector
+#ifndef BMV_MVS_ABLATE
+#define BMV_MVS_ABLATE 0
+#endif
+constexpr int kMvsAblate = BMV_MVS_ABLATE;
 // the three bf16 pieces of NK bf16 k-steps of a layer's input into B{H,M,L}[OFF ..): BEXPR is this lane's value for the
 // fp32 k-step `t` (0 .. 8 NK - 1) of that part of the input
 #define MVS_SPLIT_INPUT(NK, OFF, BEXPR, BH, BM, BL)                                                     \
   _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_)                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
-      float v_[2];                                                                                      \
+      /* the two residuals as packed fp32 subtractions (v_pk_add_f32): a wave alone on its SIMD pays ~9 cycles per     \
+         vector instruction whatever its width (profiles/r5/valu_pk_rate_ubench.txt) -- 9 instead of 11 per pair.  (The compiler's \
+         own fp32 -> bf16 conversion instead of mlp.hpp's inline asm lets it hoist the conversions: spills) */         \
+      mvs_f32x2 v_;                                                                                     \
       _Pragma("unroll") for (int jj_ = 0; jj_ < 2; ++jj_) {                                             \
         const int t = 8 * T_ + 2 * q_ + jj_;                                                            \
         v_[jj_] = (BEXPR);                                                                              \
       }                                                                                                 \
+      if constexpr ((kMvsAblate & 1) != 0) {                                                            \
+        BH[(OFF) + T_][q_] = __float_as_uint(v_[0]), BM[(OFF) + T_][q_] = __float_as_uint(v_[1]);       \
+        BL[(OFF) + T_][q_] = __float_as_uint(v_[0]);                                                    \
+        continue;                                                                                       \
+      }                                                                                                 \
       const unsigned ph_ = mlp_cvt_pk_bf16(v_[0], v_[1]);                                               \
-      const float r10_ = v_[0] - __uint_as_float(ph_ << 16), r11_ = v_[1] - __uint_as_float(ph_ & 0xffff0000u); \
-      const unsigned pm_ = mlp_cvt_pk_bf16(r10_, r11_);                                                 \
-      const float r20_ = r10_ - __uint_as_float(pm_ << 16), r21_ = r11_ - __uint_as_float(pm_ & 0xffff0000u); \
-      BH[(OFF) + T_][q_] = ph_, BM[(OFF) + T_][q_] = pm_, BL[(OFF) + T_][q_] = mlp_cvt_pk_bf16(r20_, r21_); \
+      const mvs_f32x2 h_ = {__uint_as_float(ph_ << 16), __uint_as_float(ph_ & 0xffff0000u)};            \
+      const mvs_f32x2 r1_ = v_ - h_;                                                                    \
+      const unsigned pm_ = mlp_cvt_pk_bf16(r1_[0], r1_[1]);                                             \
+      const mvs_f32x2 m_ = {__uint_as_float(pm_ << 16), __uint_as_float(pm_ & 0xffff0000u)};            \
+      const mvs_f32x2 r2_ = r1_ - m_;                                                                   \
+      BH[(OFF) + T_][q_] = ph_, BM[(OFF) + T_][q_] = pm_, BL[(OFF) + T_][q_] = mlp_cvt_pk_bf16(r2_[0], r2_[1]); \
     }
 
+#define MVS_SMALL(BASE, IDX) Sq[(BASE) + 2 * (IDX) - ((IDX) & 15)]
 template <bool SPLIT = false>
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
                                                 float* __restrict__ buf2, ChunkPipe& pipe, int lane,
                                                 const float (&e)[32], const float (&f)[10], const float (&dv)[2],
                                                 float (&out)[4]) {
   const int h = lane >> 5;
-  const float* __restrict__ Sv = small + h;
+  const float* __restrict__ Sq = small + 16 * h;   // this lane half's 16 values of a tile are contiguous: MVS_SMALL
   f32x16 bias[4], hcur[4], hnew[4];
   int chunk = 0;
   const float* buf = buf2;
@@ -624,8 +702,10 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     constexpr int DIST = kMvsBuffers - 1;              // prefetch distance in chunks
     // my pieces of this chunk have landed (distance 2: those of the next one may still be in flight) ...
     const int nxt = chunk + 1 < MvsMlp::N_CHUNKS ? chunk + 1 : pipe.more ? 0 : -1;
-    wait_vm_keep(DIST == 1 || nxt < 0 ? 0 : chunk_pieces<SPLIT>(nxt) / 4);
-    asm volatile("s_barrier" ::: "memory");            // ... everyone's have; everyone is done with the previous chunk
+    if constexpr ((kMvsAblate & 4) == 0) {
+      wait_vm_keep(DIST == 1 || nxt < 0 ? 0 : chunk_pieces<SPLIT>(nxt) / 4);
+      asm volatile("s_barrier" ::: "memory");          // ... everyone's have; everyone is done with the previous chunk
+    }
     buf = buf2 + pipe.slot * MvsMlp::CHUNK_MAX;
     const int free_slot = pipe.slot == 0 ? kMvsBuffers - 1 : pipe.slot - 1;   // the previous chunk's buffer
     if (chunk + DIST < MvsMlp::N_CHUNKS) issue_chunk<SPLIT>(blob, buf2, chunk + DIST, free_slot);
@@ -638,8 +718,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      bias[2 * tp][r] = Sv[(MvsMlp::S_BBIAS / 2 + (2 * tp) * 16 + r) * 2];
-      bias[2 * tp + 1][r] = Sv[(MvsMlp::S_BBIAS / 2 + (2 * tp + 1) * 16 + r) * 2];
+      bias[2 * tp][r] = MVS_SMALL(MvsMlp::S_BBIAS, (2 * tp) * 16 + r);
+      bias[2 * tp + 1][r] = MVS_SMALL(MvsMlp::S_BBIAS, (2 * tp + 1) * 16 + r);
     }
     next_chunk();
     MVS_GEMM(buf, 0, 10, f[t], bias[2 * tp], bias[2 * tp + 1]);
@@ -657,8 +737,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        hnew[2 * tp][r] = Sv[(MvsMlp::S_BL / 2 + layer * 64 + (2 * tp) * 16 + r) * 2];
-        hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BL / 2 + layer * 64 + (2 * tp + 1) * 16 + r) * 2];
+        hnew[2 * tp][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BL, layer * 64 + (2 * tp) * 16 + r);
+        hnew[2 * tp + 1][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BL, layer * 64 + (2 * tp + 1) * 16 + r);
       }
       next_chunk();
       if constexpr (SPLIT) {
@@ -681,7 +761,14 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hcur[tl][r] = fmaxf(hnew[tl][r] * bias[tl][r], 0.f);
+      for (int r = 0; r < 16; r += 2) {                // (pairs: v_pk_mul_f32)
+        if constexpr ((kMvsAblate & 2) != 0) {
+          hcur[tl][r] = hnew[tl][r], hcur[tl][r + 1] = hnew[tl][r + 1];
+          continue;
+        }
+        const mvs_f32x2 m = mvs_f32x2{hnew[tl][r], hnew[tl][r + 1]} * mvs_f32x2{bias[tl][r], bias[tl][r + 1]};
+        hcur[tl][r] = fmaxf(m[0], 0.f), hcur[tl][r + 1] = fmaxf(m[1], 0.f);
+      }
     BMV_FENCE();
   }
   // alpha head (network.py:220)
@@ -690,7 +777,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += Sv[(MvsMlp::S_WA / 2 + tl * 16 + r) * 2] * hcur[tl][r];
+      for (int r = 0; r < 16; ++r) s += MVS_SMALL(MvsMlp::S_WA, tl * 16 + r) * hcur[tl][r];
     out[3] = fmaxf(xhalf_sum(s) + small[MvsMlp::S_SC], 0.f);
   }
   // feature_linear (network.py:221), no activation
@@ -700,8 +787,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      hnew[2 * tp][r] = Sv[(MvsMlp::S_BF / 2 + (2 * tp) * 16 + r) * 2];
-      hnew[2 * tp + 1][r] = Sv[(MvsMlp::S_BF / 2 + (2 * tp + 1) * 16 + r) * 2];
+      hnew[2 * tp][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BF, (2 * tp) * 16 + r);
+      hnew[2 * tp + 1][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BF, (2 * tp + 1) * 16 + r);
     }
     next_chunk();
     if constexpr (SPLIT) {
@@ -715,7 +802,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hv[tl][r] = Sv[(MvsMlp::S_BV / 2 + tl * 16 + r) * 2];
+    for (int r = 0; r < 16; ++r) hv[tl][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BV, tl * 16 + r);
   next_chunk();
   if constexpr (SPLIT) {
     mlp_u32x4 vh[9], vm[9], vl[9];      // feature 8 bf16 k-steps | direction (fp32 k-steps 64, 65; zeros behind)
@@ -733,7 +820,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += Sv[(MvsMlp::S_WRGB / 2 + c * 32 + tl * 16 + r) * 2] * fmaxf(hv[tl][r], 0.f);
+      for (int r = 0; r < 16; ++r) s += MVS_SMALL(MvsMlp::S_WRGB, c * 32 + tl * 16 + r) * fmaxf(hv[tl][r], 0.f);
     float pre = xhalf_sum(s) + small[MvsMlp::S_SC + 1 + c];
     out[c] = 1.f / (1.f + __expf(-pre));
   }
@@ -757,6 +844,10 @@ template <int S>
 __device__ __forceinline__ void mvs_point_inputs(const bmv_mvs_render_args& a, const MvsCams& mc, int ray, int k,
                                                  int h, float (&e)[32], float (&f)[10], float (&dv)[2], float& z,
                                                  float& vis) {
+  // No multiply-add contraction in the geometry: which products the compiler fuses differs between the kernels this is
+  // inlined into (BMV_MVS_SPLIT 0 / 1 are two instantiations), one ulp of ndc is 6e-5 of sin(512 ndc), and six gated
+  // layers amplify that to 5e-6 of alpha -- the two forms must see the SAME MLP inputs (tests/test_gpu_mvs.py)
+#pragma clang fp contract(off)
   const float* r = a.rays + (size_t)ray * 8;
   const float o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
   const float t = linspace01(k, a.Ns);

@@ -104,7 +104,7 @@ class _mvs_split:
 def test_mlp_both_matrix_forms_match_the_reference(fx, split):
     """Renderer_ours (lib/networks/mvsnerf/network.py:201-229) in BOTH arithmetic forms of the fused kernel against the
     reference's own MLP outputs: BMV_MVS_SPLIT=0 (`mvs_render_kernel<..., false>` / the fp32-MFMA instantiation of the
-    stand-alone MLP) and the default 1 (the ten 128 -> 128 chunks as bf16 MFMAs on three-piece fp32 operands)."""
+    stand-alone MLP) and the default 1 (every chunk but pts_bias as bf16 MFMAs on three-piece fp32 operands)."""
     from boostmvsnerfs_amd import ops
     x = chunks(fx, "run_network_mvs").to(DEV)
     with _mvs_split(split):
@@ -119,7 +119,9 @@ def test_mvs_split_frames_agree_to_fp32_rounding(fx, Ns):
     """BMV_MVS_SPLIT 0 vs 1 through the FUSED renderer (ray march + lookups + embedding + MLP in one launch) on the
     fixture's volume, at the fixture's 8 samples per ray and at config 4's 128: the two forms' raw outputs agree to
     2e-6 of the output scale (rgb in [0, 1]; alpha relative to its own maximum) and are NOT bit-equal (the split form
-    ran), z / mask are untouched by the switch."""
+    ran), z / mask AND the MLP inputs the fused kernel computes are untouched by the switch (the two forms are two
+    instantiations of the kernel: the geometry is compiled without multiply-add contraction so that both see the same
+    ndc -- one ulp of it is 6e-5 of sin(512 ndc) and 5e-6 of alpha, measured round 6)."""
     from boostmvsnerfs_amd import ops
     from oracle import mvsnerf as M
     b = fx.batch(DEV)
@@ -167,7 +169,7 @@ def test_mvs_split_network_frames_agree(fx):
 def test_mvs_split_mlp_is_as_accurate_as_the_fp32_mlp_against_float64(fx, wscale):
     """The arithmetic claim behind the default (csrc/tuning.hip: 'at fp32 accuracy'): on the same fp32 inputs and
     weights -- 2^17 points drawn from the reference's own MLP inputs, the fixture's weights and a trial with 3 x larger
-    weight matrices (six 128-wide layers with a multiplicative gate amplify) -- the kernel with its 128 -> 128 chunks on
+    weight matrices (six 128-wide layers with a multiplicative gate amplify) -- the kernel with its matrix chunks on
     the bf16 pipe is no farther from a float64 evaluation of Renderer_ours (oracle/mvsnerf.py renderer_mlp,
     lib/networks/mvsnerf/network.py:201-229) than the all-fp32-MFMA form is."""
     from boostmvsnerfs_amd import ops
