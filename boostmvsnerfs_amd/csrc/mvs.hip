@@ -488,6 +488,10 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
 struct ChunkPipe {
   int slot;    // LDS buffer (0 .. kMvsBuffers - 1) of the next chunk this workgroup consumes
   bool more;   // another tile follows this one: prefetch its first chunks
+#ifdef BMV_MVS_STAMPS
+  int tile_no = 0;
+  unsigned long long prev_start = 0;
+#endif
 };
 #ifndef BMV_MVS_BUFFERS
 #define BMV_MVS_BUFFERS 2     // 3 measured 3 % SLOWER than 2 on config 4 (profiles/r6/mvs_pipeline.txt): the stream was never the stall
@@ -590,7 +594,7 @@ __device__ __forceinline__ void mvs_static_for(F&& f) {
     mvs_static_for<I + 1, N>(f);
   }
 }
-#define MVS_GEMM_SPLIT(buf, KS, BH, BM, BL, ACC0, ACC1)                                                 \
+#define MVS_GEMM_SPLIT(buf, KS, BH, BM, BL, ACC0, ACC1, DMA_)                                                 \
   {                                                                                                     \
     /* 2 KS groups g = (bf16 k-step T, tile tl) of 3 A pieces and 6 MFMAs; the pieces of group g + BMV_MVS_ADIST are   \
        read from LDS under the MFMAs of group g */                                                      \
@@ -637,6 +641,7 @@ __device__ __forceinline__ void mvs_static_for(F&& f) {
       if constexpr ((kMvsAblate & 8) != 0) {                                                            \
         asm volatile("" :: "v"(Al_), "v"(Am_), "v"(Ah_), "v"(Bh_), "v"(Bm_), "v"(Bl_));                 \
         if constexpr (BMV_MVS_ASPREAD) { read_(std::integral_constant<int, 0>{}); read_(std::integral_constant<int, 1>{}); read_(std::integral_constant<int, 2>{}); } \
+        DMA_(); DMA_();                                                                                 \
       } else {                                                                                          \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                            \
         if constexpr (BMV_MVS_ASPREAD) { BMV_FENCE(); read_(std::integral_constant<int, 0>{}); BMV_FENCE(); } \
@@ -645,7 +650,9 @@ __device__ __forceinline__ void mvs_static_for(F&& f) {
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bm_, c_, 0, 0, 0);                            \
         if constexpr (BMV_MVS_ASPREAD) { BMV_FENCE(); read_(std::integral_constant<int, 2>{}); BMV_FENCE(); } \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am_, Bh_, c_, 0, 0, 0);                            \
+        BMV_FENCE(); DMA_(); BMV_FENCE();     /* two pieces of the next chunk's request per group */     \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bm_, c_, 0, 0, 0);                            \
+        BMV_FENCE(); DMA_(); BMV_FENCE();                                                               \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bh_, c_, 0, 0, 0);                            \
         if constexpr (tl_ == 0) ACC0 = c_; else ACC1 = c_;                                              \
       }                                                                                                 \
@@ -688,6 +695,30 @@ constexpr int kMvsAblate = BMV_MVS_ABLATE;
     }
 
 #define MVS_SMALL(BASE, IDX) Sq[(BASE) + 2 * (IDX) - ((IDX) & 15)]
+// -DBMV_MVS_STAMPS: shader-clock stamps at the phase boundaries of every wave's third tile (scripts/stamps_mvs_mlp.py reads
+// them through bmv_debug_fetch_mvs_stamps); a tuning build, never the shipped library -- the stamps drain every counter,
+// so they serialise what the shipped kernel overlaps
+#ifdef BMV_MVS_STAMPS
+constexpr int kMvsStamps = 52;
+__device__ float g_mvs_stamps[256 * 4 * kMvsStamps];
+#define MSTAMP(i)                                                       \
+  {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
+    st[i] = __builtin_amdgcn_s_memtime();                               \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+  }
+#elif defined(BMV_MVS_PHASE_FENCE)
+#if BMV_MVS_PHASE_FENCE == 2
+#define MSTAMP(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#elif BMV_MVS_PHASE_FENCE == 3
+#define MSTAMP(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MSTAMP(i) __builtin_amdgcn_sched_barrier(0);
+#endif
+#else
+#define MSTAMP(i)
+#endif
 template <bool SPLIT = false>
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
                                                 float* __restrict__ buf2, ChunkPipe& pipe, int lane,
@@ -698,21 +729,53 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   f32x16 bias[4], hcur[4], hnew[4];
   int chunk = 0;
   const float* buf = buf2;
+  // The weight stream.  The request for the chunk behind chunk c is SET UP at the barrier in front of c and issued piece
+  // by piece between the MFMAs of c (MVS_GEMM_SPLIT calls dma_step twice per group), not as a burst behind the barrier:
+  // a wave issues in order, and its 6 - 18 global_load_lds of 1 KB queue behind the other three waves' at the CU's one
+  // address path -- 1 - 2 k cycles per chunk in which no MFMA of the wave was issued, 37 k of the 114 k cycles of a tile
+  // (scripts/stamps_mvs_mlp.py, profiles/r6/mvs_pipeline.txt).  In front of an fp32 chunk (pts_bias; BMV_MVS_SPLIT=0) the
+  // request is flushed at once as before.  All counts below fold to constants once the chunk loop is unrolled.
+  static_assert(kMvsBuffers == 2, "prefetch distance 1");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int dma_np = 0, dma_i = 0;            // 1 KB pieces of the request; pieces of THIS wave (p = wave + 4 i) issued so far
+  const char* dma_src = nullptr;        // this lane's 16 bytes of this wave's first piece (+ 4 KB per piece)
+  char* dma_dst = nullptr;
+  auto dma_step = [&]() {
+    if (dma_i < (dma_np + 3) / 4) {
+      if (dma_i < dma_np / 4 || 4 * dma_i + wave < dma_np)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + dma_i * 4096),
+                                         (__attribute__((address_space(3))) void*)(dma_dst + dma_i * 4096), 16, 0, 0);
+      ++dma_i;
+    }
+  };
+  auto dma_flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < (MvsMlp::CHUNK_MAX / 256 + 3) / 4; ++k) dma_step();
+  };
   auto next_chunk = [&]() {
-    constexpr int DIST = kMvsBuffers - 1;              // prefetch distance in chunks
-    // my pieces of this chunk have landed (distance 2: those of the next one may still be in flight) ...
-    const int nxt = chunk + 1 < MvsMlp::N_CHUNKS ? chunk + 1 : pipe.more ? 0 : -1;
+    dma_flush();                                       // (nothing left behind a split chunk)
     if constexpr ((kMvsAblate & 4) == 0) {
-      wait_vm_keep(DIST == 1 || nxt < 0 ? 0 : chunk_pieces<SPLIT>(nxt) / 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my pieces of this chunk have landed ...
       asm volatile("s_barrier" ::: "memory");          // ... everyone's have; everyone is done with the previous chunk
     }
     buf = buf2 + pipe.slot * MvsMlp::CHUNK_MAX;
     const int free_slot = pipe.slot == 0 ? kMvsBuffers - 1 : pipe.slot - 1;   // the previous chunk's buffer
-    if (chunk + DIST < MvsMlp::N_CHUNKS) issue_chunk<SPLIT>(blob, buf2, chunk + DIST, free_slot);
-    else if (pipe.more) issue_chunk<SPLIT>(blob, buf2, chunk + DIST - MvsMlp::N_CHUNKS, free_slot);
+    const bool last = chunk + 1 == MvsMlp::N_CHUNKS;
+    const int nc = last ? 0 : chunk + 1;               // (the next tile's first chunk under this tile's last one)
+    const bool sp = SPLIT && MvsMlp::is_split(nc);
+    dma_np = last && !pipe.more ? 0 : chunk_pieces<SPLIT>(nc);
+    dma_i = 0;
+    dma_src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_offset(nc) : blob + MvsMlp::offset(nc)) +
+              wave * 1024 + lane * 16;
+    dma_dst = reinterpret_cast<char*>(buf2 + free_slot * MvsMlp::CHUNK_MAX) + wave * 1024;
+    if constexpr (!SPLIT) dma_flush();
     pipe.slot = pipe.slot == kMvsBuffers - 1 ? 0 : pipe.slot + 1;
     ++chunk;
   };
+#ifdef BMV_MVS_STAMPS
+  unsigned long long st[kMvsStamps];
+#endif
+  MSTAMP(0)
   // pts_bias (network.py:210): bias = W_b feat + b_b
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp) {
@@ -722,8 +785,10 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       bias[2 * tp + 1][r] = MVS_SMALL(MvsMlp::S_BBIAS, (2 * tp + 1) * 16 + r);
     }
     next_chunk();
+    dma_flush();                                       // (an fp32 chunk: no groups to spread the request over)
     MVS_GEMM(buf, 0, 10, f[t], bias[2 * tp], bias[2 * tp + 1]);
   }
+  MSTAMP(1)
   // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4
 #pragma unroll
   for (int layer = 0; layer < 6; ++layer) {
@@ -733,6 +798,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       if (layer == 5) { MVS_SPLIT_INPUT(8, 4, hcur[t >> 4][t & 15], bh, bm, bl) }
       if (layer >= 1 && layer <= 4) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], bh, bm, bl) }
     }
+    MSTAMP(2 + 6 * layer)
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -741,13 +807,14 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
         hnew[2 * tp + 1][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BL, layer * 64 + (2 * tp + 1) * 16 + r);
       }
       next_chunk();
+      MSTAMP(3 + 6 * layer + 2 * tp)
       if constexpr (SPLIT) {
         if (layer == 0) {
-          MVS_GEMM_SPLIT(buf, 4, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+          MVS_GEMM_SPLIT(buf, 4, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
         } else if (layer == 5) {
-          MVS_GEMM_SPLIT(buf, 12, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+          MVS_GEMM_SPLIT(buf, 12, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
         } else {
-          MVS_GEMM_SPLIT(buf, 8, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1]);
+          MVS_GEMM_SPLIT(buf, 8, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
         }
       } else if (layer == 0) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
@@ -757,6 +824,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       } else {
         MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
       }
+      MSTAMP(4 + 6 * layer + 2 * tp)
     }
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl)
@@ -770,6 +838,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
         hcur[tl][r] = fmaxf(m[0], 0.f), hcur[tl][r + 1] = fmaxf(m[1], 0.f);
       }
     BMV_FENCE();
+    MSTAMP(7 + 6 * layer)
   }
   // alpha head (network.py:220)
   {
@@ -780,9 +849,11 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       for (int r = 0; r < 16; ++r) s += MVS_SMALL(MvsMlp::S_WA, tl * 16 + r) * hcur[tl][r];
     out[3] = fmaxf(xhalf_sum(s) + small[MvsMlp::S_SC], 0.f);
   }
+  MSTAMP(38)
   // feature_linear (network.py:221), no activation
   mlp_u32x4 fh[8], fm[8], fl[8];
   if constexpr (SPLIT) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], fh, fm, fl) }
+  MSTAMP(39)
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp) {
 #pragma unroll
@@ -791,11 +862,13 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       hnew[2 * tp + 1][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BF, (2 * tp + 1) * 16 + r);
     }
     next_chunk();
+    MSTAMP(40 + 2 * tp)
     if constexpr (SPLIT) {
-      MVS_GEMM_SPLIT(buf, 8, fh, fm, fl, hnew[2 * tp], hnew[2 * tp + 1]);
+      MVS_GEMM_SPLIT(buf, 8, fh, fm, fl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
     } else {
       MVS_GEMM(buf, 0, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
     }
+    MSTAMP(41 + 2 * tp)
   }
   // views_linears.0 (network.py:222-226): relu(W_v [feature, dir] + b_v), 131 -> 64
   f32x16 hv[2];
@@ -804,11 +877,14 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[tl][r] = (kMvsAblate & 32) != 0 ? 0.f : MVS_SMALL(MvsMlp::S_BV, tl * 16 + r);
   next_chunk();
+  MSTAMP(44)
   if constexpr (SPLIT) {
     mlp_u32x4 vh[9], vm[9], vl[9];      // feature 8 bf16 k-steps | direction (fp32 k-steps 64, 65; zeros behind)
     MVS_SPLIT_INPUT(8, 0, hnew[t >> 4][t & 15], vh, vm, vl)
     MVS_SPLIT_INPUT(1, 8, (t < 2 ? dv[t & 1] : 0.f), vh, vm, vl)
-    MVS_GEMM_SPLIT(buf, 9, vh, vm, vl, hv[0], hv[1]);
+    MSTAMP(45)
+    MVS_GEMM_SPLIT(buf, 9, vh, vm, vl, hv[0], hv[1], dma_step);
+    MSTAMP(46)
   } else {
     MVS_GEMM(buf, 0, 64, hnew[t >> 4][t & 15], hv[0], hv[1]);
     MVS_GEMM(buf, 64, 2, dv[t], hv[0], hv[1]);
@@ -824,6 +900,21 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     float pre = xhalf_sum(s) + small[MvsMlp::S_SC + 1 + c];
     out[c] = 1.f / (1.f + __expf(-pre));
   }
+  MSTAMP(47)
+#ifdef BMV_MVS_STAMPS
+  if constexpr (SPLIT) {
+    if (lane == 0 && blockIdx.x < 256) {
+      float* o = g_mvs_stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kMvsStamps;
+      if (pipe.tile_no == 2) {
+        for (int i = 1; i < 48; ++i) o[i] = (float)(unsigned)(st[i] - st[0]);
+        o[0] = 1.f;
+      }
+      if (pipe.tile_no == 3) o[48] = (float)(unsigned)(st[0] - pipe.prev_start);
+    }
+    pipe.prev_start = st[0];
+    ++pipe.tile_no;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1236,6 +1327,11 @@ int bmv_mvs_march_mask(const float* rays, const float* src_exts, const float* sr
   BMV_LAUNCH_END("bmv_mvs_march_mask");
 }
 
+#ifdef BMV_MVS_STAMPS
+int bmv_debug_fetch_mvs_stamps(float* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mvs_stamps), sizeof(float) * 256 * 4 * kMvsStamps);
+}
+#endif
 int bmv_mvs_mlp_blob_size(void) { return MvsMlp::TOTAL_S; }   // (fp32 chunks + small tables + the fifteen bf16 x 3 chunks)
 
 int bmv_mvs_mlp_pack_weights(const bmv_mvs_mlp_params* p, float* blob, bmv_stream_t stream) {
