@@ -23,7 +23,7 @@ Knob g_knobs[] = {
     {"BMV_RENDER_GRID", "fused renderer: workgroups (default 256 x waves per SIMD)"},
     {"BMV_RENDER_PC", "0 = fused renderer instead of the producer / consumer one"},
     {"BMV_RENDER_SPLIT", "0 = every chain of the fused MLP on fp32 MFMAs; default 1: its two-tile chains on the bf16 matrix pipe with three-piece fp32 operands at fp32 accuracy (the producer / consumer renderer and the stand-alone feat_ch 8 MLP)"},
-    {"BMV_MVS_SPLIT", "0 = every layer of MVSNeRF's 6 x 128 MLP on fp32 MFMAs; default 1: its ten 128 -> 128 weight chunks (pts_linears.1-4, feature_linear) as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy"},
+    {"BMV_MVS_SPLIT", "0 = every layer of MVSNeRF's 6 x 128 MLP on fp32 MFMAs; default 1: 15 of its 17 weight chunks (every layer but the 20-input pts_bias) as bf16 MFMAs on three-piece fp32 operands at fp32 accuracy"},
     {"BMV_RENDER_PC_GRID", "producer / consumer renderer: workgroups (default 256: one per CU, all resident)"},
     {"BMV_MVS_SWEEP_AUX", "MVS padded sweep: cache-policy bits of its stores (default 0x102)"},
     {"BMV_SWEEP_QUAD_DBL", "1 = a workgroup of the quad plane sweep whose windows fit its share of the CU's LDS twice requests the next channel quad's windows before it blends the current one (two window sets, hand-written LDS reads); default 0: one set (measured round 6: the headline frame's windows do not fit twice at its occupancy, profiles/r6/sweep_double_buffer.txt)"},
