@@ -333,10 +333,10 @@ struct MvsMlp {
   __host__ __device__ static constexpr int steps(int c) {
     return c < 2 ? 10 : c < 4 ? 32 : c < 12 ? 64 : c < 14 ? 96 : c < 16 ? 64 : 66;
   }
+  // (closed forms: the chunk counter is a RUN-TIME value in the loop over pts_linears.1-4, see mvs_mlp_forward)
   __host__ __device__ static constexpr int offset(int c) {
-    int o = 0;
-    for (int i = 0; i < c; ++i) o += steps(i) * 128;
-    return o;
+    return 128 * (c < 2 ? 10 * c : c < 4 ? 20 + 32 * (c - 2) : c < 12 ? 84 + 64 * (c - 4) : c < 14 ? 596 + 96 * (c - 12)
+                  : c < 16 ? 788 + 64 * (c - 14) : 916 + 66 * (c - 16));
   }
   static constexpr int A_TOTAL = 2 * 10 * 128 + 2 * 32 * 128 + 8 * 64 * 128 + 2 * 96 * 128 + 2 * 64 * 128 + 66 * 128;
   // resident small tables, [tile][half][reg 16] (entry idx = tile * 16 + reg of a lane half: MVS_SMALL in the forward)
@@ -362,9 +362,8 @@ struct MvsMlp {
   static constexpr int SPLIT_KSTEP = 3 * 2 * 64 * 4;                 // floats (dwords) of one bf16 k-step: 6 KB
   __host__ __device__ static constexpr int split_size(int c) { return split_ks(c) * SPLIT_KSTEP; }
   __host__ __device__ static constexpr int split_offset(int c) {
-    int o = 0;
-    for (int i = 0; i < c; ++i) o += split_size(i);
-    return o;
+    return SPLIT_KSTEP * (c < 2 ? 0 : c < 4 ? 4 * (c - 2) : c < 12 ? 8 + 8 * (c - 4) : c < 14 ? 72 + 12 * (c - 12)
+                          : c < 16 ? 96 + 8 * (c - 14) : 112 + 9 * (c - 16));
   }
   static constexpr int CHUNK_MAX = 12 * SPLIT_KSTEP;                 // floats: 72 KB (>= the 48 KB of a 96-step fp32 chunk)
   static constexpr int S_SPLIT = (TOTAL + 255) / 256 * 256;
@@ -373,6 +372,15 @@ struct MvsMlp {
 static_assert(MvsMlp::S_SPLIT + MvsMlp::split_offset(MvsMlp::N_CHUNKS) == MvsMlp::TOTAL_S, "split chunk table");
 static_assert(MvsMlp::split_size(12) == MvsMlp::CHUNK_MAX && MvsMlp::steps(12) * 128 <= MvsMlp::CHUNK_MAX, "largest chunk");
 static_assert(MvsMlp::offset(MvsMlp::N_CHUNKS) == MvsMlp::A_TOTAL, "chunk table");
+constexpr bool mvs_chunk_tables_consistent() {
+  int o = 0, so = 0;
+  for (int c = 0; c <= MvsMlp::N_CHUNKS; ++c) {
+    if (MvsMlp::offset(c) != o || MvsMlp::split_offset(c) != so) return false;
+    if (c < MvsMlp::N_CHUNKS) o += MvsMlp::steps(c) * 128, so += MvsMlp::split_size(c);
+  }
+  return true;
+}
+static_assert(mvs_chunk_tables_consistent(), "closed forms of the chunk offsets");
 static constexpr int kMvsSmall = ((MvsMlp::S_TOTAL + 255) / 256) * 256;   // floats of LDS in front of the chunk buffers
 
 __device__ __forceinline__ int hid_index(int u, int h) { return 32 * (u >> 4) + n16(u & 15, h); }  // k-step u of a 128-wide input
@@ -504,6 +512,19 @@ __device__ __forceinline__ int chunk_pieces(int c) {   // 1 KB pieces of chunk c
   return (SPLIT && MvsMlp::is_split(c)) ? MvsMlp::split_size(c) / 256 : MvsMlp::steps(c) / 2;
 }
 
+// One 1 KB piece of a chunk by LDS-DMA: 16 bytes per lane from src + lane16 to LDS byte address dst + 16 lane, src and dst
+// WAVE-UNIFORM.  Hand-written in the scalar-base form (global_load_lds_dwordx4 voffset, s[base:base+1]): through the builtin the
+// compiler builds a 64-bit vector address per piece (a v_lshl_add_u64 each, ~200 per tile) and hoists the per-chunk bases out
+// of the tile loop -- up to 300 bytes of scratch once the split around it changes.  M0 (the LDS address) is put back.
+__device__ __forceinline__ void mvs_dma_piece(const char* src, unsigned dst, unsigned lane16) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane16), "s"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned mvs_lds_address(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(p);
+}
+
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, float* __restrict__ bufs, int c, int slot) {
   const bool sp = SPLIT && MvsMlp::is_split(c);      // (the bf16 x 3 form of the chunk: 24 - 72 KB)
@@ -512,9 +533,7 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
   char* dst = reinterpret_cast<char*>(bufs + slot * MvsMlp::CHUNK_MAX);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int npieces = chunk_pieces<SPLIT>(c);
-  for (int p = wave; p < npieces; p += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+  for (int p = wave; p < npieces; p += 4) mvs_dma_piece(src + p * 1024, mvs_lds_address(dst + p * 1024), lane * 16);
 }
 // the first chunk(s) of a launch (every wave, before the first tile's gathers)
 template <bool SPLIT = false>
@@ -669,12 +688,25 @@ typedef float mvs_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kMvsAblate = BMV_MVS_ABLATE;
 // the three bf16 pieces of NK bf16 k-steps of a layer's input into B{H,M,L}[OFF ..): BEXPR is this lane's value for the
 // fp32 k-step `t` (0 .. 8 NK - 1) of that part of the input
+// The pieces are TRUNCATED, not rounded (8 + 8 + 8 significand bits: hi = the value's upper 16 bits, mid = the upper 16 bits
+// of value - hi, low = value - hi - mid, which has at most 8 significant bits left -- an error-free split like the rounded
+// one of mlp.hpp, what is dropped is nothing): v_and / v_perm_b32 / v_pk_add_f32 instead of v_cvt_pk_bf16_f32 and two expands,
+// 9 instructions per pair as well but only 2 of them floating point and no inline asm -- 50 instead of 71 cycles per pair
+// for a wave alone on its SIMD (scripts/ubench/split_under_mfma.hip, profiles/r6/split_under_mfma_ubench.txt).
+#ifndef BMV_MVS_SPLIT_TRUNC
+#define BMV_MVS_SPLIT_TRUNC 0   // measured in the kernel: 111.1 k against 108.4 k cycles per tile for the rounded form and 84 bytes of scratch in the renderer
+#endif
+__device__ __forceinline__ unsigned mvs_upper_halves(mvs_f32x2 v) {   // bf16 pair (v[0] low | v[1] high) by truncation
+  unsigned p = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+  asm volatile("" : "+v"(p));   // a VGPR, here: left to itself the allocator spills (184 - 296 bytes of scratch)
+  return p;
+}
+__device__ __forceinline__ mvs_f32x2 mvs_upper_floats(mvs_f32x2 v) {
+  return mvs_f32x2{__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
+}
 #define MVS_SPLIT_INPUT(NK, OFF, BEXPR, BH, BM, BL)                                                     \
   _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_)                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
-      /* the two residuals as packed fp32 subtractions (v_pk_add_f32): a wave alone on its SIMD pays ~9 cycles per     \
-         vector instruction whatever its width (profiles/r5/valu_pk_rate_ubench.txt) -- 9 instead of 11 per pair.  (The compiler's \
-         own fp32 -> bf16 conversion instead of mlp.hpp's inline asm lets it hoist the conversions: spills) */         \
       mvs_f32x2 v_;                                                                                     \
       _Pragma("unroll") for (int jj_ = 0; jj_ < 2; ++jj_) {                                             \
         const int t = 8 * T_ + 2 * q_ + jj_;                                                            \
@@ -685,6 +717,16 @@ constexpr int kMvsAblate = BMV_MVS_ABLATE;
         BL[(OFF) + T_][q_] = __float_as_uint(v_[0]);                                                    \
         continue;                                                                                       \
       }                                                                                                 \
+      if constexpr (BMV_MVS_SPLIT_TRUNC) {                                                              \
+        const mvs_f32x2 r1_ = v_ - mvs_upper_floats(v_);                                                \
+        const mvs_f32x2 r2_ = r1_ - mvs_upper_floats(r1_);                                              \
+        BH[(OFF) + T_][q_] = mvs_upper_halves(v_), BM[(OFF) + T_][q_] = mvs_upper_halves(r1_);          \
+        BL[(OFF) + T_][q_] = mvs_upper_halves(r2_);                                                     \
+        BMV_FENCE();   /* (pair by pair: left free, the scheduler interleaves all pairs of a layer -- spills) */ \
+        continue;                                                                                       \
+      }                                                                                                 \
+      /* rounded pieces; the two residuals as packed fp32 subtractions (v_pk_add_f32): 9 instead of 11 per pair.  (The \
+         compiler's own fp32 -> bf16 conversion instead of mlp.hpp's inline asm lets it hoist the conversions: spills) */ \
       const unsigned ph_ = mlp_cvt_pk_bf16(v_[0], v_[1]);                                               \
       const mvs_f32x2 h_ = {__uint_as_float(ph_ << 16), __uint_as_float(ph_ & 0xffff0000u)};            \
       const mvs_f32x2 r1_ = v_ - h_;                                                                    \
@@ -738,13 +780,13 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   static_assert(kMvsBuffers == 2, "prefetch distance 1");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int dma_np = 0, dma_i = 0;            // 1 KB pieces of the request; pieces of THIS wave (p = wave + 4 i) issued so far
-  const char* dma_src = nullptr;        // this lane's 16 bytes of this wave's first piece (+ 4 KB per piece)
-  char* dma_dst = nullptr;
+  const char* dma_src = nullptr;        // this wave's first piece (+ 4 KB per piece), wave-uniform: mvs_dma_piece
+  unsigned dma_dst = 0;                 // its LDS byte address
+  const unsigned lane16 = lane * 16;
   auto dma_step = [&]() {
     if (dma_i < (dma_np + 3) / 4) {
       if (dma_i < dma_np / 4 || 4 * dma_i + wave < dma_np)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + dma_i * 4096),
-                                         (__attribute__((address_space(3))) void*)(dma_dst + dma_i * 4096), 16, 0, 0);
+        mvs_dma_piece(dma_src + dma_i * 4096, dma_dst + dma_i * 4096, lane16);
       ++dma_i;
     }
   };
@@ -766,8 +808,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     dma_np = last && !pipe.more ? 0 : chunk_pieces<SPLIT>(nc);
     dma_i = 0;
     dma_src = reinterpret_cast<const char*>(sp ? blob + MvsMlp::S_SPLIT + MvsMlp::split_offset(nc) : blob + MvsMlp::offset(nc)) +
-              wave * 1024 + lane * 16;
-    dma_dst = reinterpret_cast<char*>(buf2 + free_slot * MvsMlp::CHUNK_MAX) + wave * 1024;
+              wave * 1024;
+    dma_dst = mvs_lds_address(buf2 + free_slot * MvsMlp::CHUNK_MAX) + wave * 1024;
     if constexpr (!SPLIT) dma_flush();
     pipe.slot = pipe.slot == kMvsBuffers - 1 ? 0 : pipe.slot + 1;
     ++chunk;
@@ -789,14 +831,19 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     MVS_GEMM(buf, 0, 10, f[t], bias[2 * tp], bias[2 * tp + 1]);
   }
   MSTAMP(1)
-  // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4
-#pragma unroll
-  for (int layer = 0; layer < 6; ++layer) {
+  // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4.
+  // One body for the three kinds of layer -- 0: pts_linears.0 (the embedded point), 1: pts_linears.1-4 (128 -> 128),
+  // 2: pts_linears.5 (embedded point | 128) -- and the four layers of kind 1 as a LOOP: fully unrolled the tile is ~100 KB of
+  // code (the instruction cache of two CUs is 64 KB) and hipcc gives up on the unroll pragma half of the time anyway
+  // ("unrolled size is too large": which build did was a matter of what else changed).  `layer` and the chunk counter are
+  // run-time values in that loop: MvsMlp's chunk tables are closed forms.
+  auto pts_layer = [&](auto kind_, const int layer) {
+    constexpr int kind = decltype(kind_)::value;
     mlp_u32x4 bh[12], bm[12], bl[12];   // [embedded point 4 |] hidden 8 bf16 k-steps
     if constexpr (SPLIT) {
-      if (layer == 0 || layer == 5) { MVS_SPLIT_INPUT(4, 0, e[t], bh, bm, bl) }
-      if (layer == 5) { MVS_SPLIT_INPUT(8, 4, hcur[t >> 4][t & 15], bh, bm, bl) }
-      if (layer >= 1 && layer <= 4) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], bh, bm, bl) }
+      if constexpr (kind != 1) { MVS_SPLIT_INPUT(4, 0, e[t], bh, bm, bl) }
+      if constexpr (kind == 2) { MVS_SPLIT_INPUT(8, 4, hcur[t >> 4][t & 15], bh, bm, bl) }
+      if constexpr (kind == 1) { MVS_SPLIT_INPUT(8, 0, hcur[t >> 4][t & 15], bh, bm, bl) }
     }
     MSTAMP(2 + 6 * layer)
 #pragma unroll
@@ -809,16 +856,10 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       next_chunk();
       MSTAMP(3 + 6 * layer + 2 * tp)
       if constexpr (SPLIT) {
-        if (layer == 0) {
-          MVS_GEMM_SPLIT(buf, 4, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
-        } else if (layer == 5) {
-          MVS_GEMM_SPLIT(buf, 12, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
-        } else {
-          MVS_GEMM_SPLIT(buf, 8, bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
-        }
-      } else if (layer == 0) {
+        MVS_GEMM_SPLIT(buf, (kind == 0 ? 4 : kind == 1 ? 8 : 12), bh, bm, bl, hnew[2 * tp], hnew[2 * tp + 1], dma_step);
+      } else if constexpr (kind == 0) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
-      } else if (layer == 5) {
+      } else if constexpr (kind == 2) {
         MVS_GEMM(buf, 0, 32, e[t], hnew[2 * tp], hnew[2 * tp + 1]);
         MVS_GEMM(buf, 32, 64, hcur[t >> 4][t & 15], hnew[2 * tp], hnew[2 * tp + 1]);
       } else {
@@ -839,7 +880,18 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
       }
     BMV_FENCE();
     MSTAMP(7 + 6 * layer)
-  }
+  };
+  pts_layer(std::integral_constant<int, 0>{}, 0);
+#ifdef BMV_MVS_STAMPS
+  pts_layer(std::integral_constant<int, 1>{}, 1);   // (constant stamp slots)
+  pts_layer(std::integral_constant<int, 1>{}, 2);
+  pts_layer(std::integral_constant<int, 1>{}, 3);
+  pts_layer(std::integral_constant<int, 1>{}, 4);
+#else
+#pragma unroll 1
+  for (int layer = 1; layer <= 4; ++layer) pts_layer(std::integral_constant<int, 1>{}, layer);
+#endif
+  pts_layer(std::integral_constant<int, 2>{}, 5);
   // alpha head (network.py:220)
   {
     float s = 0.f;
