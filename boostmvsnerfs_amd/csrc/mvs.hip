@@ -333,7 +333,7 @@ struct MvsMlp {
   __host__ __device__ static constexpr int steps(int c) {
     return c < 2 ? 10 : c < 4 ? 32 : c < 12 ? 64 : c < 14 ? 96 : c < 16 ? 64 : 66;
   }
-  // (closed forms: the chunk counter is a RUN-TIME value in the loop over pts_linears.1-4, see mvs_mlp_forward)
+  // (closed forms: the chunk counter may be a run-time value, BMV_MVS_LAYER_LOOP in mvs_mlp_forward)
   __host__ __device__ static constexpr int offset(int c) {
     return 128 * (c < 2 ? 10 * c : c < 4 ? 20 + 32 * (c - 2) : c < 12 ? 84 + 64 * (c - 4) : c < 14 ? 596 + 96 * (c - 12)
                   : c < 16 ? 788 + 64 * (c - 14) : 916 + 66 * (c - 16));
@@ -833,10 +833,11 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   MSTAMP(1)
   // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4.
   // One body for the three kinds of layer -- 0: pts_linears.0 (the embedded point), 1: pts_linears.1-4 (128 -> 128),
-  // 2: pts_linears.5 (embedded point | 128) -- and the four layers of kind 1 as a LOOP: fully unrolled the tile is ~100 KB of
-  // code (the instruction cache of two CUs is 64 KB) and hipcc gives up on the unroll pragma half of the time anyway
-  // ("unrolled size is too large": which build did was a matter of what else changed).  `layer` and the chunk counter are
-  // run-time values in that loop: MvsMlp's chunk tables are closed forms.
+  // 2: pts_linears.5 (embedded point | 128) --, the kind a template argument: as ONE `#pragma unroll` loop over six layers
+  // with `if (layer == ...)` inside, hipcc gave up on the unrolling half of the time ("unrolled size is too large": which
+  // build did was a matter of what else changed) and then selected the kind at run time.  BMV_MVS_LAYER_LOOP=1 runs the four
+  // layers of kind 1 as a run-time loop instead of four copies (measured 1.5 % slower on config 4; MvsMlp's chunk tables are
+  // closed forms so that the chunk counter may be a run-time value there).
   auto pts_layer = [&](auto kind_, const int layer) {
     constexpr int kind = decltype(kind_)::value;
     mlp_u32x4 bh[12], bm[12], bl[12];   // [embedded point 4 |] hidden 8 bf16 k-steps
@@ -882,8 +883,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     MSTAMP(7 + 6 * layer)
   };
   pts_layer(std::integral_constant<int, 0>{}, 0);
-#ifdef BMV_MVS_STAMPS
-  pts_layer(std::integral_constant<int, 1>{}, 1);   // (constant stamp slots)
+#if !defined(BMV_MVS_LAYER_LOOP) || defined(BMV_MVS_STAMPS)
+  pts_layer(std::integral_constant<int, 1>{}, 1);
   pts_layer(std::integral_constant<int, 1>{}, 2);
   pts_layer(std::integral_constant<int, 1>{}, 3);
   pts_layer(std::integral_constant<int, 1>{}, 4);
