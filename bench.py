@@ -1032,13 +1032,32 @@ def main():
             if rname in kernels:
                 flops = 251e3 * N * Ns                                 # a25, per launch (one volume)
                 tf = flops / kernels[rname]["avg_us"] / 1e6
-                mfma = {"bound": "mfma", "kernel": "mvs_render (a21-a25 fused, 6x128 MLP: the ten 128 -> 128 weight chunks as bf16 MFMAs on "
-                                                   "three-piece fp32 operands, the rest fp32 MFMAs; BMV_MVS_SPLIT=0: all fp32)",
+                mfma = {"bound": "mfma", "kernel": "mvs_render (a21-a25 fused, 6x128 MLP: 15 of its 17 weight chunks as bf16 MFMAs on "
+                                                   "three-piece fp32 operands, pts_bias on fp32 MFMAs; BMV_MVS_SPLIT=0: all fp32)",
                         "achieved": tf,
                         "peak": FP32_MFMA_PEAK_TFLOPS, "peak_is": "the fp32 MFMA peak (the rate the same fp32 FLOPs would be bound by on "
                                                                   "fp32 matrix instructions)",
-                        "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "fp32_equivalent_over_fp32_peak": tf / FP32_MFMA_PEAK_TFLOPS,
+                        "flops_counted": "algorithmic (251 kFLOP / sample, SURVEY.md 8(d))",
                         "avg_us": kernels[rname]["avg_us"], "launches": kernels[rname]["launches"]}
+                # `frac` = the share of the kernel's time its matrix pipe is BUSY, each instruction class against its own peak
+                # (as for the ENeRF renderer above).  Per 32-sample tile (csrc/mvs.hip MvsMlp): split form 40
+                # v_mfma_f32_32x32x2_f32 (pts_bias) + 1452 v_mfma_f32_32x32x16_bf16 (6 per bf16 k-step and tile: 121 k-steps
+                # x 2 tiles); all-fp32 form 1964 x 64 cycles.
+                from boostmvsnerfs_amd import _lib as _bl3
+                msplit = (_bl3.get_tuning("BMV_MVS_SPLIT") != 0)
+                mtiles = N * Ns / 32.0
+                mt_s = kernels[rname]["avg_us"] * 1e-6
+                m32, m16 = (40, 1452) if msplit else (1964, 0)
+                mtf32 = mtiles * m32 * 4096 / mt_s / 1e12
+                mtbf = mtiles * m16 * 32768 / mt_s / 1e12
+                mfma.update({"frac": mtf32 / FP32_MFMA_PEAK_TFLOPS + mtbf / BF16_MFMA_PEAK_TFLOPS,
+                             "frac_is": "matrix-pipe busy share of the kernel's time = fp32_pipe.frac + bf16_pipe.frac",
+                             "fp32_pipe": {"achieved": mtf32, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": mtf32 / FP32_MFMA_PEAK_TFLOPS, "instructions_per_tile": m32},
+                             "bf16_pipe": {"achieved": mtbf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": mtbf / BF16_MFMA_PEAK_TFLOPS, "instructions_per_tile": m16,
+                                           "what": "every one of the six bf16 products of a three-piece fp32 product counted"}})
             sname = next((n for n in kernels if n.startswith("mvs_sweep[")), None)
             if sname:
                 h, w = H // 4, W // 4
