@@ -284,8 +284,12 @@ __device__ __forceinline__ unsigned mlp_cvt_pk_bf16(float a, float b) {   // [rn
 }
 using mlp_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using mlp_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+// BMV_SPLIT_AHEAD (a constexpr bool in scope, mlp_forward's AHEAD): the three A pieces of the NEXT group (k-step, tile) are read from
+// LDS under the six MFMAs and the operand split of this one (+ 12 VGPRs: 157 -> 168 of the 170 three waves per SIMD leave
+// the fused renderer -- only where that does not spill; renderer 143.5 -> 142.0 us, bit-identical, round 6)
 #define BMV_SPLIT_CHAIN2(SPTR, NK, NT, BEXPR, ACC0, ACC1)                                          \
   {                                                                                                \
+    mlp_u32x4 ax_[3];                                                                              \
     _Pragma("unroll") for (int T_ = 0; T_ < (NK); ++T_) {                                          \
       mlp_u32x4 bh_, bm_, bl_;                                                                     \
       _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                           \
@@ -303,9 +307,18 @@ using mlp_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
       const mlp_bf16x8 Bh_ = __builtin_bit_cast(mlp_bf16x8, bh_), Bm_ = __builtin_bit_cast(mlp_bf16x8, bm_),  \
                        Bl_ = __builtin_bit_cast(mlp_bf16x8, bl_);                                  \
       _Pragma("unroll") for (int tl_ = 0; tl_ < 2; ++tl_) {                                        \
-        const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((0 * (NK) + T_) * 2 + tl_) * 64]);  \
-        const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((1 * (NK) + T_) * 2 + tl_) * 64]);  \
-        const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, (SPTR)[((2 * (NK) + T_) * 2 + tl_) * 64]);  \
+        mlp_u32x4 an_[3];                                                                          \
+        if (BMV_SPLIT_AHEAD && !(T_ == 0 && tl_ == 0)) { an_[0] = ax_[0], an_[1] = ax_[1], an_[2] = ax_[2]; }  \
+        else {                                                                                     \
+          _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) an_[pc_] = (SPTR)[((pc_ * (NK) + T_) * 2 + tl_) * 64];  \
+        }                                                                                          \
+        if (BMV_SPLIT_AHEAD && !(T_ == (NK) - 1 && tl_ == 1)) {   /* the next group's pieces under this group's MFMAs */ \
+          const int Tn_ = tl_ == 1 ? T_ + 1 : T_, tn_ = tl_ ^ 1;                                   \
+          _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) ax_[pc_] = (SPTR)[((pc_ * (NK) + Tn_) * 2 + tn_) * 64]; \
+        }                                                                                          \
+        const mlp_bf16x8 Ah_ = __builtin_bit_cast(mlp_bf16x8, an_[0]);                             \
+        const mlp_bf16x8 Am_ = __builtin_bit_cast(mlp_bf16x8, an_[1]);                             \
+        const mlp_bf16x8 Al_ = __builtin_bit_cast(mlp_bf16x8, an_[2]);                             \
         f32x16 c_ = tl_ == 0 ? ACC0 : ACC1;                                                        \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al_, Bh_, c_, 0, 0, 0);                       \
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah_, Bl_, c_, 0, 0, 0);                       \
@@ -379,11 +392,12 @@ __device__ __forceinline__ float weighted_views(const float (&w)[NV], const f32x
 //   vox[j]     feature-volume channel 2j+h
 // W: the packed blob in LDS.  out = [r, g, b, sigma], identical in both halves.
 // --------------------------------------------------------------------------
-template <int FEAT_CH, int NV = 3, bool CSPLIT = false>
+template <int FEAT_CH, int NV = 3, bool CSPLIT = false, bool AHEAD = false>
 __device__ __forceinline__ void mlp_forward(const float* __restrict__ W, int lane,
                                             const float (&fin)[NV][MlpLayout<FEAT_CH>::KF], const float (&dir)[NV][4],
                                             const float (&vox)[4], float (&out)[4]) {
   static_assert(NV >= 2 && NV <= 4, "source views per cost volume");
+  constexpr bool BMV_SPLIT_AHEAD = AHEAD;
   using L = MlpLayout<FEAT_CH>;
   constexpr int KFC = L::KFC, KF = L::KF;
   const int h = lane >> 5;

@@ -570,7 +570,8 @@ __global__ void __launch_bounds__(64 * (kPcMlp + kPcGather), 1) render_pc_kernel
     const float vis = box[B_VIS * 64];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *flag = seq + 2;     // the next producer may refill while this tile runs through the MLP
-    mlp_forward<FEAT_CH, NV, CS>(lds, lane, fin, dir, vox, res);
+    // (A pieces read one group ahead where the 12 registers that takes do not spill: mlp.hpp BMV_SPLIT_AHEAD)
+    mlp_forward<FEAT_CH, NV, CS, (NV == 2 || (NV == 3 && NS <= 2))>(lds, lane, fin, dir, vox, res);
     if (!ok) res[0] = res[1] = res[2] = res[3] = __builtin_nanf("");   // protocol error: loud, not silent
 
     if (a.mode == 1) {  // boost path: raw network output, depths and visibility, no compositing
