@@ -693,6 +693,16 @@ constexpr int kMvsAblate = BMV_MVS_ABLATE;
 // one of mlp.hpp, what is dropped is nothing): v_and / v_perm_b32 / v_pk_add_f32 instead of v_cvt_pk_bf16_f32 and two expands,
 // 9 instructions per pair as well but only 2 of them floating point and no inline asm -- 50 instead of 71 cycles per pair
 // for a wave alone on its SIMD (scripts/ubench/split_under_mfma.hip, profiles/r6/split_under_mfma_ubench.txt).
+typedef __bf16 mvs_bf16x2 __attribute__((ext_vector_type(2)));
+// fp32 pair -> packed bf16 pair, round to nearest even: the compiler's own conversion (it selects v_cvt_pk_bf16_f32, the
+// instruction mlp.hpp's inline asm names): no hazard s_nop on either side of an asm statement (1081 -> 587 per tile) and
+// schedulable -- 1.3 % on config 4, bit-identical.  (While the layer kinds were selected at run time it made the kernel
+// spill; BMV_MVS_CVT_ASM brings the asm form back.)
+#ifdef BMV_MVS_CVT_ASM
+#define MVS_CVT_PK(V) mlp_cvt_pk_bf16((V)[0], (V)[1])
+#else
+#define MVS_CVT_PK(V) __builtin_bit_cast(unsigned, __builtin_convertvector(V, mvs_bf16x2))
+#endif
 #ifndef BMV_MVS_SPLIT_TRUNC
 #define BMV_MVS_SPLIT_TRUNC 0   // measured in the kernel: 111.1 k against 108.4 k cycles per tile for the rounded form and 84 bytes of scratch in the renderer
 #endif
@@ -725,15 +735,14 @@ __device__ __forceinline__ mvs_f32x2 mvs_upper_floats(mvs_f32x2 v) {
         BMV_FENCE();   /* (pair by pair: left free, the scheduler interleaves all pairs of a layer -- spills) */ \
         continue;                                                                                       \
       }                                                                                                 \
-      /* rounded pieces; the two residuals as packed fp32 subtractions (v_pk_add_f32): 9 instead of 11 per pair.  (The \
-         compiler's own fp32 -> bf16 conversion instead of mlp.hpp's inline asm lets it hoist the conversions: spills) */ \
-      const unsigned ph_ = mlp_cvt_pk_bf16(v_[0], v_[1]);                                               \
+      /* rounded pieces; the two residuals as packed fp32 subtractions (v_pk_add_f32): 9 instead of 11 per pair */        \
+      const unsigned ph_ = MVS_CVT_PK(v_);                                               \
       const mvs_f32x2 h_ = {__uint_as_float(ph_ << 16), __uint_as_float(ph_ & 0xffff0000u)};            \
       const mvs_f32x2 r1_ = v_ - h_;                                                                    \
-      const unsigned pm_ = mlp_cvt_pk_bf16(r1_[0], r1_[1]);                                             \
+      const unsigned pm_ = MVS_CVT_PK(r1_);                                             \
       const mvs_f32x2 m_ = {__uint_as_float(pm_ << 16), __uint_as_float(pm_ & 0xffff0000u)};            \
       const mvs_f32x2 r2_ = r1_ - m_;                                                                   \
-      BH[(OFF) + T_][q_] = ph_, BM[(OFF) + T_][q_] = pm_, BL[(OFF) + T_][q_] = mlp_cvt_pk_bf16(r2_[0], r2_[1]); \
+      BH[(OFF) + T_][q_] = ph_, BM[(OFF) + T_][q_] = pm_, BL[(OFF) + T_][q_] = MVS_CVT_PK(r2_); \
     }
 
 #define MVS_SMALL(BASE, IDX) Sq[(BASE) + 2 * (IDX) - ((IDX) & 15)]
