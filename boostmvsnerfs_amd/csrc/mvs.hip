@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(256) mvs_sweep_cl_kernel(const float* __restri
 // ---------------------------------------------------------------------------
 struct MvsMlp {
   static constexpr int N_CHUNKS = 17;
+  static constexpr int FIRST_STREAMED = 2;   // chunks 0, 1 (pts_bias: 40 floats per lane) stay in registers for the whole launch
   // k-steps per chunk: bias x2, L0 x2, L1..L4 x2 each, L5 x2, feature x2, views x1
   __host__ __device__ static constexpr int steps(int c) {
     return c < 2 ? 10 : c < 4 ? 32 : c < 12 ? 64 : c < 14 ? 96 : c < 16 ? 64 : 66;
@@ -535,11 +536,19 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ blob, floa
   const int npieces = chunk_pieces<SPLIT>(c);
   for (int p = wave; p < npieces; p += 4) mvs_dma_piece(src + p * 1024, mvs_lds_address(dst + p * 1024), lane * 16);
 }
+// pts_bias' A operands of this lane, [tile 4][k-step 10] (chunks 0, 1 of the fp32 blob): resident in registers for the whole
+// launch -- 40 of the ~150 AGPRs the kernel leaves unused -- instead of two more chunks in the stream of every tile (two
+// barriers, two DMA requests issued as bursts: there is no bf16 MFMA group in front of them to spread them over)
+__device__ __forceinline__ void load_pts_bias_weights(const float* __restrict__ blob, int lane, float (&wb)[4][10]) {
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) wb[tl][t] = blob[MvsMlp::offset(tl >> 1) + t * 128 + (tl & 1) * 64 + lane];
+}
 // the first chunk(s) of a launch (every wave, before the first tile's gathers)
 template <bool SPLIT = false>
 __device__ __forceinline__ void start_chunks(const float* __restrict__ blob, float* __restrict__ bufs) {
-  issue_chunk<SPLIT>(blob, bufs, 0, 0);
-  if constexpr (kMvsBuffers == 3) issue_chunk<SPLIT>(blob, bufs, 1, 1);
+  issue_chunk<SPLIT>(blob, bufs, MvsMlp::FIRST_STREAMED, 0);
 }
 // wait until at most `keep` of this wave's vector-memory operations are outstanding (keep: wave-uniform; the piece
 // counts of a wave are 1-2, 4, 8-9 or 12 -- rounded down, which only waits for one piece more on wave 0)
@@ -773,12 +782,12 @@ __device__ float g_mvs_stamps[256 * 4 * kMvsStamps];
 template <bool SPLIT = false>
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
                                                 float* __restrict__ buf2, ChunkPipe& pipe, int lane,
-                                                const float (&e)[32], const float (&f)[10], const float (&dv)[2],
-                                                float (&out)[4]) {
+                                                const float (&wb)[4][10], const float (&e)[32], const float (&f)[10],
+                                                const float (&dv)[2], float (&out)[4]) {
   const int h = lane >> 5;
   const float* __restrict__ Sq = small + 16 * h;   // this lane half's 16 values of a tile are contiguous: MVS_SMALL
   f32x16 bias[4], hcur[4], hnew[4];
-  int chunk = 0;
+  int chunk = MvsMlp::FIRST_STREAMED;
   const float* buf = buf2;
   // The weight stream.  The request for the chunk behind chunk c is SET UP at the barrier in front of c and issued piece
   // by piece between the MFMAs of c (MVS_GEMM_SPLIT calls dma_step twice per group), not as a burst behind the barrier:
@@ -812,7 +821,7 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
     buf = buf2 + pipe.slot * MvsMlp::CHUNK_MAX;
     const int free_slot = pipe.slot == 0 ? kMvsBuffers - 1 : pipe.slot - 1;   // the previous chunk's buffer
     const bool last = chunk + 1 == MvsMlp::N_CHUNKS;
-    const int nc = last ? 0 : chunk + 1;               // (the next tile's first chunk under this tile's last one)
+    const int nc = last ? MvsMlp::FIRST_STREAMED : chunk + 1;   // (the next tile's first chunk under this tile's last one)
     const bool sp = SPLIT && MvsMlp::is_split(nc);
     dma_np = last && !pipe.more ? 0 : chunk_pieces<SPLIT>(nc);
     dma_i = 0;
@@ -829,15 +838,11 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   MSTAMP(0)
   // pts_bias (network.py:210): bias = W_b feat + b_b
 #pragma unroll
-  for (int tp = 0; tp < 2; ++tp) {
+  for (int tl = 0; tl < 4; ++tl) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      bias[2 * tp][r] = MVS_SMALL(MvsMlp::S_BBIAS, (2 * tp) * 16 + r);
-      bias[2 * tp + 1][r] = MVS_SMALL(MvsMlp::S_BBIAS, (2 * tp + 1) * 16 + r);
-    }
-    next_chunk();
-    dma_flush();                                       // (an fp32 chunk: no groups to spread the request over)
-    MVS_GEMM(buf, 0, 10, f[t], bias[2 * tp], bias[2 * tp + 1]);
+    for (int r = 0; r < 16; ++r) bias[tl][r] = MVS_SMALL(MvsMlp::S_BBIAS, tl * 16 + r);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) bias[tl] = BMV_MFMA(wb[tl][t], f[t], bias[tl]);   // (weights resident: load_pts_bias_weights)
   }
   MSTAMP(1)
   // pts_linears.0..5 (network.py:211-216): h = relu((W_i h + b_i) * bias), skip-concat of pts after i == 4.
@@ -1095,7 +1100,11 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
   const long ntiles = (npts + 31) / 32;
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
-  if (a.blob) start_chunks<SPLIT>(a.blob, buf);   // under the gathers / sincos of the first tile
+  float wb[4][10] = {};
+  if (a.blob) {
+    start_chunks<SPLIT>(a.blob, buf);               // under the gathers / sincos of the first tile
+    load_pts_bias_weights(a.blob, lane, wb);
+  }
   for (long round = 0; round * per_round < ntiles; ++round) {   // uniform trip count across the workgroup
     pipe.more = (round + 1) * per_round < ntiles;
     long tile = round * per_round + (long)blockIdx.x * 4 + wave;
@@ -1117,7 +1126,7 @@ __global__ void __launch_bounds__(256, 1) mvs_render_kernel(bmv_mvs_render_args 
       else row[84] = dv[0];
     }
     if (a.blob) {
-      mvs_mlp_forward<SPLIT>(a.blob, small, buf, pipe, lane, e, f, dv, res);
+      mvs_mlp_forward<SPLIT>(a.blob, small, buf, pipe, lane, wb, e, f, dv, res);
       if (valid && h == 0) {
         float4 o4 = {res[0], res[1], res[2], res[3]};
         reinterpret_cast<float4*>(a.raw)[gi] = o4;
@@ -1144,6 +1153,8 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
   const long per_round = (long)gridDim.x * 4;
   ChunkPipe pipe{0, false};
   start_chunks<SPLIT>(blob, buf);
+  float wb[4][10];
+  load_pts_bias_weights(blob, lane, wb);
   for (long round = 0; round * per_round < ntiles; ++round) {
     pipe.more = (round + 1) * per_round < ntiles;
     long pt = (round * per_round + (long)blockIdx.x * 4 + wave) * 32 + s;
@@ -1163,7 +1174,7 @@ __global__ void __launch_bounds__(256, 1) mvs_mlp_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < 10; ++t) asm volatile("" ::"v"(f[t]));
     asm volatile("" ::"v"(dv[0]), "v"(dv[1]));
-    mvs_mlp_forward<SPLIT>(blob, small, buf, pipe, lane, e, f, dv, res);
+    mvs_mlp_forward<SPLIT>(blob, small, buf, pipe, lane, wb, e, f, dv, res);
     if (valid && h == 0) {
       float4 o4 = {res[0], res[1], res[2], res[3]};
       reinterpret_cast<float4*>(out)[pt] = o4;

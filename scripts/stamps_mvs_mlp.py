@@ -38,7 +38,7 @@ def child():
     s = np.frombuffer(buf, dtype=np.float32).reshape(-1, NS)
     s = s[s[:, 0] == 1.0]
     print(len(s), "waves; cycles of the shader clock (s_memtime), median over the waves")
-    names = {1: "pts_bias: 2 chunks fp32 (wait + 20 MFMAs each)"}
+    names = {1: "pts_bias: 40 fp32 MFMAs (weights resident in registers)"}
     for layer in range(6):
         o = 2 + 6 * layer
         names[o] = f"pts_linears.{layer}: operand split"
