@@ -1,10 +1,10 @@
 #!/bin/bash
 # MFMA-pipe and LDS counters per kernel over eager frames of the headline workload (one --pmc pass).
-#   bash scripts/pmc_frame.sh <outdir>
+#   bash scripts/pmc_frame.sh <outdir>          (WORKLOAD=<bench workload> STEPS=<n> for another frame, e.g. BASELINE configs[3])
 OUT=${1:-gpurun_out/pmc_frame}; R=$(pwd); mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_frame
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pmc_frame --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --graph 0 --spinup-steps 0 > /tmp/pmc_frame.out 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pmc_frame --output-format csv -- python3 $R/bench.py ${WORKLOAD:+--workload $WORKLOAD} --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --graph 0 --spinup-steps 0 > /tmp/pmc_frame.out 2>&1
 F=$(ls /tmp/pmc_frame/*/*counter_collection.csv | head -1)
 python3 - "$F" > $R/$OUT/frame_mfma_lds_counters.txt <<'PY'
 import csv, sys, collections
