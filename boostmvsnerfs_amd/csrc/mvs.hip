@@ -483,30 +483,26 @@ __global__ void mvs_mlp_pack_kernel(bmv_mvs_mlp_params p, float* __restrict__ bl
   blob[idx] = v;
 }
 
-// Weight streaming.  The chunks go through kMvsBuffers (2; build option 3) LDS buffers by LDS-DMA
-// (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR round trip) with a prefetch distance of kMvsBuffers - 1
-// chunks: the next chunk(s) are in flight while the MFMAs of chunk c run, so a chunk costs one workgroup barrier and no
-// exposed load latency.  (History: one buffer + a register-staged copy between two barriers per chunk left the matrix
-// pipe idle half of the time, 51 % of the fp32 MFMA peak at 1 wave per SIMD.  Round 6 measured the three-buffer /
-// distance-2 form 3 % slower than two buffers, also for the 1.3 us bf16 x 3 chunks: the stream is not what the split
-// form waits for -- profiles/r6/mvs_pipeline.txt.)  The wait in front of a chunk is COUNTED: with distance 2, vmcnt may
-// keep this wave's pieces of the next chunk outstanding (memory operations retire in order, so everything older --
-// this chunk -- has landed), and the workgroup barrier is a bare s_barrier: __syncthreads() carries a fence that drains
-// vmcnt to 0, i.e. the prefetch.  The buffer slot is a running count over chunks AND tiles (17 chunks per tile: the
-// first chunk(s) of the next tile are fetched under the last one(s) of this one).
+// Weight streaming.  The chunks go through TWO LDS buffers by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction,
+// no VGPR round trip): the chunk behind chunk c is in flight while the MFMAs of c run, so a chunk costs one workgroup
+// barrier and no exposed load latency.  The request is not issued as a burst behind the barrier but piece by piece between
+// the MFMAs of chunk c (mvs_mlp_forward: dma_step), each piece hand-written in the scalar-base form (mvs_dma_piece).  The
+// wait in front of a chunk is s_waitcnt vmcnt(0) + a bare s_barrier (__syncthreads() adds a fence nobody needs here).  The
+// buffer slot is a running count over chunks AND tiles (15 streamed chunks per tile: the first one of the next tile is
+// fetched under the last one of this one); pts_bias' two chunks are not streamed, their 40 floats per lane stay in
+// registers (load_pts_bias_weights).  History: one buffer + a register-staged copy between two barriers per chunk left
+// the matrix pipe idle half of the time (round 1); a third buffer with prefetch distance 2 and counted vmcnt waits was 3 %
+// SLOWER (round 6, profiles/r6/mvs_pipeline.txt part 1: the stream's latency was never the stall, its issue was -- part 2)
+// and no longer fits since a pts_linears.5 chunk is 72 KB.
 struct ChunkPipe {
-  int slot;    // LDS buffer (0 .. kMvsBuffers - 1) of the next chunk this workgroup consumes
+  int slot;    // LDS buffer (0 / 1) of the next chunk this workgroup consumes
   bool more;   // another tile follows this one: prefetch its first chunks
 #ifdef BMV_MVS_STAMPS
   int tile_no = 0;
   unsigned long long prev_start = 0;
 #endif
 };
-#ifndef BMV_MVS_BUFFERS
-#define BMV_MVS_BUFFERS 2     // 3 measured 3 % SLOWER than 2 on config 4 (profiles/r6/mvs_pipeline.txt): the stream was never the stall
-#endif
-static constexpr int kMvsBuffers = BMV_MVS_BUFFERS;
-static_assert(kMvsBuffers == 2 || kMvsBuffers == 3, "prefetch distance 1 or 2");
+static constexpr int kMvsBuffers = 2;
 
 template <bool SPLIT = false>
 __device__ __forceinline__ int chunk_pieces(int c) {   // 1 KB pieces of chunk c (128 floats per k-step = 512 B)
@@ -550,16 +546,6 @@ template <bool SPLIT = false>
 __device__ __forceinline__ void start_chunks(const float* __restrict__ blob, float* __restrict__ bufs) {
   issue_chunk<SPLIT>(blob, bufs, MvsMlp::FIRST_STREAMED, 0);
 }
-// wait until at most `keep` of this wave's vector-memory operations are outstanding (keep: wave-uniform; the piece
-// counts of a wave are 1-2, 4, 8-9 or 12 -- rounded down, which only waits for one piece more on wave 0)
-__device__ __forceinline__ void wait_vm_keep(int keep) {
-  if (keep >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (keep >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (keep >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // acc{0,1} += W_chunk[:, steps T0..T0+NT) * B, B given by `bval(t)` for the chunk-local step t
 // (A operands software-pipelined by one group of MVS_G k-steps, as BMV_CHAIN2 of mlp.hpp)
 #ifndef MVS_G
