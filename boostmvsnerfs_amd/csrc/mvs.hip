@@ -575,10 +575,6 @@ __device__ __forceinline__ void start_chunks(const float* __restrict__ blob, flo
     }                                                                                                   \
   }
 
-// e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature, dv[2]: view direction.
-// Must be called by all 4 waves of the workgroup together (chunk staging uses workgroup barriers).
-// The first kMvsBuffers - 1 chunks of this tile must already be in flight (start_chunks at the top of the launch;
-// afterwards the last chunks of the previous tile issue them).
 // a K -> 64 product of a split chunk of KS bf16 k-steps on the B pieces of the layer's input (computed once per layer:
 // both output halves use them): the bf16 x 3 form of BMV_SPLIT_CHAIN2 (mlp.hpp), small terms first
 #ifndef BMV_MVS_ADIST
@@ -765,6 +761,10 @@ __device__ float g_mvs_stamps[256 * 4 * kMvsStamps];
 #else
 #define MSTAMP(i)
 #endif
+// wb: pts_bias' weights (load_pts_bias_weights), e[32]: embedded point (slot t -> input 2t+h), f[10]: 20-ch feature,
+// dv[2]: view direction.  Must be called by all 4 waves of the workgroup together (chunk staging uses workgroup barriers).
+// The first streamed chunk of this tile must already be in flight (start_chunks at the top of the launch; afterwards
+// the last chunk of the previous tile requests it).
 template <bool SPLIT = false>
 __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, const float* __restrict__ small,
                                                 float* __restrict__ buf2, ChunkPipe& pipe, int lane,
@@ -779,8 +779,8 @@ __device__ __forceinline__ void mvs_mlp_forward(const float* __restrict__ blob, 
   // by piece between the MFMAs of c (MVS_GEMM_SPLIT calls dma_step twice per group), not as a burst behind the barrier:
   // a wave issues in order, and its 6 - 18 global_load_lds of 1 KB queue behind the other three waves' at the CU's one
   // address path -- 1 - 2 k cycles per chunk in which no MFMA of the wave was issued, 37 k of the 114 k cycles of a tile
-  // (scripts/stamps_mvs_mlp.py, profiles/r6/mvs_pipeline.txt).  In front of an fp32 chunk (pts_bias; BMV_MVS_SPLIT=0) the
-  // request is flushed at once as before.  All counts below fold to constants once the chunk loop is unrolled.
+  // (scripts/stamps_mvs_mlp.py, profiles/r6/mvs_pipeline.txt).  In front of an fp32 chunk (BMV_MVS_SPLIT=0: no groups to
+  // spread it over) the request is flushed at once as before.  All counts below fold to constants: the chunk counter does.
   static_assert(kMvsBuffers == 2, "prefetch distance 1");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int dma_np = 0, dma_i = 0;            // 1 KB pieces of the request; pieces of THIS wave (p = wave + 4 i) issued so far
