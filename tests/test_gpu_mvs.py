@@ -84,6 +84,28 @@ def test_mlp(fx):
     assert_close(raw2, chunks(fx, "nerf").reshape(-1, 4)[:1001], name="ragged")
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_mlp_three_rounds_with_a_nearly_empty_last_one(fx, split):
+    """The weight stream across tiles and rounds (csrc/mvs.hip: the first chunk of the next tile is requested under the last one
+    of this tile; a wave without a valid tile still takes part in every barrier and issues its share of every request):
+    2 x 1024 tiles + 33 points = three rounds of the 256-workgroup grid, the last one with two valid tiles, a ragged point
+    count, in both matrix forms against the oracle's MLP (oracle/mvsnerf.py renderer_mlp, torch CPU fp32) on the same rows."""
+    from boostmvsnerfs_amd import ops
+    from oracle import mvsnerf as M
+    torch.manual_seed(11)
+    n = 2 * 1024 * 32 + 33
+    x0 = chunks(fx, "run_network_mvs").reshape(-1, 86)
+    x = x0[torch.randint(0, x0.shape[0], (n,))].contiguous()
+    x[:, 63:83] += 0.05 * torch.randn(n, 20)
+    sd = {k: v for k, v in fx.group("sd").items() if k.startswith("nerf.nerf.")}
+    want = M.renderer_mlp(sd, x)
+    with _mvs_split(split):
+        got = ops.mvs_mlp(x.to(DEV), _blob(fx))
+    assert_close(got, want, name=f"6x128 mlp, three rounds, BMV_MVS_SPLIT={split}")
+    # the last points (the two valid tiles of the third round) on their own
+    assert_close(got[-33:], want[-33:], name="tail of the last round")
+
+
 class _mvs_split:
     """bmv_tuning BMV_MVS_SPLIT for the duration of a block (the suite may be running with either value set)."""
 
